@@ -1,0 +1,88 @@
+/* vpt_hip.h -- C ABI of libvpt_hip.so: the MI355X (gfx950) kernels behind the VPT policy hot path.
+ *
+ * The reference (openai/Video-Pre-Training) has no FFI of its own: its hot path is PyTorch ATen calls made
+ * from lib/policy.py, lib/impala_cnn.py, lib/util.py, lib/xf.py, lib/masked_attention.py and
+ * lib/action_head.py.  Each entry point below replaces one such group of calls (cited per function); the
+ * Python host side (video-pre-training_amd/lib/policy.py) binds them with ctypes and keeps the reference's
+ * MinecraftAgentPolicy API on top.  See INTEGRATION.md for the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (inputs, outputs, KV memory, workspaces);
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*; NULL = default stream):
+ *     no allocation, no synchronisation, no global state besides the last-error string;
+ *   - return 0 on success, <0 on a rejected argument or a launch failure (vpt_last_error() explains);
+ *   - "blocked" activations are bf16 [frames][C/32][H][W][32]; "stats" are double[frames][2] holding the
+ *     running (sum, sum of squares) of a frame, accumulated with atomics -- the caller zeroes them;
+ *   - packed weight formats are produced by video-pre-training_amd/packing.py (documented in DESIGN.md).
+ */
+#ifndef VPT_HIP_H
+#define VPT_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Library / build identification: returns "vpt_hip <version> gfx950". */
+const char* vpt_version(void);
+/* Human-readable reason for the most recent non-zero return on this thread. */
+const char* vpt_last_error(void);
+
+/* Stack-0 firstconv + ingest + ReLU + max-pool.
+ * Replaces ImgPreprocessing.forward (lib/policy.py:39-45), the permute at lib/impala_cnn.py:190,
+ * CnnDownStack.firstconv of stack 0 (lib/impala_cnn.py:86-97,115) and F.max_pool2d (lib/impala_cnn.py:117).
+ * img: uint8 [frames][H][W][3]; wfrag: bf16 [NT][4][2][64][8]; y: blocked [frames][Cout/32][H/2][W/2][32]. */
+int vpt_conv_first_forward(const uint8_t* img, const void* wfrag, void* y, double* stats_out,
+                           int frames, int H, int W, int Cout, void* stream);
+
+/* GroupNorm(1,Cin) -> Conv2d(3x3, pad 1, no bias) -> ReLU [-> + residual].
+ * Replaces FanInInitReLULayer.forward (lib/util.py:75-82) for conv layers and the residual add of
+ * CnnBasicBlock.forward (lib/impala_cnn.py:50-52).  x, res, y blocked bf16; wpk bf16 [NT][Cin/32][9][128][32];
+ * edge_sa / edge_sg fp32 [9][NT*128]; stats_in = statistics of x; stats_out (optional) receives those of y. */
+int vpt_conv3x3_forward(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg,
+                        const double* stats_in, const void* res, void* y, double* stats_out,
+                        int frames, int H, int W, int Cin, int Cout, void* stream);
+
+/* F.max_pool2d(x, 3, 2, 1) on a post-ReLU blocked tensor (lib/impala_cnn.py:117, stacks 1..2). */
+int vpt_maxpool_forward(const void* x, void* y, double* stats_out, int frames, int C, int H, int W, void* stream);
+
+/* y = (x - mean_f) * rstd_f * gain + bias with whole-frame statistics:
+ * CnnDownStack.n (GroupNorm(1,C), lib/impala_cnn.py:99-100,118-119; per_element = 0, gain[C]) and the
+ * LayerNorm of ImpalaCNN.dense over the flattened frame (lib/impala_cnn.py:177-184; per_element = 1,
+ * gain[C*H*W] already permuted to the blocked order). */
+int vpt_frame_affine_forward(const void* x, void* y, const float* gain, const float* bias,
+                             const double* stats_in, double* stats_out,
+                             int frames, int C, int HW, int per_element, void* stream);
+
+/* C[M,N] = A[M,K] W[N,K]^T (+bias) (ReLU) (+res): every nn.Linear on the path (lib/util.py:58-82,
+ * lib/xf.py:251-254, lib/action_head.py:164, lib/scaled_mse_head.py:35).  A bf16 [M][lda]; wpk bf16
+ * [ceil(N/128)][K/32][128][32]; bias fp32[N] or NULL; res fp32 [M][ldr] or NULL; out_f32 [M][ldc] and/or
+ * out_bf16 [M][ldcb].  splitk > 1 accumulates into a caller-zeroed out_f32 with atomics (no ReLU/res). */
+int vpt_linear_forward(const void* A, const void* wpk, const float* bias, const float* res,
+                       float* out_f32, void* out_bf16, int M, int N, int K,
+                       int lda, int ldr, int ldc, int ldcb, int relu, int splitk, void* stream);
+
+/* nn.LayerNorm over the last dim with optional ReLU on the input (lib/util.py:61-62,169; lib/policy.py:188,211-214). */
+int vpt_layernorm_forward(const float* x, const float* gain, const float* bias, float* out_f32, void* out_bf16,
+                          int M, int D, int relu_in, void* stream);
+
+/* Banded-causal attention with KV memory and relative-position bias: attention() (lib/xf.py:18-71) as driven
+ * by MaskedAttention.forward (lib/masked_attention.py:161-178).  qkvr fp32 [B*t][ld] = Q | K | V | R columns;
+ * kmem/vmem fp32 [B][maxlen][hid]; memvalid uint8 [B][maxlen] (= state_mask & !first[:,0]); b_nd fp32
+ * [10][maxlen]; out bf16 [B*t][hid] (heads merged, lib/xf.py:125-131). */
+int vpt_masked_attention_forward(const float* qkvr, const float* kmem, const float* vmem, const uint8_t* memvalid,
+                                 const float* b_nd, void* out, int B, int t, int heads, int hid, int ld,
+                                 int maxlen, void* stream);
+
+/* SelfAttentionLayer.update_state (lib/xf.py:366-391): kout/vout = last maxlen rows of [memory ; new]. */
+int vpt_kv_memory_update(const float* qkvr, const float* kmem, const float* vmem, float* kout, float* vout,
+                         int B, int t, int hid, int ld, int maxlen, void* stream);
+
+/* CategoricalActionHead.forward tail (lib/action_head.py:170-174): out[M][n] = log_softmax(logits[:, col0:col0+n] / T). */
+int vpt_log_softmax_forward(const float* logits, float* out, int M, int ld, int col0, int n, float temperature,
+                            void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VPT_HIP_H */

@@ -1,0 +1,49 @@
+"""The C-ABI library builds, loads, and exports every symbol include/vpt_hip.h declares (no compute calls:
+this runs without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build()
+    import vpt_amd
+    from vpt_amd import _native
+    return _native.load()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "vpt_hip.h")).read()
+    names = re.findall(r"^(?:int|const char\*)\s+(vpt_\w+)\s*\(", hdr, flags=re.M)
+    assert len(names) >= 11
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_ctypes_signatures_cover_header(lib):
+    from vpt_amd import _native
+    hdr = open(os.path.join(ROOT, "include", "vpt_hip.h")).read()
+    for name, args in _native.SIGNATURES.items():
+        m = re.search(r"int\s+" + name + r"\s*\(([^;]*)\)\s*;", hdr, flags=re.S)
+        assert m, name
+        assert len([a for a in m.group(1).split(",") if a.strip()]) == len(args), name
+
+
+def test_version_and_error_strings(lib):
+    assert b"gfx950" in lib.vpt_version()
+    assert isinstance(lib.vpt_last_error(), bytes)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    import vpt_amd  # noqa: F401
+    from vpt_amd import _native
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "_LIB_PATH", "/nonexistent/libvpt_hip.so")
+    with pytest.raises(_native.NativeLibraryError):
+        _native.load()

@@ -1,0 +1,51 @@
+"""Drop-in boundary checks that need no GPU: state_dict key set / shapes, parameter count,
+state structure, and that the HIP policy refuses to run on CPU instead of silently falling back."""
+import pytest
+import torch
+
+import vpt_amd  # noqa: F401
+from vpt_amd.lib.policy import MinecraftAgentPolicy
+from vpt_amd.lib.types import minecraft_action_space
+from oracle import vpt_oracle as O
+
+
+@pytest.fixture(scope="module")
+def policy_1x():
+    return MinecraftAgentPolicy(minecraft_action_space(), O.policy_kwargs_for("1x"), dict(temperature=2.0))
+
+
+def test_state_dict_matches_reference_keys(policy_1x):
+    cfg = O.config_from_policy_kwargs(O.policy_kwargs_for("1x"), dict(temperature=2.0))
+    spec = {k: tuple(s) for k, s, _ in O.state_dict_spec(cfg)}
+    sd = policy_1x.state_dict()
+    assert set(sd) == set(spec)
+    for k, v in sd.items():
+        assert tuple(v.shape) == spec[k], k
+    assert sum(p.numel() for p in policy_1x.parameters()) == 70_998_654
+    missing, unexpected = policy_1x.load_state_dict(O.synthetic_state_dict(cfg, 0), strict=False)
+    assert not missing and not unexpected
+
+
+def test_initial_state_structure(policy_1x):
+    st = policy_1x.initial_state(3)
+    assert len(st) == 4
+    for m, (k, v) in st:
+        assert m is None and k.shape == (3, 128, 1024) and v.dtype == torch.float32 and float(k.abs().sum()) == 0
+
+
+def test_cpu_forward_refuses(policy_1x):
+    img = torch.zeros(1, 1, 128, 128, 3, dtype=torch.uint8)
+    with pytest.raises(RuntimeError):
+        policy_1x({"img": img}, torch.zeros(1, 1, dtype=torch.bool), policy_1x.initial_state(1))
+
+
+def test_action_head_algebra():
+    from vpt_amd.lib.action_head import make_action_head
+    head = make_action_head(minecraft_action_space(11, 7), 16)
+    lp = {"buttons": torch.log_softmax(torch.randn(2, 3, 1, 11), -1), "camera": torch.log_softmax(torch.randn(2, 3, 1, 7), -1)}
+    ac = head.sample(lp, deterministic=True)
+    assert ac["buttons"].shape == (2, 3, 1) and ac["buttons"].dtype == torch.int64
+    logp = head.logprob(ac, lp)
+    ref = lp["buttons"].max(-1).values.sum(-1) + lp["camera"].max(-1).values.sum(-1)
+    assert torch.allclose(logp, ref)
+    assert torch.allclose(head.kl_divergence(lp, lp), torch.zeros(2, 3, 1), atol=1e-6)

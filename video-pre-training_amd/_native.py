@@ -1,0 +1,66 @@
+"""ctypes binding of libvpt_hip.so (the C ABI declared in include/vpt_hip.h).
+
+The library is built in-tree by build.py.  There is NO fallback: if it cannot be loaded every op raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libvpt_hip.so")
+_lib = None
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+
+# name -> argtypes, exactly as declared in include/vpt_hip.h
+SIGNATURES = {
+    "vpt_conv_first_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vpt_conv3x3_forward": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vpt_maxpool_forward": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "vpt_frame_affine_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vpt_linear_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vpt_layernorm_forward": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "vpt_masked_attention_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vpt_kv_memory_update": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vpt_log_softmax_forward": [_P, _P, _I, _I, _I, _I, _F, _P],
+}
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load (once) and type the shared library.  Raises NativeLibraryError if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise NativeLibraryError(
+            f"{_LIB_PATH} is missing: run `python __graft_entry__.py` (build()) first; there is no CPU fallback")
+    lib = ctypes.CDLL(_LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _I
+    lib.vpt_version.restype = ctypes.c_char_p
+    lib.vpt_last_error.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {lib.vpt_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,103 @@
+// C ABI (include/vpt_hip.h) on top of the per-kernel launchers.  Plain pointers and sizes only.
+#include "../../include/vpt_hip.h"
+#include "vpt_kernels.h"
+#include <stdio.h>
+
+static thread_local char g_err[256] = "ok";
+
+static int fail(int code, const char* what) {
+  snprintf(g_err, sizeof(g_err), "%s (code %d, hip: %s)", what, code, hipGetErrorString(hipPeekAtLastError()));
+  return code;
+}
+#define CHECK_LAUNCH(expr, name) do { int rc_ = (expr); if (rc_ != 0) return fail(rc_, name); return 0; } while (0)
+
+extern "C" {
+
+const char* vpt_version(void) { return "vpt_hip 0.1 gfx950"; }
+const char* vpt_last_error(void) { return g_err; }
+
+int vpt_conv_first_forward(const uint8_t* img, const void* wfrag, void* y, double* stats_out,
+                           int frames, int H, int W, int Cout, void* stream) {
+  VptConvFirstArgs a;
+  a.img = img; a.wfrag = (const vpt_bf16*)wfrag; a.y = (vpt_bf16*)y; a.stats_out = stats_out;
+  a.frames = frames; a.H = H; a.W = W; a.Cout = Cout; a.NT = (Cout + 127) / 128;
+  CHECK_LAUNCH(vpt_conv_first_launch(&a, (hipStream_t)stream), "vpt_conv_first_forward");
+}
+
+int vpt_conv3x3_forward(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg,
+                        const double* stats_in, const void* res, void* y, double* stats_out,
+                        int frames, int H, int W, int Cin, int Cout, void* stream) {
+  if (!stats_in) return fail(-1, "vpt_conv3x3_forward: stats_in is required");
+  VptConv3x3Args a;
+  a.x = (const vpt_bf16*)x; a.wpk = (const vpt_bf16*)wpk; a.edge_sa = edge_sa; a.edge_sg = edge_sg;
+  a.stats_in = stats_in; a.res = (const vpt_bf16*)res; a.y = (vpt_bf16*)y; a.stats_out = stats_out;
+  a.frames = frames; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.NT = (Cout + 127) / 128; a.CoutPad = a.NT * 128;
+  a.inv_count_in = 1.0 / ((double)Cin * H * W);
+  CHECK_LAUNCH(vpt_conv3x3_launch(&a, (hipStream_t)stream), "vpt_conv3x3_forward");
+}
+
+int vpt_maxpool_forward(const void* x, void* y, double* stats_out, int frames, int C, int H, int W, void* stream) {
+  if (C & 31) return fail(-1, "vpt_maxpool_forward: C must be a multiple of 32");
+  VptPoolArgs a;
+  a.x = (const vpt_bf16*)x; a.y = (vpt_bf16*)y; a.stats_out = stats_out;
+  a.frames = frames; a.CB = C / 32; a.H = H; a.W = W;
+  CHECK_LAUNCH(vpt_pool_launch(&a, (hipStream_t)stream), "vpt_maxpool_forward");
+}
+
+int vpt_frame_affine_forward(const void* x, void* y, const float* gain, const float* bias,
+                             const double* stats_in, double* stats_out,
+                             int frames, int C, int HW, int per_element, void* stream) {
+  if (C & 31) return fail(-1, "vpt_frame_affine_forward: C must be a multiple of 32");
+  VptAffineArgs a;
+  a.x = (const vpt_bf16*)x; a.y = (vpt_bf16*)y; a.gain = gain; a.bias = bias;
+  a.stats_in = stats_in; a.stats_out = stats_out;
+  a.frames = frames; a.CB = C / 32; a.HW = HW; a.per_element = per_element;
+  a.inv_count = 1.0 / ((double)C * HW);
+  CHECK_LAUNCH(vpt_affine_launch(&a, (hipStream_t)stream), "vpt_frame_affine_forward");
+}
+
+int vpt_linear_forward(const void* A, const void* wpk, const float* bias, const float* res,
+                       float* out_f32, void* out_bf16, int M, int N, int K,
+                       int lda, int ldr, int ldc, int ldcb, int relu, int splitk, void* stream) {
+  VptGemmArgs a;
+  a.A = (const vpt_bf16*)A; a.wpk = (const vpt_bf16*)wpk; a.bias = bias; a.res = res;
+  a.out_f32 = out_f32; a.out_bf16 = (vpt_bf16*)out_bf16;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldr = ldr; a.ldc = ldc; a.ldcb = ldcb;
+  a.relu = relu; a.splitk = splitk < 1 ? 1 : splitk; a.atomic_out = a.splitk > 1;
+  CHECK_LAUNCH(vpt_gemm_launch(&a, (hipStream_t)stream), "vpt_linear_forward");
+}
+
+int vpt_layernorm_forward(const float* x, const float* gain, const float* bias, float* out_f32, void* out_bf16,
+                          int M, int D, int relu_in, void* stream) {
+  VptLayerNormArgs a;
+  a.x = x; a.gain = gain; a.bias = bias; a.out_f32 = out_f32; a.out_bf16 = (vpt_bf16*)out_bf16;
+  a.M = M; a.D = D; a.relu_in = relu_in;
+  CHECK_LAUNCH(vpt_layernorm_launch(&a, (hipStream_t)stream), "vpt_layernorm_forward");
+}
+
+int vpt_masked_attention_forward(const float* qkvr, const float* kmem, const float* vmem, const uint8_t* memvalid,
+                                 const float* b_nd, void* out, int B, int t, int heads, int hid, int ld,
+                                 int maxlen, void* stream) {
+  VptAttnArgs a;
+  a.qkvr = qkvr; a.kmem = kmem; a.vmem = vmem; a.memvalid = memvalid; a.b_nd = b_nd; a.out = (vpt_bf16*)out;
+  a.B = B; a.t = t; a.heads = heads; a.hid = hid; a.ld = ld; a.maxlen = maxlen; a.causal = 1;
+  CHECK_LAUNCH(vpt_attn_launch(&a, (hipStream_t)stream), "vpt_masked_attention_forward");
+}
+
+int vpt_kv_memory_update(const float* qkvr, const float* kmem, const float* vmem, float* kout, float* vout,
+                         int B, int t, int hid, int ld, int maxlen, void* stream) {
+  VptKvUpdateArgs a;
+  a.qkvr = qkvr; a.kmem = kmem; a.vmem = vmem; a.kout = kout; a.vout = vout;
+  a.B = B; a.t = t; a.hid = hid; a.ld = ld; a.maxlen = maxlen;
+  CHECK_LAUNCH(vpt_kv_update_launch(&a, (hipStream_t)stream), "vpt_kv_memory_update");
+}
+
+int vpt_log_softmax_forward(const float* logits, float* out, int M, int ld, int col0, int n, float temperature,
+                            void* stream) {
+  VptLogSoftmaxArgs a;
+  a.logits = logits; a.out = out; a.M = M; a.ld = ld; a.col0 = col0; a.n = n; a.temperature = temperature;
+  CHECK_LAUNCH(vpt_logsoftmax_launch(&a, (hipStream_t)stream), "vpt_log_softmax_forward");
+}
+
+}  // extern "C"

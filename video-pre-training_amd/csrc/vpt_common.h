@@ -1,0 +1,71 @@
+// Shared device helpers for the VPT hot-path kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define VPT_NORM_EPS 1e-5f
+
+// ---- bf16 <-> f32 -------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  f32x2 v = {lo, hi};
+  bf16x2 b = __builtin_convertvector(v, bf16x2);  // v_cvt_pk_bf16_f32 (RNE)
+  return __builtin_bit_cast(uint32_t, b);
+}
+__device__ __forceinline__ float bf16_lo_to_f32(uint32_t packed) { return __builtin_bit_cast(float, packed << 16); }
+__device__ __forceinline__ float bf16_hi_to_f32(uint32_t packed) { return __builtin_bit_cast(float, packed & 0xffff0000u); }
+
+// 8 bf16 (one 16-byte chunk) -> 8 floats
+__device__ __forceinline__ void unpack8(const u32x4& c, float* f) {
+  f[0] = bf16_lo_to_f32(c.x); f[1] = bf16_hi_to_f32(c.x);
+  f[2] = bf16_lo_to_f32(c.y); f[3] = bf16_hi_to_f32(c.y);
+  f[4] = bf16_lo_to_f32(c.z); f[5] = bf16_hi_to_f32(c.z);
+  f[6] = bf16_lo_to_f32(c.w); f[7] = bf16_hi_to_f32(c.w);
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+  u32x4 c;
+  c.x = pack_bf16x2(f[0], f[1]); c.y = pack_bf16x2(f[2], f[3]);
+  c.z = pack_bf16x2(f[4], f[5]); c.w = pack_bf16x2(f[6], f[7]);
+  return c;
+}
+
+// ---- wave / block reductions ----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// per-frame statistics -> (mean, rstd).  stats[2f] = sum, stats[2f+1] = sum of squares (double)
+__device__ __forceinline__ void frame_mean_rstd(const double* __restrict__ stats, int f, double inv_count,
+                                                float& mean, float& rstd) {
+  double s = stats[2 * f], ss = stats[2 * f + 1];
+  double m = s * inv_count;
+  double var = ss * inv_count - m * m;
+  if (var < 0.0) var = 0.0;
+  mean = (float)m;
+  rstd = (float)(1.0 / sqrt(var + (double)VPT_NORM_EPS));
+}
+
+// XCD-aware bijective remap of a 1-D grid: the dispatcher places block b on XCD b%8; give every XCD a
+// contiguous range of logical tiles so neighbouring tiles (shared halos / weights) share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, k = bid >> 3;
+  const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + k;
+}

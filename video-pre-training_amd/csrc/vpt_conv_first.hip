@@ -1,0 +1,164 @@
+// Stack-0 first convolution fused with the uint8 ingest, bias, ReLU and the 3x3/stride-2 max-pool (gfx950).
+//
+// Replaces: ImgPreprocessing.forward (x/255, lib/policy.py:39-45), the NHWC->NCHW permute of
+// ImpalaCNN.forward (lib/impala_cnn.py:190), CnnDownStack.firstconv of stack 0 (Conv2d(3->C, 3x3, pad 1,
+// bias) + ReLU, lib/impala_cnn.py:86-97 with lib/util.py:64-65) and F.max_pool2d(k3,s2,p1)
+// (lib/impala_cnn.py:117).  The 128x128xC pre-pool activation (4 MB/frame at 2x) never reaches HBM.
+//
+// Formulation: K = 27 (+2 bias slots) padded to 32 -> two MFMA 32x32x16 k-steps with SWAPPED operands:
+// the weights are the MFMA A operand (rows = output channels, resident in registers for the whole
+// workgroup), the pixels are the B operand (built on the fly from the uint8 tile in LDS; 0..255 are exact
+// in bf16, the 1/255 is applied in fp32 afterwards).  With the swap each lane ends up holding 4 consecutive
+// output channels of one pixel, so the conv tile is written to LDS with packed 8-byte stores, and the
+// pool is a packed unsigned-16-bit max over bf16 bit patterns (all values are >= 0 after ReLU).
+//
+// One workgroup = 8x8 pooled pixels (17x17 conv pixels, 19x19 input pixels) x 128 output channels.
+#include "vpt_common.h"
+#include "vpt_kernels.h"
+
+#define CT_RS 272
+#define CT_BYTES (289 * CT_RS)  // 78608
+#define IN_OFF CT_BYTES
+#define IN_BYTES 1088
+
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t u8_to_bf16_bits(uint32_t b) {
+  return __builtin_bit_cast(uint32_t, (float)b) >> 16;  // exact: 0..255 fit the 8-bit significand
+}
+
+__global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[CT_BYTES + IN_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int PH = a.H >> 1, PW = a.W >> 1;
+  const int tilesX = PW >> 3, tilesY = PH >> 3;
+  int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = L % a.NT; L /= a.NT;
+  const int tx = L % tilesX; L /= tilesX;
+  const int ty = L % tilesY;
+  const int f = L / tilesY;
+  const int py0 = ty * 8, px0 = tx * 8;
+  const int iy0 = 2 * py0 - 2, ix0 = 2 * px0 - 2;
+
+  // ---- uint8 input tile 19 x 19 x 3 (zero outside the image) ----
+  unsigned char* in = smem + IN_OFF;
+  const uint8_t* img = a.img + (size_t)f * a.H * a.W * 3;
+  for (int idx = tid; idx < 19 * 57; idx += 256) {
+    const int r = idx / 57, rem = idx - r * 57;
+    const int y = iy0 + r, x = ix0 + rem / 3;
+    unsigned char v = 0;
+    if (y >= 0 && y < a.H && x >= 0 && x < a.W) v = img[((long)y * a.W + ix0) * 3 + rem];
+    in[idx] = v;
+  }
+  // ---- weight fragments: [nt][cs][ks][lane][8] ----
+  bf16x8 wfr[4][2];
+#pragma unroll
+  for (int cs = 0; cs < 4; ++cs)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      wfr[cs][ks] = *((const bf16x8*)a.wfrag + ((nt * 4 + cs) * 2 + ks) * 64 + lane);
+  __syncthreads();
+
+  for (int sub = w; sub < 10; sub += 4) {
+    const int p = sub * 32 + l31;
+    const bool pv = p < 289;
+    const int pc = pv ? p : 288;
+    const int cr = pc / 17, cc = pc - cr * 17;
+    const int gy = 2 * py0 - 1 + cr, gx = 2 * px0 - 1 + cc;
+    const bool inimg = pv && gy >= 0 && gx >= 0 && gy < a.H && gx < a.W;
+    const unsigned char* ib = in + (cr * 19 + cc) * 3;
+
+    bf16x8 pf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint32_t h[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int kA = ks * 16 + e, kB = ks * 16 + 8 + e;     // k for lanes 0-31 / 32-63
+        const int offA = kA + 48 * (kA / 9);                   // byte offset of tap (k/9, (k%9)/3), channel k%3
+        const int offB = (kB < 27) ? (kB + 48 * (kB / 9)) : 0;
+        const uint32_t byte = ib[hi ? offB : offA];
+        uint32_t bits = u8_to_bf16_bits(byte);
+        if (kB >= 27) {                                        // bias slots (k = 27, 28) carry 1.0, the rest 0
+          const uint32_t special = (kB <= 28) ? 0x3F80u : 0u;
+          bits = hi ? special : bits;
+        }
+        h[e] = bits;
+      }
+      u32x4 pk = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+      pf[ks] = __builtin_bit_cast(bf16x8, pk);
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int cs = 0; cs < 4; ++cs) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[cs][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) acc[cs] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[cs][ks], pf[ks], acc[cs], 0, 0, 0);
+    }
+    const float scale = inimg ? (1.0f / 255.0f) : 0.f;
+    if (pv) {
+      unsigned char* dst = smem + p * CT_RS + hi * 8;
+#pragma unroll
+      for (int cs = 0; cs < 4; ++cs) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float v0 = fmaxf(acc[cs][4 * g + 0], 0.f) * scale, v1 = fmaxf(acc[cs][4 * g + 1], 0.f) * scale;
+          const float v2 = fmaxf(acc[cs][4 * g + 2], 0.f) * scale, v3 = fmaxf(acc[cs][4 * g + 3], 0.f) * scale;
+          u32x2 pk = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+          *(u32x2*)(dst + (cs * 32 + g * 8) * 2) = pk;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 3x3 / stride 2 max-pool over the conv tile, store + statistics ----
+  float s_sum = 0.f, s_sq = 0.f;
+  const int CB_out = a.Cout >> 5;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int item = tid + 256 * it;
+    const int oct4 = item & 3, pxl = (item >> 2) & 7, pyl = (item >> 5) & 7, cbl = item >> 8;
+    const int cg = nt * 128 + cbl * 32 + oct4 * 8;
+    const unsigned char* src = smem + ((2 * pyl) * 17 + 2 * pxl) * CT_RS + (cbl * 32 + oct4 * 8) * 2;
+    u16x8 m = *(const u16x8*)src;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        if (dy == 0 && dx == 0) continue;
+        const u16x8 v = *(const u16x8*)(src + (dy * 17 + dx) * CT_RS);
+        m = __builtin_elementwise_max(m, v);
+      }
+    if (cg < a.Cout) {
+      const u32x4 mv = __builtin_bit_cast(u32x4, m);
+      float vals[8];
+      unpack8(mv, vals);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        s_sum += vals[k];
+        s_sq = fmaf(vals[k], vals[k], s_sq);
+      }
+      const size_t off = ((size_t)(f * CB_out + (cg >> 5)) * PH * PW + (size_t)((py0 + pyl) * PW + px0 + pxl)) * 32 + (cg & 31);
+      *(u32x4*)(a.y + off) = mv;
+    }
+  }
+  if (a.stats_out) {
+    s_sum = wave_sum(s_sum);
+    s_sq = wave_sum(s_sq);
+    if (lane == 0) {
+      atomicAdd(a.stats_out + 2 * f, (double)s_sum);
+      atomicAdd(a.stats_out + 2 * f + 1, (double)s_sq);
+    }
+  }
+}
+
+extern "C" int vpt_conv_first_launch(const VptConvFirstArgs* a, hipStream_t stream) {
+  if ((a->H & 15) || (a->W & 15) || (a->Cout & 31) || a->frames <= 0) return -1;
+  const long grid = (long)a->frames * (a->H >> 4) * (a->W >> 4) * a->NT;
+  if (grid > 0x7fffffffL) return -2;
+  hipLaunchKernelGGL(vpt_conv_first_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *a);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}

@@ -1,0 +1,123 @@
+// HBM-bound helpers of the IMPALA CNN on the channel-blocked bf16 layout [frame][C/32][H][W][32] (gfx950).
+//
+//  vpt_pool_kernel   : F.max_pool2d(x, 3, stride 2, pad 1)  (lib/impala_cnn.py:117) for stacks 1..2, whose
+//                      input is post-ReLU (>= 0), so the -inf padding can be 0 and the max is taken on the
+//                      bf16 bit patterns as packed unsigned 16-bit integers.  Emits sum / sum-of-squares of
+//                      the pooled frame for the following GroupNorm `n`.
+//  vpt_affine_kernel : y = (x - mean_f) * rstd_f * gain + bias with whole-frame statistics, i.e.
+//                      CnnDownStack.n = GroupNorm(1, C) (lib/impala_cnn.py:99-100,118-119; per-channel gain)
+//                      and ImpalaCNN.dense's LayerNorm over the flattened C*H*W vector (lib/impala_cnn.py:177-184,
+//                      lib/util.py:61-62; per-element gain, permuted host-side into the blocked order).
+//                      Emits the statistics of y for the next GroupNorm.
+// Every lane moves 16 bytes (8 bf16) per access; grids are sized to the data (one item per thread).
+#include "vpt_common.h"
+#include "vpt_kernels.h"
+
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void vpt_pool_kernel(VptPoolArgs a) {
+  const int PH = a.H >> 1, PW = a.W >> 1;
+  const int per_frame = a.CB * PH * PW * 4;  // 16-byte items
+  const int blocks_per_frame = (per_frame + 255) >> 8;
+  const int f = blockIdx.x / blocks_per_frame;
+  const int item = (blockIdx.x - f * blocks_per_frame) * 256 + threadIdx.x;
+  float s_sum = 0.f, s_sq = 0.f;
+  if (item < per_frame) {
+    const int oct = item & 3;
+    int r = item >> 2;
+    const int px = r % PW; r /= PW;
+    const int py = r % PH;
+    const int cb = r / PH;
+    const vpt_bf16* plane = a.x + ((size_t)(f * a.CB + cb) * a.H * a.W) * 32 + oct * 8;
+    u16x8 m = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int y = 2 * py + dy;
+      if (y < 0 || y >= a.H) continue;
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int x = 2 * px + dx;
+        if (x < 0 || x >= a.W) continue;
+        const u16x8 v = *(const u16x8*)(plane + (size_t)(y * a.W + x) * 32);
+        m = __builtin_elementwise_max(m, v);
+      }
+    }
+    const u32x4 mv = __builtin_bit_cast(u32x4, m);
+    float vals[8];
+    unpack8(mv, vals);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      s_sum += vals[k];
+      s_sq = fmaf(vals[k], vals[k], s_sq);
+    }
+    *(u32x4*)(a.y + ((size_t)(f * a.CB + cb) * PH * PW + (size_t)(py * PW + px)) * 32 + oct * 8) = mv;
+  }
+  if (a.stats_out) {
+    s_sum = wave_sum(s_sum);
+    s_sq = wave_sum(s_sq);
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(a.stats_out + 2 * f, (double)s_sum);
+      atomicAdd(a.stats_out + 2 * f + 1, (double)s_sq);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void vpt_affine_kernel(VptAffineArgs a) {
+  const int per_frame = a.CB * a.HW * 4;  // 16-byte items
+  const int blocks_per_frame = (per_frame + 255) >> 8;
+  const int f = blockIdx.x / blocks_per_frame;
+  const int item = (blockIdx.x - f * blocks_per_frame) * 256 + threadIdx.x;
+  float mean, rstd;
+  frame_mean_rstd(a.stats_in, f, a.inv_count, mean, rstd);
+  float s_sum = 0.f, s_sq = 0.f;
+  if (item < per_frame) {
+    const size_t off = (size_t)f * per_frame * 8 + (size_t)item * 8;
+    const u32x4 xv = *(const u32x4*)(a.x + off);
+    float v[8];
+    unpack8(xv, v);
+    int gidx;
+    if (a.per_element) {
+      gidx = item * 8;
+    } else {
+      const int cb = item / (a.HW * 4);
+      gidx = cb * 32 + (item & 3) * 8;
+    }
+    const f32x4 g0 = *(const f32x4*)(a.gain + gidx), g1 = *(const f32x4*)(a.gain + gidx + 4);
+    const f32x4 b0 = *(const f32x4*)(a.bias + gidx), b1 = *(const f32x4*)(a.bias + gidx + 4);
+    const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      v[k] = fmaf((v[k] - mean) * rstd, g[k], b[k]);
+      s_sum += v[k];
+      s_sq = fmaf(v[k], v[k], s_sq);
+    }
+    *(u32x4*)(a.y + off) = pack8(v);
+  }
+  if (a.stats_out) {
+    s_sum = wave_sum(s_sum);
+    s_sq = wave_sum(s_sq);
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(a.stats_out + 2 * f, (double)s_sum);
+      atomicAdd(a.stats_out + 2 * f + 1, (double)s_sq);
+    }
+  }
+}
+
+extern "C" int vpt_pool_launch(const VptPoolArgs* a, hipStream_t stream) {
+  if ((a->H & 1) || (a->W & 1) || a->frames <= 0) return -1;
+  const int per_frame = a->CB * (a->H >> 1) * (a->W >> 1) * 4;
+  const long grid = (long)a->frames * ((per_frame + 255) >> 8);
+  if (grid > 0x7fffffffL) return -2;
+  hipLaunchKernelGGL(vpt_pool_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *a);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+extern "C" int vpt_affine_launch(const VptAffineArgs* a, hipStream_t stream) {
+  if (a->frames <= 0) return -1;
+  const int per_frame = a->CB * a->HW * 4;
+  const long grid = (long)a->frames * ((per_frame + 255) >> 8);
+  if (grid > 0x7fffffffL) return -2;
+  hipLaunchKernelGGL(vpt_affine_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *a);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}

@@ -1,0 +1,143 @@
+// bf16 MFMA GEMM for every dense layer on the path (gfx950):  C[M,N] = A[M,K] * W[N,K]^T  (+bias, ReLU,
+// +fp32 residual), fp32 accumulate, fp32 and/or bf16 output.
+//
+// Replaces nn.Linear inside FanInInitReLULayer (lib/util.py:58-82: ImpalaCNN.dense, ImgObsProcess.linear,
+// mlp0, mlp1, lastlayer), the q/k/v/r/proj projections of SelfAttentionLayer (lib/xf.py:251-254,334-356;
+// fused into one N = 3*hid + 10*heads GEMM), and the action/value head linears (lib/action_head.py:164,
+// lib/scaled_mse_head.py:35; fused into one N = 8641+121+1 GEMM).  The preceding LayerNorm is applied by
+// vpt_layernorm_kernel, which also produces this kernel's bf16 A operand.
+//
+// Weights are pre-packed host side as [ntile][K/32][128][32] bf16 (N zero-padded to 128) so one k-step's
+// B tile is a contiguous 16 KB run.  Workgroup tile 256 x 128, k-step 64, 4 waves of 128 x 64 (4x2 MFMA
+// 32x32x16 accumulators); register-staged double-step prefetch (global loads issued before the MFMAs of
+// the current step, ds_write after the barrier); padded LDS rows (144 B / 80 B) keep ds_read_b128
+// conflict-free.  Optional split-K with fp32 atomics for the K = 65536 dense layer.
+#include "vpt_common.h"
+#include "vpt_kernels.h"
+
+#define GA_RS 144
+#define GA_BYTES (256 * GA_RS)  // 36864
+#define GB_RS 80
+#define GB_BYTES (2 * 128 * GB_RS)  // 20480
+
+__global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[GA_BYTES + GB_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  const int mtiles = (a.M + 255) >> 8, NT = (a.N + 127) >> 7;
+  int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = L % NT; L /= NT;
+  const int mt = L % mtiles;
+  const int split = L / mtiles;
+  const int m0 = mt * 256;
+  const int nsteps_total = a.K >> 6;
+  const int per = (nsteps_total + a.splitk - 1) / a.splitk;
+  const int s_begin = split * per;
+  const int s_end = min(s_begin + per, nsteps_total);
+  if (s_begin >= s_end) return;
+
+  // staging maps
+  const int arow = tid >> 3, apart = tid & 7;
+  const vpt_bf16* aptr[8];
+  bool avalid[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int grow = m0 + arow + 32 * m;
+    avalid[m] = grow < a.M;
+    aptr[m] = a.A + (size_t)(avalid[m] ? grow : 0) * a.lda + apart * 8;
+  }
+  unsigned char* ast = smem + arow * GA_RS + apart * 16;
+  const vpt_bf16* wbase = a.wpk + (size_t)nt * (a.K >> 5) * 4096 + tid * 8;
+  unsigned char* bst = smem + GA_BYTES + (tid >> 2) * GB_RS + (tid & 3) * 16;
+
+  u32x4 areg[8], breg[4];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int m = 0; m < 8; ++m) areg[m] = avalid[m] ? *(const u32x4*)(aptr[m] + (size_t)s_begin * 64) : zero4;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) breg[m] = *(const u32x4*)(wbase + (size_t)s_begin * 8192 + m * 2048);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) *(u32x4*)(ast + m * 32 * GA_RS) = areg[m];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) *(u32x4*)(bst + m * 64 * GB_RS) = breg[m];
+  __syncthreads();
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  const unsigned char* aL = smem + (wm * 128 + l31) * GA_RS + hi * 16;
+  const unsigned char* bL = smem + GA_BYTES + (wn * 64 + l31) * GB_RS + hi * 16;
+
+  for (int s = s_begin; s < s_end; ++s) {
+    const bool more = (s + 1 < s_end);
+    if (more) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) areg[m] = avalid[m] ? *(const u32x4*)(aptr[m] + (size_t)(s + 1) * 64) : zero4;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) breg[m] = *(const u32x4*)(wbase + (size_t)(s + 1) * 8192 + m * 2048);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 af[4], bf[2];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) af[m] = *(const bf16x8*)(aL + m * (32 * GA_RS) + kk * 32);
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        bf[n] = *(const bf16x8*)(bL + (kk >> 1) * (128 * GB_RS) + n * (32 * GB_RS) + (kk & 1) * 32);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) *(u32x4*)(ast + m * 32 * GA_RS) = areg[m];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) *(u32x4*)(bst + m * 64 * GB_RS) = breg[m];
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue (direct from the accumulator layout: lane = column, 16 rows) ----
+#pragma unroll
+  for (int n2 = 0; n2 < 2; ++n2) {
+    const int col = nt * 128 + wn * 64 + n2 * 32 + l31;
+    if (col >= a.N) continue;
+    const float bv = (a.bias && split == 0) ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 128 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (row >= a.M) continue;
+        float v = acc[m][n2][r] + bv;
+        if (a.atomic_out) {
+          atomicAdd(a.out_f32 + (size_t)row * a.ldc + col, v);
+        } else {
+          if (a.relu) v = fmaxf(v, 0.f);
+          if (a.res) v += a.res[(size_t)row * a.ldr + col];
+          if (a.out_f32) a.out_f32[(size_t)row * a.ldc + col] = v;
+          if (a.out_bf16) a.out_bf16[(size_t)row * a.ldcb + col] = (vpt_bf16)v;
+        }
+      }
+    }
+  }
+}
+
+extern "C" int vpt_gemm_launch(const VptGemmArgs* a, hipStream_t stream) {
+  if (a->M <= 0 || a->N <= 0 || (a->K & 63) || a->splitk < 1 || (a->lda & 7)) return -1;
+  if (a->splitk > 1 && (!a->atomic_out || a->relu || a->res || a->out_bf16)) return -1;
+  const long grid = (long)((a->M + 255) >> 8) * ((a->N + 127) >> 7) * a->splitk;
+  if (grid > 0x7fffffffL) return -2;
+  hipLaunchKernelGGL(vpt_gemm_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *a);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}

@@ -1,0 +1,104 @@
+// Internal kernel argument blocks + launcher prototypes (one launcher per .hip file).
+// The public C ABI lives in include/vpt_hip.h and is implemented in vpt_capi.hip on top of these.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 vpt_bf16;
+
+struct VptConv3x3Args {
+  const vpt_bf16* x;       // [F][Cin/32][H][W][32]
+  const vpt_bf16* wpk;     // [NT][Cin/32][9][128][32], GroupNorm gain folded
+  const float* edge_sa;    // [9][CoutPad]
+  const float* edge_sg;    // [9][CoutPad]
+  const double* stats_in;  // [F][2]  sum / sumsq of x
+  const vpt_bf16* res;     // optional residual, same layout as y
+  vpt_bf16* y;             // [F][Cout/32][H][W][32]
+  double* stats_out;       // optional [F][2], accumulated (caller zeroes)
+  int frames, H, W, Cin, Cout, CoutPad, NT;
+  double inv_count_in;     // 1 / (Cin*H*W)
+};
+
+struct VptConvFirstArgs {
+  const uint8_t* img;      // [F][H][W][3]
+  const vpt_bf16* wfrag;   // [NT][4][2][64][8]  MFMA A-operand fragments (bias folded in k=27,28)
+  vpt_bf16* y;             // pooled output [F][Cout/32][H/2][W/2][32]
+  double* stats_out;       // [F][2]
+  int frames, H, W, Cout, NT;
+};
+
+struct VptPoolArgs {
+  const vpt_bf16* x;       // [F][CB][H][W][32]  (non-negative values: post-ReLU)
+  vpt_bf16* y;             // [F][CB][H/2][W/2][32]
+  double* stats_out;       // [F][2]
+  int frames, CB, H, W;
+};
+
+struct VptAffineArgs {     // y = (x - mean_f) * rstd_f * g[idx] + b[idx]
+  const vpt_bf16* x;
+  vpt_bf16* y;
+  const float* gain;       // per channel [C] (per_element=0) or per position [C*H*W] in blocked order (=1)
+  const float* bias;
+  const double* stats_in;  // [F][2]
+  double* stats_out;       // optional [F][2]
+  int frames, CB, HW, per_element;
+  double inv_count;
+};
+
+struct VptGemmArgs {
+  const vpt_bf16* A;       // [M][lda] bf16 row-major
+  const vpt_bf16* wpk;     // [NT][K/32][128][32]
+  const float* bias;       // [N] or null
+  const float* res;        // [M][ldr] fp32 or null
+  float* out_f32;          // [M][ldc] or null
+  vpt_bf16* out_bf16;      // [M][ldcb] or null
+  int M, N, K, lda, ldr, ldc, ldcb;
+  int relu, splitk, atomic_out;
+};
+
+struct VptLayerNormArgs {
+  const float* x;          // [M][D]
+  const float* gain;
+  const float* bias;
+  float* out_f32;          // optional [M][D]
+  vpt_bf16* out_bf16;      // optional [M][D]
+  int M, D, relu_in;
+};
+
+struct VptAttnArgs {
+  const float* qkvr;       // [B*t][ld]: Q | K | V | R(10 per head, head-major)
+  const float* kmem;       // [B][maxlen][hid]
+  const float* vmem;
+  const uint8_t* memvalid; // [B][maxlen]  state_mask & !first
+  const float* b_nd;       // [10][maxlen]
+  vpt_bf16* out;           // [B*t][hid]
+  int B, t, heads, hid, ld, maxlen, causal;
+};
+
+struct VptKvUpdateArgs {
+  const float* qkvr;       // new K at col hid, V at col 2*hid
+  const float* kmem;
+  const float* vmem;
+  float* kout;
+  float* vout;
+  int B, t, hid, ld, maxlen;
+};
+
+struct VptLogSoftmaxArgs {
+  const float* logits;     // [M][ld]
+  float* out;              // [M][n]
+  int M, ld, col0, n;
+  float temperature;
+};
+
+extern "C" {
+int vpt_conv3x3_launch(const VptConv3x3Args* a, hipStream_t s);
+int vpt_conv_first_launch(const VptConvFirstArgs* a, hipStream_t s);
+int vpt_pool_launch(const VptPoolArgs* a, hipStream_t s);
+int vpt_affine_launch(const VptAffineArgs* a, hipStream_t s);
+int vpt_gemm_launch(const VptGemmArgs* a, hipStream_t s);
+int vpt_layernorm_launch(const VptLayerNormArgs* a, hipStream_t s);
+int vpt_attn_launch(const VptAttnArgs* a, hipStream_t s);
+int vpt_kv_update_launch(const VptKvUpdateArgs* a, hipStream_t s);
+int vpt_logsoftmax_launch(const VptLogSoftmaxArgs* a, hipStream_t s);
+}

@@ -1,0 +1,279 @@
+// Non-GEMM pieces of the recurrent transformer trunk and the heads (gfx950), all fp32 arithmetic:
+//
+//  vpt_layernorm_kernel : nn.LayerNorm over the last dim (pre_r_ln lib/util.py:169,195; the norm of
+//                         FanInInitReLULayer lib/util.py:61-62,78-79; final_ln lib/policy.py:188,214), optional
+//                         ReLU on the input (F.relu at lib/policy.py:211), fp32 and/or bf16 output (the bf16
+//                         copy is the next GEMM's A operand).  One wavefront per row, two-pass variance.
+//  vpt_attn_kernel      : attention() (lib/xf.py:18-71) for the "clipped_causal" MaskedAttention
+//                         (lib/masked_attention.py:38-41,75-83): per (sequence, head, 32-query tile) the band of
+//                         31+maxlen keys drawn from [KV memory ; this chunk], logits q.k/d_head (muP scale,
+//                         lib/xf.py:59) + relative-position bias R.b_nd (lib/xf.py:265-271, lib/util.py:232-267)
+//                         + visibility (state_mask & !first for memory keys), fp32 softmax, P.V.  The
+//                         [B*h, t, t+maxlen] bias / logit / weight tensors of the reference are never formed.
+//  vpt_kv_update_kernel : SelfAttentionLayer.update_state (lib/xf.py:366-391): next memory = last `maxlen`
+//                         rows of [memory ; new K/V], kept un-split in fp32 as the reference's state.
+//  vpt_logsoftmax_kernel: CategoricalActionHead.forward (lib/action_head.py:170-174): logits / temperature,
+//                         fp32 log_softmax over one head's column range; wavefront reductions.
+#include "vpt_common.h"
+#include "vpt_kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vpt_layernorm_kernel(VptLayerNormArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.M) return;
+  const float* x = a.x + (size_t)row * a.D;
+  const int n4 = a.D >> 2;
+  float s = 0.f;
+  for (int i = lane; i < n4; i += 64) {
+    f32x4 v = *(const f32x4*)(x + 4 * i);
+    if (a.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    s += (v.x + v.y) + (v.z + v.w);
+  }
+  const float mean = wave_sum(s) / (float)a.D;
+  float ss = 0.f;
+  for (int i = lane; i < n4; i += 64) {
+    f32x4 v = *(const f32x4*)(x + 4 * i);
+    if (a.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+    ss += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)a.D + VPT_NORM_EPS);
+  for (int i = lane; i < n4; i += 64) {
+    f32x4 v = *(const f32x4*)(x + 4 * i);
+    if (a.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    const f32x4 g = *(const f32x4*)(a.gain + 4 * i), b = *(const f32x4*)(a.bias + 4 * i);
+    f32x4 y;
+    y.x = fmaf((v.x - mean) * rstd, g.x, b.x);
+    y.y = fmaf((v.y - mean) * rstd, g.y, b.y);
+    y.z = fmaf((v.z - mean) * rstd, g.z, b.z);
+    y.w = fmaf((v.w - mean) * rstd, g.w, b.w);
+    if (a.out_f32) *(f32x4*)(a.out_f32 + (size_t)row * a.D + 4 * i) = y;
+    if (a.out_bf16) {
+      u32x2 p = {pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w)};
+      *(u32x2*)(a.out_bf16 + (size_t)row * a.D + 4 * i) = p;
+    }
+  }
+}
+
+extern "C" int vpt_layernorm_launch(const VptLayerNormArgs* a, hipStream_t stream) {
+  if (a->M <= 0 || (a->D & 3)) return -1;
+  hipLaunchKernelGGL(vpt_layernorm_kernel, dim3((a->M + 3) >> 2), dim3(256), 0, stream, *a);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// ------------------------------------------------------------------------------------------------
+#define ATT_DH 128
+#define ATT_QT 32
+#define ATT_NK 160                      // keys staged per query tile (31 + maxlen, maxlen <= 129)
+#define ATT_RS (ATT_DH + 4)             // padded fp32 row
+#define ATT_SS 161                      // padded score row
+#define ATT_Q_OFF 0
+#define ATT_KV_OFF (ATT_QT * ATT_RS)                      // floats
+#define ATT_S_OFF (ATT_KV_OFF + ATT_NK * ATT_RS)
+#define ATT_R_OFF (ATT_S_OFF + ATT_QT * ATT_SS)
+#define ATT_B_OFF (ATT_R_OFF + ATT_QT * 10)
+#define ATT_SC_OFF (ATT_B_OFF + 10 * 129)
+#define ATT_FLOATS (ATT_SC_OFF + ATT_QT)
+
+__global__ __launch_bounds__(256) void vpt_attn_kernel(VptAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Qs = sm + ATT_Q_OFF;
+  float* KVs = sm + ATT_KV_OFF;
+  float* Ss = sm + ATT_S_OFF;
+  float* Rs = sm + ATT_R_OFF;
+  float* Bs = sm + ATT_B_OFF;
+  float* Sc = sm + ATT_SC_OFF;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int b = blockIdx.y / a.heads, h = blockIdx.y - b * a.heads;
+  const int q0 = blockIdx.x * ATT_QT;
+  const int maxlen = a.maxlen, t = a.t, hid = a.hid;
+  const size_t tok0 = (size_t)b * t;
+
+  // ---- stage Q tile, K slab, R rows, b_nd ----
+  for (int idx = tid; idx < ATT_QT * (ATT_DH / 4); idx += 256) {
+    const int r = idx >> 5, c4 = idx & 31;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (q0 + r < t) v = *(const f32x4*)(a.qkvr + (tok0 + q0 + r) * a.ld + h * ATT_DH + c4 * 4);
+    *(f32x4*)(Qs + r * ATT_RS + c4 * 4) = v;
+  }
+  for (int idx = tid; idx < ATT_NK * (ATT_DH / 4); idx += 256) {
+    const int kk = idx >> 5, c4 = idx & 31;
+    const int j = q0 + 1 + kk;  // index into [memory ; chunk]
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (j < maxlen) v = *(const f32x4*)(a.kmem + ((size_t)b * maxlen + j) * hid + h * ATT_DH + c4 * 4);
+    else if (j - maxlen < t) v = *(const f32x4*)(a.qkvr + (tok0 + j - maxlen) * a.ld + hid + h * ATT_DH + c4 * 4);
+    *(f32x4*)(KVs + kk * ATT_RS + c4 * 4) = v;
+  }
+  for (int idx = tid; idx < ATT_QT * 10; idx += 256) {
+    const int r = idx / 10, n = idx - r * 10;
+    Rs[idx] = (q0 + r < t) ? a.qkvr[(tok0 + q0 + r) * a.ld + 3 * hid + h * 10 + n] : 0.f;
+  }
+  for (int idx = tid; idx < 10 * maxlen; idx += 256) Bs[idx] = a.b_nd[idx];
+  __syncthreads();
+
+  // ---- logits: thread = (query qi, key group kg); keys kg + 8*n ----
+  {
+    const int qi = tid & 31, kg = tid >> 5;
+    const float* qrow = Qs + qi * ATT_RS;
+    float rq[10];
+#pragma unroll
+    for (int n = 0; n < 10; ++n) rq[n] = Rs[qi * 10 + n];
+    const bool qvalid = (q0 + qi) < t;
+    for (int nb = 0; nb < 5; ++nb) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      const float* k0 = KVs + (kg + 8 * (4 * nb + 0)) * ATT_RS;
+      const float* k1 = KVs + (kg + 8 * (4 * nb + 1)) * ATT_RS;
+      const float* k2 = KVs + (kg + 8 * (4 * nb + 2)) * ATT_RS;
+      const float* k3 = KVs + (kg + 8 * (4 * nb + 3)) * ATT_RS;
+#pragma unroll 8
+      for (int d = 0; d < ATT_DH; d += 4) {
+        const f32x4 q = *(const f32x4*)(qrow + d);
+        const f32x4 x0 = *(const f32x4*)(k0 + d), x1 = *(const f32x4*)(k1 + d);
+        const f32x4 x2 = *(const f32x4*)(k2 + d), x3 = *(const f32x4*)(k3 + d);
+        acc[0] = fmaf(q.x, x0.x, fmaf(q.y, x0.y, fmaf(q.z, x0.z, fmaf(q.w, x0.w, acc[0]))));
+        acc[1] = fmaf(q.x, x1.x, fmaf(q.y, x1.y, fmaf(q.z, x1.z, fmaf(q.w, x1.w, acc[1]))));
+        acc[2] = fmaf(q.x, x2.x, fmaf(q.y, x2.y, fmaf(q.z, x2.z, fmaf(q.w, x2.w, acc[2]))));
+        acc[3] = fmaf(q.x, x3.x, fmaf(q.y, x3.y, fmaf(q.z, x3.z, fmaf(q.w, x3.w, acc[3]))));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kk = kg + 8 * (4 * nb + u);
+        const int off = maxlen - 1 + qi - kk;  // 0 = the query itself, maxlen-1 = oldest key in the band
+        const int j = q0 + 1 + kk;
+        bool vis = qvalid && off >= 0 && off < maxlen;
+        if (vis && a.causal && j < maxlen) vis = a.memvalid[(size_t)b * maxlen + j] != 0;
+        float s = -3.0e38f;
+        if (vis) {
+          float rb = 0.f;
+#pragma unroll
+          for (int n = 0; n < 10; ++n) rb = fmaf(rq[n], Bs[n * maxlen + off], rb);
+          s = acc[u] * (1.0f / ATT_DH) + rb;
+        }
+        Ss[qi * ATT_SS + kk] = s;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- softmax rows (8 per wave); stage V into the slab meanwhile ----
+  for (int r = w * 8; r < w * 8 + 8; ++r) {
+    float* srow = Ss + r * ATT_SS;
+    const float s0 = srow[lane], s1 = srow[lane + 64], s2 = (lane + 128 < ATT_NK) ? srow[lane + 128] : -3.0e38f;
+    const float m = wave_max(fmaxf(s0, fmaxf(s1, s2)));
+    const float e0 = (s0 > -1.0e38f) ? expf(s0 - m) : 0.f;
+    const float e1 = (s1 > -1.0e38f) ? expf(s1 - m) : 0.f;
+    const float e2 = (s2 > -1.0e38f) ? expf(s2 - m) : 0.f;
+    const float tot = wave_sum(e0 + e1 + e2);
+    srow[lane] = e0;
+    srow[lane + 64] = e1;
+    if (lane + 128 < ATT_NK) srow[lane + 128] = e2;
+    if (lane == 0) Sc[r] = (tot > 0.f) ? 1.0f / tot : 0.f;
+  }
+  for (int idx = tid; idx < ATT_NK * (ATT_DH / 4); idx += 256) {
+    const int kk = idx >> 5, c4 = idx & 31;
+    const int j = q0 + 1 + kk;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (j < maxlen) v = *(const f32x4*)(a.vmem + ((size_t)b * maxlen + j) * hid + h * ATT_DH + c4 * 4);
+    else if (j - maxlen < t) v = *(const f32x4*)(a.qkvr + (tok0 + j - maxlen) * a.ld + 2 * hid + h * ATT_DH + c4 * 4);
+    *(f32x4*)(KVs + kk * ATT_RS + c4 * 4) = v;
+  }
+  __syncthreads();
+
+  // ---- out = P V : thread = (query qi, 16-wide slice of d_head) ----
+  {
+    const int qi = tid & 31, dg = tid >> 5;
+    float o[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = 0.f;
+    const float* prow = Ss + qi * ATT_SS;
+    const float* vcol = KVs + dg * 16;
+    for (int kk = 0; kk < ATT_NK; ++kk) {
+      const float p = prow[kk];
+      const f32x4 v0 = *(const f32x4*)(vcol + kk * ATT_RS), v1 = *(const f32x4*)(vcol + kk * ATT_RS + 4);
+      const f32x4 v2 = *(const f32x4*)(vcol + kk * ATT_RS + 8), v3 = *(const f32x4*)(vcol + kk * ATT_RS + 12);
+      o[0] = fmaf(p, v0.x, o[0]); o[1] = fmaf(p, v0.y, o[1]); o[2] = fmaf(p, v0.z, o[2]); o[3] = fmaf(p, v0.w, o[3]);
+      o[4] = fmaf(p, v1.x, o[4]); o[5] = fmaf(p, v1.y, o[5]); o[6] = fmaf(p, v1.z, o[6]); o[7] = fmaf(p, v1.w, o[7]);
+      o[8] = fmaf(p, v2.x, o[8]); o[9] = fmaf(p, v2.y, o[9]); o[10] = fmaf(p, v2.z, o[10]); o[11] = fmaf(p, v2.w, o[11]);
+      o[12] = fmaf(p, v3.x, o[12]); o[13] = fmaf(p, v3.y, o[13]); o[14] = fmaf(p, v3.z, o[14]); o[15] = fmaf(p, v3.w, o[15]);
+    }
+    if (q0 + qi < t) {
+      const float sc = Sc[qi];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[i] *= sc;
+      vpt_bf16* dst = a.out + (tok0 + q0 + qi) * hid + h * ATT_DH + dg * 16;
+      *(u32x4*)dst = pack8(o);
+      *(u32x4*)(dst + 8) = pack8(o + 8);
+    }
+  }
+}
+
+extern "C" int vpt_attn_launch(const VptAttnArgs* a, hipStream_t stream) {
+  if (a->hid != a->heads * ATT_DH || a->maxlen < 1 || a->maxlen > 129 || !a->causal) return -1;
+  static bool attr_set = false;
+  const size_t lds = ATT_FLOATS * sizeof(float);
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)vpt_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -4;
+    attr_set = true;
+  }
+  dim3 grid((a->t + ATT_QT - 1) / ATT_QT, a->B * a->heads);
+  hipLaunchKernelGGL(vpt_attn_kernel, grid, dim3(256), lds, stream, *a);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vpt_kv_update_kernel(VptKvUpdateArgs a) {
+  const int which = blockIdx.y;  // 0 = K, 1 = V
+  const size_t n4 = (size_t)a.B * a.maxlen * (a.hid >> 2);
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n4) return;
+  const int h4 = a.hid >> 2;
+  const int c4 = (int)(idx % h4);
+  const size_t rs = idx / h4;
+  const int s = (int)(rs % a.maxlen);
+  const int b = (int)(rs / a.maxlen);
+  const int src = s + a.t;  // row of [memory ; new]
+  const float* mem = which ? a.vmem : a.kmem;
+  float* out = which ? a.vout : a.kout;
+  f32x4 v;
+  if (src < a.maxlen) v = *(const f32x4*)(mem + ((size_t)b * a.maxlen + src) * a.hid + c4 * 4);
+  else v = *(const f32x4*)(a.qkvr + ((size_t)b * a.t + (src - a.maxlen)) * a.ld + (which ? 2 : 1) * a.hid + c4 * 4);
+  *(f32x4*)(out + ((size_t)b * a.maxlen + s) * a.hid + c4 * 4) = v;
+}
+
+extern "C" int vpt_kv_update_launch(const VptKvUpdateArgs* a, hipStream_t stream) {
+  if (a->B <= 0 || (a->hid & 3)) return -1;
+  const size_t n4 = (size_t)a->B * a->maxlen * (a->hid >> 2);
+  dim3 grid((unsigned)((n4 + 255) / 256), 2);
+  hipLaunchKernelGGL(vpt_kv_update_kernel, grid, dim3(256), 0, stream, *a);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vpt_logsoftmax_kernel(VptLogSoftmaxArgs a) {
+  __shared__ float red[8];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float* z = a.logits + (size_t)row * a.ld + a.col0;
+  const float T = a.temperature;
+  float m = -3.0e38f;
+  for (int i = tid; i < a.n; i += 256) m = fmaxf(m, z[i] / T);
+  m = wave_max(m);
+  if (lane == 0) red[w] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float s = 0.f;
+  for (int i = tid; i < a.n; i += 256) s += expf(z[i] / T - m);
+  s = wave_sum(s);
+  if (lane == 0) red[4 + w] = s;
+  __syncthreads();
+  const float lse = m + logf((red[4] + red[5]) + (red[6] + red[7]));
+  float* o = a.out + (size_t)row * a.n;
+  for (int i = tid; i < a.n; i += 256) o[i] = z[i] / T - lse;
+}
+
+extern "C" int vpt_logsoftmax_launch(const VptLogSoftmaxArgs* a, hipStream_t stream) {
+  if (a->M <= 0 || a->n <= 0) return -1;
+  hipLaunchKernelGGL(vpt_logsoftmax_kernel, dim3(a->M), dim3(256), 0, stream, *a);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}

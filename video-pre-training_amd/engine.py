@@ -1,0 +1,217 @@
+"""Forward engine of the VPT policy on MI355X: packs the reference's fp32 weights once, then drives the
+HIP kernels (ops.py -> libvpt_hip.so) in the order of MinecraftPolicy.forward (lib/policy.py:193-218).
+
+Data flow for N = B*T frames (all device resident; activations bf16 channel-blocked, residual stream and
+KV memory fp32):
+
+  uint8 frames --conv_first--> P0 --affine(n)--> x --[conv3x3, conv3x3+res] x2--> stack0
+               --conv3x3--> --maxpool--> --affine(n)--> ... stack1, stack2
+               --affine(per-element LN)--> --linear(split-K 65536->256)--> --layernorm(relu)--> --linear(->hid, relu)
+  4 x [ layernorm -> linear(QKVR) -> masked_attention (+kv_memory_update) -> linear(proj,+res)
+        -> layernorm -> linear(mlp0, relu) -> linear(mlp1,+res) ]
+  layernorm(relu in) -> linear(lastlayer, relu) -> layernorm(final) -> linear(heads) -> log_softmax x2
+"""
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops, packing
+
+
+def config_from_policy_kwargs(policy_kwargs: dict, pi_head_kwargs: Optional[dict] = None) -> dict:
+    """The numbers the engine needs, from the reference's ctor kwargs (lib/policy.py:99-190, agent.py:16-38)."""
+    pk = policy_kwargs
+    width = pk.get("impala_width", 1)
+    chans = [int(width * c) for c in pk.get("impala_chans", (16, 32, 32))]
+    cfg = dict(
+        chans=chans,
+        hidsize=pk.get("hidsize", 512),
+        heads=pk.get("attention_heads", 8),
+        n_layers=pk.get("n_recurrence_layers", 1),
+        maxlen=pk.get("attention_memory_size", 2048) - (pk.get("timesteps") or 0),
+        causal=pk.get("attention_mask_style", "clipped_causal") == "clipped_causal",
+        pointwise_ratio=pk.get("pointwise_ratio", 4),
+        use_pre_lstm_ln=pk.get("use_pre_lstm_ln", True),
+        temperature=float((pi_head_kwargs or {}).get("temperature", 1.0)),
+        img_shape=list(pk.get("img_shape") or [128, 128, 3]),
+    )
+    return cfg
+
+
+def check_supported(cfg: dict):
+    """Fail loudly for configurations the HIP path does not implement yet."""
+    h, w, c = cfg["img_shape"]
+    if (h, w, c) != (128, 128, 3):
+        raise NotImplementedError(f"HIP path supports 128x128x3 frames only, got {cfg['img_shape']}")
+    if any(ch % 32 for ch in cfg["chans"]):
+        raise NotImplementedError(f"IMPALA widths must be multiples of 32, got {cfg['chans']}")
+    if cfg["hidsize"] != cfg["heads"] * 128:
+        raise NotImplementedError("attention kernel is built for d_head = 128")
+    if not cfg["causal"] or not (1 <= cfg["maxlen"] <= 129):
+        raise NotImplementedError("only the clipped_causal mask with 1 <= maxlen <= 129 is implemented")
+    if cfg["use_pre_lstm_ln"]:
+        raise NotImplementedError("use_pre_lstm_ln=True is not used by any released transformer model")
+    if cfg["hidsize"] % 256:
+        raise NotImplementedError("hidsize must be a multiple of 256")
+
+
+class PolicyEngine:
+    def __init__(self, cfg: dict, n_buttons: int, n_camera: int, cnn_chunk: int = 1024):
+        check_supported(cfg)
+        self.cfg = cfg
+        self.n_buttons, self.n_camera = n_buttons, n_camera
+        self.cnn_chunk = cnn_chunk
+        self.w: Dict[str, torch.Tensor] = {}
+        self.packed = False
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def pack(self, sd: Dict[str, torch.Tensor]):
+        """Re-pack the fp32 state_dict (reference key names) for the kernels."""
+        cfg, w = self.cfg, {}
+        f32 = lambda t: t.detach().float().contiguous()
+        cin = 3
+        for s, c in enumerate(cfg["chans"]):
+            p = f"net.img_process.cnn.stacks.{s}."
+            if s == 0:
+                w[p + "firstconv"] = packing.pack_conv_first(f32(sd[p + "firstconv.layer.weight"]), f32(sd[p + "firstconv.layer.bias"]))
+            else:
+                w[p + "firstconv"] = packing.pack_conv3x3(f32(sd[p + "firstconv.layer.weight"]),
+                                                          f32(sd[p + "firstconv.norm.weight"]), f32(sd[p + "firstconv.norm.bias"]))
+            w[p + "n.g"], w[p + "n.b"] = f32(sd[p + "n.weight"]), f32(sd[p + "n.bias"])
+            for b in range(2):
+                for cv in range(2):
+                    q = f"{p}blocks.{b}.conv{cv}"
+                    w[q] = packing.pack_conv3x3(f32(sd[q + ".layer.weight"]), f32(sd[q + ".norm.weight"]), f32(sd[q + ".norm.bias"]))
+            cin = c
+        c2 = cfg["chans"][-1]
+        p = "net.img_process.cnn.dense."
+        w[p + "g"] = packing.chw_to_blocked_vector(f32(sd[p + "norm.weight"]), c2, 16, 16)
+        w[p + "b"] = packing.chw_to_blocked_vector(f32(sd[p + "norm.bias"]), c2, 16, 16)
+        w[p + "w"] = packing.pack_linear(packing.chw_to_blocked_columns(f32(sd[p + "layer.weight"]), c2, 16, 16))
+        p = "net.img_process.linear."
+        w[p + "g"], w[p + "b"] = f32(sd[p + "norm.weight"]), f32(sd[p + "norm.bias"])
+        w[p + "w"] = packing.pack_linear(f32(sd[p + "layer.weight"]))
+        hid = cfg["hidsize"]
+        for l in range(cfg["n_layers"]):
+            p = f"net.recurrent_layer.blocks.{l}."
+            o = p + "r.orc_block."
+            w[p + "ln1.g"], w[p + "ln1.b"] = f32(sd[p + "pre_r_ln.weight"]), f32(sd[p + "pre_r_ln.bias"])
+            wq = torch.cat([f32(sd[o + "q_layer.weight"]), f32(sd[o + "k_layer.weight"]),
+                            f32(sd[o + "v_layer.weight"]), f32(sd[o + "r_layer.weight"])], dim=0)
+            nr = sd[o + "r_layer.weight"].shape[0]
+            bq = torch.cat([f32(sd[o + "q_layer.bias"]), torch.zeros(2 * hid, device=wq.device), f32(sd[o + "r_layer.bias"])])
+            w[p + "qkvr.w"], w[p + "qkvr.b"] = packing.pack_linear(wq), bq.contiguous()
+            w[p + "b_nd"] = f32(sd[o + "b_nd"])
+            w[p + "proj.w"], w[p + "proj.b"] = packing.pack_linear(f32(sd[o + "proj_layer.weight"])), f32(sd[o + "proj_layer.bias"])
+            w[p + "ln2.g"], w[p + "ln2.b"] = f32(sd[p + "mlp0.norm.weight"]), f32(sd[p + "mlp0.norm.bias"])
+            w[p + "mlp0.w"] = packing.pack_linear(f32(sd[p + "mlp0.layer.weight"]))
+            w[p + "mlp1.w"], w[p + "mlp1.b"] = packing.pack_linear(f32(sd[p + "mlp1.layer.weight"])), f32(sd[p + "mlp1.layer.bias"])
+            self.n_qkvr = 3 * hid + nr
+        w["last.g"], w["last.b"] = f32(sd["net.lastlayer.norm.weight"]), f32(sd["net.lastlayer.norm.bias"])
+        w["last.w"] = packing.pack_linear(f32(sd["net.lastlayer.layer.weight"]))
+        w["final.g"], w["final.b"] = f32(sd["net.final_ln.weight"]), f32(sd["net.final_ln.bias"])
+        wh = torch.cat([f32(sd["pi_head.buttons.linear_layer.weight"]), f32(sd["pi_head.camera.linear_layer.weight"]),
+                        f32(sd["value_head.linear.weight"])], dim=0)
+        bh = torch.cat([f32(sd["pi_head.buttons.linear_layer.bias"]), f32(sd["pi_head.camera.linear_layer.bias"]),
+                        f32(sd["value_head.linear.bias"])])
+        w["heads.w"], w["heads.b"] = packing.pack_linear(wh), bh.contiguous()
+        self.w = w
+        self.packed = True
+
+    # ------------------------------------------------------------------------------------------
+    def _cnn_chunk(self, img: torch.Tensor) -> torch.Tensor:
+        """img uint8 [F,128,128,3] -> blocked bf16 [F, C2/32, 16, 16, 32] normalised for the dense layer,
+        i.e. everything of ImpalaCNN.forward up to (and including) dense.norm."""
+        cfg, w = self.cfg, self.w
+        f = img.shape[0]
+        st = torch.zeros(24, f, 2, dtype=torch.float64, device=img.device)
+        si = 0
+
+        def nxt():
+            nonlocal si
+            si += 1
+            return st[si - 1]
+
+        x, s_x = None, None
+        for s, c in enumerate(cfg["chans"]):
+            p = f"net.img_process.cnn.stacks.{s}."
+            s_pool = nxt()
+            if s == 0:
+                pooled = ops.conv_first(img, w[p + "firstconv"], c, stats_out=s_pool)
+            else:
+                wpk, sa, sg = w[p + "firstconv"]
+                pre = ops.conv3x3(x, wpk, sa, sg, s_x, c)
+                pooled = ops.maxpool(pre, stats_out=s_pool)
+                del pre
+            s_x = nxt()
+            x = ops.frame_affine(pooled, w[p + "n.g"], w[p + "n.b"], s_pool, stats_out=s_x, out=pooled)
+            for b in range(2):
+                wpk, sa, sg = w[f"{p}blocks.{b}.conv0"]
+                s_y = nxt()
+                y = ops.conv3x3(x, wpk, sa, sg, s_x, c, stats_out=s_y)
+                wpk, sa, sg = w[f"{p}blocks.{b}.conv1"]
+                s_n = nxt()
+                x = ops.conv3x3(y, wpk, sa, sg, s_y, c, res=x, stats_out=s_n)
+                s_x = s_n
+                del y
+        p = "net.img_process.cnn.dense."
+        return ops.frame_affine(x, w[p + "g"], w[p + "b"], s_x, per_element=True)
+
+    def _img_process(self, frames: torch.Tensor) -> torch.Tensor:
+        """uint8 [N,128,128,3] -> fp32 [N,hid]  (ImgObsProcess.forward, lib/policy.py:79-80)."""
+        cfg, w = self.cfg, self.w
+        n = frames.shape[0]
+        outs = []
+        for i in range(0, n, self.cnn_chunk):
+            xn = self._cnn_chunk(frames[i:i + self.cnn_chunk])
+            flat = xn.view(xn.shape[0], -1)
+            d32, _ = ops.linear(flat, w["net.img_process.cnn.dense.w"], 256, splitk=16)
+            outs.append(d32)
+            del xn, flat
+        d = outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+        p = "net.img_process.linear."
+        _, dn = ops.layernorm(d, w[p + "g"], w[p + "b"], relu_in=True)
+        x, _ = ops.linear(dn, w[p + "w"], cfg["hidsize"], relu=True)
+        return x
+
+    @torch.no_grad()
+    def forward(self, img_u8: torch.Tensor, first: torch.Tensor, state_in: List):
+        if not self.packed:
+            raise RuntimeError("PolicyEngine.pack(state_dict) must be called before forward")
+        cfg, w = self.cfg, self.w
+        bsz, t = img_u8.shape[:2]
+        hid, heads, maxlen = cfg["hidsize"], cfg["heads"], cfg["maxlen"]
+        frames = img_u8.reshape(bsz * t, *img_u8.shape[2:]).contiguous()
+        x = self._img_process(frames)
+
+        not_first = ~first[:, 0].reshape(bsz, 1, 1)
+        state_out = []
+        for l in range(cfg["n_layers"]):
+            p = f"net.recurrent_layer.blocks.{l}."
+            state_mask, (kmem, vmem) = state_in[l]
+            if state_mask is None:
+                state_mask = torch.zeros(bsz, 1, maxlen, dtype=torch.bool, device=x.device)
+            memvalid = (state_mask & not_first).reshape(bsz, maxlen).to(torch.uint8).contiguous()
+            x1, x1b = ops.layernorm(x, w[p + "ln1.g"], w[p + "ln1.b"], out_f32=True)
+            qkvr, _ = ops.linear(x1b, w[p + "qkvr.w"], self.n_qkvr, bias=w[p + "qkvr.b"])
+            att = ops.masked_attention(qkvr, kmem.contiguous(), vmem.contiguous(), memvalid, w[p + "b_nd"], bsz, t, heads, hid)
+            kout, vout = ops.kv_memory_update(qkvr, kmem.contiguous(), vmem.contiguous(), bsz, t, hid)
+            x2, _ = ops.linear(att, w[p + "proj.w"], hid, bias=w[p + "proj.b"], res=x1)
+            _, hb = ops.layernorm(x2, w[p + "ln2.g"], w[p + "ln2.b"])
+            _, h2 = ops.linear(hb, w[p + "mlp0.w"], hid * cfg["pointwise_ratio"], relu=True, out_f32=False, out_bf16=True)
+            x, _ = ops.linear(h2, w[p + "mlp1.w"], hid, bias=w[p + "mlp1.b"], res=x2)
+            new_mask = torch.cat([state_mask[:, :, t:] & not_first,
+                                  torch.ones(bsz, 1, min(t, maxlen), dtype=torch.bool, device=x.device)], dim=-1)
+            state_out.append((new_mask, (kout, vout)))
+
+        _, xb = ops.layernorm(x, w["last.g"], w["last.b"], relu_in=True)
+        y, _ = ops.linear(xb, w["last.w"], hid, relu=True)
+        latent, lb = ops.layernorm(y, w["final.g"], w["final.b"], out_f32=True)
+        nb, nc = self.n_buttons, self.n_camera
+        logits, _ = ops.linear(lb, w["heads.w"], nb + nc + 1, bias=w["heads.b"])
+        temp = cfg["temperature"]
+        buttons = ops.log_softmax_cols(logits, 0, nb, temp).view(bsz, t, 1, nb)
+        camera = ops.log_softmax_cols(logits, nb, nc, temp).view(bsz, t, 1, nc)
+        vpred = logits[:, nb + nc:nb + nc + 1].reshape(bsz, t, 1).clone()
+        return dict(buttons=buttons, camera=camera, vpred=vpred, latent=latent.view(bsz, t, hid), state_out=state_out)

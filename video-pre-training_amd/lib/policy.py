@@ -1,0 +1,246 @@
+"""MinecraftAgentPolicy on MI355X: the reference's policy API (lib/policy.py:227-339) over the HIP engine.
+
+Drop-in surface: same constructor arguments, `nn.Module` protocol, `state_dict()` key names
+and shapes (so `.weights` files load with `load_state_dict(..., strict=False)` exactly as agent.py:134 does),
+`initial_state`, `forward`, `act`, `get_output_for_observation`, `get_logprob_of_action`,
+`get_kl_of_action_dists`, `v`.  The parameter tree below mirrors the reference's module tree only as a
+*container* (fp32 masters); all arithmetic of `forward` runs in libvpt_hip.so through engine.PolicyEngine.
+There is no CPU path: tensors must live on the GPU and the native library must be present.
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from ..engine import PolicyEngine, config_from_policy_kwargs
+from .action_head import make_action_head
+from .tree_util import tree_map
+
+
+class _Node(nn.Module):
+    """Bare container; children and parameters are attached by name so state_dict keys match the reference."""
+
+
+def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor, requires_grad: bool = True):
+    parts = dotted.split(".")
+    mod = root
+    for name in parts[:-1]:
+        if name not in mod._modules:
+            mod.add_module(name, _Node())
+        mod = mod._modules[name]
+    mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=requires_grad))
+
+
+def _fan_in_(w: torch.Tensor, scale: float):
+    """FanInInitReLULayer init: each output unit's weight vector gets L2 norm `scale` (lib/util.py:67-70)."""
+    flat = w.view(w.shape[0], -1)
+    flat.mul_(scale / flat.norm(dim=1, p=2, keepdim=True))
+    return w
+
+
+class _ImgPreprocess(_Node):
+    pass
+
+
+class MinecraftPolicy(nn.Module):
+    """Parameter container with the key names of lib/policy.py:83-224 (transformer recurrence only)."""
+
+    def __init__(self, recurrence_type="lstm", impala_width=1, impala_chans=(16, 32, 32), hidsize=512,
+                 img_shape=None, init_norm_kwargs=None, impala_kwargs=None, attention_mask_style="clipped_causal",
+                 attention_heads=8, attention_memory_size=2048, pointwise_ratio=4, n_recurrence_layers=1,
+                 timesteps=None, use_pre_lstm_ln=True, first_conv_norm=False, **unused_kwargs):
+        super().__init__()
+        if recurrence_type != "transformer":
+            raise NotImplementedError("only recurrence_type='transformer' (every released VPT model) is implemented")
+        init_norm_kwargs = init_norm_kwargs or {}
+        if init_norm_kwargs.get("group_norm_groups", None) != 1 or init_norm_kwargs.get("batch_norm", False):
+            raise NotImplementedError("only init_norm_kwargs={'group_norm_groups': 1} (every released model) is implemented")
+        if (impala_kwargs or {}).get("post_pool_groups", None) != 1:
+            raise NotImplementedError("only impala_kwargs={'post_pool_groups': 1} is implemented")
+        if first_conv_norm:
+            raise NotImplementedError("first_conv_norm=True (IDM) is not implemented yet")
+        self.hidsize = hidsize
+        chans = [int(impala_width * c) for c in impala_chans]
+        maxlen = attention_memory_size - timesteps
+        nblk_scale = math.sqrt(math.sqrt(len(chans)) / math.sqrt(2))  # lib/impala_cnn.py:33,106,169
+        cin = 3
+        for s, c in enumerate(chans):
+            p = f"img_process.cnn.stacks.{s}."
+            if s > 0:
+                _attach(self, p + "firstconv.norm.weight", torch.ones(cin))
+                _attach(self, p + "firstconv.norm.bias", torch.zeros(cin))
+            _attach(self, p + "firstconv.layer.weight", _fan_in_(torch.randn(c, cin, 3, 3), 1.0))
+            if s == 0:
+                _attach(self, p + "firstconv.layer.bias", torch.zeros(c))
+            _attach(self, p + "n.weight", torch.ones(c))
+            _attach(self, p + "n.bias", torch.zeros(c))
+            for b in range(2):
+                for cv in range(2):
+                    q = f"{p}blocks.{b}.conv{cv}."
+                    _attach(self, q + "norm.weight", torch.ones(c))
+                    _attach(self, q + "norm.bias", torch.zeros(c))
+                    _attach(self, q + "layer.weight", _fan_in_(torch.randn(c, c, 3, 3), nblk_scale))
+            cin = c
+        flat = chans[-1] * 16 * 16
+        _attach(self, "img_process.cnn.dense.norm.weight", torch.ones(flat))
+        _attach(self, "img_process.cnn.dense.norm.bias", torch.zeros(flat))
+        _attach(self, "img_process.cnn.dense.layer.weight", _fan_in_(torch.randn(256, flat), 1.4))
+        _attach(self, "img_process.linear.norm.weight", torch.ones(256))
+        _attach(self, "img_process.linear.norm.bias", torch.zeros(256))
+        _attach(self, "img_process.linear.layer.weight", _fan_in_(torch.randn(hidsize, 256), 1.0))
+        if use_pre_lstm_ln:
+            _attach(self, "pre_lstm_ln.weight", torch.ones(hidsize))
+            _attach(self, "pre_lstm_ln.bias", torch.zeros(hidsize))
+        s_blk = (n_recurrence_layers ** -0.5) * (2 ** -0.5)  # lib/util.py:107,150-151
+        for l in range(n_recurrence_layers):
+            p = f"recurrent_layer.blocks.{l}."
+            _attach(self, p + "mlp0.norm.weight", torch.ones(hidsize))
+            _attach(self, p + "mlp0.norm.bias", torch.zeros(hidsize))
+            _attach(self, p + "mlp0.layer.weight", _fan_in_(torch.randn(hidsize * pointwise_ratio, hidsize), 1.0))
+            _attach(self, p + "mlp1.layer.weight", _fan_in_(torch.randn(hidsize, hidsize * pointwise_ratio), s_blk))
+            _attach(self, p + "mlp1.layer.bias", torch.zeros(hidsize))
+            _attach(self, p + "pre_r_ln.weight", torch.ones(hidsize))
+            _attach(self, p + "pre_r_ln.bias", torch.zeros(hidsize))
+            o = p + "r.orc_block."
+            sq = math.sqrt(s_blk)  # lib/xf.py:247-254
+            _attach(self, o + "b_nd", torch.randn(10, maxlen) * 0.2)
+            _attach(self, o + "q_layer.weight", _fan_in_(torch.randn(hidsize, hidsize), 0.1))
+            _attach(self, o + "q_layer.bias", torch.zeros(hidsize))
+            _attach(self, o + "k_layer.weight", _fan_in_(torch.randn(hidsize, hidsize), 0.2))
+            _attach(self, o + "v_layer.weight", _fan_in_(torch.randn(hidsize, hidsize), sq))
+            _attach(self, o + "proj_layer.weight", _fan_in_(torch.randn(hidsize, hidsize), sq))
+            _attach(self, o + "proj_layer.bias", torch.zeros(hidsize))
+            _attach(self, o + "r_layer.weight", _fan_in_(torch.randn(10 * attention_heads, hidsize), 0.1))
+            _attach(self, o + "r_layer.bias", torch.zeros(10 * attention_heads))
+        _attach(self, "lastlayer.norm.weight", torch.ones(hidsize))
+        _attach(self, "lastlayer.norm.bias", torch.zeros(hidsize))
+        _attach(self, "lastlayer.layer.weight", _fan_in_(torch.randn(hidsize, hidsize), 1.0))
+        _attach(self, "final_ln.weight", torch.ones(hidsize))
+        _attach(self, "final_ln.bias", torch.zeros(hidsize))
+
+    def output_latent_size(self):
+        return self.hidsize
+
+
+class NormalizeEwma(nn.Module):
+    """Buffers and denormalisation of lib/normalize_ewma.py:8-31,57-60 (parameters with requires_grad=False)."""
+
+    def __init__(self, input_shape, epsilon=1e-5):
+        super().__init__()
+        self.epsilon = epsilon
+        self.running_mean = nn.Parameter(torch.zeros(input_shape, dtype=torch.float), requires_grad=False)
+        self.running_mean_sq = nn.Parameter(torch.zeros(input_shape, dtype=torch.float), requires_grad=False)
+        self.debiasing_term = nn.Parameter(torch.tensor(0.0, dtype=torch.float), requires_grad=False)
+
+    def running_mean_var(self):
+        deb = self.debiasing_term.clamp(min=self.epsilon)
+        mean = self.running_mean / deb
+        mean_sq = self.running_mean_sq / deb
+        return mean, (mean_sq - mean ** 2).clamp(min=1e-2)
+
+    def denormalize(self, x):
+        mean, var = self.running_mean_var()
+        return x * torch.sqrt(var)[(None,) * 2] + mean[(None,) * 2]
+
+
+class ScaledMSEHead(nn.Module):
+    """lib/scaled_mse_head.py:11-50: the Linear(hid -> 1) lives in the fused heads GEMM."""
+
+    def __init__(self, input_size: int, output_size: int):
+        super().__init__()
+        self.linear = nn.Linear(input_size, output_size)
+        self.normalizer = NormalizeEwma(output_size)
+
+    def denormalize(self, x):
+        return self.normalizer.denormalize(x)
+
+
+class MinecraftAgentPolicy(nn.Module):
+    def __init__(self, action_space, policy_kwargs, pi_head_kwargs):
+        super().__init__()
+        self.net = MinecraftPolicy(**policy_kwargs)
+        self.action_space = action_space
+        self.value_head = ScaledMSEHead(self.net.output_latent_size(), 1)
+        self.pi_head = make_action_head(self.action_space, self.net.output_latent_size(), **pi_head_kwargs)
+        self._cfg = config_from_policy_kwargs(policy_kwargs, pi_head_kwargs)
+        self._engine = PolicyEngine(self._cfg, n_buttons=action_space["buttons"].eltype.n,
+                                    n_camera=action_space["camera"].eltype.n)
+        self._packed_key = None
+
+    # ---- engine plumbing --------------------------------------------------------------------
+    def _device(self):
+        return next(self.parameters()).device
+
+    def _ensure_packed(self):
+        params = dict(self.named_parameters())
+        key = (str(self._device()),) + tuple((p.data_ptr(), p._version) for p in params.values())
+        if key != self._packed_key:
+            if self._device().type != "cuda":
+                raise RuntimeError("MinecraftAgentPolicy (HIP) needs its parameters on the GPU: call .to('cuda')")
+            self._engine.pack(params)
+            self._packed_key = key
+
+    def initial_state(self, batch_size: int):
+        """List (one entry per block) of (None, (K, V)) zeros fp32 [B, maxlen, hid] (lib/masked_attention.py:153-159)."""
+        dev = self._device()
+        z = lambda: torch.zeros(batch_size, self._cfg["maxlen"], self._cfg["hidsize"], dtype=torch.float32, device=dev)
+        return [(None, (z(), z())) for _ in range(self._cfg["n_layers"])]
+
+    # ---- the reference API ---------------------------------------------------------------------
+    def forward(self, obs, first: torch.Tensor, state_in):
+        if isinstance(obs, dict):
+            obs = obs.copy()
+            mask = obs.pop("mask", None)
+        else:
+            mask = None
+        if mask is not None:
+            raise NotImplementedError("logit masking (obs['mask']) is not implemented on the HIP path")
+        assert len(state_in) == self._cfg["n_layers"], (
+            f"Length of state {len(state_in)} did not match length of blocks {self._cfg['n_layers']}")
+        self._ensure_packed()
+        img = obs["img"]
+        if img.dtype != torch.uint8:
+            raise TypeError("obs['img'] must be uint8 [B,T,128,128,3] (the /255 is fused into the first conv)")
+        out = self._engine.forward(img, first, state_in)
+        pi_logits = {"camera": out["camera"], "buttons": out["buttons"]}
+        return (pi_logits, out["vpred"], None), out["state_out"]
+
+    def get_logprob_of_action(self, pd, action):
+        ac = tree_map(lambda x: x.unsqueeze(1), action)
+        log_prob = self.pi_head.logprob(ac, pd)
+        assert not torch.isnan(log_prob).any()
+        return log_prob[:, 0]
+
+    def get_kl_of_action_dists(self, pd1, pd2):
+        return self.pi_head.kl_divergence(pd1, pd2)
+
+    def get_output_for_observation(self, obs, state_in, first):
+        obs = tree_map(lambda x: x.unsqueeze(1), obs)
+        first = first.unsqueeze(1)
+        (pd, vpred, _), state_out = self(obs=obs, first=first, state_in=state_in)
+        return pd, self.value_head.denormalize(vpred)[:, 0], state_out
+
+    @torch.no_grad()
+    def act(self, obs, first, state_in, stochastic: bool = True, taken_action=None, return_pd=False):
+        obs = tree_map(lambda x: x.unsqueeze(1), obs)
+        first = first.unsqueeze(1)
+        (pd, vpred, _), state_out = self(obs=obs, first=first, state_in=state_in)
+        if taken_action is None:
+            ac = self.pi_head.sample(pd, deterministic=not stochastic)
+        else:
+            ac = tree_map(lambda x: x.unsqueeze(1), taken_action)
+        log_prob = self.pi_head.logprob(ac, pd)
+        assert not torch.isnan(log_prob).any()
+        result = {"log_prob": log_prob[:, 0], "vpred": self.value_head.denormalize(vpred)[:, 0]}
+        if return_pd:
+            result["pd"] = tree_map(lambda x: x[:, 0], pd)
+        ac = tree_map(lambda x: x[:, 0], ac)
+        return ac, state_out, result
+
+    @torch.no_grad()
+    def v(self, obs, first, state_in):
+        obs = tree_map(lambda x: x.unsqueeze(1), obs)
+        first = first.unsqueeze(1)
+        (pd, vpred, _), state_out = self(obs=obs, first=first, state_in=state_in)
+        return self.value_head.denormalize(vpred)[:, 0]

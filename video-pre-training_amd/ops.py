@@ -1,0 +1,118 @@
+"""Torch-tensor front ends of the C-ABI entry points (one function per symbol of include/vpt_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; all arithmetic happens in
+libvpt_hip.so.  Every function requires CUDA(HIP) tensors and raises if the native library is absent.
+"""
+import ctypes
+
+import torch
+
+from . import _native
+from ._native import ptr
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+
+
+def conv_first(img_u8, wfrag, cout, stats_out=None):
+    """img_u8 [F,H,W,3] uint8 -> pooled blocked bf16 [F, cout/32, H/2, W/2, 32]."""
+    _chk(img_u8, torch.uint8, "img"); _chk(wfrag, torch.bfloat16, "wfrag"); _chk(stats_out, torch.float64, "stats_out")
+    f, h, w, _ = img_u8.shape
+    y = torch.empty(f, cout // 32, h // 2, w // 2, 32, dtype=torch.bfloat16, device=img_u8.device)
+    _native.call("vpt_conv_first_forward", ptr(img_u8), ptr(wfrag), ptr(y), ptr(stats_out), f, h, w, cout, _stream())
+    return y
+
+
+def conv3x3(x, wpk, edge_sa, edge_sg, stats_in, cout, res=None, stats_out=None, out=None):
+    """x blocked bf16 [F,Cin/32,H,W,32] -> blocked bf16 [F,cout/32,H,W,32] (GN fold + ReLU [+res])."""
+    _chk(x, torch.bfloat16, "x"); _chk(wpk, torch.bfloat16, "wpk"); _chk(edge_sa, torch.float32, "edge_sa")
+    _chk(edge_sg, torch.float32, "edge_sg"); _chk(stats_in, torch.float64, "stats_in")
+    _chk(res, torch.bfloat16, "res"); _chk(stats_out, torch.float64, "stats_out")
+    f, cb, h, w, _ = x.shape
+    if out is None:
+        out = torch.empty(f, cout // 32, h, w, 32, dtype=torch.bfloat16, device=x.device)
+    _native.call("vpt_conv3x3_forward", ptr(x), ptr(wpk), ptr(edge_sa), ptr(edge_sg), ptr(stats_in), ptr(res),
+                 ptr(out), ptr(stats_out), f, h, w, cb * 32, cout, _stream())
+    return out
+
+
+def maxpool(x, stats_out=None):
+    _chk(x, torch.bfloat16, "x"); _chk(stats_out, torch.float64, "stats_out")
+    f, cb, h, w, _ = x.shape
+    y = torch.empty(f, cb, h // 2, w // 2, 32, dtype=torch.bfloat16, device=x.device)
+    _native.call("vpt_maxpool_forward", ptr(x), ptr(y), ptr(stats_out), f, cb * 32, h, w, _stream())
+    return y
+
+
+def frame_affine(x, gain, bias, stats_in, stats_out=None, per_element=False, out=None):
+    _chk(x, torch.bfloat16, "x"); _chk(gain, torch.float32, "gain"); _chk(bias, torch.float32, "bias")
+    _chk(stats_in, torch.float64, "stats_in"); _chk(stats_out, torch.float64, "stats_out")
+    f, cb, h, w, _ = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _native.call("vpt_frame_affine_forward", ptr(x), ptr(out), ptr(gain), ptr(bias), ptr(stats_in), ptr(stats_out),
+                 f, cb * 32, h * w, 1 if per_element else 0, _stream())
+    return out
+
+
+def linear(a_bf16, wpk, n, bias=None, res=None, relu=False, out_f32=True, out_bf16=False, splitk=1):
+    """a [M,K] bf16 (row stride = K) x packed weight -> ([M,n] fp32 or None, [M,n] bf16 or None)."""
+    _chk(a_bf16, torch.bfloat16, "A"); _chk(wpk, torch.bfloat16, "wpk"); _chk(bias, torch.float32, "bias")
+    _chk(res, torch.float32, "res")
+    m, k = a_bf16.shape
+    dev = a_bf16.device
+    o32 = None
+    if out_f32:
+        o32 = torch.zeros(m, n, dtype=torch.float32, device=dev) if splitk > 1 else torch.empty(m, n, dtype=torch.float32, device=dev)
+    o16 = torch.empty(m, n, dtype=torch.bfloat16, device=dev) if out_bf16 else None
+    _native.call("vpt_linear_forward", ptr(a_bf16), ptr(wpk), ptr(bias), ptr(res), ptr(o32), ptr(o16),
+                 m, n, k, k, n, n, n, 1 if relu else 0, splitk, _stream())
+    return o32, o16
+
+
+def layernorm(x, gain, bias, relu_in=False, out_f32=False, out_bf16=True):
+    _chk(x, torch.float32, "x"); _chk(gain, torch.float32, "gain"); _chk(bias, torch.float32, "bias")
+    m, d = x.shape
+    o32 = torch.empty_like(x) if out_f32 else None
+    o16 = torch.empty(m, d, dtype=torch.bfloat16, device=x.device) if out_bf16 else None
+    _native.call("vpt_layernorm_forward", ptr(x), ptr(gain), ptr(bias), ptr(o32), ptr(o16), m, d, 1 if relu_in else 0, _stream())
+    return o32, o16
+
+
+def masked_attention(qkvr, kmem, vmem, memvalid, b_nd, batch, t, heads, hid):
+    _chk(qkvr, torch.float32, "qkvr"); _chk(kmem, torch.float32, "kmem"); _chk(vmem, torch.float32, "vmem")
+    _chk(memvalid, torch.uint8, "memvalid"); _chk(b_nd, torch.float32, "b_nd")
+    maxlen = kmem.shape[1]
+    out = torch.empty(batch * t, hid, dtype=torch.bfloat16, device=qkvr.device)
+    _native.call("vpt_masked_attention_forward", ptr(qkvr), ptr(kmem), ptr(vmem), ptr(memvalid), ptr(b_nd), ptr(out),
+                 batch, t, heads, hid, qkvr.shape[1], maxlen, _stream())
+    return out
+
+
+def kv_memory_update(qkvr, kmem, vmem, batch, t, hid):
+    _chk(qkvr, torch.float32, "qkvr"); _chk(kmem, torch.float32, "kmem"); _chk(vmem, torch.float32, "vmem")
+    kout, vout = torch.empty_like(kmem), torch.empty_like(vmem)
+    _native.call("vpt_kv_memory_update", ptr(qkvr), ptr(kmem), ptr(vmem), ptr(kout), ptr(vout),
+                 batch, t, hid, qkvr.shape[1], kmem.shape[1], _stream())
+    return kout, vout
+
+
+def log_softmax_cols(logits, col0, n, temperature):
+    _chk(logits, torch.float32, "logits")
+    m = logits.shape[0]
+    out = torch.empty(m, n, dtype=torch.float32, device=logits.device)
+    _native.call("vpt_log_softmax_forward", ptr(logits), ptr(out), m, logits.shape[1], col0, n,
+                 ctypes.c_float(temperature), _stream())
+    return out

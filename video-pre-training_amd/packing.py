@@ -1,0 +1,94 @@
+"""Host-side weight re-packing into the layouts the gfx950 kernels stream (see DESIGN.md §Data layout).
+
+All functions take fp32 torch tensors with the reference's shapes (the `.weights` state_dict,
+SURVEY.md §8b) and return new tensors on the same device; the fp32 masters are left untouched.
+"""
+import math
+
+import torch
+
+
+def _ceil_div(a, b):
+    return (a + b - 1) // b
+
+
+def pack_conv3x3(weight, gain, bias):
+    """Conv2d weight [Cout,Cin,3,3] with the preceding GroupNorm(1,Cin) affine (gain, bias [Cin]) folded.
+
+    Returns (wpk bf16 [NT][Cin/32][9][128][32], edge_sa fp32 [9][NT*128], edge_sg fp32 [9][NT*128]).
+    wpk holds bf16(W * gain); edge_sg[e][o] = sum over the taps valid for edge class e and over Cin of that
+    rounded value; edge_sa[e][o] = same sum of W * bias (fp32).  e = 3*ey + ex with ey/ex in
+    {0: first row/col, 1: interior, 2: last row/col} (vpt_conv3x3.hip epilogue)."""
+    cout, cin = weight.shape[:2]
+    assert cin % 32 == 0 and cout % 32 == 0
+    nt = _ceil_div(cout, 128)
+    cp = nt * 128
+    wg = (weight * gain.view(1, -1, 1, 1)).to(torch.bfloat16)
+    wp = torch.zeros(cp, cin, 3, 3, dtype=torch.bfloat16, device=weight.device)
+    wp[:cout] = wg
+    wpk = wp.view(nt, 128, cin // 32, 32, 9).permute(0, 2, 4, 1, 3).contiguous()
+    sg_tap = torch.zeros(cp, 3, 3, dtype=torch.float64, device=weight.device)
+    sa_tap = torch.zeros(cp, 3, 3, dtype=torch.float64, device=weight.device)
+    sg_tap[:cout] = wg.double().sum(dim=1)
+    sa_tap[:cout] = (weight.double() * bias.double().view(1, -1, 1, 1)).sum(dim=1)
+    valid = {0: [1, 2], 1: [0, 1, 2], 2: [0, 1]}
+    sa = torch.zeros(9, cp, dtype=torch.float64, device=weight.device)
+    sg = torch.zeros(9, cp, dtype=torch.float64, device=weight.device)
+    for ey in range(3):
+        for ex in range(3):
+            khs, kws = valid[ey], valid[ex]
+            sg[ey * 3 + ex] = sg_tap[:, khs][:, :, kws].sum(dim=(1, 2))
+            sa[ey * 3 + ex] = sa_tap[:, khs][:, :, kws].sum(dim=(1, 2))
+    return wpk, sa.float().contiguous(), sg.float().contiguous()
+
+
+def pack_conv_first(weight, bias):
+    """Stack-0 firstconv weight [Cout,3,3,3] + bias [Cout] -> MFMA A-operand fragments
+    bf16 [NT][4][2][64][8] (vpt_conv_first.hip).  k = (kh*3+kw)*3 + ch for k < 27; k = 27 / 28 carry the
+    hi / lo bf16 halves of 255*bias (the pixel operand holds 1.0 there; 1/255 is applied after the MFMA)."""
+    cout = weight.shape[0]
+    assert weight.shape[1:] == (3, 3, 3) and cout % 32 == 0
+    nt = _ceil_div(cout, 128)
+    cp = nt * 128
+    wk = torch.zeros(cp, 32, dtype=torch.float32, device=weight.device)
+    wk[:cout, :27] = weight.permute(0, 2, 3, 1).reshape(cout, 27)
+    b255 = bias * 255.0
+    hi = b255.to(torch.bfloat16).float()
+    lo = (b255 - hi).to(torch.bfloat16).float()
+    wk[:cout, 27] = hi
+    wk[:cout, 28] = lo
+    # [nt][cs][l31][ks][hi][e] -> [nt][cs][ks][hi][l31][e]
+    frag = wk.view(nt, 4, 32, 2, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous().view(nt, 4, 2, 64, 8)
+    return frag.to(torch.bfloat16).contiguous()
+
+
+def pack_linear(weight):
+    """nn.Linear weight [N,K] -> bf16 [ceil(N/128)][K/32][128][32] (vpt_gemm.hip B operand)."""
+    n, k = weight.shape
+    assert k % 64 == 0
+    nt = _ceil_div(n, 128)
+    wp = torch.zeros(nt * 128, k, dtype=torch.bfloat16, device=weight.device)
+    wp[:n] = weight.to(torch.bfloat16)
+    return wp.view(nt, 128, k // 32, 32).permute(0, 2, 1, 3).contiguous()
+
+
+def chw_to_blocked_columns(weight, c, h, w):
+    """Permute the K axis of a [N, c*h*w] matrix from the reference's C,H,W flatten order
+    (lib/impala_cnn.py:192-193) to the blocked activation order [c/32][h][w][32]."""
+    n = weight.shape[0]
+    return weight.view(n, c // 32, 32, h, w).permute(0, 1, 3, 4, 2).reshape(n, c * h * w).contiguous()
+
+
+def chw_to_blocked_vector(v, c, h, w):
+    return v.view(c // 32, 32, h, w).permute(0, 2, 3, 1).reshape(-1).contiguous()
+
+
+def blocked_to_nchw(x_blocked, c, h, w):
+    """bf16 [F][c/32][h][w][32] -> fp32 [F][c][h][w] (tests / debugging only)."""
+    f = x_blocked.shape[0]
+    return x_blocked.view(f, c // 32, h, w, 32).permute(0, 1, 4, 2, 3).reshape(f, c, h, w).float()
+
+
+def nchw_to_blocked(x, dtype=torch.bfloat16):
+    f, c, h, w = x.shape
+    return x.view(f, c // 32, 32, h, w).permute(0, 1, 3, 4, 2).contiguous().to(dtype)
