@@ -1,0 +1,174 @@
+"""bench.py -- VPT policy forward throughput on MI355X (BASELINE.json metric: frames/sec, 2x policy,
+128x128x3 frames, seq = 128).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path (MinecraftAgentPolicy.forward through libvpt_hip.so) over one batch
+of B x T = 64 x 128 synthetic uint8 frames that are already resident in HBM, with the KV memory carried
+from the previous step (BASELINE.json configs[1]: foundation-model-2x forward on 1 MI355X).  Forward has no
+exchange step, so N > 1 runs N data-parallel replicas on disjoint batches (weak scaling, no collective on
+the data path); rank 0 prints ONE JSON line with the whole-job frames/s.
+
+Extra objects on the line:
+  roofline     : dominant kernel (vpt_conv3x3_kernel, 72 % of the forward FLOPs): algorithmic FLOPs of all
+                 its launches in one step / their summed HIP-event durations, vs the 2.5 PFLOP/s dense bf16
+                 MFMA peak (MI355X_MICROARCH.md).  `e2e_frac` = frames/s x 15.1016 GFLOP / peak.
+  cpu_baseline : the CPU oracle (fp32 port of the reference forward; the reference itself cannot travel to
+                 the GPU box) timed on the host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+FLOP_PER_FRAME = {"1x": 3.8235e9, "2x": 15.1016e9, "3x": 33.8409e9}  # BASELINE.md §3 (t = 128; 3x at t = 256)
+MFMA_BF16_PEAK = 2.5e15
+
+
+def cpu_baseline(model: str, seconds_budget: float = 25.0):
+    """Oracle forward on the host cores: B=1, T=16 frames of the same synthetic distribution."""
+    from oracle import vpt_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    pk = O.policy_kwargs_for(model)
+    cfg = O.config_from_policy_kwargs(pk, dict(temperature=2.0))
+    sd = O.synthetic_state_dict(cfg, seed=0)
+    g = torch.Generator().manual_seed(1)
+    t = 16
+    img = torch.randint(0, 256, (1, t, 128, 128, 3), generator=g, dtype=torch.uint8)
+    first = torch.zeros(1, t, dtype=torch.bool)
+    st = O.initial_state(cfg, 1)
+    O.policy_forward(sd, cfg, img, first, st)  # warm-up
+    times = []
+    t_start = time.time()
+    while len(times) < 5 and time.time() - t_start < seconds_budget:
+        t0 = time.time()
+        O.policy_forward(sd, cfg, img, first, st)
+        times.append(time.time() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return dict(value=round(t / med, 2), unit="frames/s", cores=cores, kind="port",
+                sample=f"oracle/vpt_oracle.py fp32 forward, {model} model, B=1 T={t} synthetic frames, median of {len(times)} after 1 warm-up")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="2x")
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--seq", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import __graft_entry__ as ge
+    ge.build()
+    from vpt_amd import ops
+    from vpt_amd.lib.policy import MinecraftAgentPolicy
+    from vpt_amd.lib.types import minecraft_action_space
+    from oracle import vpt_oracle as O  # weights generator + cpu_baseline leg only
+
+    pk = O.policy_kwargs_for(args.model)
+    cfg = O.config_from_policy_kwargs(pk, dict(temperature=2.0))
+    sd = O.synthetic_state_dict(cfg, seed=0)
+    pol = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0))
+    pol.load_state_dict(sd, strict=False)
+    pol = pol.to(dev)
+    del sd
+
+    B, T = args.batch, args.seq
+    g = torch.Generator().manual_seed(1 + rank)
+    img = torch.randint(0, 256, (B, T, 128, 128, 3), generator=g, dtype=torch.uint8).to(dev)
+    first = torch.zeros(B, T, dtype=torch.bool, device=dev)
+    state = pol.initial_state(B)
+
+    def step(st):
+        (pd, vpred, _), st = pol({"img": img}, first, st)
+        return st
+
+    def barrier():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        state = step(state)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        state = step(state)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # instrumented extra step (outside the timed region): per-kernel HIP-event durations
+    roof = None
+    kernels = None
+    if rank == 0:
+        ops.TIMER.enabled = True
+        ops.TIMER.reset()
+        step(state)
+        summ = ops.TIMER.summary()
+        ops.TIMER.enabled = False
+        c = summ.get("vpt_conv3x3_forward")
+        total_ms = sum(v["ms"] for v in summ.values())
+        kernels = {k: dict(ms=round(v["ms"], 3), calls=v["calls"],
+                           tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] and v["ms"] else None)
+                   for k, v in summ.items()}
+        if c and c["ms"] > 0:
+            ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
+            roof = dict(bound="mfma", kernel="vpt_conv3x3_kernel", achieved=round(ach, 1), peak=2500.0, unit="TFLOP/s",
+                        frac=round(ach / 2500.0, 4), traffic=None, launches=c["calls"],
+                        avg_launch_ms=round(c["ms"] / c["calls"], 4),
+                        share_of_step_time=round(c["ms"] / total_ms, 3))
+
+    frames_total = world * B * T * args.steps
+    fps = frames_total / elapsed
+    if rank == 0:
+        line = {
+            "metric": "frames/sec (fwd), 2x policy, 128x128x3 seq=128",
+            "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"foundation-model-{args.model} policy forward (IMPALA CNN + 4-layer banded transformer + heads), "
+                                   f"batch={B} seq={T} uint8 128x128x3 frames per GPU, KV memory carried, random-init weights",
+                       "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world} replicas (no collective in forward)"},
+            "e2e_tflops": round(fps * FLOP_PER_FRAME.get(args.model, 0) / 1e12, 1),
+            "e2e_frac_of_mfma_peak": round(fps * FLOP_PER_FRAME.get(args.model, 0) / MFMA_BF16_PEAK, 4),
+            "roofline": roof,
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.model)
+        print(json.dumps(line))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,187 @@
+"""Per-kernel parity of the HIP path (through the C ABI) against the CPU oracle.  Needs an MI355X.
+
+Tolerances: the MFMA kernels round their operands to bf16 (fp32 accumulate), so results are compared with
+an oracle fed the SAME bf16-rounded activations; what remains is the bf16 rounding of the weights and of
+the stored outputs: 2e-2 of the tensor's max magnitude (typical observed error is ~3e-3).  fp32 kernels
+(layernorm, attention, log-softmax) are held to 1e-4..2e-3 absolute as noted per test."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import vpt_amd  # noqa: E402,F401
+from vpt_amd import ops, packing  # noqa: E402
+from oracle import vpt_oracle as O  # noqa: E402
+
+DEV = "cuda"
+
+
+def _relerr(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp(min=1e-12)).item()
+
+
+def _stats_of(x_nchw):
+    f = x_nchw.shape[0]
+    flat = x_nchw.reshape(f, -1).double()
+    return torch.stack([flat.sum(1), (flat * flat).sum(1)], dim=1).contiguous()
+
+
+@pytest.mark.parametrize("frames,h,w,cin,cout,use_res", [
+    (2, 16, 16, 128, 128, True),
+    (1, 32, 32, 64, 160, False),
+    (3, 64, 64, 128, 256, False),
+    (2, 32, 32, 256, 256, True),
+])
+def test_conv3x3(frames, h, w, cin, cout, use_res):
+    g = torch.Generator().manual_seed(1)
+    W = torch.randn(cout, cin, 3, 3, generator=g) * (1.6 / (cin * 9) ** 0.5)
+    gain = 1 + 0.2 * torch.randn(cin, generator=g)
+    bias = 0.1 * torch.randn(cin, generator=g)
+    x = (torch.relu(torch.randn(frames, cin, h, w, generator=g)) + 0.2 * torch.randn(frames, cin, h, w, generator=g))
+    xb = x.to(torch.bfloat16)
+    res = torch.randn(frames, cout, h, w, generator=g).to(torch.bfloat16) if use_res else None
+    sd = {"norm.weight": gain, "norm.bias": bias, "layer.weight": W}
+    ref = O._norm_conv_relu(sd, "", xb.float())
+    if use_res:
+        ref = ref + res.float()
+    wpk, sa, sg = packing.pack_conv3x3(W.to(DEV), gain.to(DEV), bias.to(DEV))
+    st_in = _stats_of(xb.float()).to(DEV)
+    st_out = torch.zeros(frames, 2, dtype=torch.float64, device=DEV)
+    y = ops.conv3x3(packing.nchw_to_blocked(xb.float()).to(DEV), wpk, sa, sg, st_in, cout,
+                    res=packing.nchw_to_blocked(res.float()).to(DEV) if use_res else None, stats_out=st_out)
+    torch.cuda.synchronize()
+    out = packing.blocked_to_nchw(y.cpu(), cout, h, w)
+    err = _relerr(out, ref)
+    assert err < 2e-2, f"conv3x3 rel err {err}"
+    st_ref = _stats_of(ref)
+    assert torch.allclose(st_out.cpu(), st_ref, rtol=5e-3, atol=1.0), (st_out.cpu(), st_ref)
+
+
+@pytest.mark.parametrize("frames,cout", [(2, 128), (1, 64), (1, 192)])
+def test_conv_first_pool(frames, cout):
+    g = torch.Generator().manual_seed(2)
+    W = torch.randn(cout, 3, 3, 3, generator=g) * 0.3
+    b = 0.1 * torch.randn(cout, generator=g)
+    img = torch.randint(0, 256, (frames, 128, 128, 3), generator=g, dtype=torch.uint8)
+    ref = F.max_pool2d(torch.relu(F.conv2d(img.permute(0, 3, 1, 2).float() / 255.0, W, b, padding=1)), 3, 2, 1)
+    st = torch.zeros(frames, 2, dtype=torch.float64, device=DEV)
+    y = ops.conv_first(img.to(DEV), packing.pack_conv_first(W.to(DEV), b.to(DEV)), cout, stats_out=st)
+    torch.cuda.synchronize()
+    out = packing.blocked_to_nchw(y.cpu(), cout, 64, 64)
+    err = _relerr(out, ref)
+    assert err < 1.5e-2, f"conv_first rel err {err}"
+    assert torch.allclose(st.cpu(), _stats_of(out), rtol=1e-4, atol=1e-2)
+
+
+def test_maxpool_and_affine():
+    g = torch.Generator().manual_seed(3)
+    x = torch.relu(torch.randn(2, 64, 32, 32, generator=g)).to(torch.bfloat16)
+    st = torch.zeros(2, 2, dtype=torch.float64, device=DEV)
+    y = ops.maxpool(packing.nchw_to_blocked(x.float()).to(DEV), stats_out=st)
+    torch.cuda.synchronize()
+    ref = F.max_pool2d(x.float(), 3, 2, 1)
+    out = packing.blocked_to_nchw(y.cpu(), 64, 16, 16)
+    assert torch.equal(out, ref)
+    assert torch.allclose(st.cpu(), _stats_of(ref), rtol=1e-5, atol=1e-3)
+    gain = 1 + 0.2 * torch.randn(64, generator=g)
+    bias = 0.1 * torch.randn(64, generator=g)
+    st2 = torch.zeros(2, 2, dtype=torch.float64, device=DEV)
+    z = ops.frame_affine(y, gain.to(DEV), bias.to(DEV), st, stats_out=st2)
+    torch.cuda.synchronize()
+    refz = O.group_norm_1(ref, gain, bias)
+    outz = packing.blocked_to_nchw(z.cpu(), 64, 16, 16)
+    assert _relerr(outz, refz) < 8e-3
+    assert torch.allclose(st2.cpu(), _stats_of(refz), rtol=1e-3, atol=0.5)
+    # per-element affine (the 65536-wide LayerNorm of ImpalaCNN.dense) in blocked order
+    ge = 1 + 0.2 * torch.randn(64 * 256, generator=g)
+    be = 0.1 * torch.randn(64 * 256, generator=g)
+    z2 = ops.frame_affine(y, packing.chw_to_blocked_vector(ge, 64, 16, 16).to(DEV),
+                          packing.chw_to_blocked_vector(be, 64, 16, 16).to(DEV), st, per_element=True)
+    torch.cuda.synchronize()
+    ref2 = O.layer_norm(ref.reshape(2, -1), ge, be).reshape(2, 64, 16, 16)
+    assert _relerr(packing.blocked_to_nchw(z2.cpu(), 64, 16, 16), ref2) < 8e-3
+
+
+@pytest.mark.parametrize("m,n,k,bias,relu,res,splitk", [
+    (1, 121, 256, True, False, False, 1),
+    (300, 8763, 2048, True, False, False, 1),
+    (513, 2048, 8192, True, False, True, 1),
+    (256, 4096, 1024, False, True, False, 1),
+    (40, 256, 16384, False, False, False, 16),
+])
+def test_linear(m, n, k, bias, relu, res, splitk):
+    g = torch.Generator().manual_seed(4)
+    A = torch.randn(m, k, generator=g).to(torch.bfloat16)
+    W = torch.randn(n, k, generator=g) / k ** 0.5
+    b = torch.randn(n, generator=g) if bias else None
+    r = torch.randn(m, n, generator=g) if res else None
+    ref = A.float() @ W.to(torch.bfloat16).float().t()
+    if bias:
+        ref = ref + b
+    if relu:
+        ref = torch.relu(ref)
+    if res:
+        ref = ref + r
+    o32, o16 = ops.linear(A.to(DEV), packing.pack_linear(W.to(DEV)), n, bias=b.to(DEV) if bias else None,
+                          res=r.to(DEV) if res else None, relu=relu, out_f32=True, out_bf16=(splitk == 1), splitk=splitk)
+    torch.cuda.synchronize()
+    assert _relerr(o32.cpu(), ref) < 2e-3, _relerr(o32.cpu(), ref)
+    if o16 is not None:
+        assert _relerr(o16.cpu().float(), ref) < 1e-2
+
+
+@pytest.mark.parametrize("m,d,relu_in", [(5, 256, True), (130, 2048, False), (7, 3072, False)])
+def test_layernorm(m, d, relu_in):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(m, d, generator=g) * 2 + 0.5
+    gain = 1 + 0.2 * torch.randn(d, generator=g)
+    bias = 0.1 * torch.randn(d, generator=g)
+    o32, o16 = ops.layernorm(x.to(DEV), gain.to(DEV), bias.to(DEV), relu_in=relu_in, out_f32=True, out_bf16=True)
+    torch.cuda.synchronize()
+    ref = O.layer_norm(torch.relu(x) if relu_in else x, gain, bias)
+    assert (o32.cpu() - ref).abs().max() < 1e-4
+    assert _relerr(o16.cpu().float(), ref) < 5e-3
+
+
+@pytest.mark.parametrize("bsz,t,heads,first_flags", [(2, 128, 2, [False, True]), (3, 5, 2, [False, False, True]), (2, 1, 2, [False, False]), (1, 70, 2, [False])])
+def test_masked_attention_and_kv_update(bsz, t, heads, first_flags):
+    g = torch.Generator().manual_seed(6)
+    hid, maxlen = heads * 128, 128
+    ld = 3 * hid + 10 * heads
+    qkvr = torch.randn(bsz * t, ld, generator=g)
+    qkvr[:, :hid] *= 3.0  # spread the softmax
+    kmem = torch.randn(bsz, maxlen, hid, generator=g)
+    vmem = torch.randn(bsz, maxlen, hid, generator=g)
+    state_mask = torch.rand(bsz, 1, maxlen, generator=g) > 0.3
+    first_b = torch.tensor(first_flags)
+    b_nd = 0.5 * torch.randn(10, maxlen, generator=g)
+    # oracle on the same projections
+    q = qkvr[:, :hid].reshape(bsz, t, heads, 128).permute(0, 2, 1, 3)
+    k_full = torch.cat([kmem, qkvr[:, hid:2 * hid].reshape(bsz, t, hid)], 1)
+    v_full = torch.cat([vmem, qkvr[:, 2 * hid:3 * hid].reshape(bsz, t, hid)], 1)
+    kh = k_full.reshape(bsz, -1, heads, 128).permute(0, 2, 1, 3)
+    vh = v_full.reshape(bsz, -1, heads, 128).permute(0, 2, 1, 3)
+    logits = q @ kh.transpose(-1, -2) / 128.0
+    vis, new_mask = O.band_visibility(t, maxlen, first_b, state_mask)
+    logits = logits + (~vis).float().unsqueeze(1) * O.NEG_MASK
+    logits = logits + O.rel_pos_bias(qkvr[:, 3 * hid:].reshape(bsz, t, heads, 10), b_nd, t, maxlen)
+    ref = (torch.softmax(logits, -1) @ vh).permute(0, 2, 1, 3).reshape(bsz * t, hid)
+    memvalid = (state_mask & ~first_b.view(bsz, 1, 1)).reshape(bsz, maxlen).to(torch.uint8)
+    out = ops.masked_attention(qkvr.to(DEV), kmem.to(DEV), vmem.to(DEV), memvalid.to(DEV), b_nd.to(DEV), bsz, t, heads, hid)
+    kout, vout = ops.kv_memory_update(qkvr.to(DEV), kmem.to(DEV), vmem.to(DEV), bsz, t, hid)
+    torch.cuda.synchronize()
+    err = (out.cpu().float() - ref).abs().max().item()
+    assert err < 2e-2, f"attention abs err {err} (bf16 output of O(1) values)"
+    assert torch.equal(kout.cpu(), k_full[:, -maxlen:])
+    assert torch.equal(vout.cpu(), v_full[:, -maxlen:])
+
+
+def test_log_softmax_cols():
+    g = torch.Generator().manual_seed(7)
+    z = torch.randn(9, 8763, generator=g) * 3
+    for col0, n in [(0, 8641), (8641, 121)]:
+        out = ops.log_softmax_cols(z.to(DEV), col0, n, 2.0)
+        torch.cuda.synchronize()
+        ref = torch.log_softmax(z[:, col0:col0 + n] / 2.0, -1)
+        assert (out.cpu() - ref).abs().max() < 2e-5

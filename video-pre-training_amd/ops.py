@@ -15,6 +15,43 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class KernelTimer:
+    """Optional per-entry-point HIP-event timing (bench.py / profiling only).  Events are recorded on the
+    current torch stream, which is the stream every kernel is launched on."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []  # (name, start_event, stop_event, meta)
+
+    def reset(self):
+        self.records = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b, meta in self.records:
+            d = out.setdefault(name, dict(ms=0.0, calls=0, flops=0.0, bytes=0.0))
+            d["ms"] += a.elapsed_time(b)
+            d["calls"] += 1
+            d["flops"] += meta.get("flops", 0.0)
+            d["bytes"] += meta.get("bytes", 0.0)
+        return out
+
+
+TIMER = KernelTimer()
+
+
+def _call(name, meta, *args):
+    if TIMER.enabled:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _native.call(name, *args)
+        b.record()
+        TIMER.records.append((name, a, b, meta or {}))
+    else:
+        _native.call(name, *args)
+
+
 def _chk(t, dtype, name):
     if t is None:
         return
@@ -31,7 +68,7 @@ def conv_first(img_u8, wfrag, cout, stats_out=None):
     _chk(img_u8, torch.uint8, "img"); _chk(wfrag, torch.bfloat16, "wfrag"); _chk(stats_out, torch.float64, "stats_out")
     f, h, w, _ = img_u8.shape
     y = torch.empty(f, cout // 32, h // 2, w // 2, 32, dtype=torch.bfloat16, device=img_u8.device)
-    _native.call("vpt_conv_first_forward", ptr(img_u8), ptr(wfrag), ptr(y), ptr(stats_out), f, h, w, cout, _stream())
+    _call("vpt_conv_first_forward", dict(flops=2.0 * f * h * w * cout * 27, bytes=f * (h * w * 3 + h * w * cout // 2)), ptr(img_u8), ptr(wfrag), ptr(y), ptr(stats_out), f, h, w, cout, _stream())
     return y
 
 
@@ -43,7 +80,7 @@ def conv3x3(x, wpk, edge_sa, edge_sg, stats_in, cout, res=None, stats_out=None, 
     f, cb, h, w, _ = x.shape
     if out is None:
         out = torch.empty(f, cout // 32, h, w, 32, dtype=torch.bfloat16, device=x.device)
-    _native.call("vpt_conv3x3_forward", ptr(x), ptr(wpk), ptr(edge_sa), ptr(edge_sg), ptr(stats_in), ptr(res),
+    _call("vpt_conv3x3_forward", dict(flops=2.0 * f * h * w * cout * 9 * cb * 32, bytes=2.0 * f * h * w * (cb * 32 + cout * (2 if res is not None else 1))), ptr(x), ptr(wpk), ptr(edge_sa), ptr(edge_sg), ptr(stats_in), ptr(res),
                  ptr(out), ptr(stats_out), f, h, w, cb * 32, cout, _stream())
     return out
 
@@ -52,7 +89,7 @@ def maxpool(x, stats_out=None):
     _chk(x, torch.bfloat16, "x"); _chk(stats_out, torch.float64, "stats_out")
     f, cb, h, w, _ = x.shape
     y = torch.empty(f, cb, h // 2, w // 2, 32, dtype=torch.bfloat16, device=x.device)
-    _native.call("vpt_maxpool_forward", ptr(x), ptr(y), ptr(stats_out), f, cb * 32, h, w, _stream())
+    _call("vpt_maxpool_forward", dict(bytes=2.0 * f * cb * 32 * h * w * 1.25), ptr(x), ptr(y), ptr(stats_out), f, cb * 32, h, w, _stream())
     return y
 
 
@@ -62,7 +99,7 @@ def frame_affine(x, gain, bias, stats_in, stats_out=None, per_element=False, out
     f, cb, h, w, _ = x.shape
     if out is None:
         out = torch.empty_like(x)
-    _native.call("vpt_frame_affine_forward", ptr(x), ptr(out), ptr(gain), ptr(bias), ptr(stats_in), ptr(stats_out),
+    _call("vpt_frame_affine_forward", dict(bytes=4.0 * f * cb * 32 * h * w), ptr(x), ptr(out), ptr(gain), ptr(bias), ptr(stats_in), ptr(stats_out),
                  f, cb * 32, h * w, 1 if per_element else 0, _stream())
     return out
 
@@ -77,7 +114,7 @@ def linear(a_bf16, wpk, n, bias=None, res=None, relu=False, out_f32=True, out_bf
     if out_f32:
         o32 = torch.zeros(m, n, dtype=torch.float32, device=dev) if splitk > 1 else torch.empty(m, n, dtype=torch.float32, device=dev)
     o16 = torch.empty(m, n, dtype=torch.bfloat16, device=dev) if out_bf16 else None
-    _native.call("vpt_linear_forward", ptr(a_bf16), ptr(wpk), ptr(bias), ptr(res), ptr(o32), ptr(o16),
+    _call("vpt_linear_forward", dict(flops=2.0 * m * n * k, bytes=2.0 * (m * k + n * k) + 4.0 * m * n), ptr(a_bf16), ptr(wpk), ptr(bias), ptr(res), ptr(o32), ptr(o16),
                  m, n, k, k, n, n, n, 1 if relu else 0, splitk, _stream())
     return o32, o16
 
@@ -87,7 +124,7 @@ def layernorm(x, gain, bias, relu_in=False, out_f32=False, out_bf16=True):
     m, d = x.shape
     o32 = torch.empty_like(x) if out_f32 else None
     o16 = torch.empty(m, d, dtype=torch.bfloat16, device=x.device) if out_bf16 else None
-    _native.call("vpt_layernorm_forward", ptr(x), ptr(gain), ptr(bias), ptr(o32), ptr(o16), m, d, 1 if relu_in else 0, _stream())
+    _call("vpt_layernorm_forward", dict(bytes=6.0 * m * d), ptr(x), ptr(gain), ptr(bias), ptr(o32), ptr(o16), m, d, 1 if relu_in else 0, _stream())
     return o32, o16
 
 
@@ -96,7 +133,7 @@ def masked_attention(qkvr, kmem, vmem, memvalid, b_nd, batch, t, heads, hid):
     _chk(memvalid, torch.uint8, "memvalid"); _chk(b_nd, torch.float32, "b_nd")
     maxlen = kmem.shape[1]
     out = torch.empty(batch * t, hid, dtype=torch.bfloat16, device=qkvr.device)
-    _native.call("vpt_masked_attention_forward", ptr(qkvr), ptr(kmem), ptr(vmem), ptr(memvalid), ptr(b_nd), ptr(out),
+    _call("vpt_masked_attention_forward", dict(flops=4.0 * batch * t * (t + maxlen) * hid), ptr(qkvr), ptr(kmem), ptr(vmem), ptr(memvalid), ptr(b_nd), ptr(out),
                  batch, t, heads, hid, qkvr.shape[1], maxlen, _stream())
     return out
 
@@ -104,7 +141,7 @@ def masked_attention(qkvr, kmem, vmem, memvalid, b_nd, batch, t, heads, hid):
 def kv_memory_update(qkvr, kmem, vmem, batch, t, hid):
     _chk(qkvr, torch.float32, "qkvr"); _chk(kmem, torch.float32, "kmem"); _chk(vmem, torch.float32, "vmem")
     kout, vout = torch.empty_like(kmem), torch.empty_like(vmem)
-    _native.call("vpt_kv_memory_update", ptr(qkvr), ptr(kmem), ptr(vmem), ptr(kout), ptr(vout),
+    _call("vpt_kv_memory_update", dict(bytes=16.0 * batch * kmem.shape[1] * hid), ptr(qkvr), ptr(kmem), ptr(vmem), ptr(kout), ptr(vout),
                  batch, t, hid, qkvr.shape[1], kmem.shape[1], _stream())
     return kout, vout
 
@@ -113,6 +150,6 @@ def log_softmax_cols(logits, col0, n, temperature):
     _chk(logits, torch.float32, "logits")
     m = logits.shape[0]
     out = torch.empty(m, n, dtype=torch.float32, device=logits.device)
-    _native.call("vpt_log_softmax_forward", ptr(logits), ptr(out), m, logits.shape[1], col0, n,
+    _call("vpt_log_softmax_forward", dict(bytes=8.0 * m * n), ptr(logits), ptr(out), m, logits.shape[1], col0, n,
                  ctypes.c_float(temperature), _stream())
     return out
