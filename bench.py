@@ -35,7 +35,11 @@ MFMA_BF16_PEAK = 2.5e15
 def cpu_baseline(model: str, seconds_budget: float = 25.0):
     """Oracle forward on the host cores: B=1, T=16 frames of the same synthetic distribution."""
     from oracle import vpt_oracle as O
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 32))  # torch CPU ops stop scaling (and oversubscribe) far below 256 logical cores
     torch.set_num_threads(cores)
     pk = O.policy_kwargs_for(model)
     cfg = O.config_from_policy_kwargs(pk, dict(temperature=2.0))

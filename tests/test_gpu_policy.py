@@ -2,8 +2,11 @@
 vectors of the live reference and against the oracle.  Needs an MI355X.
 
 Tolerance: the conv / linear kernels take bf16 operands with fp32 accumulation; statistics, softmax, the
-residual stream of the transformer and the KV memory stay fp32.  Log-probabilities are compared as
-max|d| / max|ref| (ref magnitudes ~9-12): bound 1e-2, typical observed ~1e-3; see DESIGN.md §Precision."""
+residual stream of the transformer and the KV memory stay fp32.  A CPU emulation of exactly these rounding
+points predicts, for the synthetic 1x weights: log-prob relative-L2 error ~1e-3
+(max|d|/max|ref| ~4e-3) and ~3.5e-2 relative-L2 on the K/V memory (error grows ~0.15 %/layer through the 14
+normalised CNN layers).  Bounds used here: log-probs rel-L2 < 3e-3 and max|d|/max|ref| < 1e-2; K/V memory
+rel-L2 < 6e-2; masks exact."""
 import numpy as np
 import pytest
 import torch
@@ -16,7 +19,10 @@ from vpt_amd.lib.types import minecraft_action_space  # noqa: E402
 from oracle import vpt_oracle as O  # noqa: E402
 
 DEV = "cuda"
-TOL = 1e-2
+TOL = 1e-2      # max|d| / max|ref| on log-probs
+L2_TOL = 3e-3   # relative L2 on log-probs
+KV_TOL = 6e-2   # relative L2 on the K/V memory rows written by the chunk
+V_TOL = 0.25    # absolute, on the raw value-head output (std ~1.3 with the synthetic weights; latent rel. error ~3e-2)
 
 
 def _inputs(seed, b, t):
@@ -38,6 +44,10 @@ def _rel(a, ref):
     return float(np.abs(a - ref).max() / np.abs(ref).max())
 
 
+def _l2(a, ref):
+    return float(np.linalg.norm((a - ref).ravel()) / max(np.linalg.norm(ref.ravel()), 1e-30))
+
+
 def test_policy_chunks_vs_golden(pol_1x, golden_1x):
     pol, cfg, sd = pol_1x
     G = golden_1x
@@ -53,18 +63,18 @@ def test_policy_chunks_vs_golden(pol_1x, golden_1x):
         assert pd["buttons"].shape == (b, t, 1, 8641) and pd["camera"].shape == (b, t, 1, 121) and vpred.shape == (b, t, 1)
         assert list(pd.keys()) == ["camera", "buttons"]
         report[tag] = (_rel(pd["buttons"].cpu().numpy(), G[f"{tag}_buttons"]), _rel(pd["camera"].cpu().numpy(), G[f"{tag}_camera"]),
-                       float(np.abs(vpred.cpu().numpy() - G[f"{tag}_vpred"]).max()))
+                       float(np.abs(vpred.cpu().numpy() - G[f"{tag}_vpred"]).max()),
+                       _l2(pd["buttons"].cpu().numpy(), G[f"{tag}_buttons"]), _l2(pd["camera"].cpu().numpy(), G[f"{tag}_camera"]))
         for l, (m, (k, v)) in enumerate(state):
             assert m.dtype == torch.bool and m.shape == (b, 1, 128)
             assert np.array_equal(m.cpu().numpy(), G[f"{tag}_mask{l}"])
             assert k.dtype == torch.float32 and k.shape == (b, 128, 1024)
-            kt = np.abs(G[f"{tag}_Ktail{l}"]).max()
-            assert np.abs(k[:, -4:].cpu().numpy() - G[f"{tag}_Ktail{l}"]).max() < 3e-2 * kt
-            assert np.abs(v[:, -4:].cpu().numpy() - G[f"{tag}_Vtail{l}"]).max() < 3e-2 * np.abs(G[f"{tag}_Vtail{l}"]).max()
+            assert _l2(k[:, -t:].cpu().numpy(), G[f"{tag}_Ktail{l}"][:, -t:]) < KV_TOL
+            assert _l2(v[:, -t:].cpu().numpy(), G[f"{tag}_Vtail{l}"][:, -t:]) < KV_TOL
         assert torch.allclose(pd["buttons"].exp().sum(-1).cpu(), torch.ones(b, t, 1), atol=1e-3)
-    print("rel err (buttons, camera, |dv|) per chunk:", report)
-    for tag, (eb, ec, ev) in report.items():
-        assert eb < TOL and ec < TOL and ev < 5e-2, report
+    print("PARITY vs golden (max/max buttons, max/max camera, |dv|, relL2 buttons, relL2 camera) per chunk:", report)
+    for tag, (eb, ec, ev, lb, lc) in report.items():
+        assert eb < TOL and ec < TOL and ev < V_TOL and lb < L2_TOL and lc < L2_TOL, report
     # act(): API shapes/dtypes + agreement of the deterministic action with the reference where the
     # reference's top-2 margin exceeds the bf16 noise (bit-exactness is only defined away from near-ties)
     img = _inputs(999, b, 1)[:, 0]
@@ -91,11 +101,14 @@ def test_policy_vs_oracle_long_chunk(pol_1x):
         eb = _rel(pd["buttons"].cpu().numpy(), ref["buttons"].numpy())
         ec = _rel(pd["camera"].cpu().numpy(), ref["camera"].numpy())
         agree = (pd["buttons"].argmax(-1).cpu() == ref["buttons"].argmax(-1)).float().mean().item()
-        print(f"t={t}: rel err buttons {eb:.3e} camera {ec:.3e}; argmax agreement {agree:.3f}")
-        assert eb < TOL and ec < TOL
+        lb = _l2(pd["buttons"].cpu().numpy(), ref["buttons"].numpy())
+        lc = _l2(pd["camera"].cpu().numpy(), ref["camera"].numpy())
+        print(f"PARITY vs oracle t={t}: max/max buttons {eb:.3e} camera {ec:.3e}; relL2 buttons {lb:.3e} camera {lc:.3e}; "
+              f"argmax agreement {agree:.3f}")
+        assert eb < TOL and ec < TOL and lb < L2_TOL and lc < L2_TOL
         for (m1, (k1, v1)), (m2, (k2, v2)) in zip(sg, so):
             assert torch.equal(m1.cpu(), m2)
-            assert (k1.cpu() - k2).abs().max() < 3e-2 * k2.abs().max()
+            assert _l2(k1.cpu().numpy(), k2.numpy()) < KV_TOL and _l2(v1.cpu().numpy(), v2.numpy()) < KV_TOL
 
 
 def test_first_resets_memory(pol_1x):
