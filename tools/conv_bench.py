@@ -1,0 +1,42 @@
+"""Micro-benchmark of vpt_conv3x3_forward at the five shapes of the 2x IMPALA CNN (HIP events, per shape).
+Usage: python tools/conv_bench.py [frames] [reps]      (run under rocprofv3 --pmc ... for counters)"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import __graft_entry__ as ge
+
+ge.build()
+from vpt_amd import ops, packing  # noqa: E402
+
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dev = "cuda"
+shapes = [("s0.block", 64, 128, 128, True), ("s1.first", 64, 128, 256, False), ("s1.block", 32, 256, 256, True),
+          ("s2.first", 32, 256, 256, False), ("s2.block", 16, 256, 256, True)]
+g = torch.Generator(device="cpu").manual_seed(0)
+for name, hw, cin, cout, use_res in shapes:
+    f = frames * (64 * 64) // (hw * hw) if hw < 64 else frames
+    f = min(f, frames * 4)
+    W = torch.randn(cout, cin, 3, 3, generator=g) * (1.6 / (cin * 9) ** 0.5)
+    wpk, sa, sg = packing.pack_conv3x3(W.to(dev), torch.ones(cin, device=dev), torch.zeros(cin, device=dev))
+    x = torch.relu(torch.randn(f, cin // 32, hw, hw, 32, device=dev)).to(torch.bfloat16)
+    res = torch.randn(f, cout // 32, hw, hw, 32, device=dev).to(torch.bfloat16) if use_res else None
+    xf = x.float().reshape(f, -1).double()
+    st_in = torch.stack([xf.sum(1), (xf * xf).sum(1)], 1).contiguous()
+    st_out = torch.zeros(f, 2, dtype=torch.float64, device=dev)
+    out = torch.empty(f, cout // 32, hw, hw, 32, dtype=torch.bfloat16, device=dev)
+    for _ in range(2):
+        ops.conv3x3(x, wpk, sa, sg, st_in, cout, res=res, stats_out=st_out, out=out)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        ops.conv3x3(x, wpk, sa, sg, st_in, cout, res=res, stats_out=st_out, out=out)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / reps
+    flops = 2.0 * f * hw * hw * cout * 9 * cin
+    print(f"{name:9s} frames={f:5d} {hw}x{hw} {cin}->{cout}: {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s  ablate={os.environ.get('VPT_CONV_ABLATE', '0')}")

@@ -53,12 +53,26 @@ __device__ __forceinline__ float wave_max(float v) {
 // per-frame statistics -> (mean, rstd).  stats[2f] = sum, stats[2f+1] = sum of squares (double)
 __device__ __forceinline__ void frame_mean_rstd(const double* __restrict__ stats, int f, double inv_count,
                                                 float& mean, float& rstd) {
-  double s = stats[2 * f], ss = stats[2 * f + 1];
-  double m = s * inv_count;
-  double var = ss * inv_count - m * m;
+  const double s = stats[2 * f], ss = stats[2 * f + 1];
+  const double m = s * inv_count;
+  double var = ss * inv_count - m * m;  // fp64: no cancellation problem even when |mean| >> std
   if (var < 0.0) var = 0.0;
   mean = (float)m;
-  rstd = (float)(1.0 / sqrt(var + (double)VPT_NORM_EPS));
+  rstd = rsqrtf((float)var + VPT_NORM_EPS);
+}
+
+// block-level (256 threads) reduction of two partial sums, then ONE pair of fp64 atomics per block
+__device__ __forceinline__ void block_stats_atomic(float s_sum, float s_sq, double* stats_out, int f) {
+  __shared__ float red_[8];
+  s_sum = wave_sum(s_sum);
+  s_sq = wave_sum(s_sq);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red_[w] = s_sum; red_[4 + w] = s_sq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(stats_out + 2 * f, (double)((red_[0] + red_[1]) + (red_[2] + red_[3])));
+    atomicAdd(stats_out + 2 * f + 1, (double)((red_[4] + red_[5]) + (red_[6] + red_[7])));
+  }
 }
 
 // XCD-aware bijective remap of a 1-D grid: the dispatcher places block b on XCD b%8; give every XCD a

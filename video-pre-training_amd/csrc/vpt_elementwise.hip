@@ -9,20 +9,27 @@
 //                      and ImpalaCNN.dense's LayerNorm over the flattened C*H*W vector (lib/impala_cnn.py:177-184,
 //                      lib/util.py:61-62; per-element gain, permuted host-side into the blocked order).
 //                      Emits the statistics of y for the next GroupNorm.
-// Every lane moves 16 bytes (8 bf16) per access; grids are sized to the data (one item per thread).
+// Every lane moves 16 bytes (8 bf16) per access, EW_ITEMS accesses per thread (all loads issued before the
+// first use); one block-level reduction and one pair of fp64 atomics per block keeps the per-frame
+// statistics off the critical path.
 #include "vpt_common.h"
 #include "vpt_kernels.h"
 
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+#define EW_ITEMS 4
+#define EW_PER_BLOCK (256 * EW_ITEMS)
 
 __global__ __launch_bounds__(256) void vpt_pool_kernel(VptPoolArgs a) {
   const int PH = a.H >> 1, PW = a.W >> 1;
   const int per_frame = a.CB * PH * PW * 4;  // 16-byte items
-  const int blocks_per_frame = (per_frame + 255) >> 8;
+  const int blocks_per_frame = (per_frame + EW_PER_BLOCK - 1) / EW_PER_BLOCK;
   const int f = blockIdx.x / blocks_per_frame;
-  const int item = (blockIdx.x - f * blocks_per_frame) * 256 + threadIdx.x;
+  const int base = (blockIdx.x - f * blocks_per_frame) * EW_PER_BLOCK + threadIdx.x;
   float s_sum = 0.f, s_sq = 0.f;
-  if (item < per_frame) {
+#pragma unroll
+  for (int it = 0; it < EW_ITEMS; ++it) {
+    const int item = base + it * 256;
+    if (item >= per_frame) break;
     const int oct = item & 3;
     int r = item >> 2;
     const int px = r % PW; r /= PW;
@@ -52,29 +59,30 @@ __global__ __launch_bounds__(256) void vpt_pool_kernel(VptPoolArgs a) {
     }
     *(u32x4*)(a.y + ((size_t)(f * a.CB + cb) * PH * PW + (size_t)(py * PW + px)) * 32 + oct * 8) = mv;
   }
-  if (a.stats_out) {
-    s_sum = wave_sum(s_sum);
-    s_sq = wave_sum(s_sq);
-    if ((threadIdx.x & 63) == 0) {
-      atomicAdd(a.stats_out + 2 * f, (double)s_sum);
-      atomicAdd(a.stats_out + 2 * f + 1, (double)s_sq);
-    }
-  }
+  if (a.stats_out) block_stats_atomic(s_sum, s_sq, a.stats_out, f);
 }
 
 __global__ __launch_bounds__(256) void vpt_affine_kernel(VptAffineArgs a) {
   const int per_frame = a.CB * a.HW * 4;  // 16-byte items
-  const int blocks_per_frame = (per_frame + 255) >> 8;
+  const int blocks_per_frame = (per_frame + EW_PER_BLOCK - 1) / EW_PER_BLOCK;
   const int f = blockIdx.x / blocks_per_frame;
-  const int item = (blockIdx.x - f * blocks_per_frame) * 256 + threadIdx.x;
+  const int base = (blockIdx.x - f * blocks_per_frame) * EW_PER_BLOCK + threadIdx.x;
   float mean, rstd;
   frame_mean_rstd(a.stats_in, f, a.inv_count, mean, rstd);
+  const float shift = -mean * rstd;
+  u32x4 xv[EW_ITEMS];
+#pragma unroll
+  for (int it = 0; it < EW_ITEMS; ++it) {
+    const int item = base + it * 256;
+    if (item < per_frame) xv[it] = *(const u32x4*)(a.x + (size_t)f * per_frame * 8 + (size_t)item * 8);
+  }
   float s_sum = 0.f, s_sq = 0.f;
-  if (item < per_frame) {
-    const size_t off = (size_t)f * per_frame * 8 + (size_t)item * 8;
-    const u32x4 xv = *(const u32x4*)(a.x + off);
+#pragma unroll
+  for (int it = 0; it < EW_ITEMS; ++it) {
+    const int item = base + it * 256;
+    if (item >= per_frame) break;
     float v[8];
-    unpack8(xv, v);
+    unpack8(xv[it], v);
     int gidx;
     if (a.per_element) {
       gidx = item * 8;
@@ -88,26 +96,19 @@ __global__ __launch_bounds__(256) void vpt_affine_kernel(VptAffineArgs a) {
     const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      v[k] = fmaf((v[k] - mean) * rstd, g[k], b[k]);
+      v[k] = fmaf(fmaf(v[k], rstd, shift), g[k], b[k]);
       s_sum += v[k];
       s_sq = fmaf(v[k], v[k], s_sq);
     }
-    *(u32x4*)(a.y + off) = pack8(v);
+    *(u32x4*)(a.y + (size_t)f * per_frame * 8 + (size_t)item * 8) = pack8(v);
   }
-  if (a.stats_out) {
-    s_sum = wave_sum(s_sum);
-    s_sq = wave_sum(s_sq);
-    if ((threadIdx.x & 63) == 0) {
-      atomicAdd(a.stats_out + 2 * f, (double)s_sum);
-      atomicAdd(a.stats_out + 2 * f + 1, (double)s_sq);
-    }
-  }
+  if (a.stats_out) block_stats_atomic(s_sum, s_sq, a.stats_out, f);
 }
 
 extern "C" int vpt_pool_launch(const VptPoolArgs* a, hipStream_t stream) {
   if ((a->H & 1) || (a->W & 1) || a->frames <= 0) return -1;
   const int per_frame = a->CB * (a->H >> 1) * (a->W >> 1) * 4;
-  const long grid = (long)a->frames * ((per_frame + 255) >> 8);
+  const long grid = (long)a->frames * ((per_frame + EW_PER_BLOCK - 1) / EW_PER_BLOCK);
   if (grid > 0x7fffffffL) return -2;
   hipLaunchKernelGGL(vpt_pool_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
@@ -116,7 +117,7 @@ extern "C" int vpt_pool_launch(const VptPoolArgs* a, hipStream_t stream) {
 extern "C" int vpt_affine_launch(const VptAffineArgs* a, hipStream_t stream) {
   if (a->frames <= 0) return -1;
   const int per_frame = a->CB * a->HW * 4;
-  const long grid = (long)a->frames * ((per_frame + 255) >> 8);
+  const long grid = (long)a->frames * ((per_frame + EW_PER_BLOCK - 1) / EW_PER_BLOCK);
   if (grid > 0x7fffffffL) return -2;
   hipLaunchKernelGGL(vpt_affine_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
