@@ -27,7 +27,9 @@ def test_conv3x3_pack_layout_and_fold():
     assert wpk.shape == (nt, cin // 32, 9, 128, 32) and sa.shape == (9, 256) and sg.shape == (9, 256)
     # layout: wpk[nt, cb, tap, n, ci] == bf16(W[nt*128+n, cb*32+ci, tap//3, tap%3] * gain)
     wg = (W * gain.view(1, -1, 1, 1)).to(torch.bfloat16)
-    rec = wpk.permute(0, 3, 1, 4, 2).reshape(nt * 128, cin, 3, 3)
+    # undo the LDS-image swizzle (chunk c of row n lives at c ^ ((n >> 2) & 3)); it is an involution
+    assert not torch.equal(packing.swizzle_rows64(wpk), wpk)
+    rec = packing.swizzle_rows64(wpk).permute(0, 3, 1, 4, 2).reshape(nt * 128, cin, 3, 3)
     assert torch.equal(rec[:cout], wg) and rec[cout:].abs().max() == 0
     # emulate the kernel: raw bf16 activations through conv(W*g), then the epilogue fold
     xb = x.to(torch.bfloat16).float()

@@ -40,6 +40,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own libamdhip64.so; load it FIRST so that libvpt_hip.so binds to the same HIP
+    # runtime instance torch uses (two runtimes in one process cannot share streams or device pointers).
+    import torch  # noqa: F401
     if not os.path.exists(_LIB_PATH):
         raise NativeLibraryError(
             f"{_LIB_PATH} is missing: run `python __graft_entry__.py` (build()) first; there is no CPU fallback")

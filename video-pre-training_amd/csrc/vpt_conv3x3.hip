@@ -6,7 +6,8 @@
 //
 // Layout in HBM: activations are channel-blocked NHWC, [frame][C/32][H][W][32] bf16, so that the 18-pixel
 // halo row of one 32-channel block is one contiguous 1152-byte run.  Weights are pre-packed (host side)
-// as [ntile][C_in/32][tap][128 couts][32 cin] bf16 with the GroupNorm gain folded in.
+// as [ntile][C_in/32][tap][128 couts][32 cin] bf16 with the GroupNorm gain folded in and the four 16-byte
+// chunks of every 64-byte row XOR-swizzled by ((cout >> 2) & 3), i.e. already in their LDS image.
 //
 // GroupNorm fold: conv(W, (x-mu)*rstd*g + b) with zero padding applied AFTER the norm equals
 //     rstd * conv(W*g, x)  -  rstd*mu * SG[e][o]  +  SA[e][o]
@@ -15,26 +16,38 @@
 // per-frame statistics (sum, sum of squares; produced by the previous kernel's epilogue) enter only
 // in the epilogue.
 //
-// Tiling: one workgroup (4 waves) = 16x16 output pixels x 128 output channels of one frame.
-// K loop: for each 32-channel block the 18x18x32 halo tile is staged once in LDS and reused by all nine
-// taps; the weight tile of three taps (one kernel row) is staged per step.  Wave tile 128 px x 64 couts
-// = 4x2 MFMA 32x32x16 accumulators.  Global->register prefetch of the next step overlaps the MFMAs
-// (issue early, ds_write late); two workgroups per CU hide each other's barriers.
+// Tiling: one workgroup (4 waves) = 16x16 output pixels x 128 output channels of one frame; wave tile
+// 128 px x 64 couts = 4x2 MFMA 32x32x16 accumulators.  K loop: for each 32-channel block the 18x18x32
+// halo tile is register-staged into LDS once (zero-filled outside the image) and reused by all nine taps;
+// the weight tile of one kernel row (3 taps, 24 KB) is DMA'd global->LDS (global_load_lds, no VGPRs, no
+// ds_write) into a double buffer one step ahead, so a step costs ONE barrier.  round-1 profile: the first
+// version of this kernel was LDS-bound (SQ_LDS_IDX_ACTIVE > MFMA busy, 39 % of it bank conflicts); hence
+//   - the weight image is swizzled so ds_read_b128 of B fragments is conflict-free on 64-byte rows,
+//   - the 32 rows of an MFMA M-subtile map to pixels so that every hardware 16-lane ds_read_b128 group
+//     covers 16 consecutive pixels of ONE image row (80-byte pixel stride -> 16 distinct bank slots),
+//   - halo ds_write_b128 are ordered so each 8-lane group hits 8 distinct 16-byte slots.
+// Two workgroups per CU (78.6 KB LDS, <= 256 VGPRs) hide each other's barriers and epilogues.
 #include "vpt_common.h"
 #include "vpt_kernels.h"
 #include <stdlib.h>
 
 #define A_RS 80
-#define A_BYTES (324 * A_RS)          // 25920
-#define B_RS 80
-#define B_BYTES (3 * 128 * B_RS)      // 30720
-#define STG_F 68                      // floats per staging row (64 + 4 pad)
-#define STG_WAVE (32 * STG_F * 4)     // 8704 bytes
-#define KK_OFF (4 * STG_WAVE)         // 34816
+#define A_BYTES (324 * A_RS)            // 25920
+#define B_BYTES (3 * 128 * 64)          // 24576 per buffer (unpadded, swizzled)
+#define KK_OFF (A_BYTES + 2 * B_BYTES)  // 75072
+#define KK_BYTES (9 * 128 * 4)          // 4608
+#define SMEM_BYTES (KK_OFF + KK_BYTES + 32)  // 79712 (+32: block stats reduction)
+#define STG_F 68                        // floats per epilogue staging row (64 + 4 pad)
+#define STG_WAVE (32 * STG_F * 4)       // 8704 bytes per wave, aliases the A/B region
+
+// MFMA M-subtile row i (0..31) -> pixel (row 0/1, col 0..15) of a 2x16 patch.  Rows are swapped for columns
+// 4..11 so that each 16-lane ds_read_b128 group {0-3,12-15,20-27} / {4-11,16-19,28-31} stays in one image row.
+__device__ __forceinline__ int sub_row(int i) { return ((i >> 4) ^ (i >> 2) ^ (i >> 3)) & 1; }
 
 __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + B_BYTES];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;
   const int hi = lane >> 5, l31 = lane & 31;
 
@@ -47,16 +60,18 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   const int tx0 = tx * 16, ty0 = ty * 16;
   const int NCB = a.Cin >> 5;
   const int HW = a.H * a.W;
+  const int nsteps = NCB * 3;
 
-  // ---- staging maps (fixed for the whole K loop) ----
+  // ---- halo staging map: chunk q -> (pixel P = 8*(q>>5) + (q&7), part = (q>>3)&3) ----
   int a_goff[6], a_loff[6];
 #pragma unroll
   for (int m = 0; m < 6; ++m) {
     const int q = tid + 256 * m;
-    if (q < 1296) {
-      const int hy = q / 72, rem = q - hy * 72, hx = rem >> 2, part = rem & 3;
+    const int P = ((q >> 5) << 3) + (q & 7), part = (q >> 3) & 3;
+    if (P < 324) {
+      const int hy = P / 18, hx = P - hy * 18;
       const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
-      a_loff[m] = (hy * 18 + hx) * A_RS + part * 16;
+      a_loff[m] = P * A_RS + part * 16;
       a_goff[m] = (y >= 0 && y < a.H && x >= 0 && x < a.W) ? (y * a.W + x) * 32 + part * 8 : -1;
     } else {
       a_loff[m] = -1;
@@ -64,22 +79,38 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     }
   }
   const bf16_t* xplane = a.x + (size_t)f * NCB * HW * 32;
-  const bf16_t* wbase = a.wpk + (size_t)nt * NCB * 9 * 4096 + tid * 8;
-  unsigned char* bst = smem + A_BYTES + (tid >> 2) * B_RS + (tid & 3) * 16;
+  // weight DMA: wave w moves pieces (4*m + w), m = 0..5, of the 24 KB step tile; lane = 16-byte chunk
+  const bf16_t* wbase = a.wpk + (size_t)nt * NCB * 9 * 4096 + (size_t)(w * 64 + lane) * 8;
+  unsigned char* bdst = smem + A_BYTES + w * 1024;
 
-  u32x4 areg[6], breg[6];
+#define ISSUE_B(step_, buf_)                                                                              \
+  do {                                                                                                    \
+    const bf16_t* wp_ = wbase + (size_t)(step_) * 12288;                                                  \
+    _Pragma("unroll") for (int m_ = 0; m_ < 6; ++m_)                                                      \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp_ + m_ * 2048),  \
+                                       (__attribute__((address_space(3))) void*)(bdst + (buf_) * B_BYTES + m_ * 4096), \
+                                       16, 0, 0);                                                         \
+  } while (0)
+
+  u32x4 areg[6];
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
-  // prologue: stage channel block 0 and step 0
+  // ---- prologue: weights of step 0 (DMA), halo of channel block 0, epilogue constant table ----
+  ISSUE_B(0, 0);
 #pragma unroll
   for (int m = 0; m < 6; ++m) areg[m] = (a_goff[m] >= 0) ? *(const u32x4*)(xplane + a_goff[m]) : zero4;
-#pragma unroll
-  for (int m = 0; m < 6; ++m) breg[m] = *(const u32x4*)(wbase + m * 2048);
+  float mean, rstd;
+  frame_mean_rstd(a.stats_in, f, a.inv_count_in, mean, rstd);
+  {
+    float* kk = (float*)(smem + KK_OFF);
+    for (int idx = tid; idx < 9 * 128; idx += 256) {
+      const int e = idx >> 7, o = nt * 128 + (idx & 127);
+      kk[idx] = a.edge_sa[e * a.CoutPad + o] - rstd * mean * a.edge_sg[e * a.CoutPad + o];
+    }
+  }
 #pragma unroll
   for (int m = 0; m < 6; ++m)
     if (a_loff[m] >= 0) *(u32x4*)(smem + a_loff[m]) = areg[m];
-#pragma unroll
-  for (int m = 0; m < 6; ++m) *(u32x4*)(bst + m * 64 * B_RS) = breg[m];
   __syncthreads();
 
   f32x16 acc[4][2];
@@ -90,27 +121,29 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-  const unsigned char* aL = smem + ((wm * 8 + (l31 >> 4)) * 18 + (l31 & 15)) * A_RS + hi * 16;
-  const unsigned char* bL = smem + A_BYTES + (wn * 64 + l31) * B_RS + hi * 16;
+  // fragment base addresses
+  const unsigned char* aL = smem + ((wm * 8 + sub_row(l31)) * 18 + (l31 & 15)) * A_RS + hi * 16;
+  const int bsw = (l31 >> 2) & 3;
+  const unsigned char* bL0 = smem + A_BYTES + (wn * 64 + l31) * 64 + (((0 + hi) ^ bsw) << 4);  // ks = 0
+  const unsigned char* bL1 = smem + A_BYTES + (wn * 64 + l31) * 64 + (((2 + hi) ^ bsw) << 4);  // ks = 1
 
   const int ncb_run = (a.ablate == 2) ? 0 : NCB;
   for (int cb = 0; cb < ncb_run; ++cb) {
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
       const int s = cb * 3 + dy;
-      const bool more = (s + 1 < NCB * 3);
+      const int buf = s & 1;
+      const bool more = (s + 1 < nsteps);
       const bool nextA = (dy == 2) && (cb + 1 < NCB);
-      if (more) {
-        const bf16_t* wp = wbase + (size_t)(s + 1) * 12288;
-#pragma unroll
-        for (int m = 0; m < 6; ++m) breg[m] = *(const u32x4*)(wp + m * 2048);
-      }
+      if (more) ISSUE_B(s + 1, buf ^ 1);
       if (nextA) {
         const bf16_t* xp = xplane + (size_t)(cb + 1) * HW * 32;
 #pragma unroll
         for (int m = 0; m < 6; ++m) areg[m] = (a_goff[m] >= 0) ? *(const u32x4*)(xp + a_goff[m]) : zero4;
       }
       // ---- 3 taps x 2 k16-steps x (4x2) MFMA ----
+      const unsigned char* bB0 = bL0 + buf * B_BYTES;
+      const unsigned char* bB1 = bL1 + buf * B_BYTES;
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
 #pragma unroll
@@ -120,7 +153,8 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
           for (int m = 0; m < 4; ++m)
             af[m] = *(const bf16x8*)(aL + (dy * 18 + dx) * A_RS + m * (2 * 18 * A_RS) + ks * 32);
 #pragma unroll
-          for (int n = 0; n < 2; ++n) bf[n] = *(const bf16x8*)(bL + dx * (128 * B_RS) + n * (32 * B_RS) + ks * 32);
+          for (int n = 0; n < 2; ++n)
+            bf[n] = *(const bf16x8*)((ks ? bB1 : bB0) + dx * (128 * 64) + n * (32 * 64));
 #pragma unroll
           for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -128,17 +162,13 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
               acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
         }
       }
-      __syncthreads();
-      if (more) {
-#pragma unroll
-        for (int m = 0; m < 6; ++m) *(u32x4*)(bst + m * 64 * B_RS) = breg[m];
-      }
+      __syncthreads();  // all waves done with A / B[buf]; the DMA into B[buf^1] has landed (vmcnt(0) before the barrier)
       if (nextA) {
 #pragma unroll
         for (int m = 0; m < 6; ++m)
           if (a_loff[m] >= 0) *(u32x4*)(smem + a_loff[m]) = areg[m];
+        __syncthreads();
       }
-      __syncthreads();
     }
   }
 
@@ -154,19 +184,34 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     if (t == 12345.678f) a.y[0] = (vpt_bf16)t;
     return;
   }
-  float mean, rstd;
-  frame_mean_rstd(a.stats_in, f, a.inv_count_in, mean, rstd);
-  float* kk = (float*)(smem + KK_OFF);
-  for (int idx = tid; idx < 9 * 128; idx += 256) {
-    const int e = idx >> 7, o = nt * 128 + (idx & 127);
-    kk[idx] = a.edge_sa[e * a.CoutPad + o] - rstd * mean * a.edge_sg[e * a.CoutPad + o];
-  }
-  __syncthreads();
 
-  float* stg = (float*)(smem + w * STG_WAVE);
-  const float* kkw = kk + wn * 64 + l31;
   const int n0 = nt * 128 + wn * 64;
   const int CB_out = a.Cout >> 5;
+  // read-back map of one pass: item = lane + 64*it -> (subtile pixel p = item>>3, cout octet oc = item&7)
+  size_t ooff0[4];                       // m = 0; pass m adds m * (2 rows * W * 32) elements
+  const size_t ostep = (size_t)a.W * 64;
+  bool ovalid[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int item = lane + 64 * it;
+    const int p = item >> 3, oc = item & 7;
+    const int cg = n0 + oc * 8;
+    ovalid[it] = cg < a.Cout;
+    const int y = ty0 + wm * 8 + sub_row(p);
+    const int x = tx0 + (p & 15);
+    ooff0[it] = ((size_t)(f * CB_out + (cg >> 5)) * HW + (size_t)(y * a.W + x)) * 32 + (cg & 31);
+  }
+  // residual prefetch for the whole wave tile (64 VGPRs; the staging registers are dead by now)
+  u32x4 rres[4][4];
+  if (a.res) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) rres[m][it] = ovalid[it] ? *(const u32x4*)(a.res + ooff0[it] + m * ostep) : zero4;
+  }
+
+  float* stg = (float*)(smem + w * STG_WAVE);
+  const float* kkw = (const float*)(smem + KK_OFF) + wn * 64 + l31;
   float s_sum = 0.f, s_sq = 0.f;
 
 #pragma unroll
@@ -176,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const int y = ty0 + wm * 8 + 2 * m + (i >> 4);
+        const int y = ty0 + wm * 8 + 2 * m + sub_row(i);
         const int x = tx0 + (i & 15);
         const int ey = (y == 0) ? 0 : ((y == a.H - 1) ? 2 : 1);
         const int ex = (x == 0) ? 0 : ((x == a.W - 1) ? 2 : 1);
@@ -190,18 +235,13 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     for (int it = 0; it < 4; ++it) {
       const int item = lane + 64 * it;
       const int p = item >> 3, oc = item & 7;
-      const int cg = n0 + oc * 8;
       const f32x4 v0 = *(const f32x4*)(stg + p * STG_F + oc * 8);
       const f32x4 v1 = *(const f32x4*)(stg + p * STG_F + oc * 8 + 4);
-      if (cg < a.Cout) {
-        const int y = ty0 + wm * 8 + 2 * m + (p >> 4);
-        const int x = tx0 + (p & 15);
-        const size_t off = ((size_t)(f * CB_out + (cg >> 5)) * HW + (size_t)(y * a.W + x)) * 32 + (cg & 31);
+      if (ovalid[it]) {
         float vals[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         if (a.res) {
-          const u32x4 rr = *(const u32x4*)(a.res + off);
           float rf[8];
-          unpack8(rr, rf);
+          unpack8(rres[m][it], rf);
 #pragma unroll
           for (int k = 0; k < 8; ++k) vals[k] += rf[k];
         }
@@ -210,17 +250,20 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
           s_sum += vals[k];
           s_sq = fmaf(vals[k], vals[k], s_sq);
         }
-        *(u32x4*)(a.y + off) = pack8(vals);
+        *(u32x4*)(a.y + ooff0[it] + m * ostep) = pack8(vals);
       }
     }
     __builtin_amdgcn_wave_barrier();
   }
   if (a.stats_out) {
+    float* red = (float*)(smem + KK_OFF + KK_BYTES);
     s_sum = wave_sum(s_sum);
     s_sq = wave_sum(s_sq);
-    if (lane == 0) {
-      atomicAdd(a.stats_out + 2 * f, (double)s_sum);
-      atomicAdd(a.stats_out + 2 * f + 1, (double)s_sq);
+    if (lane == 0) { red[w] = s_sum; red[4 + w] = s_sq; }
+    __syncthreads();
+    if (tid == 0) {
+      atomicAdd(a.stats_out + 2 * f, (double)((red[0] + red[1]) + (red[2] + red[3])));
+      atomicAdd(a.stats_out + 2 * f + 1, (double)((red[4] + red[5]) + (red[6] + red[7])));
     }
   }
 }

@@ -16,7 +16,8 @@ def pack_conv3x3(weight, gain, bias):
     """Conv2d weight [Cout,Cin,3,3] with the preceding GroupNorm(1,Cin) affine (gain, bias [Cin]) folded.
 
     Returns (wpk bf16 [NT][Cin/32][9][128][32], edge_sa fp32 [9][NT*128], edge_sg fp32 [9][NT*128]).
-    wpk holds bf16(W * gain); edge_sg[e][o] = sum over the taps valid for edge class e and over Cin of that
+    wpk holds bf16(W * gain), each 64-byte row (one cout, 32 cin) stored with its four 16-byte chunks
+    XOR-swizzled by ((cout >> 2) & 3): the tile is DMA'd to LDS verbatim and read conflict-free; edge_sg[e][o] = sum over the taps valid for edge class e and over Cin of that
     rounded value; edge_sa[e][o] = same sum of W * bias (fp32).  e = 3*ey + ex with ey/ex in
     {0: first row/col, 1: interior, 2: last row/col} (vpt_conv3x3.hip epilogue)."""
     cout, cin = weight.shape[:2]
@@ -27,6 +28,7 @@ def pack_conv3x3(weight, gain, bias):
     wp = torch.zeros(cp, cin, 3, 3, dtype=torch.bfloat16, device=weight.device)
     wp[:cout] = wg
     wpk = wp.view(nt, 128, cin // 32, 32, 9).permute(0, 2, 4, 1, 3).contiguous()
+    wpk = swizzle_rows64(wpk)
     sg_tap = torch.zeros(cp, 3, 3, dtype=torch.float64, device=weight.device)
     sa_tap = torch.zeros(cp, 3, 3, dtype=torch.float64, device=weight.device)
     sg_tap[:cout] = wg.double().sum(dim=1)
@@ -40,6 +42,17 @@ def pack_conv3x3(weight, gain, bias):
             sg[ey * 3 + ex] = sg_tap[:, khs][:, :, kws].sum(dim=(1, 2))
             sa[ey * 3 + ex] = sa_tap[:, khs][:, :, kws].sum(dim=(1, 2))
     return wpk, sa.float().contiguous(), sg.float().contiguous()
+
+
+def swizzle_rows64(t):
+    """[..., rows, 32] bf16 -> same shape with chunk c (8 elements) of row r stored at chunk c ^ ((r >> 2) & 3).
+    The permutation is an involution, so applying it twice restores the logical order."""
+    rows = t.shape[-2]
+    v = t.reshape(*t.shape[:-1], 4, 8)
+    r = torch.arange(rows, device=t.device)
+    idx = (torch.arange(4, device=t.device).view(1, 4) ^ ((r >> 2) & 3).view(rows, 1))  # [rows, 4]: source chunk per slot
+    idx = idx.view(*([1] * (v.dim() - 3)), rows, 4, 1).expand(*v.shape)
+    return torch.gather(v, -2, idx).reshape(t.shape).contiguous()
 
 
 def pack_conv_first(weight, bias):
