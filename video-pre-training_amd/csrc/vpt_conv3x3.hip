@@ -37,8 +37,6 @@
 #define KK_OFF (A_BYTES + 2 * B_BYTES)  // 75072
 #define KK_BYTES (9 * 128 * 4)          // 4608
 #define SMEM_BYTES (KK_OFF + KK_BYTES + 32)  // 79712 (+32: block stats reduction)
-#define STG_F 68                        // floats per epilogue staging row (64 + 4 pad)
-#define STG_WAVE (32 * STG_F * 4)       // 8704 bytes per wave, aliases the A/B region
 
 // MFMA M-subtile row i (0..31) -> pixel (row 0/1, col 0..15) of a 2x16 patch.  Rows are swapped for columns
 // 4..11 so that each 16-lane ds_read_b128 group {0-3,12-15,20-27} / {4-11,16-19,28-31} stays in one image row.
@@ -127,41 +125,50 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   const unsigned char* bL0 = smem + A_BYTES + (wn * 64 + l31) * 64 + (((0 + hi) ^ bsw) << 4);  // ks = 0
   const unsigned char* bL1 = smem + A_BYTES + (wn * 64 + l31) * 64 + (((2 + hi) ^ bsw) << 4);  // ks = 1
 
-  const int ncb_run = (a.ablate == 2) ? 0 : NCB;
+  const int ncb_run = (a.ablate == 2) ? 0 : NCB;  // profiling: ablate bit 2 (4) = no weight DMA in the loop, bit 3 (8) = no halo reloads
   for (int cb = 0; cb < ncb_run; ++cb) {
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
       const int s = cb * 3 + dy;
       const int buf = s & 1;
-      const bool more = (s + 1 < nsteps);
+      const bool more = (s + 1 < nsteps) && !(a.ablate & 4);
       const bool nextA = (dy == 2) && (cb + 1 < NCB);
       if (more) ISSUE_B(s + 1, buf ^ 1);
-      if (nextA) {
+      // halo of the next channel block: issued three steps (one whole block) ahead of its ds_write so that the
+      // HBM latency is covered by ~150 MFMAs per wave; the registers are free now that B is DMA'd
+      if ((dy == 0) && (cb + 1 < NCB) && !(a.ablate & 8)) {
         const bf16_t* xp = xplane + (size_t)(cb + 1) * HW * 32;
 #pragma unroll
         for (int m = 0; m < 6; ++m) areg[m] = (a_goff[m] >= 0) ? *(const u32x4*)(xp + a_goff[m]) : zero4;
       }
-      // ---- 3 taps x 2 k16-steps x (4x2) MFMA ----
+      // ---- 3 taps x 2 k16-steps x (4x2) MFMA, software-pipelined: the six fragments of group g+1 are read
+      //      from LDS while the eight MFMAs of group g issue (the compiler otherwise reuses one fragment
+      //      register set and exposes the ds_read latency before every pair of MFMAs) ----
       const unsigned char* bB0 = bL0 + buf * B_BYTES;
       const unsigned char* bB1 = bL1 + buf * B_BYTES;
+      bf16x8 fa[2][4], fb[2][2];
+#define LOAD_FRAGS(g_, slot_)                                                                             \
+  do {                                                                                                    \
+    const int dx_ = (g_) >> 1, ks_ = (g_) & 1;                                                            \
+    _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                                      \
+      fa[slot_][m_] = *(const bf16x8*)(aL + (dy * 18 + dx_) * A_RS + m_ * (2 * 18 * A_RS) + ks_ * 32);   \
+    _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_)                                                      \
+      fb[slot_][n_] = *(const bf16x8*)((ks_ ? bB1 : bB0) + dx_ * (128 * 64) + n_ * (32 * 64));            \
+  } while (0)
+      LOAD_FRAGS(0, 0);
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
+      for (int g = 0; g < 6; ++g) {
+        const int cur = g & 1;
+        if (g < 5) LOAD_FRAGS(g + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this group's MFMAs (distinct registers)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          bf16x8 af[4], bf[2];
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-            af[m] = *(const bf16x8*)(aL + (dy * 18 + dx) * A_RS + m * (2 * 18 * A_RS) + ks * 32);
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
           for (int n = 0; n < 2; ++n)
-            bf[n] = *(const bf16x8*)((ks ? bB1 : bB0) + dx * (128 * 64) + n * (32 * 64));
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
-        }
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][n], fa[cur][m], acc[m][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
+#undef LOAD_FRAGS
       __syncthreads();  // all waves done with A / B[buf]; the DMA into B[buf^1] has landed (vmcnt(0) before the barrier)
       if (nextA) {
 #pragma unroll
@@ -185,75 +192,60 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     return;
   }
 
-  const int n0 = nt * 128 + wn * 64;
+  // Operands are SWAPPED in the MFMA (weights = A rows, pixels = B columns), so a lane holds ONE pixel
+  // (column l31 of the subtile) and, per accumulator, four groups of 4 consecutive output channels
+  // (rows (r&3) + 8*(r>>2) + 4*hi): the epilogue is lane-local -- 16-byte reads of the constant table,
+  // 8-byte residual loads and 8-byte bf16 stores straight from the accumulator layout, no LDS round trip.
   const int CB_out = a.Cout >> 5;
-  // read-back map of one pass: item = lane + 64*it -> (subtile pixel p = item>>3, cout octet oc = item&7)
-  size_t ooff0[4];                       // m = 0; pass m adds m * (2 rows * W * 32) elements
-  const size_t ostep = (size_t)a.W * 64;
-  bool ovalid[4];
+  const int cb0 = nt * 4 + wn * 2;                 // 32-channel block of n2 = 0
+  const bool nvalid[2] = {(cb0 + 0) < CB_out, (cb0 + 1) < CB_out};
+  // per M-subtile: this lane's pixel, its element offset in block cb0, and its edge-class row of the table
+  size_t poff[4];
+  int eoff[4];
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int item = lane + 64 * it;
-    const int p = item >> 3, oc = item & 7;
-    const int cg = n0 + oc * 8;
-    ovalid[it] = cg < a.Cout;
-    const int y = ty0 + wm * 8 + sub_row(p);
-    const int x = tx0 + (p & 15);
-    ooff0[it] = ((size_t)(f * CB_out + (cg >> 5)) * HW + (size_t)(y * a.W + x)) * 32 + (cg & 31);
+  for (int m = 0; m < 4; ++m) {
+    const int y = ty0 + wm * 8 + 2 * m + sub_row(l31);
+    const int x = tx0 + (l31 & 15);
+    const int ey = (y == 0) ? 0 : ((y == a.H - 1) ? 2 : 1);
+    const int ex = (x == 0) ? 0 : ((x == a.W - 1) ? 2 : 1);
+    eoff[m] = (ey * 3 + ex) * 128 + wn * 64 + 4 * hi;
+    poff[m] = ((size_t)(f * CB_out + cb0) * HW + (size_t)(y * a.W + x)) * 32 + 4 * hi;
   }
-  // residual prefetch for the whole wave tile (64 VGPRs; the staging registers are dead by now)
-  u32x4 rres[4][4];
-  if (a.res) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int it = 0; it < 4; ++it) rres[m][it] = ovalid[it] ? *(const u32x4*)(a.res + ooff0[it] + m * ostep) : zero4;
-  }
-
-  float* stg = (float*)(smem + w * STG_WAVE);
-  const float* kkw = (const float*)(smem + KK_OFF) + wn * 64 + l31;
+  const size_t nstep = (size_t)HW * 32;            // next 32-channel block
+  const float* kk = (const float*)(smem + KK_OFF);
   float s_sum = 0.f, s_sq = 0.f;
 
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
+    // residual for this subtile: 8 x 8-byte loads in flight before the first use
+    u32x2 rr[2][4];
+    if (a.res) {
+#pragma unroll
+      for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          rr[n2][g] = nvalid[n2] ? *(const u32x2*)(a.res + poff[m] + n2 * nstep + 8 * g) : (u32x2){0u, 0u};
+    }
 #pragma unroll
     for (int n2 = 0; n2 < 2; ++n2) {
+      if (!nvalid[n2]) continue;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const int y = ty0 + wm * 8 + 2 * m + sub_row(i);
-        const int x = tx0 + (i & 15);
-        const int ey = (y == 0) ? 0 : ((y == a.H - 1) ? 2 : 1);
-        const int ex = (x == 0) ? 0 : ((x == a.W - 1) ? 2 : 1);
-        float v = fmaf(rstd, acc[m][n2][r], kkw[(ey * 3 + ex) * 128 + n2 * 32]);
-        v = fmaxf(v, 0.f);
-        stg[i * STG_F + n2 * 32 + l31] = v;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int item = lane + 64 * it;
-      const int p = item >> 3, oc = item & 7;
-      const f32x4 v0 = *(const f32x4*)(stg + p * STG_F + oc * 8);
-      const f32x4 v1 = *(const f32x4*)(stg + p * STG_F + oc * 8 + 4);
-      if (ovalid[it]) {
-        float vals[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 k4 = *(const f32x4*)(kk + eoff[m] + n2 * 32 + 8 * g);
+        float v0 = fmaxf(fmaf(rstd, acc[m][n2][4 * g + 0], k4.x), 0.f);
+        float v1 = fmaxf(fmaf(rstd, acc[m][n2][4 * g + 1], k4.y), 0.f);
+        float v2 = fmaxf(fmaf(rstd, acc[m][n2][4 * g + 2], k4.z), 0.f);
+        float v3 = fmaxf(fmaf(rstd, acc[m][n2][4 * g + 3], k4.w), 0.f);
         if (a.res) {
-          float rf[8];
-          unpack8(rres[m][it], rf);
-#pragma unroll
-          for (int k = 0; k < 8; ++k) vals[k] += rf[k];
+          v0 += bf16_lo_to_f32(rr[n2][g].x); v1 += bf16_hi_to_f32(rr[n2][g].x);
+          v2 += bf16_lo_to_f32(rr[n2][g].y); v3 += bf16_hi_to_f32(rr[n2][g].y);
         }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          s_sum += vals[k];
-          s_sq = fmaf(vals[k], vals[k], s_sq);
-        }
-        *(u32x4*)(a.y + ooff0[it] + m * ostep) = pack8(vals);
+        s_sum += (v0 + v1) + (v2 + v3);
+        s_sq = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, fmaf(v3, v3, s_sq))));
+        const u32x2 pk = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+        *(u32x2*)(a.y + poff[m] + n2 * nstep + 8 * g) = pk;
       }
     }
-    __builtin_amdgcn_wave_barrier();
   }
   if (a.stats_out) {
     float* red = (float*)(smem + KK_OFF + KK_BYTES);
