@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
 #pragma unroll
       for (int g = 0; g < 6; ++g) {
         const int cur = g & 1;
-        if (g < 5) LOAD_FRAGS(g + 1, cur ^ 1);
+        if (g < 5 && !(a.ablate & 16)) LOAD_FRAGS(g + 1, cur ^ 1);
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this group's MFMAs (distinct registers)
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
         __builtin_amdgcn_sched_barrier(0);
       }
 #undef LOAD_FRAGS
-      __syncthreads();  // all waves done with A / B[buf]; the DMA into B[buf^1] has landed (vmcnt(0) before the barrier)
+      if (!(a.ablate & 32)) __syncthreads();  // all waves done with A / B[buf]; the DMA into B[buf^1] has landed (vmcnt(0) before the barrier)
       if (nextA) {
 #pragma unroll
         for (int m = 0; m < 6; ++m)
