@@ -1,0 +1,74 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on
+MI355X, "gloo" in the CPU tests).  The forward path shards sequences across ranks with NO data-path
+collective (each sequence's KV memory stays on its owner); the only collectives are the timing reduction
+used by bench.py and -- once the BC step exists -- the gradient all-reduce below."""
+import os
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str = "nccl"):
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun)."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver
+    if not dist.is_initialized():
+        dist.init_process_group(backend)
+    return dist.get_rank(), dist.get_world_size()
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [begin, end) slice of `n_items` sequences owned by `rank` (sizes differ by at most 1)."""
+    base, rem = divmod(n_items, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def shard_batch(obs_img: torch.Tensor, first: torch.Tensor, rank: int, world: int):
+    """Slice a [B, T, ...] batch of frame sequences (and its `first` flags) for this rank."""
+    b, e = shard_range(obs_img.shape[0], rank, world)
+    return obs_img[b:e], first[b:e]
+
+
+def max_over_ranks(value: float, device="cpu") -> float:
+    """bench.py's timing rule: the job is as slow as its slowest rank."""
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def bucketed_all_reduce_(tensors: Sequence[torch.Tensor], bucket_bytes: int = 64 << 20, average: bool = True) -> int:
+    """Sum (or average) `tensors` in place across ranks in flat buckets of ~bucket_bytes: the gradient
+    exchange of the data-parallel BC step (994 MB fp32 for the 2x model).  Returns the number
+    of collectives issued.  64 MB buckets keep each of the 7 xGMI links busy without serialising behind one
+    giant tensor; the reduce is asynchronous per bucket and waited at the end."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    world = dist.get_world_size()
+    buckets: List[List[torch.Tensor]] = [[]]
+    size = 0
+    for t in tensors:
+        nbytes = t.numel() * t.element_size()
+        if size and size + nbytes > bucket_bytes:
+            buckets.append([])
+            size = 0
+        buckets[-1].append(t)
+        size += nbytes
+    works = []
+    for bucket in buckets:
+        if not bucket:
+            continue
+        flat = torch.cat([t.reshape(-1) for t in bucket])
+        works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, bucket))
+    for work, flat, bucket in works:
+        work.wait()
+        if average:
+            flat.div_(world)
+        off = 0
+        for t in bucket:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+    return len(works)
