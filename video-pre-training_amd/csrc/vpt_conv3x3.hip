@@ -42,6 +42,7 @@
 // 4..11 so that each 16-lane ds_read_b128 group {0-3,12-15,20-27} / {4-11,16-19,28-31} stays in one image row.
 __device__ __forceinline__ int sub_row(int i) { return ((i >> 4) ^ (i >> 2) ^ (i >> 3)) & 1; }
 
+template <bool COUNTED>
 __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -49,6 +50,13 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   const int wm = w >> 1, wn = w & 1;
   const int hi = lane >> 5, l31 = lane & 31;
 
+  // De-phase the two workgroups that share a CU: the second wave of resident workgroups (blocks 256..511 with
+  // 2 per CU on 256 CUs) starts half a tile later, and every later workgroup inherits the phase of the slot it
+  // fills -- so one half of the chip is in its HBM-bound prologue/epilogue while the other half issues MFMAs.
+  if (a.stagger_ticks > 0 && blockIdx.x >= a.stagger_first && blockIdx.x < 2 * a.stagger_first) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < a.stagger_ticks) __builtin_amdgcn_s_sleep(64);
+  }
   const int tilesX = a.W >> 4, tilesY = a.H >> 4;
   int L = xcd_remap(blockIdx.x, gridDim.x);
   const int nt = L % a.NT; L /= a.NT;
@@ -77,6 +85,9 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     }
   }
   const bf16_t* xplane = a.x + (size_t)f * NCB * HW * 32;
+  unsigned a_gbyte[6];  // clamped byte offset inside one channel block (32-bit: scalar base + vector offset loads)
+#pragma unroll
+  for (int m = 0; m < 6; ++m) a_gbyte[m] = (a_goff[m] >= 0) ? (unsigned)a_goff[m] * 2u : 0u;
   // weight DMA: wave w moves pieces (4*m + w), m = 0..5, of the 24 KB step tile; lane = 16-byte chunk
   const bf16_t* wbase = a.wpk + (size_t)nt * NCB * 9 * 4096 + (size_t)(w * 64 + lane) * 8;
   unsigned char* bdst = smem + A_BYTES + w * 1024;
@@ -96,19 +107,28 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   // ---- prologue: weights of step 0 (DMA), halo of channel block 0, epilogue constant table ----
   ISSUE_B(0, 0);
 #pragma unroll
-  for (int m = 0; m < 6; ++m) areg[m] = (a_goff[m] >= 0) ? *(const u32x4*)(xplane + a_goff[m]) : zero4;
+  for (int m = 0; m < 6; ++m) areg[m] = *(const u32x4*)((const char*)xplane + a_gbyte[m]);
   float mean, rstd;
   frame_mean_rstd(a.stats_in, f, a.inv_count_in, mean, rstd);
   {
     float* kk = (float*)(smem + KK_OFF);
-    for (int idx = tid; idx < 9 * 128; idx += 256) {
-      const int e = idx >> 7, o = nt * 128 + (idx & 127);
-      kk[idx] = a.edge_sa[e * a.CoutPad + o] - rstd * mean * a.edge_sg[e * a.CoutPad + o];
+    float ksa[5], ksg[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {  // 9*128 = 4.5 * 256 entries: all ten loads in flight together
+      const int idx = tid + 256 * k;
+      const int o = (idx >> 7) * a.CoutPad + nt * 128 + (idx & 127);
+      ksa[k] = (idx < 9 * 128) ? a.edge_sa[o] : 0.f;
+      ksg[k] = (idx < 9 * 128) ? a.edge_sg[o] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int idx = tid + 256 * k;
+      if (idx < 9 * 128) kk[idx] = ksa[k] - rstd * mean * ksg[k];
     }
   }
 #pragma unroll
   for (int m = 0; m < 6; ++m)
-    if (a_loff[m] >= 0) *(u32x4*)(smem + a_loff[m]) = areg[m];
+    if (a_loff[m] >= 0) *(u32x4*)(smem + a_loff[m]) = (a_goff[m] >= 0) ? areg[m] : zero4;
   __syncthreads();
 
   f32x16 acc[4][2];
@@ -125,59 +145,91 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   const unsigned char* bL0 = smem + A_BYTES + (wn * 64 + l31) * 64 + (((0 + hi) ^ bsw) << 4);  // ks = 0
   const unsigned char* bL1 = smem + A_BYTES + (wn * 64 + l31) * 64 + (((2 + hi) ^ bsw) << 4);  // ks = 1
 
-  const int ncb_run = (a.ablate == 2) ? 0 : NCB;  // profiling: ablate bit 2 (4) = no weight DMA in the loop, bit 3 (8) = no halo reloads
-  for (int cb = 0; cb < ncb_run; ++cb) {
+  // epilogue addressing (needed early: the residual is requested at the start of the last channel block)
+  const int CB_out = a.Cout >> 5;
+  const int cb0 = nt * 4 + wn * 2;                 // 32-channel block of n2 = 0
+  const bool nvalid[2] = {(cb0 + 0) < CB_out, (cb0 + 1) < CB_out};
+  const size_t nstep = (size_t)HW * 32;            // next 32-channel block
+  size_t poff[4];
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      const int s = cb * 3 + dy;
-      const int buf = s & 1;
-      const bool more = (s + 1 < nsteps) && !(a.ablate & 4);
-      const bool nextA = (dy == 2) && (cb + 1 < NCB);
-      if (more) ISSUE_B(s + 1, buf ^ 1);
-      // halo of the next channel block: issued three steps (one whole block) ahead of its ds_write so that the
-      // HBM latency is covered by ~150 MFMAs per wave; the registers are free now that B is DMA'd
-      if ((dy == 0) && (cb + 1 < NCB) && !(a.ablate & 8)) {
-        const bf16_t* xp = xplane + (size_t)(cb + 1) * HW * 32;
-#pragma unroll
-        for (int m = 0; m < 6; ++m) areg[m] = (a_goff[m] >= 0) ? *(const u32x4*)(xp + a_goff[m]) : zero4;
-      }
-      // ---- 3 taps x 2 k16-steps x (4x2) MFMA, software-pipelined: the six fragments of group g+1 are read
-      //      from LDS while the eight MFMAs of group g issue (the compiler otherwise reuses one fragment
-      //      register set and exposes the ds_read latency before every pair of MFMAs) ----
-      const unsigned char* bB0 = bL0 + buf * B_BYTES;
-      const unsigned char* bB1 = bL1 + buf * B_BYTES;
-      bf16x8 fa[2][4], fb[2][2];
-#define LOAD_FRAGS(g_, slot_)                                                                             \
-  do {                                                                                                    \
-    const int dx_ = (g_) >> 1, ks_ = (g_) & 1;                                                            \
-    _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                                      \
-      fa[slot_][m_] = *(const bf16x8*)(aL + (dy * 18 + dx_) * A_RS + m_ * (2 * 18 * A_RS) + ks_ * 32);   \
-    _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_)                                                      \
-      fb[slot_][n_] = *(const bf16x8*)((ks_ ? bB1 : bB0) + dx_ * (128 * 64) + n_ * (32 * 64));            \
-  } while (0)
-      LOAD_FRAGS(0, 0);
-#pragma unroll
-      for (int g = 0; g < 6; ++g) {
-        const int cur = g & 1;
-        if (g < 5 && !(a.ablate & 16)) LOAD_FRAGS(g + 1, cur ^ 1);
-        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this group's MFMAs (distinct registers)
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-          for (int n = 0; n < 2; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][n], fa[cur][m], acc[m][n], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#undef LOAD_FRAGS
-      if (!(a.ablate & 32)) __syncthreads();  // all waves done with A / B[buf]; the DMA into B[buf^1] has landed (vmcnt(0) before the barrier)
-      if (nextA) {
-#pragma unroll
-        for (int m = 0; m < 6; ++m)
-          if (a_loff[m] >= 0) *(u32x4*)(smem + a_loff[m]) = areg[m];
-        __syncthreads();
-      }
-    }
+  for (int m = 0; m < 4; ++m) {
+    const int y = ty0 + wm * 8 + 2 * m + sub_row(l31);
+    const int x = tx0 + (l31 & 15);
+    // (waves whose channel blocks lie beyond Cout in a padded N tile use block 0 for the -- ignored -- loads)
+    poff[m] = ((size_t)(f * CB_out + (nvalid[0] ? cb0 : 0)) * HW + (size_t)(y * a.W + x)) * 32 + 4 * hi;
   }
+  u32x2 rr[4][2][4];
+
+  // One K step = one kernel row (3 taps) of one 32-channel block: 48 MFMAs per wave, one barrier.
+  // Memory ops are issued in a FIXED order and count per wave -- weight DMA (6), then either the halo of the
+  // next block (6, PRE_A) or the residual (32, PRE_R) -- so the wait before the barrier can be COUNTED:
+  // vmcnt(N_LATE) retires this step's weight DMA (needed by the next step) while the N_LATE younger loads stay
+  // in flight across the barrier and get a second step of MFMAs as cover (a plain __syncthreads() drains
+  // vmcnt to 0 at every barrier because an LDS-DMA is pending).  Every load is unconditional (clamped address
+  // + select) so that the count is exact.
+#define WAIT_BARRIER(n_late_)                                                                             \
+  do {                                                                                                    \
+    if constexpr (COUNTED) {                                                                              \
+      asm volatile("s_waitcnt vmcnt(" #n_late_ ") lgkmcnt(0)" ::: "memory");                              \
+      __builtin_amdgcn_s_barrier();                                                                       \
+      asm volatile("" ::: "memory");                                                                      \
+    } else {                                                                                              \
+      __syncthreads();                                                                                    \
+    }                                                                                                     \
+  } while (0)
+#define CONV_STEP(cb_, dy_, PRE_A, WR_A, PRE_R)                                                           \
+  do {                                                                                                    \
+    const int s_ = (cb_) * 3 + (dy_);                                                                     \
+    const int buf_ = s_ & 1;                                                                              \
+    if (s_ + 1 < nsteps) ISSUE_B(s_ + 1, buf_ ^ 1);                                                       \
+    if (PRE_A) {                                                                                          \
+      const unsigned cbo_ = (unsigned)((cb_) + 1) * (unsigned)HW * 64u; /* bytes; uniform */              \
+      _Pragma("unroll") for (int m_ = 0; m_ < 6; ++m_)                                                    \
+        areg[m_] = *(const u32x4*)((const char*)xplane + (cbo_ + a_gbyte[m_]));                           \
+    }                                                                                                     \
+    if ((PRE_R) && a.res) {                                                                               \
+      _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                                    \
+        _Pragma("unroll") for (int n2_ = 0; n2_ < 2; ++n2_)                                               \
+          _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                                \
+            rr[m_][n2_][g_] = *(const u32x2*)(a.res + poff[m_] + (nvalid[n2_] ? n2_ : 0) * nstep + 8 * g_); \
+    }                                                                                                     \
+    const unsigned char* bB0_ = bL0 + buf_ * B_BYTES;                                                     \
+    const unsigned char* bB1_ = bL1 + buf_ * B_BYTES;                                                     \
+    _Pragma("unroll") for (int dx_ = 0; dx_ < 3; ++dx_) {                                                 \
+      _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                               \
+        bf16x8 fa_[4], fb_[2];                                                                            \
+        _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                                  \
+          fa_[m_] = *(const bf16x8*)(aL + ((dy_) * 18 + dx_) * A_RS + m_ * (2 * 18 * A_RS) + ks_ * 32);   \
+        _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_)                                                  \
+          fb_[n_] = *(const bf16x8*)((ks_ ? bB1_ : bB0_) + dx_ * (128 * 64) + n_ * (32 * 64));            \
+        _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                                  \
+          _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_)                                                \
+            acc[m_][n_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb_[n_], fa_[m_], acc[m_][n_], 0, 0, 0); \
+      }                                                                                                   \
+    }                                                                                                     \
+    /* all waves done with the halo / B[buf]; this step's DMA into B[buf^1] has landed */                 \
+    if (PRE_A) WAIT_BARRIER(6); else if ((PRE_R) && a.res) WAIT_BARRIER(32); else WAIT_BARRIER(0);        \
+    if (WR_A) {                                                                                           \
+      _Pragma("unroll") for (int m_ = 0; m_ < 6; ++m_)                                                    \
+        if (a_loff[m_] >= 0) *(u32x4*)(smem + a_loff[m_]) = (a_goff[m_] >= 0) ? areg[m_] : zero4;         \
+      WAIT_BARRIER(0);                                                                                    \
+    }                                                                                                     \
+  } while (0)
+
+  if (a.ablate != 2) {
+    for (int cb = 0; cb + 1 < NCB; ++cb) {
+      CONV_STEP(cb, 0, true, false, false);
+      CONV_STEP(cb, 1, false, false, false);
+      CONV_STEP(cb, 2, false, true, false);
+    }
+    // last channel block: no further halo -> request the residual instead, two steps ahead of its use
+    CONV_STEP(NCB - 1, 0, false, false, true);
+    CONV_STEP(NCB - 1, 1, false, false, false);
+    CONV_STEP(NCB - 1, 2, false, false, false);
+  }
+#undef CONV_STEP
+#undef WAIT_BARRIER
+
 
   // ---------------- epilogue ----------------
   if (a.ablate == 1) {  // profiling: keep the accumulators live, skip the epilogue
@@ -196,11 +248,6 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   // (column l31 of the subtile) and, per accumulator, four groups of 4 consecutive output channels
   // (rows (r&3) + 8*(r>>2) + 4*hi): the epilogue is lane-local -- 16-byte reads of the constant table,
   // 8-byte residual loads and 8-byte bf16 stores straight from the accumulator layout, no LDS round trip.
-  const int CB_out = a.Cout >> 5;
-  const int cb0 = nt * 4 + wn * 2;                 // 32-channel block of n2 = 0
-  const bool nvalid[2] = {(cb0 + 0) < CB_out, (cb0 + 1) < CB_out};
-  // per M-subtile: this lane's pixel, its element offset in block cb0, and its edge-class row of the table
-  size_t poff[4];
   int eoff[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
@@ -209,23 +256,12 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     const int ey = (y == 0) ? 0 : ((y == a.H - 1) ? 2 : 1);
     const int ex = (x == 0) ? 0 : ((x == a.W - 1) ? 2 : 1);
     eoff[m] = (ey * 3 + ex) * 128 + wn * 64 + 4 * hi;
-    poff[m] = ((size_t)(f * CB_out + cb0) * HW + (size_t)(y * a.W + x)) * 32 + 4 * hi;
   }
-  const size_t nstep = (size_t)HW * 32;            // next 32-channel block
   const float* kk = (const float*)(smem + KK_OFF);
   float s_sum = 0.f, s_sq = 0.f;
 
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
-    // residual for this subtile: 8 x 8-byte loads in flight before the first use
-    u32x2 rr[2][4];
-    if (a.res) {
-#pragma unroll
-      for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          rr[n2][g] = nvalid[n2] ? *(const u32x2*)(a.res + poff[m] + n2 * nstep + 8 * g) : (u32x2){0u, 0u};
-    }
 #pragma unroll
     for (int n2 = 0; n2 < 2; ++n2) {
       if (!nvalid[n2]) continue;
@@ -237,8 +273,8 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
         float v2 = fmaxf(fmaf(rstd, acc[m][n2][4 * g + 2], k4.z), 0.f);
         float v3 = fmaxf(fmaf(rstd, acc[m][n2][4 * g + 3], k4.w), 0.f);
         if (a.res) {
-          v0 += bf16_lo_to_f32(rr[n2][g].x); v1 += bf16_hi_to_f32(rr[n2][g].x);
-          v2 += bf16_lo_to_f32(rr[n2][g].y); v3 += bf16_hi_to_f32(rr[n2][g].y);
+          v0 += bf16_lo_to_f32(rr[m][n2][g].x); v1 += bf16_hi_to_f32(rr[m][n2][g].x);
+          v2 += bf16_lo_to_f32(rr[m][n2][g].y); v3 += bf16_hi_to_f32(rr[m][n2][g].y);
         }
         s_sum += (v0 + v1) + (v2 + v3);
         s_sq = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, fmaf(v3, v3, s_sq))));
@@ -261,14 +297,30 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
 }
 
 extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream) {
-  static int ablate = -1;
-  if (ablate < 0) { const char* e = getenv("VPT_CONV_ABLATE"); ablate = e ? atoi(e) : 0; }
+  static int ablate = -1, stagger_pct = 0, num_cu = 256;
+  if (ablate < 0) {
+    const char* e = getenv("VPT_CONV_ABLATE");
+    ablate = e ? atoi(e) : 0;
+    const char* g = getenv("VPT_CONV_STAGGER_PCT");  // start delay of the 2nd resident workgroup, % of the tile's MFMA time
+    stagger_pct = g ? atoi(g) : 0;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      num_cu = prop.multiProcessorCount;
+  }
   VptConv3x3Args a_copy = *a_in;
   a_copy.ablate = ablate;
+  // one tile = (Cin/32)*3 steps of 48 MFMAs/wave, two waves per SIMD: ~ nsteps * 3072 cycles at ~2 GHz;
+  // wall_clock64 ticks at 100 MHz
+  a_copy.stagger_first = num_cu;
+  a_copy.stagger_ticks = (int)((long)(a_in->Cin / 32) * 3 * 3072 / 20 * stagger_pct / 100);
   const VptConv3x3Args* a = &a_copy;
   if ((a->H & 15) || (a->W & 15) || (a->Cin & 31) || (a->Cout & 31) || a->frames <= 0) return -1;
   const long grid = (long)a->frames * (a->H >> 4) * (a->W >> 4) * a->NT;
   if (grid > 0x7fffffffL) return -2;
-  hipLaunchKernelGGL(vpt_conv3x3_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *a);
+  static int counted = -1;
+  if (counted < 0) { const char* e = getenv("VPT_CONV_COUNTED"); counted = e ? atoi(e) : 0; }
+  if (counted) hipLaunchKernelGGL(vpt_conv3x3_kernel<true>, dim3((unsigned)grid), dim3(256), 0, stream, *a);
+  else hipLaunchKernelGGL(vpt_conv3x3_kernel<false>, dim3((unsigned)grid), dim3(256), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

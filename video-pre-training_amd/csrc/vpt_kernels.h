@@ -17,7 +17,8 @@ struct VptConv3x3Args {
   double* stats_out;       // optional [F][2], accumulated (caller zeroes)
   int frames, H, W, Cin, Cout, CoutPad, NT;
   double inv_count_in;     // 1 / (Cin*H*W)
-  int ablate;              // profiling only (env VPT_CONV_ABLATE): 1 = skip epilogue math/stores, 2 = skip main loop
+  int ablate;              // profiling only (env VPT_CONV_ABLATE)
+  int stagger_first, stagger_ticks;  // de-phasing of co-resident workgroups (set by the launcher)
 };
 
 struct VptConvFirstArgs {
