@@ -35,6 +35,14 @@ const char* vpt_last_error(void);
 int vpt_conv_first_forward(const uint8_t* img, const void* wfrag, void* y, double* stats_out,
                            int frames, int H, int W, int Cout, void* stream);
 
+/* IDM temporal conv + ingest + bias + ReLU.
+ * Replaces ImgPreprocessing.forward (lib/policy.py:39-45) and InverseActionNet._conv3d_forward
+ * (lib/policy.py:394-403: Conv3d(3->Cout, kernel (5,1,1), padding (2,0,0)) over time, then ReLU).
+ * img: uint8 [frames = B*T][H][W][3]; wfrag: bf16 [NT][4][64][8]; bias fp32 [NT*128];
+ * y: blocked [frames][Cout/32][H][W][32]; stats_out (optional) receives the statistics of y. */
+int vpt_conv3d_t5_forward(const uint8_t* img, const void* wfrag, const float* bias, void* y, double* stats_out,
+                          int frames, int T, int H, int W, int Cout, void* stream);
+
 /* GroupNorm(1,Cin) -> Conv2d(3x3, pad 1, no bias) -> ReLU [-> + residual].
  * Replaces FanInInitReLULayer.forward (lib/util.py:75-82) for conv layers and the residual add of
  * CnnBasicBlock.forward (lib/impala_cnn.py:50-52).  x, res, y blocked bf16; wpk bf16 [NT][Cin/32][9][128][32];
@@ -66,13 +74,15 @@ int vpt_linear_forward(const void* A, const void* wpk, const float* bias, const 
 int vpt_layernorm_forward(const float* x, const float* gain, const float* bias, float* out_f32, void* out_bf16,
                           int M, int D, int relu_in, void* stream);
 
-/* Banded-causal attention with KV memory and relative-position bias: attention() (lib/xf.py:18-71) as driven
- * by MaskedAttention.forward (lib/masked_attention.py:161-178).  qkvr fp32 [B*t][ld] = Q | K | V | R columns;
- * kmem/vmem fp32 [B][maxlen][hid]; memvalid uint8 [B][maxlen] (= state_mask & !first[:,0]); b_nd fp32
- * [10][maxlen]; out bf16 [B*t][hid] (heads merged, lib/xf.py:125-131). */
+/* Attention of MaskedAttention.forward (lib/masked_attention.py:161-178) over attention() (lib/xf.py:18-71).
+ * causal = 1 ("clipped_causal"): banded-causal with KV memory and relative-position bias; qkvr fp32 [B*t][ld] =
+ * Q | K | V | R columns; kmem/vmem fp32 [B][maxlen][hid]; memvalid uint8 [B][maxlen] (= state_mask &
+ * !first[:,0]); b_nd fp32 [10][maxlen].  causal = 0 (mask "none", the IDM): maxlen must be 0 (no memory; the
+ * rel-pos bias is identically zero, lib/util.py:256-260), every query attends to all t <= 160 rows of its
+ * chunk; kmem/vmem/memvalid/b_nd are ignored.  out bf16 [B*t][hid] (heads merged, lib/xf.py:125-131). */
 int vpt_masked_attention_forward(const float* qkvr, const float* kmem, const float* vmem, const uint8_t* memvalid,
                                  const float* b_nd, void* out, int B, int t, int heads, int hid, int ld,
-                                 int maxlen, void* stream);
+                                 int maxlen, int causal, void* stream);
 
 /* SelfAttentionLayer.update_state (lib/xf.py:366-391): kout/vout = last maxlen rows of [memory ; new]. */
 int vpt_kv_memory_update(const float* qkvr, const float* kmem, const float* vmem, float* kout, float* vout,

@@ -394,3 +394,124 @@ def policy_kwargs_for(name: str) -> dict:
     )
     base.update(MODEL_CONFIGS[name])
     return base
+
+
+# ----------------------------------------------------------------------------------------------
+# inverse dynamics model (IDM)  --  lib/policy.py:342-467
+# ----------------------------------------------------------------------------------------------
+def idm_config_from_kwargs(idm_net_kwargs: dict, pi_head_kwargs: Optional[dict] = None) -> dict:
+    cfg = config_from_policy_kwargs(idm_net_kwargs, pi_head_kwargs)
+    cfg["conv3d"] = idm_net_kwargs.get("conv3d_params")
+    cfg["first_conv_norm"] = cfg["conv3d"] is not None  # lib/policy.py:360-363
+    cfg["use_pre_lstm_ln"] = idm_net_kwargs.get("use_pre_lstm_ln", True)
+    return cfg
+
+
+def idm_kwargs_for(name: str = "4x") -> dict:
+    """Constructor kwargs of the released IDM as recalled in SURVEY.md §8a ([unverified]: no .model file is
+    available); `tiny` keeps the structure at sizes a CPU can run for golden vectors."""
+    base = dict(
+        attention_heads=32, attention_mask_style="none", attention_memory_size=128,
+        conv3d_params=dict(inchan=3, outchan=128, kernel_size=[5, 1, 1], padding=[2, 0, 0]),
+        hidsize=4096, img_shape=[128, 128, 128], impala_chans=[16, 32, 32], impala_kwargs={"post_pool_groups": 1},
+        impala_width=16, init_norm_kwargs={"batch_norm": False, "group_norm_groups": 1}, n_recurrence_layers=2,
+        only_img_input=True, pointwise_ratio=4, pointwise_use_activation=False, recurrence_is_residual=True,
+        recurrence_type="transformer", single_output=True, timesteps=128, use_pointwise_layer=True,
+        use_pre_lstm_ln=False,
+    )
+    if name == "tiny":
+        base.update(hidsize=512, attention_heads=4, impala_width=2)
+    return base
+
+
+def idm_state_dict_spec(cfg: dict, n_buttons=20, n_camera_bins=11):
+    spec = [("net.conv3d_layer.layer.weight", (cfg["conv3d"]["outchan"], cfg["conv3d"]["inchan"], 5, 1, 1), "conv3d"),
+            ("net.conv3d_layer.layer.bias", (cfg["conv3d"]["outchan"],), "bias")]
+    cin = cfg["conv3d"]["outchan"]
+    for s, c in enumerate(cfg["chans"]):
+        p = f"net.img_process.cnn.stacks.{s}."
+        spec += [(p + "firstconv.norm.weight", (cin,), "gain"), (p + "firstconv.norm.bias", (cin,), "bias"),
+                 (p + "firstconv.layer.weight", (c, cin, 3, 3), "conv")]
+        spec += [(p + "n.weight", (c,), "gain"), (p + "n.bias", (c,), "bias")]
+        for b in range(2):
+            for cv in range(2):
+                q = f"{p}blocks.{b}.conv{cv}."
+                spec += [(q + "norm.weight", (c,), "gain"), (q + "norm.bias", (c,), "bias"), (q + "layer.weight", (c, c, 3, 3), "conv")]
+        cin = c
+    policy_like = [e for e in state_dict_spec(dict(cfg, first_conv_norm=True)) if not e[0].startswith("net.img_process.cnn.stacks.")
+                   and not e[0].startswith("value_head.") and not e[0].startswith("pi_head.")]
+    spec += policy_like
+    hid = cfg["hidsize"]
+    spec += [("pi_head.buttons.linear_layer.weight", (n_buttons * 2, hid), "lin"), ("pi_head.buttons.linear_layer.bias", (n_buttons * 2,), "bias"),
+             ("pi_head.camera.linear_layer.weight", (2 * n_camera_bins, hid), "lin"), ("pi_head.camera.linear_layer.bias", (2 * n_camera_bins,), "bias")]
+    return spec
+
+
+def idm_synthetic_state_dict(cfg: dict, seed: int = 0):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for key, shape, kind in idm_state_dict_spec(cfg):
+        if kind == "conv":
+            w = torch.randn(shape, generator=g) * (1.6 / math.sqrt(shape[1] * 9))
+        elif kind == "conv3d":
+            w = torch.randn(shape, generator=g) * (1.6 / math.sqrt(shape[1] * 5))
+        elif kind == "lin":
+            w = torch.randn(shape, generator=g) * ((0.3 if "pi_head" in key else 1.0) * 1.3 / math.sqrt(shape[1]))
+        elif kind == "gain":
+            w = 1.0 + 0.2 * torch.randn(shape, generator=g)
+        elif kind == "bias":
+            w = 0.1 * torch.randn(shape, generator=g)
+        elif kind == "bnd":
+            w = 0.2 * torch.randn(shape, generator=g)
+        else:
+            raise ValueError(kind)
+        sd[key] = w.float()
+    return sd
+
+
+def conv3d_temporal(sd, x_bthwc):
+    """InverseActionNet._conv3d_forward (lib/policy.py:394-403): Conv3d(C->O, kernel (5,1,1), pad (2,0,0)) over
+    time + ReLU (FanInInitReLULayer without norm => bias).  x [B,T,H,W,C] fp32 -> [B,T,H,W,O]."""
+    w = sd["net.conv3d_layer.layer.weight"]  # [O,C,5,1,1]
+    b = sd["net.conv3d_layer.layer.bias"]
+    x = x_bthwc.permute(0, 4, 1, 2, 3)  # b c t h w
+    y = torch.relu(F.conv3d(x, w, b, padding=(2, 0, 0)))
+    return y.permute(0, 2, 3, 4, 1)
+
+
+def idm_forward(sd, cfg, img_u8, taps: Optional[dict] = None):
+    """InverseActionPolicy.forward (lib/policy.py:432-446) -> InverseActionNet.forward (lib/policy.py:374-392):
+    /255 -> temporal Conv3d -> ImpalaCNN (first conv normed) -> linear -> transformer blocks with mask "none"
+    and no memory (maxlen 0: rel-pos bias is identically zero, lib/util.py:256-260) -> ReLU -> final_ln
+    (`lastlayer` is computed and DISCARDED by the reference, lib/policy.py:390-391) -> heads.
+    Returns dict(buttons [B,T,20,2], camera [B,T,2,11]) of log-probabilities."""
+    with torch.no_grad():
+        b, t = img_u8.shape[:2]
+        x = img_u8.to(torch.float32) / 255.0
+        x = conv3d_temporal(sd, x)
+        if taps is not None:
+            taps["conv3d"] = x
+        x = impala_cnn(sd, "net.img_process.cnn.", x.reshape(b * t, *x.shape[2:]), taps)
+        p = "net.img_process.linear."
+        x = torch.relu(layer_norm(x, sd[p + "norm.weight"], sd[p + "norm.bias"]) @ sd[p + "layer.weight"].t())
+        x = x.reshape(b, t, -1)
+        hid, heads = cfg["hidsize"], cfg["heads"]
+        for l in range(cfg["n_layers"]):
+            pfx = f"net.recurrent_layer.blocks.{l}."
+            o = pfx + "r.orc_block."
+            x1 = layer_norm(x, sd[pfx + "pre_r_ln.weight"], sd[pfx + "pre_r_ln.bias"])
+            q = x1 @ sd[o + "q_layer.weight"].t() + sd[o + "q_layer.bias"]
+            k = x1 @ sd[o + "k_layer.weight"].t()
+            v = x1 @ sd[o + "v_layer.weight"].t()
+            sp = lambda z: z.reshape(b, t, heads, hid // heads).permute(0, 2, 1, 3)
+            w_ = torch.softmax(torch.matmul(sp(q), sp(k).transpose(-1, -2)) * (1.0 / (hid // heads)), dim=-1)
+            a = torch.matmul(w_, sp(v)).permute(0, 2, 1, 3).reshape(b, t, hid)
+            x2 = x1 + a @ sd[o + "proj_layer.weight"].t() + sd[o + "proj_layer.bias"]
+            h = torch.relu(layer_norm(x2, sd[pfx + "mlp0.norm.weight"], sd[pfx + "mlp0.norm.bias"]) @ sd[pfx + "mlp0.layer.weight"].t())
+            x = x2 + h @ sd[pfx + "mlp1.layer.weight"].t() + sd[pfx + "mlp1.layer.bias"]
+        x = torch.relu(x)
+        x = layer_norm(x, sd["net.final_ln.weight"], sd["net.final_ln.bias"])
+        temp = cfg["temperature"]
+        zb = (x @ sd["pi_head.buttons.linear_layer.weight"].t() + sd["pi_head.buttons.linear_layer.bias"]).reshape(b, t, -1, 2)
+        zc = (x @ sd["pi_head.camera.linear_layer.weight"].t() + sd["pi_head.camera.linear_layer.bias"]).reshape(b, t, 2, -1)
+        return dict(buttons=torch.log_softmax(zb / temp, -1), camera=torch.log_softmax(zc / temp, -1), latent=x)

@@ -185,3 +185,35 @@ def test_log_softmax_cols():
         torch.cuda.synchronize()
         ref = torch.log_softmax(z[:, col0:col0 + n] / 2.0, -1)
         assert (out.cpu() - ref).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("bsz,t,cout", [(1, 7, 128), (2, 3, 64)])
+def test_conv3d_temporal(bsz, t, cout):
+    g = torch.Generator().manual_seed(8)
+    W = torch.randn(cout, 3, 5, 1, 1, generator=g) * 0.4
+    b = 0.1 * torch.randn(cout, generator=g)
+    img = torch.randint(0, 256, (bsz, t, 128, 128, 3), generator=g, dtype=torch.uint8)
+    sd = {"net.conv3d_layer.layer.weight": W, "net.conv3d_layer.layer.bias": b}
+    ref = O.conv3d_temporal(sd, img.float() / 255.0).reshape(bsz * t, 128, 128, cout).permute(0, 3, 1, 2)
+    wfrag, bp = packing.pack_conv3d_t5(W.to(DEV), b.to(DEV))
+    st = torch.zeros(bsz * t, 2, dtype=torch.float64, device=DEV)
+    y = ops.conv3d_t5(img.reshape(bsz * t, 128, 128, 3).to(DEV), wfrag, bp, cout, t, stats_out=st)
+    torch.cuda.synchronize()
+    out = packing.blocked_to_nchw(y.cpu(), cout, 128, 128)
+    err = _relerr(out, ref)
+    assert err < 1.5e-2, f"conv3d rel err {err}"
+    assert torch.allclose(st.cpu(), _stats_of(out), rtol=1e-4, atol=1e-1)
+
+
+@pytest.mark.parametrize("bsz,t,heads", [(1, 128, 2), (2, 12, 2)])
+def test_full_attention(bsz, t, heads):
+    g = torch.Generator().manual_seed(9)
+    hid = heads * 128
+    qkv = torch.randn(bsz * t, 3 * hid, generator=g)
+    qkv[:, :hid] *= 3.0
+    sp = lambda z: z.reshape(bsz, t, heads, 128).permute(0, 2, 1, 3)
+    q, k, v = sp(qkv[:, :hid]), sp(qkv[:, hid:2 * hid]), sp(qkv[:, 2 * hid:])
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / 128.0, -1) @ v).permute(0, 2, 1, 3).reshape(bsz * t, hid)
+    out = ops.full_attention(qkv.to(DEV), bsz, t, heads, hid)
+    torch.cuda.synchronize()
+    assert (out.cpu().float() - ref).abs().max() < 2e-2

@@ -84,3 +84,21 @@ def test_chunked_equals_one_pass():
         st = o["state_out"]
         outs.append(o["buttons"])
     np.testing.assert_allclose(torch.cat(outs, 1).numpy(), one["buttons"].numpy(), atol=1e-4)
+
+
+def test_idm_matches_reference():
+    """Inverse dynamics model (lib/policy.py:342-467) on the `tiny` structure-preserving config."""
+    import os
+    G = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "idm_tiny_seed0.npz")))
+    kw = O.idm_kwargs_for("tiny")
+    cfg = O.idm_config_from_kwargs(kw, dict(temperature=2.0))
+    sd = O.idm_synthetic_state_dict(cfg, seed=0)
+    g = torch.Generator().manual_seed(42)
+    img = torch.randint(0, 256, (1, 12, 128, 128, 3), generator=g, dtype=torch.uint8)
+    out = O.idm_forward(sd, cfg, img)
+    np.testing.assert_allclose(out["buttons"].numpy(), G["buttons"], atol=1e-4)
+    np.testing.assert_allclose(out["camera"].numpy(), G["camera"], atol=1e-4)
+    assert np.array_equal(out["buttons"].argmax(-1).numpy(), G["ac_buttons"])
+    assert np.array_equal(out["camera"].argmax(-1).numpy(), G["ac_camera"])
+    lp = out["buttons"].max(-1).values.sum(-1) + out["camera"].max(-1).values.sum(-1)
+    np.testing.assert_allclose(lp.numpy(), G["log_prob"], atol=1e-3)

@@ -24,6 +24,14 @@ int vpt_conv_first_forward(const uint8_t* img, const void* wfrag, void* y, doubl
   CHECK_LAUNCH(vpt_conv_first_launch(&a, (hipStream_t)stream), "vpt_conv_first_forward");
 }
 
+int vpt_conv3d_t5_forward(const uint8_t* img, const void* wfrag, const float* bias, void* y, double* stats_out,
+                          int frames, int T, int H, int W, int Cout, void* stream) {
+  VptConv3dArgs a;
+  a.img = img; a.wfrag = (const vpt_bf16*)wfrag; a.bias = bias; a.y = (vpt_bf16*)y; a.stats_out = stats_out;
+  a.frames = frames; a.T = T; a.H = H; a.W = W; a.Cout = Cout; a.NT = (Cout + 127) / 128;
+  CHECK_LAUNCH(vpt_conv3d_launch(&a, (hipStream_t)stream), "vpt_conv3d_t5_forward");
+}
+
 int vpt_conv3x3_forward(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg,
                         const double* stats_in, const void* res, void* y, double* stats_out,
                         int frames, int H, int W, int Cin, int Cout, void* stream) {
@@ -78,10 +86,10 @@ int vpt_layernorm_forward(const float* x, const float* gain, const float* bias, 
 
 int vpt_masked_attention_forward(const float* qkvr, const float* kmem, const float* vmem, const uint8_t* memvalid,
                                  const float* b_nd, void* out, int B, int t, int heads, int hid, int ld,
-                                 int maxlen, void* stream) {
+                                 int maxlen, int causal, void* stream) {
   VptAttnArgs a;
   a.qkvr = qkvr; a.kmem = kmem; a.vmem = vmem; a.memvalid = memvalid; a.b_nd = b_nd; a.out = (vpt_bf16*)out;
-  a.B = B; a.t = t; a.heads = heads; a.hid = hid; a.ld = ld; a.maxlen = maxlen; a.causal = 1;
+  a.B = B; a.t = t; a.heads = heads; a.hid = hid; a.ld = ld; a.maxlen = maxlen; a.causal = causal;
   CHECK_LAUNCH(vpt_attn_launch(&a, (hipStream_t)stream), "vpt_masked_attention_forward");
 }
 

@@ -29,6 +29,15 @@ struct VptConvFirstArgs {
   int frames, H, W, Cout, NT;
 };
 
+struct VptConv3dArgs {
+  const uint8_t* img;      // [B*T][H][W][3]
+  const vpt_bf16* wfrag;   // [NT][4][64][8]  MFMA A-operand fragments, k = dt*3 + ch (15 used)
+  const float* bias;       // [NT*128]
+  vpt_bf16* y;             // [B*T][Cout/32][H][W][32]
+  double* stats_out;       // [B*T][2]
+  int frames, T, H, W, Cout, NT;
+};
+
 struct VptPoolArgs {
   const vpt_bf16* x;       // [F][CB][H][W][32]  (non-negative values: post-ReLU)
   vpt_bf16* y;             // [F][CB][H/2][W/2][32]
@@ -96,6 +105,7 @@ struct VptLogSoftmaxArgs {
 extern "C" {
 int vpt_conv3x3_launch(const VptConv3x3Args* a, hipStream_t s);
 int vpt_conv_first_launch(const VptConvFirstArgs* a, hipStream_t s);
+int vpt_conv3d_launch(const VptConv3dArgs* a, hipStream_t s);
 int vpt_pool_launch(const VptPoolArgs* a, hipStream_t s);
 int vpt_affine_launch(const VptAffineArgs* a, hipStream_t s);
 int vpt_gemm_launch(const VptGemmArgs* a, hipStream_t s);

@@ -90,6 +90,9 @@ __global__ __launch_bounds__(256) void vpt_attn_kernel(VptAttnArgs a) {
   const int q0 = blockIdx.x * ATT_QT;
   const int maxlen = a.maxlen, t = a.t, hid = a.hid;
   const size_t tok0 = (size_t)b * t;
+  // causal (clipped band): staged key kk is row q0+1+kk of [memory ; chunk].  mask "none" (IDM,
+  // lib/masked_attention.py:139-141 with maxlen = 0): every query sees all t <= ATT_NK rows of the chunk.
+  const int jbase = a.causal ? q0 + 1 : 0;
 
   // ---- stage Q tile, K slab, R rows, b_nd ----
   for (int idx = tid; idx < ATT_QT * (ATT_DH / 4); idx += 256) {
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void vpt_attn_kernel(VptAttnArgs a) {
   }
   for (int idx = tid; idx < ATT_NK * (ATT_DH / 4); idx += 256) {
     const int kk = idx >> 5, c4 = idx & 31;
-    const int j = q0 + 1 + kk;  // index into [memory ; chunk]
+    const int j = jbase + kk;  // index into [memory ; chunk]
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (j < maxlen) v = *(const f32x4*)(a.kmem + ((size_t)b * maxlen + j) * hid + h * ATT_DH + c4 * 4);
     else if (j - maxlen < t) v = *(const f32x4*)(a.qkvr + (tok0 + j - maxlen) * a.ld + hid + h * ATT_DH + c4 * 4);
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256) void vpt_attn_kernel(VptAttnArgs a) {
   }
   for (int idx = tid; idx < ATT_QT * 10; idx += 256) {
     const int r = idx / 10, n = idx - r * 10;
-    Rs[idx] = (q0 + r < t) ? a.qkvr[(tok0 + q0 + r) * a.ld + 3 * hid + h * 10 + n] : 0.f;
+    Rs[idx] = (a.causal && q0 + r < t) ? a.qkvr[(tok0 + q0 + r) * a.ld + 3 * hid + h * 10 + n] : 0.f;
   }
   for (int idx = tid; idx < 10 * maxlen; idx += 256) Bs[idx] = a.b_nd[idx];
   __syncthreads();
@@ -141,14 +144,16 @@ __global__ __launch_bounds__(256) void vpt_attn_kernel(VptAttnArgs a) {
       for (int u = 0; u < 4; ++u) {
         const int kk = kg + 8 * (4 * nb + u);
         const int off = maxlen - 1 + qi - kk;  // 0 = the query itself, maxlen-1 = oldest key in the band
-        const int j = q0 + 1 + kk;
-        bool vis = qvalid && off >= 0 && off < maxlen;
+        const int j = jbase + kk;
+        bool vis = a.causal ? (qvalid && off >= 0 && off < maxlen) : (qvalid && kk < t);
         if (vis && a.causal && j < maxlen) vis = a.memvalid[(size_t)b * maxlen + j] != 0;
         float s = -3.0e38f;
         if (vis) {
           float rb = 0.f;
+          if (a.causal) {
 #pragma unroll
-          for (int n = 0; n < 10; ++n) rb = fmaf(rq[n], Bs[n * maxlen + off], rb);
+            for (int n = 0; n < 10; ++n) rb = fmaf(rq[n], Bs[n * maxlen + off], rb);
+          }
           s = acc[u] * (1.0f / ATT_DH) + rb;
         }
         Ss[qi * ATT_SS + kk] = s;
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(256) void vpt_attn_kernel(VptAttnArgs a) {
   }
   for (int idx = tid; idx < ATT_NK * (ATT_DH / 4); idx += 256) {
     const int kk = idx >> 5, c4 = idx & 31;
-    const int j = q0 + 1 + kk;
+    const int j = jbase + kk;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (j < maxlen) v = *(const f32x4*)(a.vmem + ((size_t)b * maxlen + j) * hid + h * ATT_DH + c4 * 4);
     else if (j - maxlen < t) v = *(const f32x4*)(a.qkvr + (tok0 + j - maxlen) * a.ld + 2 * hid + h * ATT_DH + c4 * 4);
@@ -210,7 +215,8 @@ __global__ __launch_bounds__(256) void vpt_attn_kernel(VptAttnArgs a) {
 }
 
 extern "C" int vpt_attn_launch(const VptAttnArgs* a, hipStream_t stream) {
-  if (a->hid != a->heads * ATT_DH || a->maxlen < 1 || a->maxlen > 129 || !a->causal) return -1;
+  if (a->hid != a->heads * ATT_DH) return -1;
+  if (a->causal ? (a->maxlen < 1 || a->maxlen > 129) : (a->maxlen != 0 || a->t > ATT_NK)) return -1;
   static bool attr_set = false;
   const size_t lds = ATT_FLOATS * sizeof(float);
   if (!attr_set) {

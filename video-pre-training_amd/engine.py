@@ -38,19 +38,23 @@ def config_from_policy_kwargs(policy_kwargs: dict, pi_head_kwargs: Optional[dict
     return cfg
 
 
-def check_supported(cfg: dict):
+def check_supported(cfg: dict, idm: bool = False):
     """Fail loudly for configurations the HIP path does not implement yet."""
     h, w, c = cfg["img_shape"]
-    if (h, w, c) != (128, 128, 3):
+    if (h, w) != (128, 128) or (c != 3 and not idm):
         raise NotImplementedError(f"HIP path supports 128x128x3 frames only, got {cfg['img_shape']}")
     if any(ch % 32 for ch in cfg["chans"]):
         raise NotImplementedError(f"IMPALA widths must be multiples of 32, got {cfg['chans']}")
     if cfg["hidsize"] != cfg["heads"] * 128:
         raise NotImplementedError("attention kernel is built for d_head = 128")
-    if not cfg["causal"] or not (1 <= cfg["maxlen"] <= 129):
-        raise NotImplementedError("only the clipped_causal mask with 1 <= maxlen <= 129 is implemented")
-    if cfg["use_pre_lstm_ln"]:
-        raise NotImplementedError("use_pre_lstm_ln=True is not used by any released transformer model")
+    if idm:
+        if cfg["causal"] or cfg["maxlen"] != 0:
+            raise NotImplementedError("IDM path implements attention_mask_style='none' without memory (maxlen 0) only")
+    else:
+        if not cfg["causal"] or not (1 <= cfg["maxlen"] <= 129):
+            raise NotImplementedError("only the clipped_causal mask with 1 <= maxlen <= 129 is implemented")
+        if cfg["use_pre_lstm_ln"]:
+            raise NotImplementedError("use_pre_lstm_ln=True is not used by any released transformer model")
     if cfg["hidsize"] % 256:
         raise NotImplementedError("hidsize must be a multiple of 256")
 
@@ -120,12 +124,14 @@ class PolicyEngine:
         self.packed = True
 
     # ------------------------------------------------------------------------------------------
-    def _cnn_chunk(self, img: torch.Tensor) -> torch.Tensor:
+    def _cnn_chunk(self, img: torch.Tensor, x0=None, s_x0=None) -> torch.Tensor:
         """img uint8 [F,128,128,3] -> blocked bf16 [F, C2/32, 16, 16, 32] normalised for the dense layer,
-        i.e. everything of ImpalaCNN.forward up to (and including) dense.norm."""
+        i.e. everything of ImpalaCNN.forward up to (and including) dense.norm.  With (x0, s_x0) given (IDM:
+        the temporal conv's blocked output and its frame statistics) stack 0 uses the normed conv3x3 path."""
         cfg, w = self.cfg, self.w
-        f = img.shape[0]
-        st = torch.zeros(24, f, 2, dtype=torch.float64, device=img.device)
+        f = img.shape[0] if x0 is None else x0.shape[0]
+        dev = img.device if x0 is None else x0.device
+        st = torch.zeros(24, f, 2, dtype=torch.float64, device=dev)
         si = 0
 
         def nxt():
@@ -133,11 +139,11 @@ class PolicyEngine:
             si += 1
             return st[si - 1]
 
-        x, s_x = None, None
+        x, s_x = x0, s_x0
         for s, c in enumerate(cfg["chans"]):
             p = f"net.img_process.cnn.stacks.{s}."
             s_pool = nxt()
-            if s == 0:
+            if s == 0 and x0 is None:
                 pooled = ops.conv_first(img, w[p + "firstconv"], c, stats_out=s_pool)
             else:
                 wpk, sa, sg = w[p + "firstconv"]
@@ -215,3 +221,105 @@ class PolicyEngine:
         camera = ops.log_softmax_cols(logits, nb, nc, temp).view(bsz, t, 1, nc)
         vpred = logits[:, nb + nc:nb + nc + 1].reshape(bsz, t, 1).clone()
         return dict(buttons=buttons, camera=camera, vpred=vpred, latent=latent.view(bsz, t, hid), state_out=state_out)
+
+
+class IDMEngine(PolicyEngine):
+    """InverseActionNet.forward (lib/policy.py:374-392) on the same kernels: temporal Conv3d + ReLU, IMPALA CNN
+    with a normed first conv, transformer blocks with mask "none" and no memory, ReLU, final_ln (the reference
+    computes `lastlayer` and discards it, lib/policy.py:390-391 -- so it is not computed here), two heads."""
+
+    def __init__(self, cfg: dict, button_shape, camera_shape, cnn_chunk: int = 128):
+        check_supported(cfg, idm=True)
+        self.cfg = cfg
+        self.button_shape, self.camera_shape = tuple(button_shape), tuple(camera_shape)  # (20, 2), (2, 11)
+        self.cnn_chunk = cnn_chunk
+        self.w = {}
+        self.packed = False
+
+    @torch.no_grad()
+    def pack(self, sd):
+        cfg, w = self.cfg, {}
+        f32 = lambda t: t.detach().float().contiguous()
+        w["conv3d"] = packing.pack_conv3d_t5(f32(sd["net.conv3d_layer.layer.weight"]), f32(sd["net.conv3d_layer.layer.bias"]))
+        self.c3d_out = sd["net.conv3d_layer.layer.weight"].shape[0]
+        for s, c in enumerate(cfg["chans"]):
+            p = f"net.img_process.cnn.stacks.{s}."
+            w[p + "firstconv"] = packing.pack_conv3x3(f32(sd[p + "firstconv.layer.weight"]),
+                                                      f32(sd[p + "firstconv.norm.weight"]), f32(sd[p + "firstconv.norm.bias"]))
+            w[p + "n.g"], w[p + "n.b"] = f32(sd[p + "n.weight"]), f32(sd[p + "n.bias"])
+            for b in range(2):
+                for cv in range(2):
+                    q = f"{p}blocks.{b}.conv{cv}"
+                    w[q] = packing.pack_conv3x3(f32(sd[q + ".layer.weight"]), f32(sd[q + ".norm.weight"]), f32(sd[q + ".norm.bias"]))
+        c2 = cfg["chans"][-1]
+        p = "net.img_process.cnn.dense."
+        w[p + "g"] = packing.chw_to_blocked_vector(f32(sd[p + "norm.weight"]), c2, 16, 16)
+        w[p + "b"] = packing.chw_to_blocked_vector(f32(sd[p + "norm.bias"]), c2, 16, 16)
+        w[p + "w"] = packing.pack_linear(packing.chw_to_blocked_columns(f32(sd[p + "layer.weight"]), c2, 16, 16))
+        p = "net.img_process.linear."
+        w[p + "g"], w[p + "b"] = f32(sd[p + "norm.weight"]), f32(sd[p + "norm.bias"])
+        w[p + "w"] = packing.pack_linear(f32(sd[p + "layer.weight"]))
+        hid = cfg["hidsize"]
+        for l in range(cfg["n_layers"]):
+            p = f"net.recurrent_layer.blocks.{l}."
+            o = p + "r.orc_block."
+            w[p + "ln1.g"], w[p + "ln1.b"] = f32(sd[p + "pre_r_ln.weight"]), f32(sd[p + "pre_r_ln.bias"])
+            wq = torch.cat([f32(sd[o + "q_layer.weight"]), f32(sd[o + "k_layer.weight"]), f32(sd[o + "v_layer.weight"])], dim=0)
+            bq = torch.cat([f32(sd[o + "q_layer.bias"]), torch.zeros(2 * hid, device=wq.device)])
+            w[p + "qkv.w"], w[p + "qkv.b"] = packing.pack_linear(wq), bq.contiguous()
+            w[p + "proj.w"], w[p + "proj.b"] = packing.pack_linear(f32(sd[o + "proj_layer.weight"])), f32(sd[o + "proj_layer.bias"])
+            w[p + "ln2.g"], w[p + "ln2.b"] = f32(sd[p + "mlp0.norm.weight"]), f32(sd[p + "mlp0.norm.bias"])
+            w[p + "mlp0.w"] = packing.pack_linear(f32(sd[p + "mlp0.layer.weight"]))
+            w[p + "mlp1.w"], w[p + "mlp1.b"] = packing.pack_linear(f32(sd[p + "mlp1.layer.weight"])), f32(sd[p + "mlp1.layer.bias"])
+        w["final.g"], w["final.b"] = f32(sd["net.final_ln.weight"]), f32(sd["net.final_ln.bias"])
+        for h in ("buttons", "camera"):
+            w[h + ".w"] = packing.pack_linear(f32(sd[f"pi_head.{h}.linear_layer.weight"]))
+            w[h + ".b"] = f32(sd[f"pi_head.{h}.linear_layer.bias"])
+        self.w = w
+        self.packed = True
+
+    @torch.no_grad()
+    def forward(self, img_u8: torch.Tensor):
+        if not self.packed:
+            raise RuntimeError("IDMEngine.pack(state_dict) must be called before forward")
+        cfg, w = self.cfg, self.w
+        bsz, t = img_u8.shape[:2]
+        if t > 160:
+            raise NotImplementedError("the mask='none' attention kernel handles chunks of at most 160 frames")
+        hid, heads = cfg["hidsize"], cfg["heads"]
+        frames = img_u8.reshape(bsz * t, *img_u8.shape[2:]).contiguous()
+        # temporal conv needs whole sequences; the CNN behind it runs in frame chunks to bound the 4 MB/frame tensor
+        wfrag, bias = w["conv3d"]
+        outs = []
+        step = max(1, self.cnn_chunk // t) * t if t <= self.cnn_chunk else t
+        for i in range(0, bsz * t, step):
+            fr = frames[i:i + step]
+            s0 = torch.zeros(fr.shape[0], 2, dtype=torch.float64, device=fr.device)
+            x0 = ops.conv3d_t5(fr, wfrag, bias, self.c3d_out, t, stats_out=s0)
+            xn = self._cnn_chunk(None, x0=x0, s_x0=s0)
+            d32, _ = ops.linear(xn.view(xn.shape[0], -1), w["net.img_process.cnn.dense.w"], 256, splitk=16)
+            outs.append(d32)
+            del x0, xn
+        d = outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+        p = "net.img_process.linear."
+        _, dn = ops.layernorm(d, w[p + "g"], w[p + "b"], relu_in=True)
+        x, _ = ops.linear(dn, w[p + "w"], hid, relu=True)
+        for l in range(cfg["n_layers"]):
+            p = f"net.recurrent_layer.blocks.{l}."
+            x1, x1b = ops.layernorm(x, w[p + "ln1.g"], w[p + "ln1.b"], out_f32=True)
+            qkv, _ = ops.linear(x1b, w[p + "qkv.w"], 3 * hid, bias=w[p + "qkv.b"])
+            att = ops.full_attention(qkv, bsz, t, heads, hid)
+            x2, _ = ops.linear(att, w[p + "proj.w"], hid, bias=w[p + "proj.b"], res=x1)
+            _, hb = ops.layernorm(x2, w[p + "ln2.g"], w[p + "ln2.b"])
+            _, h2 = ops.linear(hb, w[p + "mlp0.w"], hid * cfg["pointwise_ratio"], relu=True, out_f32=False, out_bf16=True)
+            x, _ = ops.linear(h2, w[p + "mlp1.w"], hid, bias=w[p + "mlp1.b"], res=x2)
+        latent, lb = ops.layernorm(x, w["final.g"], w["final.b"], relu_in=True, out_f32=True)
+        out = {}
+        temp = cfg["temperature"]
+        for h, shape in (("buttons", self.button_shape), ("camera", self.camera_shape)):
+            n_groups, n = shape
+            z, _ = ops.linear(lb, w[h + ".w"], n_groups * n, bias=w[h + ".b"])
+            lp = ops.log_softmax_cols(z.view(bsz * t * n_groups, n), 0, n, temp)
+            out[h] = lp.view(bsz, t, n_groups, n)
+        out["latent"] = latent.view(bsz, t, hid)
+        return out

@@ -13,7 +13,7 @@ from typing import Dict, Optional
 import torch
 from torch import nn
 
-from ..engine import PolicyEngine, config_from_policy_kwargs
+from ..engine import IDMEngine, PolicyEngine, config_from_policy_kwargs
 from .action_head import make_action_head
 from .tree_util import tree_map
 
@@ -49,7 +49,7 @@ class MinecraftPolicy(nn.Module):
     def __init__(self, recurrence_type="lstm", impala_width=1, impala_chans=(16, 32, 32), hidsize=512,
                  img_shape=None, init_norm_kwargs=None, impala_kwargs=None, attention_mask_style="clipped_causal",
                  attention_heads=8, attention_memory_size=2048, pointwise_ratio=4, n_recurrence_layers=1,
-                 timesteps=None, use_pre_lstm_ln=True, first_conv_norm=False, **unused_kwargs):
+                 timesteps=None, use_pre_lstm_ln=True, first_conv_norm=False, first_conv_inchan=3, **unused_kwargs):
         super().__init__()
         if recurrence_type != "transformer":
             raise NotImplementedError("only recurrence_type='transformer' (every released VPT model) is implemented")
@@ -58,20 +58,18 @@ class MinecraftPolicy(nn.Module):
             raise NotImplementedError("only init_norm_kwargs={'group_norm_groups': 1} (every released model) is implemented")
         if (impala_kwargs or {}).get("post_pool_groups", None) != 1:
             raise NotImplementedError("only impala_kwargs={'post_pool_groups': 1} is implemented")
-        if first_conv_norm:
-            raise NotImplementedError("first_conv_norm=True (IDM) is not implemented yet")
         self.hidsize = hidsize
         chans = [int(impala_width * c) for c in impala_chans]
         maxlen = attention_memory_size - timesteps
         nblk_scale = math.sqrt(math.sqrt(len(chans)) / math.sqrt(2))  # lib/impala_cnn.py:33,106,169
-        cin = 3
+        cin = first_conv_inchan
         for s, c in enumerate(chans):
             p = f"img_process.cnn.stacks.{s}."
-            if s > 0:
+            if s > 0 or first_conv_norm:
                 _attach(self, p + "firstconv.norm.weight", torch.ones(cin))
                 _attach(self, p + "firstconv.norm.bias", torch.zeros(cin))
             _attach(self, p + "firstconv.layer.weight", _fan_in_(torch.randn(c, cin, 3, 3), 1.0))
-            if s == 0:
+            if s == 0 and not first_conv_norm:
                 _attach(self, p + "firstconv.layer.bias", torch.zeros(c))
             _attach(self, p + "n.weight", torch.ones(c))
             _attach(self, p + "n.bias", torch.zeros(c))
@@ -244,3 +242,78 @@ class MinecraftAgentPolicy(nn.Module):
         first = first.unsqueeze(1)
         (pd, vpred, _), state_out = self(obs=obs, first=first, state_in=state_in)
         return self.value_head.denormalize(vpred)[:, 0]
+
+
+class InverseActionNet(MinecraftPolicy):
+    """Parameter container of lib/policy.py:342-372: MinecraftPolicy with a normed first conv plus the temporal
+    Conv3d layer in front (`conv3d_layer.layer.{weight,bias}`)."""
+
+    def __init__(self, hidsize=512, conv3d_params=None, **kwargs):
+        if conv3d_params is None:
+            raise NotImplementedError("the IDM without conv3d_params is not a released configuration")
+        if list(conv3d_params.get("kernel_size", [])) != [5, 1, 1] or list(conv3d_params.get("padding", [])) != [2, 0, 0] \
+                or conv3d_params.get("inchan") != 3:
+            raise NotImplementedError("only Conv3d(3 -> C, kernel (5,1,1), padding (2,0,0)) is implemented")
+        kwargs.pop("first_conv_norm", None)
+        super().__init__(hidsize=hidsize, first_conv_norm=True, first_conv_inchan=conv3d_params["outchan"], **kwargs)
+        oc = conv3d_params["outchan"]
+        _attach(self, "conv3d_layer.layer.weight", _fan_in_(torch.randn(oc, 3, 5, 1, 1), 1.0))
+        _attach(self, "conv3d_layer.layer.bias", torch.zeros(oc))
+
+
+class InverseActionPolicy(nn.Module):
+    """lib/policy.py:406-467 over the HIP engine: same constructor, `initial_state`, `forward`, `predict`."""
+
+    def __init__(self, action_space, pi_head_kwargs=None, idm_net_kwargs=None):
+        super().__init__()
+        self.action_space = action_space
+        self.net = InverseActionNet(**idm_net_kwargs)
+        pi_head_kwargs = {} if pi_head_kwargs is None else pi_head_kwargs
+        self.pi_head = make_action_head(self.action_space, self.net.output_latent_size(), **pi_head_kwargs)
+        self._cfg = config_from_policy_kwargs(idm_net_kwargs, pi_head_kwargs)
+        bt, ct = action_space["buttons"], action_space["camera"]
+        self._engine = IDMEngine(self._cfg, (bt.size, bt.eltype.n), (ct.size, ct.eltype.n))
+        self._packed_key = None
+
+    def _device(self):
+        return next(self.parameters()).device
+
+    def _ensure_packed(self):
+        params = dict(self.named_parameters())
+        key = (str(self._device()),) + tuple((p.data_ptr(), p._version) for p in params.values())
+        if key != self._packed_key:
+            if self._device().type != "cuda":
+                raise RuntimeError("InverseActionPolicy (HIP) needs its parameters on the GPU: call .to('cuda')")
+            self._engine.pack(params)
+            self._packed_key = key
+
+    def initial_state(self, batch_size: int):
+        """maxlen = 0: empty K/V memories, as the reference returns (lib/masked_attention.py:153-159)."""
+        dev = self._device()
+        z = lambda: torch.zeros(batch_size, 0, self._cfg["hidsize"], dtype=torch.float32, device=dev)
+        return [(None, (z(), z())) for _ in range(self._cfg["n_layers"])]
+
+    def forward(self, obs, first: torch.Tensor, state_in, **kwargs):
+        if isinstance(obs, dict):
+            obs = obs.copy()
+            mask = obs.pop("mask", None)
+        else:
+            mask = None
+        if mask is not None:
+            raise NotImplementedError("logit masking (obs['mask']) is not implemented on the HIP path")
+        self._ensure_packed()
+        img = obs["img"]
+        if img.dtype != torch.uint8:
+            raise TypeError("obs['img'] must be uint8 [B,T,128,128,3]")
+        out = self._engine.forward(img)
+        pi_logits = {"buttons": out["buttons"], "camera": out["camera"]}
+        # mask "none" / maxlen 0: the state passes through empty (lib/xf.py:366-391 with cache_keep_len = 0)
+        return (pi_logits, None, None), state_in
+
+    @torch.no_grad()
+    def predict(self, obs, deterministic: bool = True, **kwargs):
+        (pd, _, _), state_out = self(obs=obs, **kwargs)
+        ac = self.pi_head.sample(pd, deterministic=deterministic)
+        log_prob = self.pi_head.logprob(ac, pd)
+        assert not torch.isnan(log_prob).any()
+        return ac, state_out, {"log_prob": log_prob, "pd": pd}

@@ -38,3 +38,8 @@ def minecraft_action_space(n_buttons: int = 8641, n_camera: int = 121):
     """The space CameraHierarchicalMapping.get_action_space_update() yields (lib/action_mapping.py:227-231):
     11 camera bins -> 121 joint camera actions, 8641 joint button combinations; insertion order camera, buttons."""
     return DictType(camera=TensorType(Discrete(n_camera), (1,)), buttons=TensorType(Discrete(n_buttons), (1,)))
+
+
+def idm_action_space(n_buttons: int = 20, n_camera_bins: int = 11):
+    """IDMActionMapping.get_action_space_update() (lib/action_mapping.py:110-115): 20 binary buttons, 2 x 11 camera bins."""
+    return DictType(buttons=TensorType(Discrete(2), (n_buttons,)), camera=TensorType(Discrete(n_camera_bins), (2,)))

@@ -128,13 +128,33 @@ def layernorm(x, gain, bias, relu_in=False, out_f32=False, out_bf16=True):
     return o32, o16
 
 
+def conv3d_t5(img_u8, wfrag, bias, cout, t, stats_out=None):
+    """img_u8 [F = B*t, H, W, 3] uint8 -> blocked bf16 [F, cout/32, H, W, 32] (IDM temporal conv + ReLU)."""
+    _chk(img_u8, torch.uint8, "img"); _chk(wfrag, torch.bfloat16, "wfrag"); _chk(bias, torch.float32, "bias")
+    _chk(stats_out, torch.float64, "stats_out")
+    f, h, w, _ = img_u8.shape
+    y = torch.empty(f, cout // 32, h, w, 32, dtype=torch.bfloat16, device=img_u8.device)
+    _call("vpt_conv3d_t5_forward", dict(flops=2.0 * f * h * w * cout * 15, bytes=f * h * w * (3 + 2 * cout)),
+          ptr(img_u8), ptr(wfrag), ptr(bias), ptr(y), ptr(stats_out), f, t, h, w, cout, _stream())
+    return y
+
+
+def full_attention(qkv, batch, t, heads, hid):
+    """Mask "none", no memory (IDM): every query attends to all t rows of its chunk.  qkv [B*t, 3*hid] fp32."""
+    _chk(qkv, torch.float32, "qkv")
+    out = torch.empty(batch * t, hid, dtype=torch.bfloat16, device=qkv.device)
+    _call("vpt_masked_attention_forward", dict(flops=4.0 * batch * t * t * hid), ptr(qkv), None, None, None, None, ptr(out),
+          batch, t, heads, hid, qkv.shape[1], 0, 0, _stream())
+    return out
+
+
 def masked_attention(qkvr, kmem, vmem, memvalid, b_nd, batch, t, heads, hid):
     _chk(qkvr, torch.float32, "qkvr"); _chk(kmem, torch.float32, "kmem"); _chk(vmem, torch.float32, "vmem")
     _chk(memvalid, torch.uint8, "memvalid"); _chk(b_nd, torch.float32, "b_nd")
     maxlen = kmem.shape[1]
     out = torch.empty(batch * t, hid, dtype=torch.bfloat16, device=qkvr.device)
     _call("vpt_masked_attention_forward", dict(flops=4.0 * batch * t * (t + maxlen) * hid), ptr(qkvr), ptr(kmem), ptr(vmem), ptr(memvalid), ptr(b_nd), ptr(out),
-                 batch, t, heads, hid, qkvr.shape[1], maxlen, _stream())
+                 batch, t, heads, hid, qkvr.shape[1], maxlen, 1, _stream())
     return out
 
 

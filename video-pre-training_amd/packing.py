@@ -75,6 +75,21 @@ def pack_conv_first(weight, bias):
     return frag.to(torch.bfloat16).contiguous()
 
 
+def pack_conv3d_t5(weight, bias):
+    """IDM Conv3d weight [O,3,5,1,1] + bias [O] -> (MFMA A-operand fragments bf16 [NT][4][64][8], bias fp32 [NT*128]).
+    k = dt*3 + ch for k < 15 (dt = temporal tap 0..4), k = 15 is zero padding (vpt_conv3d.hip)."""
+    o = weight.shape[0]
+    assert tuple(weight.shape[1:]) == (3, 5, 1, 1) and o % 32 == 0
+    nt = _ceil_div(o, 128)
+    cp = nt * 128
+    wk = torch.zeros(cp, 16, dtype=torch.float32, device=weight.device)
+    wk[:o, :15] = weight.reshape(o, 3, 5).permute(0, 2, 1).reshape(o, 15)
+    frag = wk.view(nt, 4, 32, 2, 8).permute(0, 1, 3, 2, 4).contiguous().view(nt, 4, 64, 8)
+    bp = torch.zeros(cp, dtype=torch.float32, device=weight.device)
+    bp[:o] = bias
+    return frag.to(torch.bfloat16).contiguous(), bp
+
+
 def pack_linear(weight):
     """nn.Linear weight [N,K] -> bf16 [ceil(N/128)][K/32][128][32] (vpt_gemm.hip B operand)."""
     n, k = weight.shape
