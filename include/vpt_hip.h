@@ -92,6 +92,12 @@ int vpt_kv_memory_update(const float* qkvr, const float* kmem, const float* vmem
 int vpt_log_softmax_forward(const float* logits, float* out, int M, int ld, int col0, int n, float temperature,
                             void* stream);
 
+/* Fused Adam update of one flat fp32 bucket: th.optim.Adam(lr, weight_decay).step() as configured by
+ * behavioural_cloning.py:63-67,122 (L2 weight decay folded into the gradient, bias-corrected moments).
+ * `step` counts from 1; grad_scale multiplies the gradient first (1/world_size of the data-parallel mean). */
+int vpt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, int step,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

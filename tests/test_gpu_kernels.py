@@ -217,3 +217,30 @@ def test_full_attention(bsz, t, heads):
     out = ops.full_attention(qkv.to(DEV), bsz, t, heads, hid)
     torch.cuda.synchronize()
     assert (out.cpu().float() - ref).abs().max() < 2e-2
+
+
+def test_adam_step_matches_torch():
+    """vpt_adam_step vs torch.optim.Adam with the BC script's hyper-parameters (behavioural_cloning.py:38-40,63-67)."""
+    g = torch.Generator().manual_seed(10)
+    n = 100003  # not a multiple of 4: exercises the tail
+    p0 = torch.randn(n, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=0.000181, weight_decay=0.039428)
+    p = p0.clone().to(DEV)
+    m = torch.zeros(n, device=DEV)
+    v = torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g) * 0.1
+        ref.grad = grad.clone()
+        opt.step()
+        ops.adam_step_(p, grad.to(DEV), m, v, step, lr=0.000181, weight_decay=0.039428)
+    torch.cuda.synchronize()
+    assert (p.cpu() - ref.detach()).abs().max() < 2e-6
+    # grad_scale = 1/world folds the data-parallel mean into the update
+    p2, m2, v2 = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    p3, m3, v3 = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    gsum = torch.randn(n, generator=g).to(DEV)
+    ops.adam_step_(p2, gsum, m2, v2, 1, lr=1e-3, grad_scale=0.125)
+    ops.adam_step_(p3, gsum * 0.125, m3, v3, 1, lr=1e-3)
+    torch.cuda.synchronize()
+    assert torch.allclose(p2, p3, atol=1e-7)

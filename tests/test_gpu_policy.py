@@ -122,3 +122,29 @@ def test_first_resets_memory(pol_1x):
     (pd2, _, _), _ = pol({"img": img}, first, pol.initial_state(1))
     torch.cuda.synchronize()
     assert torch.equal(pd1["buttons"], pd2["buttons"])
+
+
+def test_policy_full_chunk_t128(pol_1x):
+    """One full training-size chunk (T = 128, B = 2) against the oracle: all four query tiles of the band, the
+    memory fully replaced by the chunk, then a T = 1 step on the carried state (the run_agent.py shape)."""
+    pol, cfg, sd = pol_1x
+    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
+    b, t = 2, 128
+    img = _inputs(41, b, t)
+    first = torch.zeros(b, t, dtype=torch.bool)
+    ref = O.policy_forward(sd, cfg, img, first, O.initial_state(cfg, b))
+    (pd, vpred, _), sg = pol({"img": img.to(DEV)}, first.to(DEV), pol.initial_state(b))
+    torch.cuda.synchronize()
+    lb = _l2(pd["buttons"].cpu().numpy(), ref["buttons"].numpy())
+    lc = _l2(pd["camera"].cpu().numpy(), ref["camera"].numpy())
+    print(f"PARITY vs oracle t=128: relL2 buttons {lb:.3e} camera {lc:.3e}")
+    assert lb < L2_TOL and lc < L2_TOL
+    for (m1, (k1, v1)), (m2, (k2, v2)) in zip(sg, ref["state_out"]):
+        assert torch.equal(m1.cpu(), m2) and bool(m2.all())
+        assert _l2(k1.cpu().numpy(), k2.numpy()) < KV_TOL
+    img1 = _inputs(42, b, 1)
+    f1 = torch.zeros(b, 1, dtype=torch.bool)
+    ref1 = O.policy_forward(sd, cfg, img1, f1, ref["state_out"])
+    (pd1, _, _), _ = pol({"img": img1.to(DEV)}, f1.to(DEV), sg)
+    torch.cuda.synchronize()
+    assert _l2(pd1["buttons"].cpu().numpy(), ref1["buttons"].numpy()) < L2_TOL

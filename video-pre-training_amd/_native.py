@@ -25,6 +25,7 @@ SIGNATURES = {
     "vpt_masked_attention_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "vpt_kv_memory_update": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_log_softmax_forward": [_P, _P, _I, _I, _I, _I, _F, _P],
+    "vpt_adam_step": [_P, _P, _P, _P, ctypes.c_uint64, _I, _F, _F, _F, _F, _F, _F, _P],
 }
 
 

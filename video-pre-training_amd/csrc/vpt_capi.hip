@@ -2,6 +2,7 @@
 #include "../../include/vpt_hip.h"
 #include "vpt_kernels.h"
 #include <stdio.h>
+#include <math.h>
 
 static thread_local char g_err[256] = "ok";
 
@@ -106,6 +107,17 @@ int vpt_log_softmax_forward(const float* logits, float* out, int M, int ld, int 
   VptLogSoftmaxArgs a;
   a.logits = logits; a.out = out; a.M = M; a.ld = ld; a.col0 = col0; a.n = n; a.temperature = temperature;
   CHECK_LAUNCH(vpt_logsoftmax_launch(&a, (hipStream_t)stream), "vpt_log_softmax_forward");
+}
+
+int vpt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, int step,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
+  if (step < 1) return fail(-1, "vpt_adam_step: step counts from 1");
+  VptAdamArgs a;
+  a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = (size_t)n;
+  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.grad_scale = grad_scale;
+  a.step_size = (float)((double)lr / (1.0 - pow((double)beta1, (double)step)));
+  a.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+  CHECK_LAUNCH(vpt_adam_launch(&a, (hipStream_t)stream), "vpt_adam_step");
 }
 
 }  // extern "C"

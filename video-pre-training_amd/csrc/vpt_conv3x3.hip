@@ -202,9 +202,11 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
           fa_[m_] = *(const bf16x8*)(aL + ((dy_) * 18 + dx_) * A_RS + m_ * (2 * 18 * A_RS) + ks_ * 32);   \
         _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_)                                                  \
           fb_[n_] = *(const bf16x8*)((ks_ ? bB1_ : bB0_) + dx_ * (128 * 64) + n_ * (32 * 64));            \
+        if (a.ablate & 64) __builtin_amdgcn_s_setprio(1);                                                 \
         _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                                  \
           _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_)                                                \
             acc[m_][n_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb_[n_], fa_[m_], acc[m_][n_], 0, 0, 0); \
+        if (a.ablate & 64) __builtin_amdgcn_s_setprio(0);                                                 \
       }                                                                                                   \
     }                                                                                                     \
     /* all waves done with the halo / B[buf]; this step's DMA into B[buf^1] has landed */                 \

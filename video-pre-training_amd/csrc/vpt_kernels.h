@@ -102,7 +102,19 @@ struct VptLogSoftmaxArgs {
   float temperature;
 };
 
+struct VptAdamArgs {
+  float* p;                // parameters (updated in place)
+  const float* g;          // gradients
+  float* m;                // first moment
+  float* v;                // second moment
+  size_t n;
+  float beta1, beta2, eps, weight_decay, grad_scale;
+  float step_size;         // lr / (1 - beta1^t)
+  float inv_sqrt_bc2;      // 1 / sqrt(1 - beta2^t)
+};
+
 extern "C" {
+int vpt_adam_launch(const VptAdamArgs* a, hipStream_t s);
 int vpt_conv3x3_launch(const VptConv3x3Args* a, hipStream_t s);
 int vpt_conv_first_launch(const VptConvFirstArgs* a, hipStream_t s);
 int vpt_conv3d_launch(const VptConv3dArgs* a, hipStream_t s);

@@ -173,3 +173,14 @@ def log_softmax_cols(logits, col0, n, temperature):
     _call("vpt_log_softmax_forward", dict(bytes=8.0 * m * n), ptr(logits), ptr(out), m, logits.shape[1], col0, n,
                  ctypes.c_float(temperature), _stream())
     return out
+
+
+def adam_step_(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    """In-place fused Adam on flat fp32 tensors (torch.optim.Adam semantics, L2 weight decay)."""
+    for t, nme in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _chk(t, torch.float32, nme)
+    n = param.numel()
+    assert grad.numel() == n and exp_avg.numel() == n and exp_avg_sq.numel() == n
+    _call("vpt_adam_step", dict(bytes=28.0 * n), ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), ctypes.c_uint64(n), int(step),
+          ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps), ctypes.c_float(weight_decay),
+          ctypes.c_float(grad_scale), _stream())
