@@ -87,7 +87,14 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import __graft_entry__ as ge
-    ge.build()
+    if distributed:  # one rank compiles (a no-op when the in-tree .so is current), the others wait
+        if rank == 0:
+            ge.build()
+        dist.barrier()
+        if rank != 0:
+            ge.build()
+    else:
+        ge.build()
     from vpt_amd import ops
     from vpt_amd.lib.policy import MinecraftAgentPolicy
     from vpt_amd.lib.types import minecraft_action_space
@@ -134,11 +141,14 @@ def main():
     roof = None
     kernels = None
     if rank == 0:
+        streams_saved = pol._engine.cnn_streams
+        pol._engine.cnn_streams = 1  # per-kernel durations are only meaningful without cross-stream overlap
         ops.TIMER.enabled = True
         ops.TIMER.reset()
         step(state)
         summ = ops.TIMER.summary()
         ops.TIMER.enabled = False
+        pol._engine.cnn_streams = streams_saved
         c = summ.get("vpt_conv3x3_forward")
         total_ms = sum(v["ms"] for v in summ.values())
         kernels = {k: dict(ms=round(v["ms"], 3), calls=v["calls"],

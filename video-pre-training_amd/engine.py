@@ -11,6 +11,7 @@ KV memory fp32):
         -> layernorm -> linear(mlp0, relu) -> linear(mlp1,+res) ]
   layernorm(relu in) -> linear(lastlayer, relu) -> layernorm(final) -> linear(heads) -> log_softmax x2
 """
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -59,12 +60,22 @@ def check_supported(cfg: dict, idm: bool = False):
         raise NotImplementedError("hidsize must be a multiple of 256")
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
 class PolicyEngine:
-    def __init__(self, cfg: dict, n_buttons: int, n_camera: int, cnn_chunk: int = 1024):
+    def __init__(self, cfg: dict, n_buttons: int, n_camera: int, cnn_chunk: int = 1024, cnn_streams: int = 3):
         check_supported(cfg)
         self.cfg = cfg
         self.n_buttons, self.n_camera = n_buttons, n_camera
-        self.cnn_chunk = cnn_chunk
+        self.cnn_chunk = int(os.environ.get("VPT_CNN_CHUNK", cnn_chunk))
+        self.cnn_streams = int(os.environ.get("VPT_CNN_STREAMS", cnn_streams))
+        self._streams = []
         self.w: Dict[str, torch.Tensor] = {}
         self.packed = False
 
@@ -169,12 +180,27 @@ class PolicyEngine:
         cfg, w = self.cfg, self.w
         n = frames.shape[0]
         outs = []
-        for i in range(0, n, self.cnn_chunk):
-            xn = self._cnn_chunk(frames[i:i + self.cnn_chunk])
-            flat = xn.view(xn.shape[0], -1)
-            d32, _ = ops.linear(flat, w["net.img_process.cnn.dense.w"], 256, splitk=16)
-            outs.append(d32)
-            del xn, flat
+        n_chunks = (n + self.cnn_chunk - 1) // self.cnn_chunk
+        # Frame chunks are independent: alternate them over `cnn_streams` HIP streams so that one chunk's
+        # HBM-bound kernels (pool / affine / first conv) and launch tails overlap the other's MFMA-bound convs.
+        n_streams = min(self.cnn_streams, n_chunks)
+        main = torch.cuda.current_stream()
+        if n_streams > 1:
+            if len(self._streams) < n_streams:
+                self._streams = [torch.cuda.Stream() for _ in range(n_streams)]
+            for st in self._streams[:n_streams]:
+                st.wait_stream(main)
+        for ci, i in enumerate(range(0, n, self.cnn_chunk)):
+            ctx = torch.cuda.stream(self._streams[ci % n_streams]) if n_streams > 1 else _NullCtx()
+            with ctx:
+                xn = self._cnn_chunk(frames[i:i + self.cnn_chunk])
+                flat = xn.view(xn.shape[0], -1)
+                d32, _ = ops.linear(flat, w["net.img_process.cnn.dense.w"], 256, splitk=16)
+                outs.append(d32)
+                del xn, flat
+        if n_streams > 1:
+            for st in self._streams[:n_streams]:
+                main.wait_stream(st)
         d = outs[0] if len(outs) == 1 else torch.cat(outs, 0)
         p = "net.img_process.linear."
         _, dn = ops.layernorm(d, w[p + "g"], w[p + "b"], relu_in=True)
@@ -233,6 +259,8 @@ class IDMEngine(PolicyEngine):
         self.cfg = cfg
         self.button_shape, self.camera_shape = tuple(button_shape), tuple(camera_shape)  # (20, 2), (2, 11)
         self.cnn_chunk = cnn_chunk
+        self.cnn_streams = 1
+        self._streams = []
         self.w = {}
         self.packed = False
 
