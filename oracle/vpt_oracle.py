@@ -255,11 +255,12 @@ def initial_state(cfg: dict, batch: int):
 
 
 def policy_forward(sd: Dict[str, torch.Tensor], cfg: dict, img_u8: torch.Tensor, first: torch.Tensor,
-                   state_in: List[Tuple], taps: Optional[dict] = None):
+                   state_in: List[Tuple], taps: Optional[dict] = None, grad: bool = False):
     """MinecraftAgentPolicy.forward (lib/policy.py:252-269) -> MinecraftPolicy.forward (lib/policy.py:193-218).
     img_u8 [B,T,128,128,3] uint8, first [B,T] bool (only first[:,0] is honoured, lib/masked_attention.py:167).
-    Returns dict(buttons, camera log-probs [B,T,1,n]; vpred [B,T,1]; latent [B,T,hid]; state_out)."""
-    with torch.no_grad():
+    Returns dict(buttons, camera log-probs [B,T,1,n]; vpred [B,T,1]; latent [B,T,hid]; state_out).
+    grad=True keeps the autograd graph (used by bc_loss_and_grads)."""
+    with torch.set_grad_enabled(grad):
         x = img_obs_process(sd, "net.img_process.", img_u8, taps)
         if taps is not None:
             taps["img_process"] = x
@@ -515,3 +516,26 @@ def idm_forward(sd, cfg, img_u8, taps: Optional[dict] = None):
         zb = (x @ sd["pi_head.buttons.linear_layer.weight"].t() + sd["pi_head.buttons.linear_layer.bias"]).reshape(b, t, -1, 2)
         zc = (x @ sd["pi_head.camera.linear_layer.weight"].t() + sd["pi_head.camera.linear_layer.bias"]).reshape(b, t, 2, -1)
         return dict(buttons=torch.log_softmax(zb / temp, -1), camera=torch.log_softmax(zc / temp, -1), latent=x)
+
+
+# ----------------------------------------------------------------------------------------------
+# behavioural-cloning step (behavioural_cloning.py:86-123), generalised to [B, T] chunks
+# ----------------------------------------------------------------------------------------------
+def bc_loss_and_grads(sd, cfg, img_u8, first, state_in, act_buttons, act_camera):
+    """loss = -mean_{b,t}[ log pi(buttons_bt) + log pi(camera_bt) ] and its gradient w.r.t. every tensor of `sd`
+    via torch autograd through this restatement.  The reference computes exactly this per sample with T = 1 and
+    B = 1 (`-log_prob / BATCH_SIZE`, behavioural_cloning.py:107-119, log_prob = pi_head.logprob = sum of the two
+    heads' gathers, lib/action_head.py:176-184,252-253) and the KV memory enters detached
+    (behavioural_cloning.py:111); here the mean runs over the B*T frames of a chunk.  act_* : int64 [B,T].
+    Returns (loss float, dict name -> grad tensor (zeros for tensors the loss does not reach), state_out)."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point}
+    state_det = [(m, (k.detach(), v.detach())) for m, (k, v) in state_in]
+    out = policy_forward(leaves, cfg, img_u8, first, state_det, grad=True)
+    lp = out["buttons"][:, :, 0].gather(-1, act_buttons.unsqueeze(-1)).squeeze(-1) \
+        + out["camera"][:, :, 0].gather(-1, act_camera.unsqueeze(-1)).squeeze(-1)
+    loss = -lp.mean()
+    names = list(leaves)
+    grads = torch.autograd.grad(loss, [leaves[n] for n in names], allow_unused=True)
+    gd = {n: (g if g is not None else torch.zeros_like(leaves[n])) for n, g in zip(names, grads)}
+    state_out = [(m, (k.detach(), v.detach())) for m, (k, v) in out["state_out"]]
+    return float(loss.detach()), gd, state_out

@@ -102,3 +102,28 @@ def test_idm_matches_reference():
     assert np.array_equal(out["camera"].argmax(-1).numpy(), G["ac_camera"])
     lp = out["buttons"].max(-1).values.sum(-1) + out["camera"].max(-1).values.sum(-1)
     np.testing.assert_allclose(lp.numpy(), G["log_prob"], atol=1e-3)
+
+
+def test_bc_gradients_match_reference():
+    """Oracle autograd of the BC loss vs the live reference's loss.backward() (tests/golden/make_golden_bc.py)."""
+    import os
+    G = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "bc_1x_seed0.npz")))
+    cfg, sd = _setup()
+    b, t = 2, 3
+    state = O.initial_state(cfg, b)
+    warm = O.policy_forward(sd, cfg, _inputs(300, b, 4), torch.zeros(b, 4, dtype=torch.bool), state)
+    img = _inputs(301, b, t)
+    first = torch.zeros(b, t, dtype=torch.bool)
+    loss, grads, _ = O.bc_loss_and_grads(sd, cfg, img, first, warm["state_out"],
+                                         torch.from_numpy(G["act_buttons"]), torch.from_numpy(G["act_camera"]))
+    assert abs(loss - float(G["loss"])) < 1e-4
+    checked = 0
+    for name, gr in grads.items():
+        ref_norm = float(G["norm/" + name])
+        mine = float(gr.double().norm())
+        assert abs(mine - ref_norm) <= 2e-3 * max(ref_norm, 1e-6) + 1e-7, (name, mine, ref_norm)
+        np.testing.assert_allclose(gr.reshape(-1)[:16].numpy(), G["head/" + name], rtol=1e-2, atol=1e-7 + 2e-2 * ref_norm / max(gr.numel() ** 0.5, 1))
+        checked += 1
+    assert checked == 134
+    # value head receives no gradient from the BC loss (SURVEY §4)
+    assert float(G["norm/value_head.linear.weight"]) == 0.0
