@@ -65,10 +65,13 @@ int vpt_frame_affine_forward(const void* x, void* y, const float* gain, const fl
 /* C[M,N] = A[M,K] W[N,K]^T (+bias) (ReLU) (+res): every nn.Linear on the path (lib/util.py:58-82,
  * lib/xf.py:251-254, lib/action_head.py:164, lib/scaled_mse_head.py:35).  A bf16 [M][lda]; wpk bf16
  * [ceil(N/128)][K/32][128][32]; bias fp32[N] or NULL; res fp32 [M][ldr] or NULL; out_f32 [M][ldc] and/or
- * out_bf16 [M][ldcb].  splitk > 1 accumulates into a caller-zeroed out_f32 with atomics (no ReLU/res). */
+ * out_bf16 [M][ldcb].  splitk > 1 accumulates into a caller-zeroed out_f32 with atomics (no ReLU/res).
+ * mask (optional, bf16 [M][ldm]) zeroes outputs where mask <= 0 before the residual add: the ReLU backward of
+ * the BC step's dgrad GEMMs.  The same entry point serves forward, dgrad (W^T packed) and wgrad (A = dY^T). */
 int vpt_linear_forward(const void* A, const void* wpk, const float* bias, const float* res,
                        float* out_f32, void* out_bf16, int M, int N, int K,
-                       int lda, int ldr, int ldc, int ldcb, int relu, int splitk, void* stream);
+                       int lda, int ldr, int ldc, int ldcb, int relu, int splitk, const void* mask, int ldm,
+                       void* stream);
 
 /* nn.LayerNorm over the last dim with optional ReLU on the input (lib/util.py:61-62,169; lib/policy.py:188,211-214). */
 int vpt_layernorm_forward(const float* x, const float* gain, const float* bias, float* out_f32, void* out_bf16,
@@ -97,6 +100,33 @@ int vpt_log_softmax_forward(const float* logits, float* out, int M, int ld, int 
  * `step` counts from 1; grad_scale multiplies the gradient first (1/world_size of the data-parallel mean). */
 int vpt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, int step,
                   float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+
+/* ---- behavioural-cloning step: backward of the heads / trunk / transformer (the reference uses torch autograd,
+ * behavioural_cloning.py:117-119).  Linear layers reuse vpt_linear_forward (dgrad: W^T packed; wgrad: A = dY^T). */
+
+/* d loss / d logits for loss = -sum_rows[ log_softmax(z_b/T)[a_b] + log_softmax(z_c/T)[a_c] ] * (scale*T), written as
+ * bf16 [M][ldz] (columns >= nb+nc zero): scale = 1 / (global frames * temperature).  lib/action_head.py:170-184. */
+int vpt_bc_nll_backward(const float* lp_buttons, const float* lp_camera, const int64_t* act_buttons,
+                        const int64_t* act_camera, void* dz, int M, int nb, int nc, int ldz, float scale, void* stream);
+
+/* nn.LayerNorm backward (optionally through a ReLU on the LayerNorm's input): dx = dx_add + dLN(x, dy);
+ * dgain / dbias are accumulated with atomics (caller zeroes). */
+int vpt_layernorm_backward(const float* x, const float* gain, const float* dy, const float* dx_add, float* dx,
+                           float* dgain, float* dbias, int M, int D, int relu_in, void* stream);
+
+/* out_bf16[M][ldo] = (mask > 0 ? x : 0) with columns >= N zeroed: the ReLU backward gate (F.relu at lib/util.py:81,
+ * lib/policy.py:211) fused with the cast / K-padding that turns an fp32 gradient into a GEMM A operand. */
+int vpt_gate_cast_bf16(const float* x, const void* mask, void* out, int M, int N, int ldx, int ldm, int ldo, void* stream);
+
+/* out[N] += column sums of a bf16 [M][ld] matrix (bias gradients). */
+int vpt_column_sum(const void* x_bf16, float* out, int M, int N, int ld, void* stream);
+
+/* Backward of vpt_masked_attention_forward (causal = 1): dqkvr [B*t][ld] receives dQ and dR (written) and dK, dV
+ * (accumulated: caller zeroes); db_nd [10][maxlen] accumulated.  The KV memory is detached state
+ * (behavioural_cloning.py:111) and gets no gradient. */
+int vpt_masked_attention_backward(const float* qkvr, const float* kmem, const float* vmem, const uint8_t* memvalid,
+                                  const float* b_nd, const float* dout, float* dqkvr, float* db_nd,
+                                  int B, int t, int heads, int hid, int ld, int maxlen, void* stream);
 
 #ifdef __cplusplus
 }

@@ -20,11 +20,16 @@ SIGNATURES = {
     "vpt_conv3x3_forward": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_maxpool_forward": [_P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_frame_affine_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "vpt_linear_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vpt_linear_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "vpt_layernorm_forward": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "vpt_masked_attention_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "vpt_kv_memory_update": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_log_softmax_forward": [_P, _P, _I, _I, _I, _I, _F, _P],
+    "vpt_bc_nll_backward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "vpt_layernorm_backward": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "vpt_gate_cast_bf16": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vpt_column_sum": [_P, _P, _I, _I, _I, _P],
+    "vpt_masked_attention_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vpt_adam_step": [_P, _P, _P, _P, ctypes.c_uint64, _I, _F, _F, _F, _F, _F, _F, _P],
 }
 

@@ -68,8 +68,10 @@ int vpt_frame_affine_forward(const void* x, void* y, const float* gain, const fl
 
 int vpt_linear_forward(const void* A, const void* wpk, const float* bias, const float* res,
                        float* out_f32, void* out_bf16, int M, int N, int K,
-                       int lda, int ldr, int ldc, int ldcb, int relu, int splitk, void* stream) {
+                       int lda, int ldr, int ldc, int ldcb, int relu, int splitk, const void* mask, int ldm,
+                       void* stream) {
   VptGemmArgs a;
+  a.mask = (const vpt_bf16*)mask; a.ldm = ldm;
   a.A = (const vpt_bf16*)A; a.wpk = (const vpt_bf16*)wpk; a.bias = bias; a.res = res;
   a.out_f32 = out_f32; a.out_bf16 = (vpt_bf16*)out_bf16;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldr = ldr; a.ldc = ldc; a.ldcb = ldcb;
@@ -118,6 +120,43 @@ int vpt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
   a.step_size = (float)((double)lr / (1.0 - pow((double)beta1, (double)step)));
   a.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
   CHECK_LAUNCH(vpt_adam_launch(&a, (hipStream_t)stream), "vpt_adam_step");
+}
+
+int vpt_bc_nll_backward(const float* lp_buttons, const float* lp_camera, const int64_t* act_buttons,
+                        const int64_t* act_camera, void* dz, int M, int nb, int nc, int ldz, float scale, void* stream) {
+  VptNllBwdArgs a;
+  a.lp_buttons = lp_buttons; a.lp_camera = lp_camera; a.act_buttons = (const long*)act_buttons;
+  a.act_camera = (const long*)act_camera; a.dz = (vpt_bf16*)dz; a.M = M; a.nb = nb; a.nc = nc; a.ldz = ldz; a.scale = scale;
+  CHECK_LAUNCH(vpt_nll_bwd_launch(&a, (hipStream_t)stream), "vpt_bc_nll_backward");
+}
+
+int vpt_layernorm_backward(const float* x, const float* gain, const float* dy, const float* dx_add, float* dx,
+                           float* dgain, float* dbias, int M, int D, int relu_in, void* stream) {
+  VptLnBwdArgs a;
+  a.x = x; a.gain = gain; a.dy = dy; a.dx_add = dx_add; a.dx = dx; a.dgain = dgain; a.dbias = dbias;
+  a.M = M; a.D = D; a.relu_in = relu_in;
+  CHECK_LAUNCH(vpt_ln_bwd_launch(&a, (hipStream_t)stream), "vpt_layernorm_backward");
+}
+
+int vpt_gate_cast_bf16(const float* x, const void* mask, void* out, int M, int N, int ldx, int ldm, int ldo, void* stream) {
+  VptGateCastArgs a;
+  a.x = x; a.mask = (const vpt_bf16*)mask; a.out = (vpt_bf16*)out; a.M = M; a.N = N; a.ldx = ldx; a.ldm = ldm; a.ldo = ldo;
+  CHECK_LAUNCH(vpt_gate_cast_launch(&a, (hipStream_t)stream), "vpt_gate_cast_bf16");
+}
+
+int vpt_column_sum(const void* x_bf16, float* out, int M, int N, int ld, void* stream) {
+  VptColsumArgs a;
+  a.x = (const vpt_bf16*)x_bf16; a.out = out; a.M = M; a.N = N; a.ld = ld;
+  CHECK_LAUNCH(vpt_colsum_launch(&a, (hipStream_t)stream), "vpt_column_sum");
+}
+
+int vpt_masked_attention_backward(const float* qkvr, const float* kmem, const float* vmem, const uint8_t* memvalid,
+                                  const float* b_nd, const float* dout, float* dqkvr, float* db_nd,
+                                  int B, int t, int heads, int hid, int ld, int maxlen, void* stream) {
+  VptAttnBwdArgs a;
+  a.qkvr = qkvr; a.kmem = kmem; a.vmem = vmem; a.memvalid = memvalid; a.b_nd = b_nd; a.dout = dout;
+  a.dqkvr = dqkvr; a.db_nd = db_nd; a.B = B; a.t = t; a.heads = heads; a.hid = hid; a.ld = ld; a.maxlen = maxlen;
+  CHECK_LAUNCH(vpt_attn_bwd_launch(&a, (hipStream_t)stream), "vpt_masked_attention_backward");
 }
 
 }  // extern "C"

@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
           atomicAdd(a.out_f32 + (size_t)row * a.ldc + col, v);
         } else {
           if (a.relu) v = fmaxf(v, 0.f);
+          if (a.mask && !((float)a.mask[(size_t)row * a.ldm + col] > 0.f)) v = 0.f;  // ReLU backward: gate by the saved activation
           if (a.res) v += a.res[(size_t)row * a.ldr + col];
           if (a.out_f32) a.out_f32[(size_t)row * a.ldc + col] = v;
           if (a.out_bf16) a.out_bf16[(size_t)row * a.ldcb + col] = (vpt_bf16)v;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
 
 extern "C" int vpt_gemm_launch(const VptGemmArgs* a, hipStream_t stream) {
   if (a->M <= 0 || a->N <= 0 || (a->K & 63) || a->splitk < 1 || (a->lda & 7)) return -1;
-  if (a->splitk > 1 && (!a->atomic_out || a->relu || a->res || a->out_bf16)) return -1;
+  if (a->splitk > 1 && (!a->atomic_out || a->relu || a->res || a->out_bf16 || a->mask)) return -1;
   const long grid = (long)((a->M + 255) >> 8) * ((a->N + 127) >> 7) * a->splitk;
   if (grid > 0x7fffffffL) return -2;
   hipLaunchKernelGGL(vpt_gemm_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *a);

@@ -65,6 +65,8 @@ struct VptGemmArgs {
   vpt_bf16* out_bf16;      // [M][ldcb] or null
   int M, N, K, lda, ldr, ldc, ldcb;
   int relu, splitk, atomic_out;
+  const vpt_bf16* mask;    // optional [M][ldm]: output is zeroed where mask <= 0 (ReLU backward)
+  int ldm;
 };
 
 struct VptLayerNormArgs {
@@ -102,6 +104,52 @@ struct VptLogSoftmaxArgs {
   float temperature;
 };
 
+struct VptNllBwdArgs {
+  const float* lp_buttons; // [M][nb] log-probabilities (forward output)
+  const float* lp_camera;  // [M][nc]
+  const long* act_buttons; // [M]
+  const long* act_camera;  // [M]
+  vpt_bf16* dz;            // [M][ldz]: d loss / d (pre-softmax logits), columns nb+nc.. zero
+  int M, nb, nc, ldz;
+  float scale;             // 1 / (frames in the global batch * temperature)
+};
+
+struct VptGateCastArgs {
+  const float* x;          // [M][ldx]
+  const vpt_bf16* mask;    // optional [M][ldm]
+  vpt_bf16* out;           // [M][ldo]
+  int M, N, ldx, ldm, ldo;
+};
+
+struct VptLnBwdArgs {
+  const float* x;          // [M][D] the LayerNorm's input (before the optional ReLU)
+  const float* gain;       // [D]
+  const float* dy;         // [M][D]
+  const float* dx_add;     // optional [M][D] added to the result (skip connections)
+  float* dx;               // [M][D]
+  float* dgain;            // [D] accumulated (caller zeroes)
+  float* dbias;            // [D]
+  int M, D, relu_in;
+};
+
+struct VptColsumArgs {
+  const vpt_bf16* x;       // [M][ld]
+  float* out;              // [N] accumulated (caller zeroes)
+  int M, N, ld;
+};
+
+struct VptAttnBwdArgs {
+  const float* qkvr;       // forward projections [B*t][ld]
+  const float* kmem;       // [B][maxlen][hid] (detached state: no gradient)
+  const float* vmem;
+  const uint8_t* memvalid; // [B][maxlen]
+  const float* b_nd;       // [10][maxlen]
+  const float* dout;       // [B*t][hid] gradient w.r.t. the merged attention output
+  float* dqkvr;            // [B*t][ld]: Q and R columns written, K and V columns accumulated (caller zeroes)
+  float* db_nd;            // [10][maxlen] accumulated (caller zeroes)
+  int B, t, heads, hid, ld, maxlen;
+};
+
 struct VptAdamArgs {
   float* p;                // parameters (updated in place)
   const float* g;          // gradients
@@ -115,6 +163,11 @@ struct VptAdamArgs {
 
 extern "C" {
 int vpt_adam_launch(const VptAdamArgs* a, hipStream_t s);
+int vpt_nll_bwd_launch(const VptNllBwdArgs* a, hipStream_t s);
+int vpt_ln_bwd_launch(const VptLnBwdArgs* a, hipStream_t s);
+int vpt_gate_cast_launch(const VptGateCastArgs* a, hipStream_t s);
+int vpt_colsum_launch(const VptColsumArgs* a, hipStream_t s);
+int vpt_attn_bwd_launch(const VptAttnBwdArgs* a, hipStream_t s);
 int vpt_conv3x3_launch(const VptConv3x3Args* a, hipStream_t s);
 int vpt_conv_first_launch(const VptConvFirstArgs* a, hipStream_t s);
 int vpt_conv3d_launch(const VptConv3dArgs* a, hipStream_t s);

@@ -104,18 +104,24 @@ def frame_affine(x, gain, bias, stats_in, stats_out=None, per_element=False, out
     return out
 
 
-def linear(a_bf16, wpk, n, bias=None, res=None, relu=False, out_f32=True, out_bf16=False, splitk=1):
-    """a [M,K] bf16 (row stride = K) x packed weight -> ([M,n] fp32 or None, [M,n] bf16 or None)."""
+def linear(a_bf16, wpk, n, bias=None, res=None, relu=False, out_f32=True, out_bf16=False, splitk=1, mask=None,
+           out_bf16_ld=None):
+    """a [M,K] bf16 (row stride = K) x packed weight -> ([M,n] fp32 or None, [M,ld] bf16 or None).
+    mask: optional bf16 [M, >=n] gate (output zeroed where mask <= 0).  out_bf16_ld: row stride of the bf16
+    output (>= n, extra columns zero) so it can feed the next GEMM as an A operand with K padded to 64."""
     _chk(a_bf16, torch.bfloat16, "A"); _chk(wpk, torch.bfloat16, "wpk"); _chk(bias, torch.float32, "bias")
-    _chk(res, torch.float32, "res")
+    _chk(res, torch.float32, "res"); _chk(mask, torch.bfloat16, "mask")
     m, k = a_bf16.shape
     dev = a_bf16.device
     o32 = None
     if out_f32:
         o32 = torch.zeros(m, n, dtype=torch.float32, device=dev) if splitk > 1 else torch.empty(m, n, dtype=torch.float32, device=dev)
-    o16 = torch.empty(m, n, dtype=torch.bfloat16, device=dev) if out_bf16 else None
+    o16, ld16 = None, n
+    if out_bf16:
+        ld16 = out_bf16_ld or n
+        o16 = torch.zeros(m, ld16, dtype=torch.bfloat16, device=dev) if ld16 > n else torch.empty(m, n, dtype=torch.bfloat16, device=dev)
     _call("vpt_linear_forward", dict(flops=2.0 * m * n * k, bytes=2.0 * (m * k + n * k) + 4.0 * m * n), ptr(a_bf16), ptr(wpk), ptr(bias), ptr(res), ptr(o32), ptr(o16),
-                 m, n, k, k, n, n, n, 1 if relu else 0, splitk, _stream())
+          m, n, k, k, n, n, ld16, 1 if relu else 0, splitk, ptr(mask), mask.shape[1] if mask is not None else 0, _stream())
     return o32, o16
 
 
@@ -184,3 +190,50 @@ def adam_step_(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.99
     _call("vpt_adam_step", dict(bytes=28.0 * n), ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), ctypes.c_uint64(n), int(step),
           ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps), ctypes.c_float(weight_decay),
           ctypes.c_float(grad_scale), _stream())
+
+
+# ---- backward (behavioural-cloning step) ---------------------------------------------------------------
+def nll_backward(lp_buttons, lp_camera, act_buttons, act_camera, ldz, scale):
+    """bf16 [M, ldz] gradient of the BC loss w.r.t. the fused head logits (value column and padding zero)."""
+    _chk(lp_buttons, torch.float32, "lp_buttons"); _chk(lp_camera, torch.float32, "lp_camera")
+    _chk(act_buttons, torch.int64, "act_buttons"); _chk(act_camera, torch.int64, "act_camera")
+    m, nb = lp_buttons.shape
+    nc = lp_camera.shape[1]
+    dz = torch.empty(m, ldz, dtype=torch.bfloat16, device=lp_buttons.device)
+    _call("vpt_bc_nll_backward", dict(bytes=6.0 * m * ldz), ptr(lp_buttons), ptr(lp_camera), ptr(act_buttons), ptr(act_camera),
+          ptr(dz), m, nb, nc, ldz, ctypes.c_float(scale), _stream())
+    return dz
+
+
+def layernorm_backward(x, gain, dy, dgain, dbias, relu_in=False, dx_add=None):
+    for t, nme in ((x, "x"), (gain, "gain"), (dy, "dy"), (dgain, "dgain"), (dbias, "dbias"), (dx_add, "dx_add")):
+        _chk(t, torch.float32, nme)
+    m, d = x.shape
+    dx = torch.empty_like(x)
+    _call("vpt_layernorm_backward", dict(bytes=20.0 * m * d), ptr(x), ptr(gain), ptr(dy), ptr(dx_add), ptr(dx), ptr(dgain), ptr(dbias),
+          m, d, 1 if relu_in else 0, _stream())
+    return dx
+
+
+def gate_cast(x, ldo, mask=None):
+    """fp32 [M, N] -> bf16 [M, ldo] (zero padded), zeroed where mask <= 0."""
+    _chk(x, torch.float32, "x"); _chk(mask, torch.bfloat16, "mask")
+    m, n = x.shape
+    out = torch.empty(m, ldo, dtype=torch.bfloat16, device=x.device)
+    _call("vpt_gate_cast_bf16", dict(bytes=6.0 * m * ldo), ptr(x), ptr(mask), ptr(out), m, n, n, mask.shape[1] if mask is not None else 0, ldo, _stream())
+    return out
+
+
+def column_sum_(out, x_bf16, n):
+    _chk(x_bf16, torch.bfloat16, "x"); _chk(out, torch.float32, "out")
+    _call("vpt_column_sum", dict(bytes=2.0 * x_bf16.numel()), ptr(x_bf16), ptr(out), x_bf16.shape[0], n, x_bf16.shape[1], _stream())
+
+
+def masked_attention_backward(qkvr, kmem, vmem, memvalid, b_nd, dout, db_nd, batch, t, heads, hid):
+    for tt, nme in ((qkvr, "qkvr"), (kmem, "kmem"), (vmem, "vmem"), (b_nd, "b_nd"), (dout, "dout"), (db_nd, "db_nd")):
+        _chk(tt, torch.float32, nme)
+    _chk(memvalid, torch.uint8, "memvalid")
+    dqkvr = torch.zeros_like(qkvr)
+    _call("vpt_masked_attention_backward", dict(flops=10.0 * batch * t * (t + kmem.shape[1]) * hid), ptr(qkvr), ptr(kmem), ptr(vmem),
+          ptr(memvalid), ptr(b_nd), ptr(dout), ptr(dqkvr), ptr(db_nd), batch, t, heads, hid, qkvr.shape[1], kmem.shape[1], _stream())
+    return dqkvr

@@ -1,0 +1,238 @@
+"""Behavioural-cloning step on MI355X (behavioural_cloning.py:86-123 generalised to [B, T] chunks).
+
+    loss = -mean_{b,t}[ log pi(buttons_bt) + log pi(camera_bt) ]      (lib/action_head.py:176-184,252-253)
+    th.optim.Adam(lr=1.81e-4, weight_decay=0.039428)                   (behavioural_cloning.py:38-40,63-67)
+    gradient clipping: none -- the reference's clip_grad_norm_ receives an exhausted generator and is a no-op
+                       (behavioural_cloning.py:60,63,121; SURVEY.md §2 'latent bugs'); reproduced, i.e. NOT applied
+    state: the KV memory is carried between chunks detached (behavioural_cloning.py:111)
+
+Status: the backward exists for everything BEHIND the IMPALA CNN -- both action heads, final_ln,
+lastlayer, the four transformer blocks (attention incl. the relative-position bias and b_nd, MLPs, LayerNorms)
+and ImgObsProcess.linear + its LayerNorm, all on the HIP kernels (vpt_gemm_kernel as dgrad / wgrad,
+vpt_attn_bwd_kernel, vpt_ln_bwd_kernel, vpt_nll_bwd_kernel, vpt_adam_kernel).  The CNN's backward (conv dgrad /
+wgrad through the GroupNorm fold, pool, first conv) is not built yet, so `train_cnn=True` raises and the CNN
+parameters (incl. its dense layer) stay frozen: this trainer fine-tunes the 71 % of the 2x model's parameters
+that live in the trunk and heads.  Data parallelism: one process per GPU, sequences sharded by rank, ONE
+bucketed RCCL all-reduce of the gradients per step (distributed.bucketed_all_reduce_), averaged inside the
+fused Adam (grad_scale = 1 / world)."""
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import distributed as D
+from . import ops, packing
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def linear_backward(dy16: torch.Tensor, n: int, x16: Optional[torch.Tensor], weight: torch.Tensor, need_dx: bool = True,
+                    res: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
+                    dx_f32: bool = True, dx_bf16_ld: Optional[int] = None, need_dw: bool = True):
+    """Backward of y = x W^T on the MFMA GEMM kernel.
+    dy16: bf16 [M, Np] (Np >= n, Np % 64 == 0, padding zero); x16: bf16 [M, K]; weight fp32 [n, K].
+    Returns (dx fp32 or None, dx bf16 or None, dW fp32 [n, K] or None).
+    dgrad:  dx = dy W      -> GEMM(A = dy, weights = W^T packed), optional ReLU gate `mask` and skip-sum `res`;
+    wgrad:  dW = dy^T x    -> GEMM(A = dy^T [n, M], weights = x^T packed), reduction over the M frames."""
+    m, np_ = dy16.shape
+    k = weight.shape[1]
+    dev = dy16.device
+    dx32 = dx16 = dw = None
+    if need_dx:
+        wt = torch.zeros(k, np_, dtype=torch.bfloat16, device=dev)
+        wt[:, :n] = weight.t()
+        dx32, dx16 = ops.linear(dy16, packing.pack_linear(wt), k, res=res, mask=mask, out_f32=dx_f32,
+                                out_bf16=dx_bf16_ld is not None, out_bf16_ld=dx_bf16_ld)
+        del wt
+    if need_dw:
+        mp = _round_up(m, 64)
+        a = torch.zeros(n, mp, dtype=torch.bfloat16, device=dev)
+        a[:, :m] = dy16[:, :n].t()
+        xt = torch.zeros(k, mp, dtype=torch.bfloat16, device=dev)
+        xt[:, :m] = x16.t()
+        dw, _ = ops.linear(a, packing.pack_linear(xt), k)
+        del a, xt
+    return dx32, dx16, dw
+
+
+class BCTrainer:
+    def __init__(self, policy, lr: float = 0.000181, weight_decay: float = 0.039428, betas=(0.9, 0.999), eps: float = 1e-8,
+                 train_cnn: bool = False):
+        if train_cnn:
+            raise NotImplementedError("the IMPALA CNN's backward kernels are not built yet (DESIGN.md §8): train_cnn=False only")
+        self.policy = policy
+        self.engine = policy._engine
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.step_count = 0
+        self.params: Dict[str, torch.nn.Parameter] = dict(policy.named_parameters())
+        self.trainable = [n for n in self.params if self._is_trainable(n)]
+        self.m = {n: torch.zeros_like(self.params[n], dtype=torch.float32) for n in self.trainable}
+        self.v = {n: torch.zeros_like(self.params[n], dtype=torch.float32) for n in self.trainable}
+
+    @staticmethod
+    def _is_trainable(name: str) -> bool:
+        if name.startswith("net.img_process.cnn."):
+            return False            # frozen until the CNN backward exists
+        if name.startswith("value_head."):
+            return False            # no gradient under the BC loss; normaliser buffers are not trained
+        return True
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def loss_and_grads(self, img_u8, first, state_in, act_buttons, act_camera, global_frames: Optional[int] = None):
+        """Forward (saving activations) + backward.  Returns (loss of this rank's frames, grads dict, state_out).
+        global_frames: number of frames in the global (all-rank) batch the mean runs over (default: local)."""
+        pol, eng = self.policy, self.engine
+        pol._ensure_packed()
+        cfg, w = eng.cfg, eng.w
+        P = {n: p.detach() for n, p in self.params.items()}
+        bsz, t = img_u8.shape[:2]
+        m = bsz * t
+        hid, heads, maxlen = cfg["hidsize"], cfg["heads"], cfg["maxlen"]
+        ratio = cfg["pointwise_ratio"]
+        dev = img_u8.device
+        nb, nc = eng.n_buttons, eng.n_camera
+        frames = img_u8.reshape(m, *img_u8.shape[2:]).contiguous()
+
+        # ---------------- forward, keeping what the backward needs ----------------
+        outs = []
+        for i in range(0, m, eng.cnn_chunk):
+            xn = eng._cnn_chunk(frames[i:i + eng.cnn_chunk])
+            d32, _ = ops.linear(xn.view(xn.shape[0], -1), w["net.img_process.cnn.dense.w"], 256, splitk=16)
+            outs.append(d32)
+            del xn
+        d = outs[0] if len(outs) == 1 else torch.cat(outs, 0)                     # [M,256] pre-ReLU dense output
+        pl = "net.img_process.linear."
+        _, dn = ops.layernorm(d, w[pl + "g"], w[pl + "b"], relu_in=True)          # bf16
+        x, x16 = ops.linear(dn, w[pl + "w"], hid, relu=True, out_f32=True, out_bf16=True)
+        x_lin16 = x16
+        not_first = ~first[:, 0].reshape(bsz, 1, 1)
+        saved: List[dict] = []
+        state_out = []
+        for l in range(cfg["n_layers"]):
+            p = f"net.recurrent_layer.blocks.{l}."
+            state_mask, (kmem, vmem) = state_in[l]
+            if state_mask is None:
+                state_mask = torch.zeros(bsz, 1, maxlen, dtype=torch.bool, device=dev)
+            memvalid = (state_mask & not_first).reshape(bsz, maxlen).to(torch.uint8).contiguous()
+            kmem, vmem = kmem.contiguous(), vmem.contiguous()
+            x1, x1b = ops.layernorm(x, w[p + "ln1.g"], w[p + "ln1.b"], out_f32=True)
+            qkvr, _ = ops.linear(x1b, w[p + "qkvr.w"], eng.n_qkvr, bias=w[p + "qkvr.b"])
+            att = ops.masked_attention(qkvr, kmem, vmem, memvalid, w[p + "b_nd"], bsz, t, heads, hid)
+            kout, vout = ops.kv_memory_update(qkvr, kmem, vmem, bsz, t, hid)
+            x2, _ = ops.linear(att, w[p + "proj.w"], hid, bias=w[p + "proj.b"], res=x1)
+            _, hb = ops.layernorm(x2, w[p + "ln2.g"], w[p + "ln2.b"])
+            _, h2 = ops.linear(hb, w[p + "mlp0.w"], hid * ratio, relu=True, out_f32=False, out_bf16=True)
+            xo, _ = ops.linear(h2, w[p + "mlp1.w"], hid, bias=w[p + "mlp1.b"], res=x2)
+            saved.append(dict(x=x, x1b=x1b, qkvr=qkvr, kmem=kmem, vmem=vmem, memvalid=memvalid, att=att, x2=x2, hb=hb, h2=h2))
+            new_mask = torch.cat([state_mask[:, :, t:] & not_first,
+                                  torch.ones(bsz, 1, min(t, maxlen), dtype=torch.bool, device=dev)], dim=-1)
+            state_out.append((new_mask, (kout, vout)))
+            x = xo
+        x_trunk = x
+        _, xb = ops.layernorm(x_trunk, w["last.g"], w["last.b"], relu_in=True)
+        y, y16 = ops.linear(xb, w["last.w"], hid, relu=True, out_f32=True, out_bf16=True)
+        _, lb = ops.layernorm(y, w["final.g"], w["final.b"])
+        logits, _ = ops.linear(lb, w["heads.w"], nb + nc + 1, bias=w["heads.b"])
+        temp = cfg["temperature"]
+        lp_b = ops.log_softmax_cols(logits, 0, nb, temp)
+        lp_c = ops.log_softmax_cols(logits, nb, nc, temp)
+        ab = act_buttons.reshape(m).to(torch.int64).contiguous()
+        ac = act_camera.reshape(m).to(torch.int64).contiguous()
+        loss = -(lp_b.gather(1, ab[:, None]) + lp_c.gather(1, ac[:, None])).mean()
+
+        # ---------------- backward ----------------
+        g: Dict[str, torch.Tensor] = {}
+        zeros = lambda n_: torch.zeros(n_, dtype=torch.float32, device=dev)
+        gf = global_frames or m
+        nh = nb + nc + 1
+        ldz = _round_up(nh, 64)
+        dz = ops.nll_backward(lp_b, lp_c, ab, ac, ldz, 1.0 / (gf * temp))
+        # heads (fused [buttons; camera; value] GEMM): dlat, dW, db
+        wh = torch.cat([P["pi_head.buttons.linear_layer.weight"], P["pi_head.camera.linear_layer.weight"],
+                        P["value_head.linear.weight"]], 0)
+        dlat, _, dwh = linear_backward(dz, nh, lb, wh)
+        dbh = zeros(nh)
+        ops.column_sum_(dbh, dz, nh)
+        g["pi_head.buttons.linear_layer.weight"], g["pi_head.camera.linear_layer.weight"] = dwh[:nb], dwh[nb:nb + nc]
+        g["pi_head.buttons.linear_layer.bias"], g["pi_head.camera.linear_layer.bias"] = dbh[:nb], dbh[nb:nb + nc]
+        del dz, dwh
+        # final_ln
+        g["net.final_ln.weight"], g["net.final_ln.bias"] = zeros(hid), zeros(hid)
+        dy = ops.layernorm_backward(y, P["net.final_ln.weight"], dlat, g["net.final_ln.weight"], g["net.final_ln.bias"])
+        # lastlayer: y = relu(xb Wl^T); gate dy by y > 0 while casting to the GEMM operand
+        dy16 = ops.gate_cast(dy, hid, mask=y16)
+        dxb, _, g["net.lastlayer.layer.weight"] = linear_backward(dy16, hid, xb, P["net.lastlayer.layer.weight"])
+        g["net.lastlayer.norm.weight"], g["net.lastlayer.norm.bias"] = zeros(hid), zeros(hid)
+        dx = ops.layernorm_backward(x_trunk, P["net.lastlayer.norm.weight"], dxb, g["net.lastlayer.norm.weight"],
+                                    g["net.lastlayer.norm.bias"], relu_in=True)
+        del dy, dy16, dxb, dlat
+        # transformer blocks, last to first
+        for l in reversed(range(cfg["n_layers"])):
+            p = f"net.recurrent_layer.blocks.{l}."
+            o = p + "r.orc_block."
+            s = saved[l]
+            dout16 = ops.gate_cast(dx, hid)
+            # mlp1: out = x2 + h2 W1^T + b1
+            _, dh16, g[p + "mlp1.layer.weight"] = linear_backward(dout16, hid, s["h2"], P[p + "mlp1.layer.weight"], mask=s["h2"],
+                                                                  dx_f32=False, dx_bf16_ld=hid * ratio)
+            g[p + "mlp1.layer.bias"] = zeros(hid)
+            ops.column_sum_(g[p + "mlp1.layer.bias"], dout16, hid)
+            # mlp0: h2 = relu(hb W0^T)  (the ReLU gate was applied by the mask above)
+            dhb, _, g[p + "mlp0.layer.weight"] = linear_backward(dh16, hid * ratio, s["hb"], P[p + "mlp0.layer.weight"])
+            g[p + "mlp0.norm.weight"], g[p + "mlp0.norm.bias"] = zeros(hid), zeros(hid)
+            dx2 = ops.layernorm_backward(s["x2"], P[p + "mlp0.norm.weight"], dhb, g[p + "mlp0.norm.weight"], g[p + "mlp0.norm.bias"], dx_add=dx)
+            del dh16, dhb, dout16
+            # proj: x2 = x1 + att Wp^T + bp
+            dx2_16 = ops.gate_cast(dx2, hid)
+            datt, _, g[o + "proj_layer.weight"] = linear_backward(dx2_16, hid, s["att"], P[o + "proj_layer.weight"])
+            g[o + "proj_layer.bias"] = zeros(hid)
+            ops.column_sum_(g[o + "proj_layer.bias"], dx2_16, hid)
+            # attention
+            g[o + "b_nd"] = torch.zeros(10, maxlen, dtype=torch.float32, device=dev)
+            dqkvr = ops.masked_attention_backward(s["qkvr"], s["kmem"], s["vmem"], s["memvalid"], w[p + "b_nd"], datt,
+                                                  g[o + "b_nd"], bsz, t, heads, hid)
+            nq = eng.n_qkvr
+            dq16 = ops.gate_cast(dqkvr, _round_up(nq, 64))
+            wq = torch.cat([P[o + "q_layer.weight"], P[o + "k_layer.weight"], P[o + "v_layer.weight"], P[o + "r_layer.weight"]], 0)
+            dx1, _, dwq = linear_backward(dq16, nq, s["x1b"], wq, res=dx2)   # dx1 = dx2 (skip) + dqkvr Wqkvr
+            g[o + "q_layer.weight"], g[o + "k_layer.weight"] = dwq[:hid], dwq[hid:2 * hid]
+            g[o + "v_layer.weight"], g[o + "r_layer.weight"] = dwq[2 * hid:3 * hid], dwq[3 * hid:]
+            dbq = zeros(nq)
+            ops.column_sum_(dbq, dq16, nq)
+            g[o + "q_layer.bias"], g[o + "r_layer.bias"] = dbq[:hid], dbq[3 * hid:]
+            g[p + "pre_r_ln.weight"], g[p + "pre_r_ln.bias"] = zeros(hid), zeros(hid)
+            dx = ops.layernorm_backward(s["x"], P[p + "pre_r_ln.weight"], dx1, g[p + "pre_r_ln.weight"], g[p + "pre_r_ln.bias"])
+            del dx2, dx2_16, datt, dqkvr, dq16, dx1, dwq
+        # ImgObsProcess.linear: x = relu(dn Wlin^T)
+        dx16 = ops.gate_cast(dx, hid, mask=x_lin16)
+        ddn, _, g[pl + "layer.weight"] = linear_backward(dx16, hid, dn, P[pl + "layer.weight"])
+        g[pl + "norm.weight"], g[pl + "norm.bias"] = zeros(256), zeros(256)
+        ops.layernorm_backward(d, P[pl + "norm.weight"], ddn, g[pl + "norm.weight"], g[pl + "norm.bias"], relu_in=True)
+        # (the gradient w.r.t. `d` would continue into the CNN's dense layer -- not built yet)
+        return loss, g, state_out
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, img_u8, first, state_in, act_buttons, act_camera):
+        """One optimiser step on this rank's shard of the batch.  Returns (global mean loss, state_out)."""
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        m_local = img_u8.shape[0] * img_u8.shape[1]
+        loss, grads, state_out = self.loss_and_grads(img_u8, first, state_in, act_buttons, act_camera,
+                                                     global_frames=m_local * world)
+        names = [n for n in self.trainable if n in grads]
+        if world > 1:
+            D.bucketed_all_reduce_([grads[n] for n in names], average=False)   # sum: the 1/global_frames is already inside
+            lt = loss.detach().clone()
+            dist.all_reduce(lt)
+            loss = lt / world
+        self.step_count += 1
+        for n in names:
+            gr = grads[n].contiguous().view(-1)
+            p = self.params[n].data.view(-1)
+            ops.adam_step_(p, gr, self.m[n].view(-1), self.v[n].view(-1), self.step_count, lr=self.lr, beta1=self.betas[0],
+                           beta2=self.betas[1], eps=self.eps, weight_decay=self.wd)
+        self.policy._packed_key = None  # weights changed: re-pack before the next forward
+        return float(loss), state_out
