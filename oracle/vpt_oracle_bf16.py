@@ -1,0 +1,112 @@
+"""bf16-rounding emulation of the HIP path on the CPU  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+The same restatement as oracle/vpt_oracle.py with a round-to-bf16 at exactly the points where the MI355X
+kernels round: MFMA operands (conv / linear inputs and weights, GroupNorm gain folded into the
+conv weight before rounding), CNN activations as stored between kernels (incl. the CNN residual stream and the
+normalised input of the dense layer), the attention output and the MLP hidden activation.  Statistics,
+LayerNorms, softmax, the transformer's residual stream, K/V and the head logits stay fp32.
+
+Two uses: (1) it predicts how far a correct bf16 pipeline sits from the fp32 reference (the tolerances of
+tests/test_gpu_policy.py); (2) because ReLU gates flip wherever the forward differs, gradients of a bf16 forward
+differ from fp32-forward gradients by 15-30 % relative L2 per tensor even with exact autograd -- so the BC step's
+backward is checked against THIS oracle's autograd (same gates), and only loosely (cosine) against the fp32 one.
+torch's cast ops are differentiable (straight-through), so autograd through this file is the matched oracle."""
+import torch
+import torch.nn.functional as F
+
+from . import vpt_oracle as O
+
+
+def bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def conv_fold(sd, pfx, x_bf, res=None):
+    """vpt_conv3x3_kernel: raw bf16 activations through conv(bf16(W*gain)), GroupNorm applied as the epilogue fold."""
+    g, b, W = sd[pfx + "norm.weight"], sd[pfx + "norm.bias"], sd[pfx + "layer.weight"]
+    n = x_bf.shape[0]
+    flat = x_bf.reshape(n, -1)
+    mu = flat.mean(1)
+    rstd = torch.rsqrt(flat.var(1, unbiased=False) + O.NORM_EPS)
+    Wg = bf(W * g.view(1, -1, 1, 1))
+    acc = F.conv2d(x_bf, Wg, padding=1)
+    ones = torch.ones(1, x_bf.shape[1], *x_bf.shape[2:])
+    sg = F.conv2d(ones, Wg, padding=1)
+    sa = F.conv2d(b.view(1, -1, 1, 1) * ones, W, padding=1)
+    out = torch.relu(rstd.view(-1, 1, 1, 1) * acc - (rstd * mu).view(-1, 1, 1, 1) * sg + sa)
+    if res is not None:
+        out = out + res
+    return bf(out)
+
+
+def policy_forward(sd, cfg, img_u8, first, state_in, grad=False):
+    with torch.set_grad_enabled(grad):
+        b, t = img_u8.shape[:2]
+        x = img_u8.reshape(b * t, 128, 128, 3).float().permute(0, 3, 1, 2)
+        p = "net.img_process.cnn.stacks.0."
+        y = torch.relu(F.conv2d(x, bf(sd[p + "firstconv.layer.weight"]), padding=1) / 255.0 + sd[p + "firstconv.layer.bias"].view(1, -1, 1, 1))
+        cur = None
+        for s in range(3):
+            p = f"net.img_process.cnn.stacks.{s}."
+            if s > 0:
+                y = conv_fold(sd, p + "firstconv.", cur)
+            y = bf(F.max_pool2d(bf(y), 3, 2, 1))
+            cur = bf(O.group_norm_1(y, sd[p + "n.weight"], sd[p + "n.bias"]))
+            for blk in range(2):
+                q = f"{p}blocks.{blk}."
+                h = conv_fold(sd, q + "conv0.", cur)
+                cur = conv_fold(sd, q + "conv1.", h, res=cur)
+        flat = cur.reshape(b * t, -1)
+        p = "net.img_process.cnn.dense."
+        xn = bf(O.layer_norm(flat, sd[p + "norm.weight"], sd[p + "norm.bias"]))
+        d = xn @ bf(sd[p + "layer.weight"]).t()
+        p = "net.img_process.linear."
+        dn = bf(O.layer_norm(torch.relu(d), sd[p + "norm.weight"], sd[p + "norm.bias"]))
+        x = torch.relu(dn @ bf(sd[p + "layer.weight"]).t()).reshape(b, t, -1)
+        first_b = first[:, 0]
+        state_out = []
+        hid, heads, maxlen = cfg["hidsize"], cfg["heads"], cfg["maxlen"]
+        dh = hid // heads
+        for l in range(cfg["n_layers"]):
+            p = f"net.recurrent_layer.blocks.{l}."
+            o = p + "r.orc_block."
+            x1 = O.layer_norm(x, sd[p + "pre_r_ln.weight"], sd[p + "pre_r_ln.bias"])
+            x1b = bf(x1)
+            sm, (km, vm) = state_in[l]
+            q = x1b @ bf(sd[o + "q_layer.weight"]).t() + sd[o + "q_layer.bias"]
+            k = x1b @ bf(sd[o + "k_layer.weight"]).t()
+            v = x1b @ bf(sd[o + "v_layer.weight"]).t()
+            r = x1b @ bf(sd[o + "r_layer.weight"]).t() + sd[o + "r_layer.bias"]
+            kf, vf = torch.cat([km, k], 1), torch.cat([vm, v], 1)
+            split = lambda z: z.reshape(b, z.shape[1], heads, dh).permute(0, 2, 1, 3)
+            lg = split(q) @ split(kf).transpose(-1, -2) / dh
+            vis, nm = O.band_visibility(t, maxlen, first_b, sm)
+            lg = lg + (~vis).float().unsqueeze(1) * O.NEG_MASK + O.rel_pos_bias(r.reshape(b, t, heads, -1), sd[o + "b_nd"], t, maxlen)
+            a = bf((torch.softmax(lg, -1) @ split(vf)).permute(0, 2, 1, 3).reshape(b, t, hid))
+            x2 = x1 + a @ bf(sd[o + "proj_layer.weight"]).t() + sd[o + "proj_layer.bias"]
+            hb = bf(O.layer_norm(x2, sd[p + "mlp0.norm.weight"], sd[p + "mlp0.norm.bias"]))
+            h2 = bf(torch.relu(hb @ bf(sd[p + "mlp0.layer.weight"]).t()))
+            x = x2 + h2 @ bf(sd[p + "mlp1.layer.weight"]).t() + sd[p + "mlp1.layer.bias"]
+            state_out.append((nm, (kf[:, -maxlen:], vf[:, -maxlen:])))
+        xb = bf(O.layer_norm(torch.relu(x), sd["net.lastlayer.norm.weight"], sd["net.lastlayer.norm.bias"]))
+        y = torch.relu(xb @ bf(sd["net.lastlayer.layer.weight"]).t())
+        lat = O.layer_norm(y, sd["net.final_ln.weight"], sd["net.final_ln.bias"])
+        latb = bf(lat)
+        out = {"latent": lat, "state_out": state_out}
+        for hname in ("buttons", "camera"):
+            z = latb @ bf(sd[f"pi_head.{hname}.linear_layer.weight"]).t() + sd[f"pi_head.{hname}.linear_layer.bias"]
+            out[hname] = torch.log_softmax(z / cfg["temperature"], -1).unsqueeze(-2)
+        return out
+
+
+def bc_loss_and_grads(sd, cfg, img_u8, first, state_in, act_buttons, act_camera):
+    """As vpt_oracle.bc_loss_and_grads, through the bf16-emulating forward."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point}
+    state_det = [(m, (k.detach(), v.detach())) for m, (k, v) in state_in]
+    out = policy_forward(leaves, cfg, img_u8, first, state_det, grad=True)
+    lp = out["buttons"][:, :, 0].gather(-1, act_buttons.unsqueeze(-1)).squeeze(-1) \
+        + out["camera"][:, :, 0].gather(-1, act_camera.unsqueeze(-1)).squeeze(-1)
+    loss = -lp.mean()
+    names = list(leaves)
+    grads = torch.autograd.grad(loss, [leaves[n] for n in names], allow_unused=True)
+    return float(loss.detach()), {n: (g if g is not None else torch.zeros_like(leaves[n])) for n, g in zip(names, grads)}

@@ -81,7 +81,7 @@ class BCTrainer:
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def loss_and_grads(self, img_u8, first, state_in, act_buttons, act_camera, global_frames: Optional[int] = None):
+    def loss_and_grads(self, img_u8, first, state_in, act_buttons, act_camera, global_frames: Optional[int] = None, debug: Optional[dict] = None):
         """Forward (saving activations) + backward.  Returns (loss of this rank's frames, grads dict, state_out).
         global_frames: number of frames in the global (all-rank) batch the mean runs over (default: local)."""
         pol, eng = self.policy, self.engine
@@ -154,6 +154,8 @@ class BCTrainer:
         wh = torch.cat([P["pi_head.buttons.linear_layer.weight"], P["pi_head.camera.linear_layer.weight"],
                         P["value_head.linear.weight"]], 0)
         dlat, _, dwh = linear_backward(dz, nh, lb, wh)
+        if debug is not None:
+            debug['dlatent'] = dlat.clone(); debug['latent'] = lb.float().clone(); debug['y'] = y.clone()
         dbh = zeros(nh)
         ops.column_sum_(dbh, dz, nh)
         g["pi_head.buttons.linear_layer.weight"], g["pi_head.camera.linear_layer.weight"] = dwh[:nb], dwh[nb:nb + nc]
@@ -168,6 +170,8 @@ class BCTrainer:
         g["net.lastlayer.norm.weight"], g["net.lastlayer.norm.bias"] = zeros(hid), zeros(hid)
         dx = ops.layernorm_backward(x_trunk, P["net.lastlayer.norm.weight"], dxb, g["net.lastlayer.norm.weight"],
                                     g["net.lastlayer.norm.bias"], relu_in=True)
+        if debug is not None:
+            debug['dy'] = dy.clone(); debug['dx_trunk'] = dx.clone(); debug['x_trunk'] = x_trunk.clone()
         del dy, dy16, dxb, dlat
         # transformer blocks, last to first
         for l in reversed(range(cfg["n_layers"])):
@@ -205,6 +209,8 @@ class BCTrainer:
             g[o + "q_layer.bias"], g[o + "r_layer.bias"] = dbq[:hid], dbq[3 * hid:]
             g[p + "pre_r_ln.weight"], g[p + "pre_r_ln.bias"] = zeros(hid), zeros(hid)
             dx = ops.layernorm_backward(s["x"], P[p + "pre_r_ln.weight"], dx1, g[p + "pre_r_ln.weight"], g[p + "pre_r_ln.bias"])
+            if debug is not None:
+                debug[f'dx_block{l}'] = dx.clone(); debug[f'dx2_block{l}'] = dx2.clone(); debug[f'datt{l}'] = datt.clone(); debug[f'dqkvr{l}'] = dqkvr.clone()
             del dx2, dx2_16, datt, dqkvr, dq16, dx1, dwq
         # ImgObsProcess.linear: x = relu(dn Wlin^T)
         dx16 = ops.gate_cast(dx, hid, mask=x_lin16)
