@@ -277,6 +277,8 @@ def policy_forward(sd: Dict[str, torch.Tensor], cfg: dict, img_u8: torch.Tensor,
         x = torch.relu(x)
         x = layer_norm(x, sd["net.lastlayer.norm.weight"], sd["net.lastlayer.norm.bias"])
         x = torch.relu(x @ sd["net.lastlayer.layer.weight"].t())
+        if taps is not None:
+            taps["y"] = x
         x = layer_norm(x, sd["net.final_ln.weight"], sd["net.final_ln.bias"])
         out = dict(
             buttons=categorical_head(sd, "pi_head.buttons.", x, cfg["temperature"]),

@@ -39,7 +39,7 @@ def conv_fold(sd, pfx, x_bf, res=None):
     return bf(out)
 
 
-def policy_forward(sd, cfg, img_u8, first, state_in, grad=False):
+def policy_forward(sd, cfg, img_u8, first, state_in, grad=False, taps=None):
     with torch.set_grad_enabled(grad):
         b, t = img_u8.shape[:2]
         x = img_u8.reshape(b * t, 128, 128, 3).float().permute(0, 3, 1, 2)
@@ -63,6 +63,8 @@ def policy_forward(sd, cfg, img_u8, first, state_in, grad=False):
         p = "net.img_process.linear."
         dn = bf(O.layer_norm(torch.relu(d), sd[p + "norm.weight"], sd[p + "norm.bias"]))
         x = torch.relu(dn @ bf(sd[p + "layer.weight"]).t()).reshape(b, t, -1)
+        if taps is not None:
+            taps["img_process"] = x
         first_b = first[:, 0]
         state_out = []
         hid, heads, maxlen = cfg["hidsize"], cfg["heads"], cfg["maxlen"]
@@ -88,8 +90,12 @@ def policy_forward(sd, cfg, img_u8, first, state_in, grad=False):
             h2 = bf(torch.relu(hb @ bf(sd[p + "mlp0.layer.weight"]).t()))
             x = x2 + h2 @ bf(sd[p + "mlp1.layer.weight"]).t() + sd[p + "mlp1.layer.bias"]
             state_out.append((nm, (kf[:, -maxlen:], vf[:, -maxlen:])))
+            if taps is not None:
+                taps[f"block{l}"] = x
         xb = bf(O.layer_norm(torch.relu(x), sd["net.lastlayer.norm.weight"], sd["net.lastlayer.norm.bias"]))
         y = torch.relu(xb @ bf(sd["net.lastlayer.layer.weight"]).t())
+        if taps is not None:
+            taps["y"] = y
         lat = O.layer_norm(y, sd["net.final_ln.weight"], sd["net.final_ln.bias"])
         latb = bf(lat)
         out = {"latent": lat, "state_out": state_out}
