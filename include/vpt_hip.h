@@ -128,6 +128,35 @@ int vpt_masked_attention_backward(const float* qkvr, const float* kmem, const fl
                                   const float* b_nd, const float* dout, float* dqkvr, float* db_nd,
                                   int B, int t, int heads, int hid, int ld, int maxlen, void* stream);
 
+/* ---- backward of the IMPALA CNN (behavioural_cloning.py:117-119 obtains these from torch autograd) ---- */
+
+/* Per-element preparation of GN -> conv3x3 -> ReLU (+res) backward: dacc = rstd * dY * [v > 0] (blocked, Cout
+ * channels); t12[f] += (sum dz (v - SA), sum dz SG); d_sa / d_sg [9][CoutPad] += sum dz / sum dz (-rstd mu).
+ * stats_in are the statistics of the layer's INPUT (Cin*H*W elements). */
+int vpt_conv_backward_prepare(const void* dy, const void* y, const void* res, const double* stats_in,
+                              const float* edge_sa, const float* edge_sg, void* dacc, double* t12,
+                              float* d_sa, float* d_sg, int frames, int H, int W, int Cin, int Cout, void* stream);
+
+/* Input gradient of the layer: dx = conv^T(W', dacc) + skip + coef[f][0] + coef[f][1] * xin, i.e. the implicit-GEMM
+ * kernel of vpt_conv3x3_forward on the transposed, spatially flipped weights (wpk_t: [ceil(Cin/128)][Cout/32][9][128][32])
+ * with the GroupNorm-statistics terms c0_f + c1_f x added in its epilogue.  dacc has Cout channels, dx / xin / skip Cin. */
+int vpt_conv3x3_dgrad(const void* dacc, const void* wpk_t, const void* skip, const void* xin, const float* coef, void* dx,
+                      int frames, int H, int W, int Cout, int Cin, void* stream);
+
+/* Weight gradient of the folded convolution: dw[o][tap][c] += sum_{f,p} dacc[f][o][p] * x[f][c][p + tap] (fp32, atomics;
+ * caller zeroes).  W in {16, 32, 64}.  The host maps it to dW, dgain, dbias (training.py). */
+int vpt_conv3x3_wgrad(const void* dacc, const void* x, float* dw, int frames, int H, int W, int Cin, int Cout, void* stream);
+
+/* F.max_pool2d(3, 2, 1) backward with torch's first-maximum tie rule. */
+int vpt_maxpool_backward(const void* pre, const void* pooled, const void* dpooled, void* dpre,
+                         int frames, int C, int H, int W, void* stream);
+
+/* Backward of vpt_frame_affine_forward.  pass 1: ab[f] += (sum dy g, sum dy g xhat) and (per_element = 0) dgain/dbias;
+ * pass 2: dx = rstd (dy g - ab0/n - xhat ab1/n) + dx_add; pass 3 (per_element = 1): dgain/dbias reduced over frames. */
+int vpt_frame_affine_backward(const void* x, const void* dy, const void* dx_add, void* dx, const float* gain,
+                              const double* stats_in, double* ab, float* dgain, float* dbias,
+                              int frames, int C, int HW, int per_element, int pass, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

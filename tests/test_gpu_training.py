@@ -180,3 +180,106 @@ def test_bc_step_reduces_loss(trainer_1x):
     torch.cuda.synchronize()
     print("BC losses on a fixed batch:", losses)
     assert losses[-1] < losses[0] - 0.05
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CNN backward pieces
+# ---------------------------------------------------------------------------------------------------------
+def _stats_of(x_nchw):
+    f = x_nchw.shape[0]
+    flat = x_nchw.reshape(f, -1).double()
+    return torch.stack([flat.sum(1), (flat * flat).sum(1)], dim=1).contiguous()
+
+
+VALID = {0: [1, 2], 1: [0, 1, 2], 2: [0, 1]}
+
+
+def _tap_sum(tab, cout):
+    """tab [9 edge classes, >=cout] -> [cout, 3, 3]: sum over the edge classes in which tap (kh, kw) is inside the image."""
+    out = torch.zeros(cout, 3, 3, dtype=tab.dtype)
+    for ey in range(3):
+        for ex in range(3):
+            for kh in VALID[ey]:
+                for kw in VALID[ex]:
+                    out[:, kh, kw] += tab[ey * 3 + ex, :cout]
+    return out
+
+
+@pytest.mark.parametrize("per_element", [False, True])
+def test_frame_affine_backward(per_element):
+    g = torch.Generator().manual_seed(11)
+    f, c, h, w = 3, 64, 16, 16
+    x = torch.randn(f, c, h, w, generator=g).to(torch.bfloat16).float().requires_grad_(True)
+    n_g = c * h * w if per_element else c
+    gain = (1 + 0.2 * torch.randn(n_g, generator=g)).requires_grad_(True)
+    bias = (0.1 * torch.randn(n_g, generator=g)).requires_grad_(True)
+    dy = torch.randn(f, c, h, w, generator=g).to(torch.bfloat16).float()
+    if per_element:
+        y = O.layer_norm(x.reshape(f, -1), gain, bias).reshape(f, c, h, w)
+        gk = packing.chw_to_blocked_vector(gain.detach(), c, h, w)
+    else:
+        y = O.group_norm_1(x, gain, bias)
+        gk = gain.detach()
+    gx, gg, gb = torch.autograd.grad((y * dy).sum(), [x, gain, bias])
+    dg, db = torch.zeros(n_g, device=DEV), torch.zeros(n_g, device=DEV)
+    dx = ops.frame_affine_backward(packing.nchw_to_blocked(x.detach()).to(DEV), packing.nchw_to_blocked(dy).to(DEV), gk.to(DEV),
+                                   _stats_of(x.detach()).to(DEV), dg, db, per_element=per_element)
+    torch.cuda.synchronize()
+    assert _l2(packing.blocked_to_nchw(dx.cpu(), c, h, w), gx) < 8e-3
+    if per_element:
+        dg_c, db_c = dg.cpu(), db.cpu()
+        assert _l2(dg_c, packing.chw_to_blocked_vector(gg, c, h, w)) < 1e-3 and _l2(db_c, packing.chw_to_blocked_vector(gb, c, h, w)) < 1e-3
+    else:
+        assert _l2(dg.cpu(), gg) < 1e-3 and _l2(db.cpu(), gb) < 1e-3
+
+
+def test_maxpool_backward():
+    g = torch.Generator().manual_seed(12)
+    f, c, h, w = 2, 32, 16, 16
+    pre = torch.relu(torch.randn(f, c, h, w, generator=g)).to(torch.bfloat16).float()
+    pre[0, :, 4:8, 4:8] = 0.5  # plateaus: exercise the first-maximum tie rule
+    pre.requires_grad_(True)
+    pooled = torch.nn.functional.max_pool2d(pre, 3, 2, 1)
+    dp = torch.randn(f, c, h // 2, w // 2, generator=g).to(torch.bfloat16).float()
+    (gpre,) = torch.autograd.grad((pooled * dp).sum(), [pre])
+    out = ops.maxpool_backward(packing.nchw_to_blocked(pre.detach()).to(DEV), packing.nchw_to_blocked(pooled.detach()).to(DEV),
+                               packing.nchw_to_blocked(dp).to(DEV))
+    torch.cuda.synchronize()
+    assert _l2(packing.blocked_to_nchw(out.cpu(), c, h, w), gpre) < 8e-3
+
+
+@pytest.mark.parametrize("frames,h,cin,cout,use_res", [(2, 16, 64, 128, True), (2, 32, 128, 96, False)])
+def test_conv_layer_backward_dx_and_bias(frames, h, cin, cout, use_res):
+    """GN -> conv3x3 -> ReLU (+res): input gradient (dgrad kernel + statistics terms) and GroupNorm-bias gradient
+    (edge-table path) against autograd on the same bf16 inputs."""
+    g = torch.Generator().manual_seed(13)
+    w_ = h
+    W = (torch.randn(cout, cin, 3, 3, generator=g) * (1.6 / (cin * 9) ** 0.5)).requires_grad_(True)
+    gain = (1 + 0.2 * torch.randn(cin, generator=g)).requires_grad_(True)
+    bias = (0.1 * torch.randn(cin, generator=g)).requires_grad_(True)
+    x = (torch.relu(torch.randn(frames, cin, h, w_, generator=g)) + 0.2 * torch.randn(frames, cin, h, w_, generator=g)).to(torch.bfloat16).float().requires_grad_(True)
+    res = torch.randn(frames, cout, h, w_, generator=g).to(torch.bfloat16).float() if use_res else None
+    dY = torch.randn(frames, cout, h, w_, generator=g).to(torch.bfloat16).float()
+    sd = {"norm.weight": gain, "norm.bias": bias, "layer.weight": W}
+    y = O._norm_conv_relu(sd, "", x) + (res if use_res else 0)
+    gx, gW, gg, gb = torch.autograd.grad((y * dY).sum(), [x, W, gain, bias])
+    # GPU: forward (for the saved output), prepare, dgrad
+    wpk, sa, sg = packing.pack_conv3x3(W.detach().to(DEV), gain.detach().to(DEV), bias.detach().to(DEV))
+    xb = packing.nchw_to_blocked(x.detach()).to(DEV)
+    st_in = _stats_of(x.detach()).to(DEV)
+    resb = packing.nchw_to_blocked(res).to(DEV) if use_res else None
+    yb = ops.conv3x3(xb, wpk, sa, sg, st_in, cout, res=resb)
+    dacc, t12, d_sa, d_sg = ops.conv_backward_prepare(packing.nchw_to_blocked(dY).to(DEV), yb, resb, st_in, sa, sg, cin)
+    n = cin * h * w_
+    mu = (st_in[:, 0] / n)
+    rstd = torch.rsqrt((st_in[:, 1] / n - mu * mu).clamp(min=0) + 1e-5)
+    t1, t2 = t12[:, 0], t12[:, 1]
+    c1 = -(rstd * rstd) * t1 / n
+    c0 = -(rstd / n) * t2 - c1 * mu
+    coef = torch.stack([c0, c1], 1).float().contiguous()
+    dx = ops.conv3x3_dgrad(dacc, packing.pack_conv3x3_dgrad(W.detach().to(DEV), gain.detach().to(DEV)), cin, xin=xb, coef=coef)
+    torch.cuda.synchronize()
+    err = _l2(packing.blocked_to_nchw(dx.cpu(), cin, h, w_), gx)
+    assert err < 8e-2, f"dx rel L2 {err}"  # a few ReLU gates differ between the GPU and CPU forwards
+    dbeta = (_tap_sum(d_sa.cpu(), cout).unsqueeze(1) * W.detach()).sum(dim=(0, 2, 3))
+    assert _l2(dbeta, gb) < 5e-2

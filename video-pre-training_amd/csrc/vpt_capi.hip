@@ -43,7 +43,55 @@ int vpt_conv3x3_forward(const void* x, const void* wpk, const float* edge_sa, co
   a.frames = frames; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.NT = (Cout + 127) / 128; a.CoutPad = a.NT * 128;
   a.inv_count_in = 1.0 / ((double)Cin * H * W);
+  a.bwd = 0; a.xin = nullptr; a.coef = nullptr;
   CHECK_LAUNCH(vpt_conv3x3_launch(&a, (hipStream_t)stream), "vpt_conv3x3_forward");
+}
+
+int vpt_conv3x3_dgrad(const void* dacc, const void* wpk_t, const void* skip, const void* xin, const float* coef, void* dx,
+                      int frames, int H, int W, int Cout, int Cin, void* stream) {
+  VptConv3x3Args a;
+  a.x = (const vpt_bf16*)dacc; a.wpk = (const vpt_bf16*)wpk_t; a.edge_sa = nullptr; a.edge_sg = nullptr;
+  a.stats_in = nullptr; a.res = (const vpt_bf16*)skip; a.y = (vpt_bf16*)dx; a.stats_out = nullptr;
+  a.frames = frames; a.H = H; a.W = W; a.Cin = Cout; a.Cout = Cin;   // roles swap in the transposed convolution
+  a.NT = (Cin + 127) / 128; a.CoutPad = a.NT * 128; a.inv_count_in = 1.0;
+  a.bwd = 1; a.xin = (const vpt_bf16*)xin; a.coef = coef;
+  CHECK_LAUNCH(vpt_conv3x3_launch(&a, (hipStream_t)stream), "vpt_conv3x3_dgrad");
+}
+
+int vpt_conv_backward_prepare(const void* dy, const void* y, const void* res, const double* stats_in,
+                              const float* edge_sa, const float* edge_sg, void* dacc, double* t12,
+                              float* d_sa, float* d_sg, int frames, int H, int W, int Cin, int Cout, void* stream) {
+  VptConvBwdPrepArgs a;
+  a.dy = (const vpt_bf16*)dy; a.y = (const vpt_bf16*)y; a.res = (const vpt_bf16*)res; a.stats_in = stats_in;
+  a.edge_sa = edge_sa; a.edge_sg = edge_sg; a.dacc = (vpt_bf16*)dacc; a.t12 = t12; a.d_sa = d_sa; a.d_sg = d_sg;
+  a.frames = frames; a.CB = Cout / 32; a.H = H; a.W = W; a.CoutPad = ((Cout + 127) / 128) * 128;
+  a.inv_count_in = 1.0 / ((double)Cin * H * W);
+  CHECK_LAUNCH(vpt_conv_bwd_prep_launch(&a, (hipStream_t)stream), "vpt_conv_backward_prepare");
+}
+
+int vpt_conv3x3_wgrad(const void* dacc, const void* x, float* dw, int frames, int H, int W, int Cin, int Cout, void* stream) {
+  VptConvWgradArgs a;
+  a.dacc = (const vpt_bf16*)dacc; a.x = (const vpt_bf16*)x; a.dw = dw;
+  a.frames = frames; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.OT = 0; a.frames_per_wg = 0;
+  CHECK_LAUNCH(vpt_conv_wgrad_launch(&a, (hipStream_t)stream), "vpt_conv3x3_wgrad");
+}
+
+int vpt_maxpool_backward(const void* pre, const void* pooled, const void* dpooled, void* dpre,
+                         int frames, int C, int H, int W, void* stream) {
+  VptPoolBwdArgs a;
+  a.pre = (const vpt_bf16*)pre; a.pooled = (const vpt_bf16*)pooled; a.dpooled = (const vpt_bf16*)dpooled;
+  a.dpre = (vpt_bf16*)dpre; a.frames = frames; a.CB = C / 32; a.H = H; a.W = W;
+  CHECK_LAUNCH(vpt_pool_bwd_launch(&a, (hipStream_t)stream), "vpt_maxpool_backward");
+}
+
+int vpt_frame_affine_backward(const void* x, const void* dy, const void* dx_add, void* dx, const float* gain,
+                              const double* stats_in, double* ab, float* dgain, float* dbias,
+                              int frames, int C, int HW, int per_element, int pass, void* stream) {
+  VptAffineBwdArgs a;
+  a.x = (const vpt_bf16*)x; a.dy = (const vpt_bf16*)dy; a.dx_add = (const vpt_bf16*)dx_add; a.dx = (vpt_bf16*)dx;
+  a.gain = gain; a.stats_in = stats_in; a.ab = ab; a.dgain = dgain; a.dbias = dbias;
+  a.frames = frames; a.CB = C / 32; a.HW = HW; a.per_element = per_element; a.inv_count = 1.0 / ((double)C * HW);
+  CHECK_LAUNCH(vpt_affine_bwd_launch(&a, pass, (hipStream_t)stream), "vpt_frame_affine_backward");
 }
 
 int vpt_maxpool_forward(const void* x, void* y, double* stats_out, int frames, int C, int H, int W, void* stream) {

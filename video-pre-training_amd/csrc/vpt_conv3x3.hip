@@ -108,8 +108,13 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   ISSUE_B(0, 0);
 #pragma unroll
   for (int m = 0; m < 6; ++m) areg[m] = *(const u32x4*)((const char*)xplane + a_gbyte[m]);
-  float mean, rstd;
-  frame_mean_rstd(a.stats_in, f, a.inv_count_in, mean, rstd);
+  float mean = 0.f, rstd = 1.f, c0f = 0.f, c1f = 0.f;
+  if (!a.bwd) {
+    frame_mean_rstd(a.stats_in, f, a.inv_count_in, mean, rstd);
+  } else if (a.coef) {
+    c0f = a.coef[2 * f];
+    c1f = a.coef[2 * f + 1];
+  }
   {
     float* kk = (float*)(smem + KK_OFF);
     float ksa[5], ksg[5];
@@ -117,8 +122,8 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     for (int k = 0; k < 5; ++k) {  // 9*128 = 4.5 * 256 entries: all ten loads in flight together
       const int idx = tid + 256 * k;
       const int o = (idx >> 7) * a.CoutPad + nt * 128 + (idx & 127);
-      ksa[k] = (idx < 9 * 128) ? a.edge_sa[o] : 0.f;
-      ksg[k] = (idx < 9 * 128) ? a.edge_sg[o] : 0.f;
+      ksa[k] = (idx < 9 * 128 && !a.bwd) ? a.edge_sa[o] : 0.f;
+      ksg[k] = (idx < 9 * 128 && !a.bwd) ? a.edge_sg[o] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -270,10 +275,15 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 k4 = *(const f32x4*)(kk + eoff[m] + n2 * 32 + 8 * g);
-        float v0 = fmaxf(fmaf(rstd, acc[m][n2][4 * g + 0], k4.x), 0.f);
-        float v1 = fmaxf(fmaf(rstd, acc[m][n2][4 * g + 1], k4.y), 0.f);
-        float v2 = fmaxf(fmaf(rstd, acc[m][n2][4 * g + 2], k4.z), 0.f);
-        float v3 = fmaxf(fmaf(rstd, acc[m][n2][4 * g + 3], k4.w), 0.f);
+        float v0 = fmaf(rstd, acc[m][n2][4 * g + 0], k4.x), v1 = fmaf(rstd, acc[m][n2][4 * g + 1], k4.y);
+        float v2 = fmaf(rstd, acc[m][n2][4 * g + 2], k4.z), v3 = fmaf(rstd, acc[m][n2][4 * g + 3], k4.w);
+        if (!a.bwd) {
+          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+        } else if (a.xin) {  // dgrad: + d(mu, rstd)/dx terms of the GroupNorm statistics
+          const u32x2 xi = *(const u32x2*)(a.xin + poff[m] + n2 * nstep + 8 * g);
+          v0 += fmaf(c1f, bf16_lo_to_f32(xi.x), c0f); v1 += fmaf(c1f, bf16_hi_to_f32(xi.x), c0f);
+          v2 += fmaf(c1f, bf16_lo_to_f32(xi.y), c0f); v3 += fmaf(c1f, bf16_hi_to_f32(xi.y), c0f);
+        }
         if (a.res) {
           v0 += bf16_lo_to_f32(rr[m][n2][g].x); v1 += bf16_hi_to_f32(rr[m][n2][g].x);
           v2 += bf16_lo_to_f32(rr[m][n2][g].y); v3 += bf16_hi_to_f32(rr[m][n2][g].y);
@@ -312,6 +322,7 @@ extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream
   }
   VptConv3x3Args a_copy = *a_in;
   a_copy.ablate = ablate;
+  if (!a_copy.bwd && !a_copy.stats_in) return -1;
   // one tile = (Cin/32)*3 steps of 48 MFMAs/wave, two waves per SIMD: ~ nsteps * 3072 cycles at ~2 GHz;
   // wall_clock64 ticks at 100 MHz
   a_copy.stagger_first = num_cu;

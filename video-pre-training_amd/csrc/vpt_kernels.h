@@ -19,6 +19,10 @@ struct VptConv3x3Args {
   double inv_count_in;     // 1 / (Cin*H*W)
   int ablate;              // profiling only (env VPT_CONV_ABLATE)
   int stagger_first, stagger_ticks;  // de-phasing of co-resident workgroups (set by the launcher)
+  // dgrad mode (bwd != 0): no GroupNorm fold, no ReLU; out = conv + res + coef[f][0] + coef[f][1] * xin
+  int bwd;
+  const vpt_bf16* xin;     // the forward layer's input x (same shape as this call's output)
+  const float* coef;       // [F][2]
 };
 
 struct VptConvFirstArgs {
@@ -104,6 +108,51 @@ struct VptLogSoftmaxArgs {
   float temperature;
 };
 
+struct VptAffineBwdArgs {
+  const vpt_bf16* x;       // the affine's INPUT, blocked
+  const vpt_bf16* dy;      // gradient w.r.t. its output
+  const vpt_bf16* dx_add;  // optional, added to dx (pass 2)
+  vpt_bf16* dx;            // pass 2 output
+  const float* gain;
+  const double* stats_in;  // statistics of x
+  double* ab;              // [F][2] sum dy g, sum dy g xhat (pass 1 accumulates, pass 2 reads)
+  float* dgain;            // accumulated
+  float* dbias;
+  int frames, CB, HW, per_element;
+  double inv_count;
+};
+
+struct VptPoolBwdArgs {
+  const vpt_bf16* pre;     // pre-pool tensor [F][CB][H][W][32]
+  const vpt_bf16* pooled;  // [F][CB][H/2][W/2][32]
+  const vpt_bf16* dpooled;
+  vpt_bf16* dpre;
+  int frames, CB, H, W;
+};
+
+struct VptConvBwdPrepArgs {
+  const vpt_bf16* dy;      // gradient w.r.t. the layer output (after ReLU and residual add)
+  const vpt_bf16* y;       // saved layer output
+  const vpt_bf16* res;     // saved residual input or null
+  const double* stats_in;  // statistics of the conv's INPUT x
+  const float* edge_sa;    // [9][CoutPad]
+  const float* edge_sg;
+  vpt_bf16* dacc;          // rstd * dz, blocked like y
+  double* t12;             // [F][2]: T1 = sum dz (v - SA), T2 = sum dz SG   (accumulated)
+  float* d_sa;             // [9][CoutPad] accumulated
+  float* d_sg;
+  int frames, CB, H, W, CoutPad;
+  double inv_count_in;     // 1 / (Cin*H*W)
+};
+
+struct VptConvWgradArgs {
+  const vpt_bf16* dacc;    // [F][Cout/32][H][W][32]
+  const vpt_bf16* x;       // [F][Cin/32][H][W][32]
+  float* dw;               // [Cout][9][Cin] accumulated (caller zeroes)
+  int frames, H, W, Cin, Cout;
+  int OT, frames_per_wg;   // set by the launcher
+};
+
 struct VptNllBwdArgs {
   const float* lp_buttons; // [M][nb] log-probabilities (forward output)
   const float* lp_camera;  // [M][nc]
@@ -163,6 +212,10 @@ struct VptAdamArgs {
 
 extern "C" {
 int vpt_adam_launch(const VptAdamArgs* a, hipStream_t s);
+int vpt_affine_bwd_launch(const VptAffineBwdArgs* a, int pass, hipStream_t s);
+int vpt_pool_bwd_launch(const VptPoolBwdArgs* a, hipStream_t s);
+int vpt_conv_bwd_prep_launch(const VptConvBwdPrepArgs* a, hipStream_t s);
+int vpt_conv_wgrad_launch(const VptConvWgradArgs* a, hipStream_t s);
 int vpt_nll_bwd_launch(const VptNllBwdArgs* a, hipStream_t s);
 int vpt_ln_bwd_launch(const VptLnBwdArgs* a, hipStream_t s);
 int vpt_gate_cast_launch(const VptGateCastArgs* a, hipStream_t s);

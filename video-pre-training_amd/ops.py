@@ -237,3 +237,63 @@ def masked_attention_backward(qkvr, kmem, vmem, memvalid, b_nd, dout, db_nd, bat
     _call("vpt_masked_attention_backward", dict(flops=10.0 * batch * t * (t + kmem.shape[1]) * hid), ptr(qkvr), ptr(kmem), ptr(vmem),
           ptr(memvalid), ptr(b_nd), ptr(dout), ptr(dqkvr), ptr(db_nd), batch, t, heads, hid, qkvr.shape[1], kmem.shape[1], _stream())
     return dqkvr
+
+
+def conv_backward_prepare(dy, y, res, stats_in, edge_sa, edge_sg, cin):
+    """-> (dacc bf16 blocked, t12 double [F,2], d_sa fp32 [9,CoutPad], d_sg fp32 [9,CoutPad])."""
+    for t, nme in ((dy, "dy"), (y, "y"), (res, "res")):
+        _chk(t, torch.bfloat16, nme)
+    _chk(stats_in, torch.float64, "stats_in"); _chk(edge_sa, torch.float32, "edge_sa"); _chk(edge_sg, torch.float32, "edge_sg")
+    f, cb, h, w, _ = y.shape
+    dev = y.device
+    dacc = torch.empty_like(y)
+    t12 = torch.zeros(f, 2, dtype=torch.float64, device=dev)
+    d_sa, d_sg = torch.zeros_like(edge_sa), torch.zeros_like(edge_sg)
+    _call("vpt_conv_backward_prepare", dict(bytes=6.0 * y.numel()), ptr(dy), ptr(y), ptr(res), ptr(stats_in), ptr(edge_sa), ptr(edge_sg),
+          ptr(dacc), ptr(t12), ptr(d_sa), ptr(d_sg), f, h, w, cin, cb * 32, _stream())
+    return dacc, t12, d_sa, d_sg
+
+
+def conv3x3_dgrad(dacc, wpk_t, cin, skip=None, xin=None, coef=None):
+    """dacc blocked [F,Cout/32,H,W,32] -> dx blocked [F,cin/32,H,W,32] (transposed conv + skip + c0 + c1*xin)."""
+    _chk(dacc, torch.bfloat16, "dacc"); _chk(wpk_t, torch.bfloat16, "wpk_t"); _chk(skip, torch.bfloat16, "skip")
+    _chk(xin, torch.bfloat16, "xin"); _chk(coef, torch.float32, "coef")
+    f, cb, h, w, _ = dacc.shape
+    dx = torch.empty(f, cin // 32, h, w, 32, dtype=torch.bfloat16, device=dacc.device)
+    _call("vpt_conv3x3_dgrad", dict(flops=2.0 * f * h * w * cin * 9 * cb * 32), ptr(dacc), ptr(wpk_t), ptr(skip), ptr(xin), ptr(coef), ptr(dx),
+          f, h, w, cb * 32, cin, _stream())
+    return dx
+
+
+def maxpool_backward(pre, pooled, dpooled):
+    for t, nme in ((pre, "pre"), (pooled, "pooled"), (dpooled, "dpooled")):
+        _chk(t, torch.bfloat16, nme)
+    f, cb, h, w, _ = pre.shape
+    dpre = torch.empty_like(pre)
+    _call("vpt_maxpool_backward", dict(bytes=5.0 * pre.numel()), ptr(pre), ptr(pooled), ptr(dpooled), ptr(dpre), f, cb * 32, h, w, _stream())
+    return dpre
+
+
+def frame_affine_backward(x, dy, gain, stats_in, dgain, dbias, per_element=False, dx_add=None):
+    """Backward of frame_affine: returns dx (bf16 blocked); dgain / dbias accumulated in place."""
+    _chk(x, torch.bfloat16, "x"); _chk(dy, torch.bfloat16, "dy"); _chk(dx_add, torch.bfloat16, "dx_add")
+    _chk(gain, torch.float32, "gain"); _chk(stats_in, torch.float64, "stats_in"); _chk(dgain, torch.float32, "dgain"); _chk(dbias, torch.float32, "dbias")
+    f, cb, h, w, _ = x.shape
+    ab = torch.zeros(f, 2, dtype=torch.float64, device=x.device)
+    dx = torch.empty_like(x)
+    args = (ptr(x), ptr(dy), ptr(dx_add), ptr(dx), ptr(gain), ptr(stats_in), ptr(ab), ptr(dgain), ptr(dbias), f, cb * 32, h * w, 1 if per_element else 0)
+    _call("vpt_frame_affine_backward", dict(bytes=4.0 * x.numel()), *args, 1, _stream())
+    _call("vpt_frame_affine_backward", dict(bytes=6.0 * x.numel()), *args, 2, _stream())
+    if per_element:
+        _call("vpt_frame_affine_backward", dict(bytes=4.0 * x.numel()), *args, 3, _stream())
+    return dx
+
+
+def conv3x3_wgrad(dacc, x):
+    """-> fp32 [Cout, 9, Cin]: sum over frames and pixels of dacc (x) shifted x."""
+    _chk(dacc, torch.bfloat16, "dacc"); _chk(x, torch.bfloat16, "x")
+    f, cbo, h, w, _ = dacc.shape
+    cbi = x.shape[1]
+    dw = torch.zeros(cbo * 32, 9, cbi * 32, dtype=torch.float32, device=x.device)
+    _call("vpt_conv3x3_wgrad", dict(flops=2.0 * f * h * w * cbo * 32 * 9 * cbi * 32), ptr(dacc), ptr(x), ptr(dw), f, h, w, cbi * 32, cbo * 32, _stream())
+    return dw

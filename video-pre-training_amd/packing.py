@@ -44,6 +44,15 @@ def pack_conv3x3(weight, gain, bias):
     return wpk, sa.float().contiguous(), sg.float().contiguous()
 
 
+def pack_conv3x3_dgrad(weight, gain):
+    """Weights of the input-gradient convolution of a normed conv layer: Wd[c, o, kh, kw] = bf16(W * gain)[o, c, 2-kh, 2-kw]
+    in the same packed format (a conv with Cin' = Cout, Cout' = Cin, no further gain)."""
+    wg = (weight * gain.view(1, -1, 1, 1)).to(torch.bfloat16).float()
+    wd = wg.permute(1, 0, 2, 3).flip(2, 3).contiguous()
+    wpk, _, _ = pack_conv3x3(wd, torch.ones(wd.shape[1], device=weight.device), torch.zeros(wd.shape[1], device=weight.device))
+    return wpk
+
+
 def swizzle_rows64(t):
     """[..., rows, 32] bf16 -> same shape with chunk c (8 elements) of row r stored at chunk c ^ ((r >> 2) & 3).
     The permutation is an involution, so applying it twice restores the logical order."""
