@@ -242,3 +242,48 @@ class BCTrainer:
                            beta2=self.betas[1], eps=self.eps, weight_decay=self.wd)
         self.policy._packed_key = None  # weights changed: re-pack before the next forward
         return float(loss), state_out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# host mapping of the folded-conv gradients to the reference's parameters (small tensors: [Cout, Cin, 3, 3])
+# ---------------------------------------------------------------------------------------------------------
+_VALID_TAPS = {0: [1, 2], 1: [0, 1, 2], 2: [0, 1]}
+
+
+def _tap_sum(tab: torch.Tensor, cout: int) -> torch.Tensor:
+    """[9 edge classes, >= cout] -> [cout, 3, 3]: for every tap, the sum over the edge classes in which it is inside the image."""
+    out = torch.zeros(cout, 3, 3, dtype=tab.dtype, device=tab.device)
+    for ey in range(3):
+        for ex in range(3):
+            for kh in _VALID_TAPS[ey]:
+                for kw in _VALID_TAPS[ex]:
+                    out[:, kh, kw] += tab[ey * 3 + ex, :cout]
+    return out
+
+
+def conv_param_grads(dw_raw: torch.Tensor, d_sa: torch.Tensor, d_sg: torch.Tensor, weight: torch.Tensor,
+                     gain: torch.Tensor, bias: torch.Tensor):
+    """Gradients of a GN -> conv layer's parameters from the kernels' outputs.
+    Forward (vpt_conv3x3.hip): W' = W * gain[c];  v = rstd conv(W', x) + SA[e,o] - rstd mu SG[e,o],
+    SG[e,o] = sum_{taps valid in e, c} W'[o,c,tap],  SA[e,o] = sum_{valid taps, c} W[o,c,tap] bias[c].
+      dW'  = dw_raw (wgrad kernel, [Cout,9,Cin])  +  tap_sum(d_sg)  (broadcast over c)
+      dW   = dW' * gain  +  bias[c] * tap_sum(d_sa)
+      dgain[c] = sum_{o,tap} dW' W ;   dbias[c] = sum_{o,tap} W tap_sum(d_sa)
+    Returns (dW [Cout,Cin,3,3], dgain [Cin], dbias [Cin])."""
+    cout, cin = weight.shape[:2]
+    dwp = dw_raw.view(cout, 3, 3, cin).permute(0, 3, 1, 2)                  # [Cout, Cin, 3, 3]
+    dwp = dwp + _tap_sum(d_sg, cout).unsqueeze(1)
+    ta = _tap_sum(d_sa, cout).unsqueeze(1)                                  # [Cout, 1, 3, 3]
+    dW = dwp * gain.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1) * ta
+    dgain = (dwp * weight).sum(dim=(0, 2, 3))
+    dbias = (weight * ta).sum(dim=(0, 2, 3))
+    return dW.contiguous(), dgain, dbias
+
+
+def conv_dgrad_coef(stats_in: torch.Tensor, t12: torch.Tensor, n: int) -> torch.Tensor:
+    """Per-frame (c0, c1) of the statistics terms of dx:  dx += c0 + c1 x,  c1 = -rstd^2 T1 / n,  c0 = -rstd T2 / n - c1 mu."""
+    mu = stats_in[:, 0] / n
+    rstd = torch.rsqrt((stats_in[:, 1] / n - mu * mu).clamp(min=0) + 1e-5)
+    c1 = -(rstd * rstd) * t12[:, 0] / n
+    c0 = -(rstd / n) * t12[:, 1] - c1 * mu
+    return torch.stack([c0, c1], 1).float().contiguous()
