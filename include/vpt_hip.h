@@ -143,6 +143,12 @@ int vpt_conv_backward_prepare(const void* dy, const void* y, const void* res, co
 int vpt_conv3x3_dgrad(const void* dacc, const void* wpk_t, const void* skip, const void* xin, const float* coef, void* dx,
                       int frames, int H, int W, int Cout, int Cin, void* stream);
 
+/* Backward of vpt_conv_first_forward w.r.t. its weight and bias (the input is the uint8 image): recomputes the pre-pool
+ * tile, routes dpooled to the arg-max conv pixel of every pooling window and accumulates dw[Cout][27] (kh, kw, ch order)
+ * and db[Cout] (fp32 atomics; caller zeroes). */
+int vpt_conv_first_backward(const uint8_t* img, const void* wfrag, const void* dpooled, float* dw, float* db,
+                            int frames, int H, int W, int Cout, void* stream);
+
 /* Weight gradient of the folded convolution: dw[o][tap][c] += sum_{f,p} dacc[f][o][p] * x[f][c][p + tap] (fp32, atomics;
  * caller zeroes).  W in {16, 32, 64}.  The host maps it to dW, dgain, dbias (training.py). */
 int vpt_conv3x3_wgrad(const void* dacc, const void* x, float* dw, int frames, int H, int W, int Cin, int Cout, void* stream);

@@ -326,3 +326,21 @@ def test_conv_layer_param_grads():
     eW, eg, eb = _l2(dW.cpu(), gW), _l2(dgain.cpu(), gg), _l2(dbias.cpu(), gb)
     print(f"PARITY conv layer param grads: dW {eW:.3e} dgain {eg:.3e} dbias {eb:.3e}")
     assert eW < 6e-2 and eg < 1e-1 and eb < 1e-1
+
+
+@pytest.mark.parametrize("frames,cout", [(2, 128), (1, 64)])
+def test_conv_first_backward(frames, cout):
+    g = torch.Generator().manual_seed(16)
+    W = (torch.randn(cout, 3, 3, 3, generator=g) * 0.3).requires_grad_(True)
+    b = (0.1 * torch.randn(cout, generator=g)).requires_grad_(True)
+    img = torch.randint(0, 256, (frames, 128, 128, 3), generator=g, dtype=torch.uint8)
+    dP = torch.randn(frames, cout, 64, 64, generator=g).to(torch.bfloat16).float()
+    Wb = W.detach().to(torch.bfloat16).float().requires_grad_(True)  # the kernel rounds the weights; compare like for like
+    pooled = torch.nn.functional.max_pool2d(torch.relu(torch.nn.functional.conv2d(img.permute(0, 3, 1, 2).float() / 255.0, Wb, b, padding=1)), 3, 2, 1)
+    gW, gb = torch.autograd.grad((pooled * dP).sum(), [Wb, b])
+    dW, db = ops.conv_first_backward(img.to(DEV), packing.pack_conv_first(W.detach().to(DEV), b.detach().to(DEV)),
+                                     packing.nchw_to_blocked(dP).to(DEV), cout)
+    torch.cuda.synchronize()
+    eW, eb = _l2(dW.cpu(), gW), _l2(db.cpu(), gb)
+    print(f"PARITY conv_first backward: dW {eW:.3e} db {eb:.3e}")
+    assert eW < 3e-2 and eb < 3e-2

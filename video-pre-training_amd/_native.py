@@ -27,6 +27,7 @@ SIGNATURES = {
     "vpt_log_softmax_forward": [_P, _P, _I, _I, _I, _I, _F, _P],
     "vpt_conv_backward_prepare": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_conv3x3_dgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vpt_conv_first_backward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_conv3x3_wgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_maxpool_backward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_frame_affine_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

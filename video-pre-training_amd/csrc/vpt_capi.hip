@@ -69,6 +69,14 @@ int vpt_conv_backward_prepare(const void* dy, const void* y, const void* res, co
   CHECK_LAUNCH(vpt_conv_bwd_prep_launch(&a, (hipStream_t)stream), "vpt_conv_backward_prepare");
 }
 
+int vpt_conv_first_backward(const uint8_t* img, const void* wfrag, const void* dpooled, float* dw, float* db,
+                            int frames, int H, int W, int Cout, void* stream) {
+  VptConvFirstBwdArgs a;
+  a.img = img; a.wfrag = (const vpt_bf16*)wfrag; a.dpooled = (const vpt_bf16*)dpooled; a.dw = dw; a.db = db;
+  a.frames = frames; a.H = H; a.W = W; a.Cout = Cout;
+  CHECK_LAUNCH(vpt_conv_first_bwd_launch(&a, (hipStream_t)stream), "vpt_conv_first_backward");
+}
+
 int vpt_conv3x3_wgrad(const void* dacc, const void* x, float* dw, int frames, int H, int W, int Cin, int Cout, void* stream) {
   VptConvWgradArgs a;
   a.dacc = (const vpt_bf16*)dacc; a.x = (const vpt_bf16*)x; a.dw = dw;

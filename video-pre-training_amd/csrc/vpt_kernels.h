@@ -145,6 +145,15 @@ struct VptConvBwdPrepArgs {
   double inv_count_in;     // 1 / (Cin*H*W)
 };
 
+struct VptConvFirstBwdArgs {
+  const uint8_t* img;      // [F][H][W][3]
+  const vpt_bf16* wfrag;   // forward weight fragments (the pre-pool tile is recomputed)
+  const vpt_bf16* dpooled; // gradient w.r.t. the pooled output [F][Cout/32][H/2][W/2][32]
+  float* dw;               // [Cout][27] in (kh, kw, ch) order, accumulated
+  float* db;               // [Cout] accumulated
+  int frames, H, W, Cout;
+};
+
 struct VptConvWgradArgs {
   const vpt_bf16* dacc;    // [F][Cout/32][H][W][32]
   const vpt_bf16* x;       // [F][Cin/32][H][W][32]
@@ -215,6 +224,7 @@ int vpt_adam_launch(const VptAdamArgs* a, hipStream_t s);
 int vpt_affine_bwd_launch(const VptAffineBwdArgs* a, int pass, hipStream_t s);
 int vpt_pool_bwd_launch(const VptPoolBwdArgs* a, hipStream_t s);
 int vpt_conv_bwd_prep_launch(const VptConvBwdPrepArgs* a, hipStream_t s);
+int vpt_conv_first_bwd_launch(const VptConvFirstBwdArgs* a, hipStream_t s);
 int vpt_conv_wgrad_launch(const VptConvWgradArgs* a, hipStream_t s);
 int vpt_nll_bwd_launch(const VptNllBwdArgs* a, hipStream_t s);
 int vpt_ln_bwd_launch(const VptLnBwdArgs* a, hipStream_t s);

@@ -297,3 +297,14 @@ def conv3x3_wgrad(dacc, x):
     dw = torch.zeros(cbo * 32, 9, cbi * 32, dtype=torch.float32, device=x.device)
     _call("vpt_conv3x3_wgrad", dict(flops=2.0 * f * h * w * cbo * 32 * 9 * cbi * 32), ptr(dacc), ptr(x), ptr(dw), f, h, w, cbi * 32, cbo * 32, _stream())
     return dw
+
+
+def conv_first_backward(img_u8, wfrag, dpooled, cout):
+    """-> (dW fp32 [cout, 3, 3, 3] in the reference's (o, ch, kh, kw) order, db fp32 [cout])."""
+    _chk(img_u8, torch.uint8, "img"); _chk(wfrag, torch.bfloat16, "wfrag"); _chk(dpooled, torch.bfloat16, "dpooled")
+    f, h, w, _ = img_u8.shape
+    dw = torch.zeros(cout, 27, dtype=torch.float32, device=img_u8.device)
+    db = torch.zeros(cout, dtype=torch.float32, device=img_u8.device)
+    _call("vpt_conv_first_backward", dict(flops=2.0 * f * (h // 2) * (w // 2) * cout * 27), ptr(img_u8), ptr(wfrag), ptr(dpooled), ptr(dw), ptr(db),
+          f, h, w, cout, _stream())
+    return dw.view(cout, 3, 3, 3).permute(0, 3, 1, 2).contiguous(), db
