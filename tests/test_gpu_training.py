@@ -336,7 +336,9 @@ def test_conv_first_backward(frames, cout):
     img = torch.randint(0, 256, (frames, 128, 128, 3), generator=g, dtype=torch.uint8)
     dP = torch.randn(frames, cout, 64, 64, generator=g).to(torch.bfloat16).float()
     Wb = W.detach().to(torch.bfloat16).float().requires_grad_(True)  # the kernel rounds the weights; compare like for like
-    pooled = torch.nn.functional.max_pool2d(torch.relu(torch.nn.functional.conv2d(img.permute(0, 3, 1, 2).float() / 255.0, Wb, b, padding=1)), 3, 2, 1)
+    y = torch.relu(torch.nn.functional.conv2d(img.permute(0, 3, 1, 2).float() / 255.0, Wb, b, padding=1))
+    y = y + (y.detach().to(torch.bfloat16).float() - y.detach())  # the kernel pools bf16-rounded values (straight-through here)
+    pooled = torch.nn.functional.max_pool2d(y, 3, 2, 1)
     gW, gb = torch.autograd.grad((pooled * dP).sum(), [Wb, b])
     dW, db = ops.conv_first_backward(img.to(DEV), packing.pack_conv_first(W.detach().to(DEV), b.detach().to(DEV)),
                                      packing.nchw_to_blocked(dP).to(DEV), cout)
