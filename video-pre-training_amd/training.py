@@ -6,13 +6,14 @@
                        (behavioural_cloning.py:60,63,121; SURVEY.md §2 'latent bugs'); reproduced, i.e. NOT applied
     state: the KV memory is carried between chunks detached (behavioural_cloning.py:111)
 
-Status: the backward exists for everything BEHIND the IMPALA CNN -- both action heads, final_ln,
-lastlayer, the four transformer blocks (attention incl. the relative-position bias and b_nd, MLPs, LayerNorms)
-and ImgObsProcess.linear + its LayerNorm, all on the HIP kernels (vpt_gemm_kernel as dgrad / wgrad,
-vpt_attn_bwd_kernel, vpt_ln_bwd_kernel, vpt_nll_bwd_kernel, vpt_adam_kernel).  The CNN's backward (conv dgrad /
-wgrad through the GroupNorm fold, pool, first conv) is not built yet, so `train_cnn=True` raises and the CNN
-parameters (incl. its dense layer) stay frozen: this trainer fine-tunes the 71 % of the 2x model's parameters
-that live in the trunk and heads.  Data parallelism: one process per GPU, sequences sharded by rank, ONE
+Every layer's backward runs on the HIP kernels: both action heads, final_ln, lastlayer, the four transformer blocks
+(attention incl. the relative-position bias and b_nd, MLPs, LayerNorms), ImgObsProcess.linear + its LayerNorm
+(vpt_gemm_kernel as dgrad / wgrad, vpt_attn_bwd_kernel, vpt_ln_bwd_kernel, vpt_nll_bwd_kernel), and -- with
+train_cnn=True, the reference's behaviour (behavioural_cloning.py:57-63 trains every parameter) -- the IMPALA CNN:
+dense layer GEMMs, per-element / per-channel affine backward, max-pool routing, the folded GroupNorm convolutions
+(vpt_conv_bwd_prep_kernel -> vpt_conv3x3_kernel in dgrad mode + vpt_conv_wgrad_kernel -> conv_param_grads) and the
+fused first conv (vpt_conv_first_bwd_kernel).  train_cnn=False freezes `net.img_process.cnn.*` and fine-tunes the
+trunk and heads only (71 % of the 2x model's parameters).  Data parallelism: one process per GPU, sequences sharded by rank, ONE
 bucketed RCCL all-reduce of the gradients per step (distributed.bucketed_all_reduce_), averaged inside the
 fused Adam (grad_scale = 1 / world)."""
 from typing import Dict, List, Optional
@@ -60,8 +61,7 @@ def linear_backward(dy16: torch.Tensor, n: int, x16: Optional[torch.Tensor], wei
 class BCTrainer:
     def __init__(self, policy, lr: float = 0.000181, weight_decay: float = 0.039428, betas=(0.9, 0.999), eps: float = 1e-8,
                  train_cnn: bool = False):
-        if train_cnn:
-            raise NotImplementedError("the IMPALA CNN's backward kernels are not built yet (DESIGN.md §8): train_cnn=False only")
+        self.train_cnn = bool(train_cnn)
         self.policy = policy
         self.engine = policy._engine
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
@@ -71,10 +71,9 @@ class BCTrainer:
         self.m = {n: torch.zeros_like(self.params[n], dtype=torch.float32) for n in self.trainable}
         self.v = {n: torch.zeros_like(self.params[n], dtype=torch.float32) for n in self.trainable}
 
-    @staticmethod
-    def _is_trainable(name: str) -> bool:
-        if name.startswith("net.img_process.cnn."):
-            return False            # frozen until the CNN backward exists
+    def _is_trainable(self, name: str) -> bool:
+        if name.startswith("net.img_process.cnn.") and not self.train_cnn:
+            return False            # train_cnn=False: fine-tune the trunk and heads only
         if name.startswith("value_head."):
             return False            # no gradient under the BC loss; normaliser buffers are not trained
         return True
@@ -97,9 +96,13 @@ class BCTrainer:
         frames = img_u8.reshape(m, *img_u8.shape[2:]).contiguous()
 
         # ---------------- forward, keeping what the backward needs ----------------
-        outs = []
+        outs, cnn_saved = [], []
         for i in range(0, m, eng.cnn_chunk):
-            xn = eng._cnn_chunk(frames[i:i + eng.cnn_chunk])
+            if self.train_cnn:
+                xn, sv = self._cnn_forward_saving(frames[i:i + eng.cnn_chunk])
+                cnn_saved.append(sv)
+            else:
+                xn = eng._cnn_chunk(frames[i:i + eng.cnn_chunk])
             d32, _ = ops.linear(xn.view(xn.shape[0], -1), w["net.img_process.cnn.dense.w"], 256, splitk=16)
             outs.append(d32)
             del xn
@@ -216,9 +219,166 @@ class BCTrainer:
         dx16 = ops.gate_cast(dx, hid, mask=x_lin16)
         ddn, _, g[pl + "layer.weight"] = linear_backward(dx16, hid, dn, P[pl + "layer.weight"])
         g[pl + "norm.weight"], g[pl + "norm.bias"] = zeros(256), zeros(256)
-        ops.layernorm_backward(d, P[pl + "norm.weight"], ddn, g[pl + "norm.weight"], g[pl + "norm.bias"], relu_in=True)
-        # (the gradient w.r.t. `d` would continue into the CNN's dense layer -- not built yet)
+        dd = ops.layernorm_backward(d, P[pl + "norm.weight"], ddn, g[pl + "norm.weight"], g[pl + "norm.bias"], relu_in=True)
+        if self.train_cnn:
+            acc = self._cnn_backward_begin(P)
+            for ci, i in enumerate(range(0, m, eng.cnn_chunk)):
+                self._cnn_backward_chunk(cnn_saved[ci], dd[i:i + eng.cnn_chunk].contiguous(), acc)
+                cnn_saved[ci] = None
+            self._cnn_backward_finish(acc, P, g)
         return loss, g, state_out
+
+    # ------------------------------------------------------------------------------------------
+    # IMPALA CNN: forward that keeps every activation (6.2 MB / frame on the 2x model: a 64 x 128 batch is 50 GB of
+    # the 288 GB HBM, so nothing is recomputed), and the backward through the folded GroupNorm convolutions.
+    # ------------------------------------------------------------------------------------------
+    def _cnn_forward_saving(self, img: torch.Tensor):
+        """PolicyEngine._cnn_chunk without in-place reuse; returns (xn, saved)."""
+        eng = self.engine
+        cfg, w = eng.cfg, eng.w
+        f = img.shape[0]
+        st = torch.zeros(24, f, 2, dtype=torch.float64, device=img.device)
+        si = 0
+
+        def nxt():
+            nonlocal si
+            si += 1
+            return st[si - 1]
+
+        sv = dict(img=img, stacks=[])
+        x, s_x = None, None
+        for s, c in enumerate(cfg["chans"]):
+            p = f"net.img_process.cnn.stacks.{s}."
+            rec = dict(x_prev=x, s_prev=s_x)
+            s_pool = nxt()
+            if s == 0:
+                pooled = ops.conv_first(img, w[p + "firstconv"], c, stats_out=s_pool)
+            else:
+                wpk, sa, sg = w[p + "firstconv"]
+                rec["pre"] = ops.conv3x3(x, wpk, sa, sg, s_x, c)
+                pooled = ops.maxpool(rec["pre"], stats_out=s_pool)
+            s_x = nxt()
+            x = ops.frame_affine(pooled, w[p + "n.g"], w[p + "n.b"], s_pool, stats_out=s_x)
+            rec.update(pooled=pooled, s_pool=s_pool, blocks=[])
+            for b in range(2):
+                wpk, sa, sg = w[f"{p}blocks.{b}.conv0"]
+                s_y = nxt()
+                y = ops.conv3x3(x, wpk, sa, sg, s_x, c, stats_out=s_y)
+                wpk, sa, sg = w[f"{p}blocks.{b}.conv1"]
+                s_n = nxt()
+                xo = ops.conv3x3(y, wpk, sa, sg, s_y, c, res=x, stats_out=s_n)
+                rec["blocks"].append(dict(x_in=x, s_in=s_x, y=y, s_y=s_y, x_out=xo))
+                x, s_x = xo, s_n
+            sv["stacks"].append(rec)
+        sv["x_last"], sv["s_last"] = x, s_x
+        p = "net.img_process.cnn.dense."
+        return ops.frame_affine(x, w[p + "g"], w[p + "b"], s_x, per_element=True), sv
+
+    def _conv_names(self):
+        names = []
+        for s in range(len(self.engine.cfg["chans"])):
+            p = f"net.img_process.cnn.stacks.{s}."
+            if s > 0:
+                names.append(p + "firstconv")
+            for b in range(2):
+                for cv in range(2):
+                    names.append(f"{p}blocks.{b}.conv{cv}")
+        return names
+
+    def _cnn_backward_begin(self, P):
+        """Per-step operands of the CNN backward (transposed conv weights, dense W^T) and zeroed accumulators."""
+        cfg = self.engine.cfg
+        dev = next(iter(P.values())).device
+        c2 = cfg["chans"][-1]
+        acc = dict(wt={}, raw={}, n={}, dense=None)
+        for q in self._conv_names():
+            acc["wt"][q] = packing.pack_conv3x3_dgrad(P[q + ".layer.weight"].float(), P[q + ".norm.weight"].float())
+        pd = "net.img_process.cnn.dense."
+        wd_blk = packing.chw_to_blocked_columns(P[pd + "layer.weight"].float(), c2, 16, 16)      # [256, K] in activation order
+        acc["dense_wt"] = packing.pack_linear(wd_blk.t().contiguous())                           # dgrad operand: N = K, K = 256
+        k = wd_blk.shape[1]
+        acc["dense_dwT"] = torch.zeros(k, 256, dtype=torch.float32, device=dev)
+        acc["dense_dg"], acc["dense_db"] = torch.zeros(k, dtype=torch.float32, device=dev), torch.zeros(k, dtype=torch.float32, device=dev)
+        for s, c in enumerate(cfg["chans"]):
+            acc["n"][s] = (torch.zeros(c, dtype=torch.float32, device=dev), torch.zeros(c, dtype=torch.float32, device=dev))
+        return acc
+
+    def _conv_layer_backward(self, q, acc, dy, y, res, x_in, s_in, skip, need_dx=True):
+        """One GN -> conv3x3 -> ReLU (+res) layer: accumulates the raw weight-gradient pieces and returns dx (+skip)."""
+        w = self.engine.w
+        _, sa, sg = w[q]
+        cin = x_in.shape[1] * 32
+        n = cin * x_in.shape[2] * x_in.shape[3]
+        dacc, t12, d_sa, d_sg = ops.conv_backward_prepare(dy, y, res, s_in, sa, sg, cin)
+        dw_raw = ops.conv3x3_wgrad(dacc, x_in)
+        if q in acc["raw"]:
+            r = acc["raw"][q]
+            r[0] += dw_raw; r[1] += d_sa; r[2] += d_sg
+        else:
+            acc["raw"][q] = [dw_raw, d_sa, d_sg]
+        if not need_dx:
+            return None
+        return ops.conv3x3_dgrad(dacc, acc["wt"][q], cin, skip=skip, xin=x_in, coef=conv_dgrad_coef(s_in, t12, n))
+
+    def _cnn_backward_chunk(self, sv, dd, acc):
+        """dd: fp32 [f, 256] gradient w.r.t. the dense layer's pre-activation output for this chunk's frames."""
+        eng = self.engine
+        cfg, w = eng.cfg, eng.w
+        pd = "net.img_process.cnn.dense."
+        x_last, s_last = sv["x_last"], sv["s_last"]
+        f = x_last.shape[0]
+        k = x_last[0].numel()
+        # dense: d = xn Wd^T.   dxn = dd Wd ;  dWd^T += xn^T dd  (GEMM rows = the K activations, reduction over frames)
+        dd16 = ops.gate_cast(dd, 256)
+        _, dxn = ops.linear(dd16, acc["dense_wt"], k, out_f32=False, out_bf16=True)
+        xn = ops.frame_affine(x_last, w[pd + "g"], w[pd + "b"], s_last, per_element=True)
+        fp = _round_up(f, 64)
+        xt = torch.zeros(k, fp, dtype=torch.bfloat16, device=dd.device)
+        xt[:, :f] = xn.view(f, k).t()
+        ddt = torch.zeros(256, fp, dtype=torch.bfloat16, device=dd.device)
+        ddt[:, :f] = dd16.t()
+        acc["dense_dwT"], _ = ops.linear(xt, packing.pack_linear(ddt), 256, res=acc["dense_dwT"])
+        del xt, xn, ddt
+        dx = ops.frame_affine_backward(x_last, dxn.view_as(x_last), w[pd + "g"], s_last, acc["dense_dg"], acc["dense_db"], per_element=True)
+        del dxn
+        for s in reversed(range(len(cfg["chans"]))):
+            p = f"net.img_process.cnn.stacks.{s}."
+            rec = sv["stacks"][s]
+            for b in (1, 0):
+                blk = rec["blocks"][b]
+                dy = self._conv_layer_backward(f"{p}blocks.{b}.conv1", acc, dx, blk["x_out"], blk["x_in"], blk["y"], blk["s_y"], None)
+                dx = self._conv_layer_backward(f"{p}blocks.{b}.conv0", acc, dy, blk["y"], None, blk["x_in"], blk["s_in"], dx)
+                del dy
+            dgn, dbn = acc["n"][s]
+            dpooled = ops.frame_affine_backward(rec["pooled"], dx, w[p + "n.g"], rec["s_pool"], dgn, dbn)
+            if s == 0:
+                c = cfg["chans"][0]
+                dw, db = ops.conv_first_backward(sv["img"], w[p + "firstconv"], dpooled, c)
+                if "first" in acc:
+                    acc["first"][0] += dw; acc["first"][1] += db
+                else:
+                    acc["first"] = [dw, db]
+            else:
+                dpre = ops.maxpool_backward(rec["pre"], rec["pooled"], dpooled)
+                dx = self._conv_layer_backward(p + "firstconv", acc, dpre, rec["pre"], None, rec["x_prev"], rec["s_prev"], None)
+                del dpre
+            del dpooled
+
+    def _cnn_backward_finish(self, acc, P, g):
+        cfg = self.engine.cfg
+        c2 = cfg["chans"][-1]
+        for q, (dw_raw, d_sa, d_sg) in acc["raw"].items():
+            dW, dgain, dbias = conv_param_grads(dw_raw, d_sa, d_sg, P[q + ".layer.weight"].float(), P[q + ".norm.weight"].float(),
+                                                P[q + ".norm.bias"].float())
+            g[q + ".layer.weight"], g[q + ".norm.weight"], g[q + ".norm.bias"] = dW, dgain, dbias
+        g["net.img_process.cnn.stacks.0.firstconv.layer.weight"], g["net.img_process.cnn.stacks.0.firstconv.layer.bias"] = acc["first"]
+        for s in range(len(cfg["chans"])):
+            g[f"net.img_process.cnn.stacks.{s}.n.weight"], g[f"net.img_process.cnn.stacks.{s}.n.bias"] = acc["n"][s]
+        pd = "net.img_process.cnn.dense."
+        unblock = lambda v: v.view(c2 // 32, 16, 16, 32).permute(0, 3, 1, 2).reshape(-1).contiguous()
+        g[pd + "norm.weight"], g[pd + "norm.bias"] = unblock(acc["dense_dg"]), unblock(acc["dense_db"])
+        dwd = acc["dense_dwT"].t()                                                               # [256, K] in activation order
+        g[pd + "layer.weight"] = dwd.reshape(256, c2 // 32, 16, 16, 32).permute(0, 1, 4, 2, 3).reshape(256, -1).contiguous()
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
