@@ -51,8 +51,9 @@ int vpt_conv3x3_forward(const void* x, const void* wpk, const float* edge_sa, co
                         const double* stats_in, const void* res, void* y, double* stats_out,
                         int frames, int H, int W, int Cin, int Cout, void* stream);
 
-/* F.max_pool2d(x, 3, 2, 1) on a post-ReLU blocked tensor (lib/impala_cnn.py:117, stacks 1..2). */
-int vpt_maxpool_forward(const void* x, void* y, double* stats_out, int frames, int C, int H, int W, void* stream);
+/* F.max_pool2d(x, 3, 2, 1) on a post-ReLU blocked tensor (lib/impala_cnn.py:117, stacks 1..2).  argmax (optional, for
+ * training): uint8, shaped like y, the window position kh*3+kw of the first maximum (15 when the window is all zero). */
+int vpt_maxpool_forward(const void* x, void* y, double* stats_out, uint8_t* argmax, int frames, int C, int H, int W, void* stream);
 
 /* y = (x - mean_f) * rstd_f * gain + bias with whole-frame statistics:
  * CnnDownStack.n (GroupNorm(1,C), lib/impala_cnn.py:99-100,118-119; per_element = 0, gain[C]) and the
@@ -132,10 +133,12 @@ int vpt_masked_attention_backward(const float* qkvr, const float* kmem, const fl
 
 /* Per-element preparation of GN -> conv3x3 -> ReLU (+res) backward: dacc = rstd * dY * [v > 0] (blocked, Cout
  * channels); t12[f] += (sum dz (v - SA), sum dz SG); d_sa / d_sg [9][CoutPad] += sum dz / sum dz (-rstd mu).
- * stats_in are the statistics of the layer's INPUT (Cin*H*W elements). */
-int vpt_conv_backward_prepare(const void* dy, const void* y, const void* res, const double* stats_in,
-                              const float* edge_sa, const float* edge_sg, void* dacc, double* t12,
-                              float* d_sa, float* d_sg, int frames, int H, int W, int Cin, int Cout, void* stream);
+ * stats_in are the statistics of the layer's INPUT (Cin*H*W elements).  With dy = NULL the layer is followed by the
+ * max-pool and (dpooled, argmax) are given instead: the pool's backward is applied on the fly.  scratch: fp32
+ * [frames][9][Cout] work buffer.  W must be 8, 16, 32 or 64. */
+int vpt_conv_backward_prepare(const void* dy, const void* dpooled, const uint8_t* argmax, const void* y, const void* res,
+                              const double* stats_in, const float* edge_sa, const float* edge_sg, void* dacc, double* t12,
+                              float* d_sa, float* d_sg, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream);
 
 /* Input gradient of the layer: dx = conv^T(W', dacc) + skip + coef[f][0] + coef[f][1] * xin, i.e. the implicit-GEMM
  * kernel of vpt_conv3x3_forward on the transposed, spatially flipped weights (wpk_t: [ceil(Cin/128)][Cout/32][9][128][32])

@@ -362,3 +362,26 @@ def test_conv_first_backward(frames, cout):
     eW, eb = _l2(dW.cpu(), gW), _l2(db.cpu(), gb)
     print(f"PARITY conv_first backward: dW {eW:.3e} db {eb:.3e}")
     assert eW < 3e-2 and eb < 3e-2
+
+
+def test_conv_prepare_fused_pool_backward():
+    """prepare(dy=None, dpooled, argmax) vs prepare(dy = maxpool_backward(...)): same routing (all-zero windows differ only
+    where the ReLU gate is closed); the fused route skips one bf16 rounding where a pixel wins several windows."""
+    g = torch.Generator().manual_seed(17)
+    f, cin, cout, h = 3, 64, 64, 32
+    W = torch.randn(cout, cin, 3, 3, generator=g) * (1.6 / (cin * 9) ** 0.5)
+    gain, bias = 1 + 0.2 * torch.randn(cin, generator=g), 0.1 * torch.randn(cin, generator=g)
+    x = torch.relu(torch.randn(f, cin, h, h, generator=g)).to(torch.bfloat16).float()
+    wpk, sa, sg = packing.pack_conv3x3(W.to(DEV), gain.to(DEV), bias.to(DEV))
+    xb, st_in = packing.nchw_to_blocked(x).to(DEV), _stats_of(x).to(DEV)
+    pre = ops.conv3x3(xb, wpk, sa, sg, st_in, cout)
+    pooled, am = ops.maxpool(pre, want_argmax=True)
+    dp = packing.nchw_to_blocked(torch.randn(f, cout, h // 2, h // 2, generator=g)).to(DEV)
+    dpre = ops.maxpool_backward(pre, pooled, dp)
+    ref = ops.conv_backward_prepare(dpre, pre, None, st_in, sa, sg, cin)
+    got = ops.conv_backward_prepare(None, pre, None, st_in, sa, sg, cin, dpooled=dp, argmax=am)
+    torch.cuda.synchronize()
+    assert ((ref[0] != 0) == (got[0] != 0)).all()
+    assert _l2(got[0].float().cpu(), ref[0].float().cpu()) < 2e-3
+    for r, o in zip(ref[1:], got[1:]):
+        assert _l2(o.double().cpu(), r.double().cpu()) < 2e-3

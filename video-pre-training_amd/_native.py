@@ -18,14 +18,14 @@ SIGNATURES = {
     "vpt_conv_first_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_conv3d_t5_forward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_conv3x3_forward": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "vpt_maxpool_forward": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "vpt_maxpool_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_frame_affine_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_linear_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "vpt_layernorm_forward": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "vpt_masked_attention_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "vpt_kv_memory_update": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_log_softmax_forward": [_P, _P, _I, _I, _I, _I, _F, _P],
-    "vpt_conv_backward_prepare": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vpt_conv_backward_prepare": [_P] * 13 + [_I, _I, _I, _I, _I, _P],
     "vpt_conv3x3_dgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_conv_first_backward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_conv3x3_wgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _P],

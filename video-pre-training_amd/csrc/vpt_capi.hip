@@ -58,10 +58,12 @@ int vpt_conv3x3_dgrad(const void* dacc, const void* wpk_t, const void* skip, con
   CHECK_LAUNCH(vpt_conv3x3_launch(&a, (hipStream_t)stream), "vpt_conv3x3_dgrad");
 }
 
-int vpt_conv_backward_prepare(const void* dy, const void* y, const void* res, const double* stats_in,
-                              const float* edge_sa, const float* edge_sg, void* dacc, double* t12,
-                              float* d_sa, float* d_sg, int frames, int H, int W, int Cin, int Cout, void* stream) {
+int vpt_conv_backward_prepare(const void* dy, const void* dpooled, const uint8_t* argmax, const void* y, const void* res,
+                              const double* stats_in, const float* edge_sa, const float* edge_sg, void* dacc, double* t12,
+                              float* d_sa, float* d_sg, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream) {
+  if (Cout & 31) return fail(-1, "vpt_conv_backward_prepare: Cout must be a multiple of 32");
   VptConvBwdPrepArgs a;
+  a.dpooled = (const vpt_bf16*)dpooled; a.argmax = argmax; a.sbuf = scratch; a.wshift = 0;
   a.dy = (const vpt_bf16*)dy; a.y = (const vpt_bf16*)y; a.res = (const vpt_bf16*)res; a.stats_in = stats_in;
   a.edge_sa = edge_sa; a.edge_sg = edge_sg; a.dacc = (vpt_bf16*)dacc; a.t12 = t12; a.d_sa = d_sa; a.d_sg = d_sg;
   a.frames = frames; a.CB = Cout / 32; a.H = H; a.W = W; a.CoutPad = ((Cout + 127) / 128) * 128;
@@ -102,10 +104,10 @@ int vpt_frame_affine_backward(const void* x, const void* dy, const void* dx_add,
   CHECK_LAUNCH(vpt_affine_bwd_launch(&a, pass, (hipStream_t)stream), "vpt_frame_affine_backward");
 }
 
-int vpt_maxpool_forward(const void* x, void* y, double* stats_out, int frames, int C, int H, int W, void* stream) {
+int vpt_maxpool_forward(const void* x, void* y, double* stats_out, uint8_t* argmax, int frames, int C, int H, int W, void* stream) {
   if (C & 31) return fail(-1, "vpt_maxpool_forward: C must be a multiple of 32");
   VptPoolArgs a;
-  a.x = (const vpt_bf16*)x; a.y = (vpt_bf16*)y; a.stats_out = stats_out;
+  a.x = (const vpt_bf16*)x; a.y = (vpt_bf16*)y; a.stats_out = stats_out; a.argmax = argmax;
   a.frames = frames; a.CB = C / 32; a.H = H; a.W = W;
   CHECK_LAUNCH(vpt_pool_launch(&a, (hipStream_t)stream), "vpt_maxpool_forward");
 }

@@ -33,45 +33,73 @@ __device__ __forceinline__ void block_sum2_atomic_f64(float a, float b, double* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// pass 1: AB[f] += (sum dy g, sum dy g xhat); per-channel dgain[c] += sum dy xhat, dbias[c] += sum dy
+// pass 1: AB[f] += (sum dy g, sum dy g xhat); per-channel dgain[c] += sum dy xhat, dbias[c] += sum dy.
+// One workgroup = up to RED_PIX pixels of one (frame, channel block); thread = (channel octet, pixel phase), so the
+// per-channel sums stay in 16 registers and are reduced by shuffles -> LDS -> 64 global atomics per workgroup.
+#define RED_PIX 1024
+__device__ __forceinline__ float sum_oct16(float v) {  // over the 16 lanes sharing (lane & 3)
+#pragma unroll
+  for (int o = 32; o >= 4; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
 __global__ __launch_bounds__(256) void vpt_affine_bwd_reduce_kernel(VptAffineBwdArgs a) {
-  __shared__ float chan_[2 * 512];
-  const int per_frame = a.CB * a.HW * 4;
-  const int blocks_per_frame = (per_frame + EW_PER_BLOCK - 1) / EW_PER_BLOCK;
-  const int f = blockIdx.x / blocks_per_frame;
-  const int base = (blockIdx.x - f * blocks_per_frame) * EW_PER_BLOCK + threadIdx.x;
+  __shared__ float part_[4 * 64];
+  const int chunks = (a.HW + RED_PIX - 1) / RED_PIX;
+  int L = blockIdx.x;
+  const int chunk = L % chunks; L /= chunks;
+  const int cb = L % a.CB, f = L / a.CB;
   float mean, rstd;
   frame_mean_rstd(a.stats_in, f, a.inv_count, mean, rstd);
-  const int C = a.CB * 32;
-  if (!a.per_element)
-    for (int i = threadIdx.x; i < 2 * C; i += 256) chan_[i] = 0.f;
-  __syncthreads();
-  float s1 = 0.f, s2 = 0.f;
+  const int oct = threadIdx.x & 3;
+  const size_t fbase = (size_t)f * a.CB * a.HW * 32;
+  float g[8], dgc[8], dbc[8];
 #pragma unroll
-  for (int it = 0; it < EW_ITEMS; ++it) {
-    const int item = base + it * 256;
-    if (item >= per_frame) break;
-    const size_t off = (size_t)f * per_frame * 8 + (size_t)item * 8;
+  for (int k = 0; k < 8; ++k) {
+    g[k] = a.per_element ? 0.f : a.gain[cb * 32 + oct * 8 + k];
+    dgc[k] = dbc[k] = 0.f;
+  }
+  float s1 = 0.f, s2 = 0.f;
+  const int p_end = min(a.HW, (chunk + 1) * RED_PIX);
+#pragma unroll 4
+  for (int pix = chunk * RED_PIX + (threadIdx.x >> 2); pix < p_end; pix += 64) {
+    const size_t eoff = ((size_t)cb * a.HW + pix) * 32 + oct * 8;
     float x[8], dy[8];
-    unpack8(*(const u32x4*)(a.x + off), x);
-    unpack8(*(const u32x4*)(a.dy + off), dy);
-    const int gidx = a.per_element ? item * 8 : (item / (a.HW * 4)) * 32 + (item & 3) * 8;
+    unpack8(*(const u32x4*)(a.x + fbase + eoff), x);
+    unpack8(*(const u32x4*)(a.dy + fbase + eoff), dy);
+    if (a.per_element) {
+      const f32x4 g0 = *(const f32x4*)(a.gain + eoff), g1 = *(const f32x4*)(a.gain + eoff + 4);
+      g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float xh = (x[k] - mean) * rstd, dg = dy[k] * a.gain[gidx + k];
+      const float xh = (x[k] - mean) * rstd, dg = dy[k] * g[k];
       s1 += dg;
       s2 = fmaf(dg, xh, s2);
-      if (!a.per_element) {
-        atomicAdd(&chan_[gidx + k], dy[k] * xh);
-        atomicAdd(&chan_[C + gidx + k], dy[k]);
-      }
+      dgc[k] = fmaf(dy[k], xh, dgc[k]);
+      dbc[k] += dy[k];
     }
   }
   block_sum2_atomic_f64(s1, s2, a.ab + 2 * f);
   if (!a.per_element) {
-    for (int i = threadIdx.x; i < C; i += 256) {
-      if (chan_[i] != 0.f) atomicAdd(a.dgain + i, chan_[i]);
-      if (chan_[C + i] != 0.f) atomicAdd(a.dbias + i, chan_[C + i]);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      dgc[k] = sum_oct16(dgc[k]);
+      dbc[k] = sum_oct16(dbc[k]);
+    }
+    if (lane < 4) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        part_[w * 64 + lane * 8 + k] = dgc[k];
+        part_[w * 64 + 32 + lane * 8 + k] = dbc[k];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const float v = (part_[threadIdx.x] + part_[64 + threadIdx.x]) + (part_[128 + threadIdx.x] + part_[192 + threadIdx.x]);
+      float* dst = (threadIdx.x < 32) ? a.dgain : a.dbias;
+      atomicAdd(dst + cb * 32 + (threadIdx.x & 31), v);
     }
   }
 }
@@ -138,11 +166,15 @@ __global__ __launch_bounds__(256) void vpt_affine_bwd_elem_kernel(VptAffineBwdAr
 }
 
 extern "C" int vpt_affine_bwd_launch(const VptAffineBwdArgs* a, int pass, hipStream_t stream) {
-  if (a->frames <= 0 || (!a->per_element && a->CB * 32 > 512)) return -1;
+  if (a->frames <= 0) return -1;
   const int per_frame = a->CB * a->HW * 4;
   const long grid = (long)a->frames * ((per_frame + EW_PER_BLOCK - 1) / EW_PER_BLOCK);
   if (grid > 0x7fffffffL) return -2;
-  if (pass == 1) hipLaunchKernelGGL(vpt_affine_bwd_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *a);
+  if (pass == 1) {
+    const long g1 = (long)a->frames * a->CB * ((a->HW + RED_PIX - 1) / RED_PIX);
+    if (g1 > 0x7fffffffL) return -2;
+    hipLaunchKernelGGL(vpt_affine_bwd_reduce_kernel, dim3((unsigned)g1), dim3(256), 0, stream, *a);
+  }
   else if (pass == 2) hipLaunchKernelGGL(vpt_affine_bwd_apply_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *a);
   else {
     const int gy = a->frames >= 512 ? 32 : (a->frames >= 16 ? 8 : 1);
@@ -209,71 +241,176 @@ extern "C" int vpt_pool_bwd_launch(const VptPoolBwdArgs* a, hipStream_t stream) 
 }
 
 // ------------------------------------------------------------------------------------------------
-// One workgroup = CBP_PIX consecutive pixels of one (frame, 32-channel block).
-#define CBP_PIX 1024
+// vpt_conv_bwd_prep: one workgroup = one (frame, 32-channel block) plane.  Thread = (channel octet, image column,
+// row phase): the column's edge class is a thread constant and the row's is a loop-position test, so the nine
+// per-edge-class sums S[e][o] = sum dz live in 24 registers (all rows / first row / last row) and reach LDS once
+// per thread.  Everything that is linear in S is finished by vpt_conv_bwd_finish_kernel from the per-frame
+// partials:  dSA = sum_f S_f,  dSG = sum_f (-rstd_f mu_f) S_f,  T1_f = sum dz v - <SA, S_f>,  T2_f = <SG, S_f>.
+// With (dpooled, argmax) instead of dy the max-pool backward is fused in: dy(y,x) = sum over the <= 4 windows that
+// contain (y,x) of dpooled[window] * [argmax[window] == position code of (y,x)].
 
 __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_kernel(VptConvBwdPrepArgs a) {
-  __shared__ float tab_[2 * 9 * 32];  // dSA / dSG partials of this block's 32 channels
+  __shared__ float tab_[9 * 32];
   const int HW = a.H * a.W;
-  const int chunks = (HW + CBP_PIX - 1) / CBP_PIX;
-  int L = blockIdx.x;
-  const int chunk = L % chunks; L /= chunks;
-  const int cb = L % a.CB;
-  const int f = L / a.CB;
+  const int cb = blockIdx.x % a.CB, f = blockIdx.x / a.CB;
   float mean, rstd;
   frame_mean_rstd(a.stats_in, f, a.inv_count_in, mean, rstd);
-  const float nrm = -rstd * mean;
-  for (int i = threadIdx.x; i < 2 * 9 * 32; i += 256) tab_[i] = 0.f;
+  for (int i = threadIdx.x; i < 9 * 32; i += 256) tab_[i] = 0.f;
   __syncthreads();
-  const int oct = threadIdx.x & 3;
-  const int c0 = cb * 32 + oct * 8;
+  const int oct = threadIdx.x & 3, pi = threadIdx.x >> 2;
+  const int x = pi & (a.W - 1), ry = pi >> a.wshift, R = 64 >> a.wshift;
   const size_t plane = ((size_t)(f * a.CB + cb) * HW) * 32 + oct * 8;
-  float t1 = 0.f, t2 = 0.f;
-  for (int pp = threadIdx.x >> 2; pp < CBP_PIX; pp += 64) {
-    const int p = chunk * CBP_PIX + pp;
-    if (p >= HW) break;
-    const int y = p / a.W, x = p - y * a.W;
-    const int ey = (y == 0) ? 0 : ((y == a.H - 1) ? 2 : 1);
-    const int ex = (x == 0) ? 0 : ((x == a.W - 1) ? 2 : 1);
-    const int e = ey * 3 + ex;
-    const size_t off = plane + (size_t)p * 32;
+  const int PH = a.H >> 1, PW = a.W >> 1;
+  const size_t pplane = ((size_t)(f * a.CB + cb) * PH * PW) * 32 + oct * 8;
+  const int px_lo = x >> 1, px_hi = min((x + 1) >> 1, PW - 1);
+  float all[8], top[8], bot[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) all[k] = top[k] = bot[k] = 0.f;
+  float tv = 0.f;
+#pragma unroll 2
+  for (int y = ry; y < a.H; y += R) {
+    const size_t off = plane + (size_t)(y * a.W + x) * 32;
     float dy[8], v[8], o[8];
-    unpack8(*(const u32x4*)(a.dy + off), dy);
     unpack8(*(const u32x4*)(a.y + off), v);
+    if (a.dy) {
+      unpack8(*(const u32x4*)(a.dy + off), dy);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dy[k] = 0.f;
+      const int py_lo = y >> 1, py_hi = min((y + 1) >> 1, PH - 1);
+      for (int py = py_lo; py <= py_hi; ++py)
+        for (int px = px_lo; px <= px_hi; ++px) {
+          const unsigned code = (unsigned)((y - 2 * py + 1) * 3 + (x - 2 * px + 1));
+          const size_t po = pplane + (size_t)(py * PW + px) * 32;
+          const uint64_t am = *(const uint64_t*)(a.argmax + po);
+          float d[8];
+          unpack8(*(const u32x4*)(a.dpooled + po), d);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) dy[k] += (((unsigned)(am >> (8 * k)) & 0xffu) == code) ? d[k] : 0.f;
+        }
+    }
     if (a.res) {
       float rr[8];
       unpack8(*(const u32x4*)(a.res + off), rr);
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] -= rr[k];
     }
-    const float* sa = a.edge_sa + e * a.CoutPad + c0;
-    const float* sg = a.edge_sg + e * a.CoutPad + c0;
+    const bool is_top = (y == 0), is_bot = (y == a.H - 1);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float dz = (v[k] > 0.f) ? dy[k] : 0.f;
       o[k] = dz * rstd;
-      t1 = fmaf(dz, v[k] - sa[k], t1);
-      t2 = fmaf(dz, sg[k], t2);
-      if (dz != 0.f) {
-        atomicAdd(&tab_[e * 32 + oct * 8 + k], dz);
-        atomicAdd(&tab_[9 * 32 + e * 32 + oct * 8 + k], dz * nrm);
-      }
+      tv = fmaf(dz, v[k], tv);
+      all[k] += dz;
+      top[k] = is_top ? dz : top[k];
+      bot[k] = is_bot ? dz : bot[k];
     }
     *(u32x4*)(a.dacc + off) = pack8(o);
   }
-  block_sum2_atomic_f64(t1, t2, a.t12 + 2 * f);
-  for (int i = threadIdx.x; i < 9 * 32; i += 256) {
-    const int e = i >> 5, c = cb * 32 + (i & 31);
-    if (tab_[i] != 0.f) atomicAdd(a.d_sa + e * a.CoutPad + c, tab_[i]);
-    if (tab_[9 * 32 + i] != 0.f) atomicAdd(a.d_sg + e * a.CoutPad + c, tab_[9 * 32 + i]);
+  // S[ey][ex][channel]: reduce over the threads of this column class
+  const int ex = (x == 0) ? 0 : ((x == a.W - 1) ? 2 : 1);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) all[k] -= top[k] + bot[k];
+  // interior columns are most lanes: shuffle-reduce them per wave first (edge-column lanes contribute zero)
+  float red[24];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    red[k] = (ex == 1) ? top[k] : 0.f;
+    red[8 + k] = (ex == 1) ? all[k] : 0.f;
+    red[16 + k] = (ex == 1) ? bot[k] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 24; ++i) red[i] = sum_oct16(red[i]);
+  const int lane = threadIdx.x & 63;
+  if (lane < 4) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      atomicAdd(&tab_[(0 * 3 + 1) * 32 + oct * 8 + k], red[k]);
+      atomicAdd(&tab_[(1 * 3 + 1) * 32 + oct * 8 + k], red[8 + k]);
+      atomicAdd(&tab_[(2 * 3 + 1) * 32 + oct * 8 + k], red[16 + k]);
+    }
+  }
+  if (ex != 1) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      atomicAdd(&tab_[(0 * 3 + ex) * 32 + oct * 8 + k], top[k]);
+      atomicAdd(&tab_[(1 * 3 + ex) * 32 + oct * 8 + k], all[k]);
+      atomicAdd(&tab_[(2 * 3 + ex) * 32 + oct * 8 + k], bot[k]);
+    }
+  }
+  // sum dz v -> t12[f].x  (the <SA, S> correction and T2 are added by the finish kernel)
+  tv = wave_sum(tv);
+  __shared__ float red_[4];
+  if (lane == 0) red_[threadIdx.x >> 6] = tv;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(a.t12 + 2 * f, (double)((red_[0] + red_[1]) + (red_[2] + red_[3])));
+  const int Cout = a.CB * 32;
+  for (int i = threadIdx.x; i < 9 * 32; i += 256)
+    a.sbuf[((size_t)f * 9 + (i >> 5)) * Cout + cb * 32 + (i & 31)] = tab_[i];
+}
+
+#define FIN_COLS 16  // 256 * 16 >= 9 * Cout  (Cout <= 448)
+// finish: grid = ceil(frames / 16) workgroups, each walks 16 frames; thread = columns (e, c) of the [9][Cout] table
+__global__ __launch_bounds__(256) void vpt_conv_bwd_finish_kernel(VptConvBwdPrepArgs a) {
+  __shared__ float red_[8];
+  const int Cout = a.CB * 32, ncol = 9 * Cout;
+  const int f0 = blockIdx.x * 16, f1 = min(f0 + 16, a.frames);
+  float acc_sa[FIN_COLS], acc_sg[FIN_COLS], sa[FIN_COLS], sg[FIN_COLS];
+#pragma unroll
+  for (int j = 0; j < FIN_COLS; ++j) {
+    acc_sa[j] = acc_sg[j] = 0.f;
+    const int i = threadIdx.x + 256 * j;
+    const int e = i / Cout, c = i - e * Cout;
+    sa[j] = (i < ncol) ? a.edge_sa[e * a.CoutPad + c] : 0.f;
+    sg[j] = (i < ncol) ? a.edge_sg[e * a.CoutPad + c] : 0.f;
+  }
+  for (int f = f0; f < f1; ++f) {
+    float mean, rstd;
+    frame_mean_rstd(a.stats_in, f, a.inv_count_in, mean, rstd);
+    const float nrm = -rstd * mean;
+    float t1c = 0.f, t2c = 0.f;
+#pragma unroll
+    for (int j = 0; j < FIN_COLS; ++j) {
+      const int i = threadIdx.x + 256 * j;
+      if (i < ncol) {
+        const float S = a.sbuf[(size_t)f * ncol + i];
+        acc_sa[j] += S;
+        acc_sg[j] = fmaf(nrm, S, acc_sg[j]);
+        t1c = fmaf(sa[j], S, t1c);
+        t2c = fmaf(sg[j], S, t2c);
+      }
+    }
+    t1c = wave_sum(t1c);
+    t2c = wave_sum(t2c);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red_[w] = t1c; red_[4 + w] = t2c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      a.t12[2 * f] -= (double)((red_[0] + red_[1]) + (red_[2] + red_[3]));
+      a.t12[2 * f + 1] += (double)((red_[4] + red_[5]) + (red_[6] + red_[7]));
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < FIN_COLS; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    if (i < ncol) {
+      const int e = i / Cout, c = i - e * Cout;
+      atomicAdd(a.d_sa + e * a.CoutPad + c, acc_sa[j]);
+      atomicAdd(a.d_sg + e * a.CoutPad + c, acc_sg[j]);
+    }
   }
 }
 
-extern "C" int vpt_conv_bwd_prep_launch(const VptConvBwdPrepArgs* a, hipStream_t stream) {
-  if (a->frames <= 0) return -1;
-  const int HW = a->H * a->W;
-  const long grid = (long)a->frames * a->CB * ((HW + CBP_PIX - 1) / CBP_PIX);
+extern "C" int vpt_conv_bwd_prep_launch(const VptConvBwdPrepArgs* a0, hipStream_t stream) {
+  VptConvBwdPrepArgs a = *a0;
+  if (a.frames <= 0 || !a.sbuf) return -1;
+  if (a.W < 8 || a.W > 64 || (a.W & (a.W - 1)) || a.CB * 32 * 9 > 256 * FIN_COLS) return -1;  // column-per-thread mapping: W in {8,16,32,64}
+  if (!a.dy && (!a.dpooled || !a.argmax || (a.H & 1) || (a.W & 1))) return -1;
+  a.wshift = 31 - __builtin_clz((unsigned)a.W);
+  const long grid = (long)a.frames * a.CB;
   if (grid > 0x7fffffffL) return -2;
-  hipLaunchKernelGGL(vpt_conv_bwd_prep_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *a);
+  hipLaunchKernelGGL(vpt_conv_bwd_prep_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(vpt_conv_bwd_finish_kernel, dim3((unsigned)((a.frames + 15) / 16)), dim3(256), 0, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void vpt_pool_kernel(VptPoolArgs a) {
     const int cb = r / PH;
     const vpt_bf16* plane = a.x + ((size_t)(f * a.CB + cb) * a.H * a.W) * 32 + oct * 8;
     u16x8 m = {0, 0, 0, 0, 0, 0, 0, 0};
+    u16x8 am = {15, 15, 15, 15, 15, 15, 15, 15};
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy) {
       const int y = 2 * py + dy;
@@ -46,8 +47,19 @@ __global__ __launch_bounds__(256) void vpt_pool_kernel(VptPoolArgs a) {
         const int x = 2 * px + dx;
         if (x < 0 || x >= a.W) continue;
         const u16x8 v = *(const u16x8*)(plane + (size_t)(y * a.W + x) * 32);
+        if (a.argmax) {  // strict > keeps the FIRST maximum in scan order (torch's rule); an all-zero window keeps 15
+          const unsigned short code = (unsigned short)((dy + 1) * 3 + (dx + 1));
+#pragma unroll
+          for (int k = 0; k < 8; ++k) am[k] = (v[k] > m[k]) ? code : am[k];
+        }
         m = __builtin_elementwise_max(m, v);
       }
+    }
+    if (a.argmax) {
+      uint64_t pk = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) pk |= (uint64_t)(am[k] & 0xff) << (8 * k);
+      *(uint64_t*)(a.argmax + ((size_t)(f * a.CB + cb) * PH * PW + (size_t)(py * PW + px)) * 32 + oct * 8) = pk;
     }
     const u32x4 mv = __builtin_bit_cast(u32x4, m);
     float vals[8];

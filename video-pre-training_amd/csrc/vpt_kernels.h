@@ -46,6 +46,7 @@ struct VptPoolArgs {
   const vpt_bf16* x;       // [F][CB][H][W][32]  (non-negative values: post-ReLU)
   vpt_bf16* y;             // [F][CB][H/2][W/2][32]
   double* stats_out;       // [F][2]
+  uint8_t* argmax;         // optional [F][CB][H/2][W/2][32]: window position code kh*3+kw of the first maximum (15: window all zero)
   int frames, CB, H, W;
 };
 
@@ -131,7 +132,11 @@ struct VptPoolBwdArgs {
 };
 
 struct VptConvBwdPrepArgs {
-  const vpt_bf16* dy;      // gradient w.r.t. the layer output (after ReLU and residual add)
+  const vpt_bf16* dy;      // gradient w.r.t. the layer output (after ReLU and residual add); null -> (dpooled, argmax)
+  const vpt_bf16* dpooled; // gradient w.r.t. max_pool(y) [F][CB][H/2][W/2][32]   (fused max-pool backward)
+  const uint8_t* argmax;   // window position code kh*3+kw of the maximum, same shape (vpt_pool_kernel)
+  float* sbuf;             // scratch [F][9][Cout] fp32: per-frame edge-class sums of dz
+  int wshift;              // log2(W), filled by the launcher
   const vpt_bf16* y;       // saved layer output
   const vpt_bf16* res;     // saved residual input or null
   const double* stats_in;  // statistics of the conv's INPUT x

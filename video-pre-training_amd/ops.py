@@ -85,12 +85,14 @@ def conv3x3(x, wpk, edge_sa, edge_sg, stats_in, cout, res=None, stats_out=None, 
     return out
 
 
-def maxpool(x, stats_out=None):
+def maxpool(x, stats_out=None, want_argmax=False):
+    """-> pooled, or (pooled, argmax uint8) with want_argmax (training: vpt_conv_backward_prepare routes through it)."""
     _chk(x, torch.bfloat16, "x"); _chk(stats_out, torch.float64, "stats_out")
     f, cb, h, w, _ = x.shape
     y = torch.empty(f, cb, h // 2, w // 2, 32, dtype=torch.bfloat16, device=x.device)
-    _call("vpt_maxpool_forward", dict(bytes=2.0 * f * cb * 32 * h * w * 1.25), ptr(x), ptr(y), ptr(stats_out), f, cb * 32, h, w, _stream())
-    return y
+    am = torch.empty(f, cb, h // 2, w // 2, 32, dtype=torch.uint8, device=x.device) if want_argmax else None
+    _call("vpt_maxpool_forward", dict(bytes=2.0 * f * cb * 32 * h * w * 1.25), ptr(x), ptr(y), ptr(stats_out), ptr(am), f, cb * 32, h, w, _stream())
+    return (y, am) if want_argmax else y
 
 
 def frame_affine(x, gain, bias, stats_in, stats_out=None, per_element=False, out=None):
@@ -239,18 +241,24 @@ def masked_attention_backward(qkvr, kmem, vmem, memvalid, b_nd, dout, db_nd, bat
     return dqkvr
 
 
-def conv_backward_prepare(dy, y, res, stats_in, edge_sa, edge_sg, cin):
-    """-> (dacc bf16 blocked, t12 double [F,2], d_sa fp32 [9,CoutPad], d_sg fp32 [9,CoutPad])."""
-    for t, nme in ((dy, "dy"), (y, "y"), (res, "res")):
+def conv_backward_prepare(dy, y, res, stats_in, edge_sa, edge_sg, cin, dpooled=None, argmax=None):
+    """-> (dacc bf16 blocked, t12 double [F,2], d_sa fp32 [9,CoutPad], d_sg fp32 [9,CoutPad]).
+    dy=None with (dpooled, argmax): the layer feeds a max-pool whose backward is applied on the fly."""
+    for t, nme in ((dy, "dy"), (y, "y"), (res, "res"), (dpooled, "dpooled")):
         _chk(t, torch.bfloat16, nme)
+    _chk(argmax, torch.uint8, "argmax")
     _chk(stats_in, torch.float64, "stats_in"); _chk(edge_sa, torch.float32, "edge_sa"); _chk(edge_sg, torch.float32, "edge_sg")
+    if (dy is None) == (dpooled is None or argmax is None):
+        raise ValueError("conv_backward_prepare: give either dy or (dpooled, argmax)")
     f, cb, h, w, _ = y.shape
     dev = y.device
     dacc = torch.empty_like(y)
     t12 = torch.zeros(f, 2, dtype=torch.float64, device=dev)
     d_sa, d_sg = torch.zeros_like(edge_sa), torch.zeros_like(edge_sg)
-    _call("vpt_conv_backward_prepare", dict(bytes=6.0 * y.numel()), ptr(dy), ptr(y), ptr(res), ptr(stats_in), ptr(edge_sa), ptr(edge_sg),
-          ptr(dacc), ptr(t12), ptr(d_sa), ptr(d_sg), f, h, w, cin, cb * 32, _stream())
+    scratch = torch.empty(f, 9, cb * 32, dtype=torch.float32, device=dev)
+    _call("vpt_conv_backward_prepare", dict(bytes=(6.0 if dy is not None else 4.75) * y.numel() + (2.0 * y.numel() if res is not None else 0)),
+          ptr(dy), ptr(dpooled), ptr(argmax), ptr(y), ptr(res), ptr(stats_in), ptr(edge_sa), ptr(edge_sg),
+          ptr(dacc), ptr(t12), ptr(d_sa), ptr(d_sg), ptr(scratch), f, h, w, cin, cb * 32, _stream())
     return dacc, t12, d_sa, d_sg
 
 

@@ -256,7 +256,7 @@ class BCTrainer:
             else:
                 wpk, sa, sg = w[p + "firstconv"]
                 rec["pre"] = ops.conv3x3(x, wpk, sa, sg, s_x, c)
-                pooled = ops.maxpool(rec["pre"], stats_out=s_pool)
+                pooled, rec["argmax"] = ops.maxpool(rec["pre"], stats_out=s_pool, want_argmax=True)
             s_x = nxt()
             x = ops.frame_affine(pooled, w[p + "n.g"], w[p + "n.b"], s_pool, stats_out=s_x)
             rec.update(pooled=pooled, s_pool=s_pool, blocks=[])
@@ -303,13 +303,15 @@ class BCTrainer:
             acc["n"][s] = (torch.zeros(c, dtype=torch.float32, device=dev), torch.zeros(c, dtype=torch.float32, device=dev))
         return acc
 
-    def _conv_layer_backward(self, q, acc, dy, y, res, x_in, s_in, skip, need_dx=True):
-        """One GN -> conv3x3 -> ReLU (+res) layer: accumulates the raw weight-gradient pieces and returns dx (+skip)."""
+    def _conv_layer_backward(self, q, acc, dy, y, res, x_in, s_in, skip, need_dx=True, pool=None):
+        """One GN -> conv3x3 -> ReLU (+res) layer: accumulates the raw weight-gradient pieces and returns dx (+skip).
+        pool = (dpooled, argmax) when the layer feeds the stack's max-pool (dy is then None)."""
         w = self.engine.w
         _, sa, sg = w[q]
         cin = x_in.shape[1] * 32
         n = cin * x_in.shape[2] * x_in.shape[3]
-        dacc, t12, d_sa, d_sg = ops.conv_backward_prepare(dy, y, res, s_in, sa, sg, cin)
+        dacc, t12, d_sa, d_sg = ops.conv_backward_prepare(dy, y, res, s_in, sa, sg, cin, dpooled=pool[0] if pool else None,
+                                                          argmax=pool[1] if pool else None)
         dw_raw = ops.conv3x3_wgrad(dacc, x_in)
         if q in acc["raw"]:
             r = acc["raw"][q]
@@ -359,9 +361,8 @@ class BCTrainer:
                 else:
                     acc["first"] = [dw, db]
             else:
-                dpre = ops.maxpool_backward(rec["pre"], rec["pooled"], dpooled)
-                dx = self._conv_layer_backward(p + "firstconv", acc, dpre, rec["pre"], None, rec["x_prev"], rec["s_prev"], None)
-                del dpre
+                dx = self._conv_layer_backward(p + "firstconv", acc, None, rec["pre"], None, rec["x_prev"], rec["s_prev"], None,
+                                               pool=(dpooled, rec["argmax"]))
             del dpooled
 
     def _cnn_backward_finish(self, acc, P, g):
