@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--seq", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bc-steps", type=int, default=3, help="timed behavioural-cloning steps after the forward measurement (0: skip)")
+    ap.add_argument("--bc-warmup", type=int, default=1)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -161,11 +163,45 @@ def main():
                         avg_launch_ms=round(c["ms"] / c["calls"], 4),
                         share_of_step_time=round(c["ms"] / total_ms, 3))
 
+    # ---- second half of BASELINE.json's metric: BC-step time (forward + backward through every layer + gradient
+    # all-reduce over RCCL when N > 1 + fused Adam), same batch per GPU, KV memory carried between steps ----
+    bc = None
+    if args.bc_steps > 0:
+        try:
+            from vpt_amd.training import BCTrainer
+            tr = BCTrainer(pol, train_cnn=True)
+            ab = torch.randint(0, pol._engine.n_buttons, (B, T), generator=g).to(dev)
+            ac = torch.randint(0, pol._engine.n_camera, (B, T), generator=g).to(dev)
+            st_bc = pol.initial_state(B)
+            losses = []
+            for _ in range(args.bc_warmup):
+                l, st_bc = tr.step(img, first, st_bc, ab, ac)
+                losses.append(l)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.bc_steps):
+                l, st_bc = tr.step(img, first, st_bc, ab, ac)
+                losses.append(l)
+            barrier()
+            bc_el = time.perf_counter() - t0
+            if distributed:
+                tt = torch.tensor([bc_el], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                bc_el = float(tt.item())
+            bc = dict(ms_per_step=round(1e3 * bc_el / args.bc_steps, 2), frames_per_s=round(world * B * T * args.bc_steps / bc_el, 1),
+                      steps=args.bc_steps, warmup=args.bc_warmup, global_batch=world * B, seq_len=T, trained="all parameters (CNN + trunk + heads)",
+                      optimizer="Adam lr 1.81e-4 wd 0.039428 (behavioural_cloning.py:38-40)",
+                      allreduce=("one bucketed RCCL all-reduce of the fp32 gradients per step" if distributed else "none (1 GPU)"),
+                      loss_first=round(losses[0], 4), loss_last=round(losses[-1], 4),
+                      peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1))
+        except Exception as e:  # the forward line must survive a failure of the training leg
+            bc = dict(error=f"{type(e).__name__}: {e}")
+
     frames_total = world * B * T * args.steps
     fps = frames_total / elapsed
     if rank == 0:
         line = {
-            "metric": "frames/sec (fwd), 2x policy, 128x128x3 seq=128",
+            "metric": "frames/sec (fwd) [+ bc_step.ms_per_step], 2x policy, 128x128x3 seq=128",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -175,6 +211,7 @@ def main():
             "e2e_tflops": round(fps * FLOP_PER_FRAME.get(args.model, 0) / 1e12, 1),
             "e2e_frac_of_mfma_peak": round(fps * FLOP_PER_FRAME.get(args.model, 0) / MFMA_BF16_PEAK, 4),
             "roofline": roof,
+            "bc_step": bc,
             "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
