@@ -152,9 +152,11 @@ int vpt_conv3x3_dgrad(const void* dacc, const void* wpk_t, const void* skip, con
 int vpt_conv_first_backward(const uint8_t* img, const void* wfrag, const void* dpooled, float* dw, float* db,
                             int frames, int H, int W, int Cout, void* stream);
 
-/* Weight gradient of the folded convolution: dw[o][tap][c] += sum_{f,p} dacc[f][o][p] * x[f][c][p + tap] (fp32, atomics;
- * caller zeroes).  W in {16, 32, 64}.  The host maps it to dW, dgain, dbias (training.py). */
-int vpt_conv3x3_wgrad(const void* dacc, const void* x, float* dw, int frames, int H, int W, int Cin, int Cout, void* stream);
+/* Weight gradient of the folded convolution: dw[o][tap][c] += sum_{f,p} dacc[f][o][p] * x[f][c][p + tap] (fp32; caller
+ * zeroes or accumulates).  W in {16, 32, 64}.  scratch: fp32 work buffer of vpt_conv3x3_wgrad_scratch_floats() elements
+ * (per-frame-group partial sums).  The host maps dw to dW, dgain, dbias (training.py). */
+long vpt_conv3x3_wgrad_scratch_floats(int frames, int Cin, int Cout);
+int vpt_conv3x3_wgrad(const void* dacc, const void* x, float* dw, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream);
 
 /* F.max_pool2d(3, 2, 1) backward with torch's first-maximum tie rule. */
 int vpt_maxpool_backward(const void* pre, const void* pooled, const void* dpooled, void* dpre,

@@ -382,6 +382,14 @@ def test_conv_prepare_fused_pool_backward():
     got = ops.conv_backward_prepare(None, pre, None, st_in, sa, sg, cin, dpooled=dp, argmax=am)
     torch.cuda.synchronize()
     assert ((ref[0] != 0) == (got[0] != 0)).all()
-    assert _l2(got[0].float().cpu(), ref[0].float().cpu()) < 2e-3
+    assert _l2(got[0].float().cpu(), ref[0].float().cpu()) < 5e-3      # two bf16 roundings vs one
     for r, o in zip(ref[1:], got[1:]):
         assert _l2(o.double().cpu(), r.double().cpu()) < 2e-3
+    # exact reference: torch's max-pool backward on the same pre-pool values, gate, times rstd -- one bf16 rounding away
+    pre_n = packing.blocked_to_nchw(pre.cpu(), cout, h, h).requires_grad_(True)
+    (gpre,) = torch.autograd.grad((torch.nn.functional.max_pool2d(pre_n, 3, 2, 1) * packing.blocked_to_nchw(dp.cpu(), cout, h // 2, h // 2)).sum(), [pre_n])
+    n = cin * h * h
+    mu = x.reshape(f, -1).double().mean(1)
+    rstd = torch.rsqrt(x.reshape(f, -1).double().var(1, unbiased=False) + 1e-5).float()
+    exact = gpre * (pre_n.detach() > 0) * rstd.view(f, 1, 1, 1)
+    assert _l2(packing.blocked_to_nchw(got[0].cpu(), cout, h, h), exact) < 3e-3

@@ -20,7 +20,7 @@ def lib():
 
 def test_header_symbols_exported(lib):
     hdr = open(os.path.join(ROOT, "include", "vpt_hip.h")).read()
-    names = re.findall(r"^(?:int|const char\*)\s+(vpt_\w+)\s*\(", hdr, flags=re.M)
+    names = re.findall(r"^(?:int|long|const char\*)\s+(vpt_\w+)\s*\(", hdr, flags=re.M)
     assert len(names) >= 11
     for n in names:
         assert hasattr(lib, n), n
@@ -30,7 +30,7 @@ def test_ctypes_signatures_cover_header(lib):
     from vpt_amd import _native
     hdr = open(os.path.join(ROOT, "include", "vpt_hip.h")).read()
     for name, args in _native.SIGNATURES.items():
-        m = re.search(r"int\s+" + name + r"\s*\(([^;]*)\)\s*;", hdr, flags=re.S)
+        m = re.search(r"(?:int|long)\s+" + name + r"\s*\(([^;]*)\)\s*;", hdr, flags=re.S)
         assert m, name
         assert len([a for a in m.group(1).split(",") if a.strip()]) == len(args), name
 

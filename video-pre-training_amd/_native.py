@@ -28,7 +28,8 @@ SIGNATURES = {
     "vpt_conv_backward_prepare": [_P] * 13 + [_I, _I, _I, _I, _I, _P],
     "vpt_conv3x3_dgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_conv_first_backward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "vpt_conv3x3_wgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vpt_conv3x3_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vpt_conv3x3_wgrad_scratch_floats": [_I, _I, _I],
     "vpt_maxpool_backward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_frame_affine_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_bc_nll_backward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
@@ -65,6 +66,7 @@ def load():
         fn.argtypes = argtypes
         fn.restype = _I
     lib.vpt_version.restype = ctypes.c_char_p
+    lib.vpt_conv3x3_wgrad_scratch_floats.restype = ctypes.c_long
     lib.vpt_last_error.restype = ctypes.c_char_p
     _lib = lib
     return lib

@@ -79,9 +79,13 @@ int vpt_conv_first_backward(const uint8_t* img, const void* wfrag, const void* d
   CHECK_LAUNCH(vpt_conv_first_bwd_launch(&a, (hipStream_t)stream), "vpt_conv_first_backward");
 }
 
-int vpt_conv3x3_wgrad(const void* dacc, const void* x, float* dw, int frames, int H, int W, int Cin, int Cout, void* stream) {
+long vpt_conv3x3_wgrad_scratch_floats(int frames, int Cin, int Cout) {
+  return (long)vpt_conv_wgrad_groups(frames, Cin, Cout) * Cout * 9 * Cin;
+}
+
+int vpt_conv3x3_wgrad(const void* dacc, const void* x, float* dw, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream) {
   VptConvWgradArgs a;
-  a.dacc = (const vpt_bf16*)dacc; a.x = (const vpt_bf16*)x; a.dw = dw;
+  a.dacc = (const vpt_bf16*)dacc; a.x = (const vpt_bf16*)x; a.dw = dw; a.partial = scratch;
   a.frames = frames; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.OT = 0; a.frames_per_wg = 0;
   CHECK_LAUNCH(vpt_conv_wgrad_launch(&a, (hipStream_t)stream), "vpt_conv3x3_wgrad");
 }

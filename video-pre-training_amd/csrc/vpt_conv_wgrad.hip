@@ -3,47 +3,64 @@
 // i.e. the wgrad of FanInInitReLULayer's Conv2d (lib/util.py:58-65) with the GroupNorm gain already folded
 // (vpt_conv_bwd_prep supplies dacc = rstd * dz; the host maps dW' to dW, dgain, dbias).
 //
-// The reduction runs over PIXELS, but both tensors are stored channel-fastest ([frame][C/32][H][W][32]), so a
-// fragment's 8 consecutive k values (pixels) are 64 bytes apart in HBM.  They are transposed on the way into
-// LDS: each 16-byte chunk (8 channels of one pixel) is scattered with eight ds_write_b16 into channel-major
-// rows, after which both MFMA operands are plain ds_read_b128.  The +-1 pixel shifts of the three kernel
-// columns would break the 16-byte alignment of those reads, so x is written three times, pre-shifted by
-// 0/1/2 pixels (zero halo columns are cleared once and never overwritten).
+// The reduction runs over PIXELS while both tensors are stored channel-fastest ([frame][C/32][H][W][32]), so
+// an MFMA fragment's 8 consecutive k values (pixels) are 64 bytes apart.  gfx950's LDS transpose read
+// (ds_read_b64_tr_b16: 16 lanes read a [4 pixel][16 channel] block and each receives one channel's 4 pixels)
+// does that transposition for free, so LDS holds both tiles exactly as they lie in HBM (plain 16-byte copies).
 //
-// Workgroup = 128 couts (4 waves x 32) x 32 cins x 9 taps = 9 MFMA 32x32x16 accumulators per wave; one step
-// = 64 pixels (64/W whole rows) of one frame; a workgroup sweeps `frames_per_wg` frames and adds its
-// partial sums into the fp32 result with atomics (coalesced along cin).
+// Operand reuse: with k = the x pixel q of row r+dy, tap (dy,dx) is  sum_q dacc[o][r][q-dx+1] x[c][r+dy][q]:
+// the three kernel COLUMNS are three 64-byte-shifted reads of the dacc row (zero halo columns in LDS), the three
+// kernel ROWS three x rows -- 3 + 3 fragment reads feed 9 MFMAs.
+//
+// Workgroup = 8 waves = 4 (32-cout blocks of a 128-cout tile) x 2 (32-cin blocks); a wave owns the 9 taps of its
+// (cout block, cin block) pair = 9 MFMA 32x32x16 accumulators.  One step = 64 pixels (64/W image rows) of one
+// frame, double-buffered in LDS with the next step's global loads in flight during the MFMAs.  A workgroup
+// sweeps a contiguous range of frames (the grid is one workgroup per CU) and writes its partial sums to scratch;
+// vpt_conv_wgrad_reduce_kernel adds the per-group partials into the fp32 result.
 #include "vpt_common.h"
 #include "vpt_kernels.h"
 
-#define WG_DT_RS 144                    // bytes per cout row of the transposed dacc tile (64 px + pad)
-#define WG_DT_BYTES (128 * WG_DT_RS)    // 18432
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
-__global__ __launch_bounds__(256, 2) void vpt_conv_wgrad_kernel(VptConvWgradArgs a) {
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {  // 8 pixels of this lane's channel: two 4-pixel transposes
+  const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
+  const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 256));
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int W>
+__global__ __launch_bounds__(512, 1) void vpt_conv_wgrad_kernel(VptConvWgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int RB = 64 / W;            // image rows per step
+  constexpr int XR = RB + 2;            // x rows per step (halo rows above / below)
+  constexpr int DP = W + 2;             // dacc pixels per row in LDS (halo columns, kept zero)
+  constexpr int DCB = RB * DP * 64;     // bytes of one cout block's dacc slab
+  constexpr int XCB = XR * W * 64;      // bytes of one cin block's x slab
+  constexpr int BUF = 4 * DCB + 2 * XCB;
+  constexpr int NXC = 2 * XR * W * 4;   // 16-byte x chunks per step
+  constexpr int NX = (NXC + 511) / 512;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wo = w & 3, wi = w >> 2;
   const int hi = lane >> 5, l31 = lane & 31;
-  const int W = a.W, H = a.H, HW = a.H * a.W;
-  const int RB = 64 / W;                // rows per step
-  const int Wp = W + 16;                // padded row pitch (elements) of the shifted x copies
-  const int SC = (RB + 2) * Wp * 2 + 16;  // bytes per cin row (odd multiple of 16 -> conflict-free b128 reads)
-  const int COPY = 32 * SC;
-  unsigned char* DT = smem;
-  unsigned char* XT = smem + WG_DT_BYTES;
-
+  const int H = a.H, HW = a.H * W;
   const int CBi = a.Cin >> 5, CBo = a.Cout >> 5;
-  int L = blockIdx.x;
-  const int cbi = L % CBi; L /= CBi;
-  const int ot = L % a.OT;
-  const int grp = L / a.OT;
+  const int CP = (CBi + 1) >> 1;
+  const int L = blockIdx.x;
+  const int tiles = a.OT * CP;
+  const int tile = L % tiles, grp = L / tiles;
+  const int cp = tile % CP, ot = tile / CP;
   const int f0 = grp * a.frames_per_wg, f1 = min(f0 + a.frames_per_wg, a.frames);
-  const int cbo = ot * 4 + w;           // this wave's 32 output channels
-  const bool ovalid = cbo < CBo;
 
-  // clear the x copies once (halo columns / pad stay zero for the whole kernel)
-  for (int i = tid * 16; i < 3 * COPY; i += 256 * 16) *(u32x4*)(XT + i) = (u32x4){0u, 0u, 0u, 0u};
-  __syncthreads();
+  // dacc halo columns of both buffers: zero once, never overwritten
+  for (int i = tid; i < 2 * 4 * RB * 2 * 4; i += 512) {
+    int q = i;
+    const int part = q & 3; q >>= 2;
+    const int side = q & 1; q >>= 1;
+    const int r = q % RB; q /= RB;
+    const int cb = q & 3, buf = q >> 2;
+    *(u32x4*)(smem + buf * BUF + cb * DCB + (r * DP + side * (W + 1)) * 64 + part * 16) = (u32x4){0u, 0u, 0u, 0u};
+  }
 
   f32x16 acc[9];
 #pragma unroll
@@ -51,120 +68,136 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_wgrad_kernel(VptConvWgradArgs
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  const int xchunks = (RB + 2) * W * 4;     // 16-byte chunks of the x slab per step (<= 768)
   const int steps_per_frame = H / RB;
   const int nsteps = (f1 - f0) * steps_per_frame;
-
-  u32x4 dreg[4], xreg[3];
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  u32x4 dreg[2], xreg[NX];
+
+  // branch-free staging: every load executes from a clamped (valid) address and is zeroed afterwards when it lies
+  // outside the image / beyond the channel count
   auto load_step = [&](int s) {
     const int f = f0 + s / steps_per_frame, y0 = (s % steps_per_frame) * RB;
-    if (ovalid) {
-      const vpt_bf16* dp = a.dacc + ((size_t)(f * CBo + cbo) * HW + (size_t)y0 * W) * 32;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) dreg[m] = *(const u32x4*)(dp + (lane + 64 * m) * 8);
+    for (int m = 0; m < 2; ++m) {          // 4 cout blocks x 64 pixels x 4 parts = 1024 chunks; a block's 64 pixels are contiguous in HBM
+      const int q = tid + 512 * m;
+      const int cbo = ot * 4 + (q >> 8);
+      const u32x4 v = *(const u32x4*)(a.dacc + ((size_t)(f * CBo + min(cbo, CBo - 1)) * HW + (size_t)y0 * W) * 32 + (q & 255) * 8);
+      dreg[m] = (cbo < CBo) ? v : zero4;
     }
-    const vpt_bf16* xp = a.x + ((size_t)(f * CBi + cbi) * HW) * 32;
 #pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      const int q = tid + 256 * m;
-      u32x4 v = zero4;
-      if (q < xchunks) {
-        const int pix = q >> 2, part = q & 3;
-        const int r = pix / W, x = pix - r * W;
-        const int y = y0 - 1 + r;
-        if (y >= 0 && y < H) v = *(const u32x4*)(xp + ((size_t)y * W + x) * 32 + part * 8);
-      }
-      xreg[m] = v;
+    for (int m = 0; m < NX; ++m) {
+      const int q = min(tid + 512 * m, NXC - 1);
+      const int cb = q / (XR * W * 4), rem = q % (XR * W * 4);
+      const int r = rem / (W * 4), rem2 = rem % (W * 4);
+      const int y = y0 - 1 + r, cbi = cp * 2 + cb;
+      const u32x4 v = *(const u32x4*)(a.x + ((size_t)(f * CBi + min(cbi, CBi - 1)) * HW + (size_t)min(max(y, 0), H - 1) * W) * 32 + rem2 * 8);
+      xreg[m] = (y >= 0 && y < H && cbi < CBi) ? v : zero4;
     }
   };
-  auto store_step = [&]() {
-    if (ovalid) {
+  auto store_step = [&](int buf) {
+    unsigned char* base = smem + buf * BUF;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int q = lane + 64 * m;          // chunk of this wave's 32-cout block: pixel q>>2, channels (q&3)*8..+7
-        const int pix = q >> 2, part = q & 3;
-        unsigned char* dst = DT + (w * 32 + part * 8) * WG_DT_RS + pix * 2;
-        const uint32_t u[4] = {dreg[m].x, dreg[m].y, dreg[m].z, dreg[m].w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          *(unsigned short*)(dst + (2 * k) * WG_DT_RS) = (unsigned short)(u[k] & 0xffffu);
-          *(unsigned short*)(dst + (2 * k + 1) * WG_DT_RS) = (unsigned short)(u[k] >> 16);
-        }
-      }
+    for (int m = 0; m < 2; ++m) {
+      const int q = tid + 512 * m;
+      const int pix = (q & 255) >> 2, part = q & 3;
+      *(u32x4*)(base + (q >> 8) * DCB + ((pix / W) * DP + (pix % W) + 1) * 64 + part * 16) = dreg[m];
     }
 #pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      const int q = tid + 256 * m;
-      if (q < xchunks) {
-        const int pix = q >> 2, part = q & 3;
-        const int r = pix / W, x = pix - r * W;
-        const uint32_t u[4] = {xreg[m].x, xreg[m].y, xreg[m].z, xreg[m].w};
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {       // copy s holds image column j at index j + 9 - s
-          unsigned char* dst = XT + s * COPY + (part * 8) * SC + (r * Wp + x + 9 - s) * 2;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            *(unsigned short*)(dst + (2 * k) * SC) = (unsigned short)(u[k] & 0xffffu);
-            *(unsigned short*)(dst + (2 * k + 1) * SC) = (unsigned short)(u[k] >> 16);
-          }
-        }
-      }
+    for (int m = 0; m < NX; ++m) {
+      const int q = tid + 512 * m;
+      if (NXC % 512 == 0 || q < NXC) *(u32x4*)(base + 4 * DCB + q * 16) = xreg[m];   // x slabs are stored exactly in chunk order
     }
   };
 
-  if (nsteps > 0) load_step(0);
+  // per-lane part of every fragment address: 16-lane group g reads pixels 8*(g>>1) + (i>>2) (+4), channels 16*(g&1) + 4*(i&3)..+3
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int lane_off = (8 * (g16 >> 1) + (i16 >> 2)) * 64 + (16 * (g16 & 1) + 4 * (i16 & 3)) * 2;
+
+  if (nsteps > 0) {
+    load_step(0);
+    store_step(0);
+  }
+  __syncthreads();
   for (int s = 0; s < nsteps; ++s) {
-    store_step();
-    __syncthreads();
-    if (s + 1 < nsteps) load_step(s + 1);
-    if (ovalid) {
+    load_step(min(s + 1, nsteps - 1));   // the last iteration re-stages its own step into the idle buffer (harmless)
+    const unsigned char* base = smem + (s & 1) * BUF;
+    const unsigned char* dA = base + wo * DCB + lane_off;
+    const unsigned char* xB = base + 4 * DCB + wi * XCB + lane_off;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int q0 = ks * 16 + 8 * hi;       // first of this lane's 8 pixels within the 64-pixel step
-        const int r = q0 / W, x0 = q0 - r * W;
-        const bf16x8 af = *(const bf16x8*)(DT + (w * 32 + l31) * WG_DT_RS + q0 * 2);
+    for (int ks = 0; ks < 4; ++ks) {
+      const int q0 = ks * 16;
+      const int r = q0 / W, x0 = q0 % W;
+      bf16x8 af[3], bfr[3];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+      for (int dx = 0; dx < 3; ++dx) af[dx] = tr_frag(dA + (r * DP + x0 - dx + 2) * 64);
 #pragma unroll
-          for (int dx = 0; dx < 3; ++dx) {
-            const bf16x8 bfr = *(const bf16x8*)(XT + dx * COPY + l31 * SC + ((r + dy) * Wp + x0 + 8) * 2);
-            acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[dy * 3 + dx], 0, 0, 0);
-          }
-      }
+      for (int dy = 0; dy < 3; ++dy) bfr[dy] = tr_frag(xB + ((r + dy) * W + x0) * 64);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+          acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[dx], bfr[dy], acc[dy * 3 + dx], 0, 0, 0);
     }
+    store_step((s + 1) & 1);
     __syncthreads();
   }
 
-  if (ovalid) {
+  // partial sums of this frame group -> scratch [grp][Cout][9][Cin]
+  const int cbi = cp * 2 + wi, cbo = ot * 4 + wo;
+  if (cbi < CBi && cbo < CBo) {
+    float* part = a.partial + (size_t)grp * a.Cout * 9 * a.Cin;
     const int c = cbi * 32 + l31;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = cbo * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        atomicAdd(a.dw + ((size_t)o * 9 + t) * a.Cin + c, acc[t][r]);
+        part[((size_t)o * 9 + t) * a.Cin + c] = acc[t][r];
       }
   }
 }
 
+// dw[i] += sum over frame groups of partial[g][i]
+__global__ __launch_bounds__(256) void vpt_conv_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int n4, int groups) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int g = 0; g < groups; ++g) s += *((const f32x4*)partial + (size_t)g * n4 + i);
+  f32x4* d = (f32x4*)dw + i;
+  *d = *d + s;
+}
+
+extern "C" int vpt_conv_wgrad_groups(int frames, int Cin, int Cout) {
+  const int tiles = ((Cout + 127) / 128) * (((Cin >> 5) + 1) >> 1);
+  int groups = 256 / tiles;
+  if (groups < 1) groups = 1;
+  if (groups > frames) groups = frames;
+  const int fpg = (frames + groups - 1) / groups;
+  return (frames + fpg - 1) / fpg;
+}
+
 extern "C" int vpt_conv_wgrad_launch(const VptConvWgradArgs* a_in, hipStream_t stream) {
   VptConvWgradArgs a = *a_in;
-  if ((a.Cin & 31) || (a.Cout & 31) || a.frames <= 0 || (a.W != 16 && a.W != 32 && a.W != 64) || (a.H % (64 / a.W))) return -1;
+  if ((a.Cin & 31) || (a.Cout & 31) || a.frames <= 0 || (a.W != 16 && a.W != 32 && a.W != 64) || (a.H % (64 / a.W)) || !a.partial) return -1;
   a.OT = (a.Cout + 127) / 128;
-  const int tiles = a.OT * (a.Cin >> 5);
-  int groups = (2048 + tiles - 1) / tiles;          // aim at ~2048 workgroups
-  if (groups > a.frames) groups = a.frames;
+  const int tiles = a.OT * (((a.Cin >> 5) + 1) >> 1);
+  const int groups = vpt_conv_wgrad_groups(a.frames, a.Cin, a.Cout);
   a.frames_per_wg = (a.frames + groups - 1) / groups;
-  groups = (a.frames + a.frames_per_wg - 1) / a.frames_per_wg;
-  const int RB = 64 / a.W, Wp = a.W + 16;
-  const int SC = (RB + 2) * Wp * 2 + 16;
-  const size_t lds = WG_DT_BYTES + 3 * 32 * SC;
+  const int RB = 64 / a.W;
+  const size_t lds = 2 * (size_t)(4 * RB * (a.W + 2) * 64 + 2 * (RB + 2) * a.W * 64);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)vpt_conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return -4;
+    if (hipFuncSetAttribute((const void*)vpt_conv_wgrad_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)vpt_conv_wgrad_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)vpt_conv_wgrad_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+      return -4;
     attr_set = true;
   }
-  hipLaunchKernelGGL(vpt_conv_wgrad_kernel, dim3((unsigned)(tiles * groups)), dim3(256), lds, stream, a);
+  const dim3 grid((unsigned)(tiles * groups));
+  if (a.W == 64) hipLaunchKernelGGL(vpt_conv_wgrad_kernel<64>, grid, dim3(512), lds, stream, a);
+  else if (a.W == 32) hipLaunchKernelGGL(vpt_conv_wgrad_kernel<32>, grid, dim3(512), lds, stream, a);
+  else hipLaunchKernelGGL(vpt_conv_wgrad_kernel<16>, grid, dim3(512), lds, stream, a);
+  const int n4 = a.Cout * 9 * a.Cin / 4;
+  hipLaunchKernelGGL(vpt_conv_wgrad_reduce_kernel, dim3((n4 + 255) / 256), dim3(256), 0, stream, a.partial, a.dw, n4, groups);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

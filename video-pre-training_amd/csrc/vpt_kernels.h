@@ -163,6 +163,7 @@ struct VptConvWgradArgs {
   const vpt_bf16* dacc;    // [F][Cout/32][H][W][32]
   const vpt_bf16* x;       // [F][Cin/32][H][W][32]
   float* dw;               // [Cout][9][Cin] accumulated (caller zeroes)
+  float* partial;          // scratch [vpt_conv_wgrad_groups()][Cout][9][Cin]
   int frames, H, W, Cin, Cout;
   int OT, frames_per_wg;   // set by the launcher
 };
@@ -230,6 +231,7 @@ int vpt_affine_bwd_launch(const VptAffineBwdArgs* a, int pass, hipStream_t s);
 int vpt_pool_bwd_launch(const VptPoolBwdArgs* a, hipStream_t s);
 int vpt_conv_bwd_prep_launch(const VptConvBwdPrepArgs* a, hipStream_t s);
 int vpt_conv_first_bwd_launch(const VptConvFirstBwdArgs* a, hipStream_t s);
+int vpt_conv_wgrad_groups(int frames, int Cin, int Cout);
 int vpt_conv_wgrad_launch(const VptConvWgradArgs* a, hipStream_t s);
 int vpt_nll_bwd_launch(const VptNllBwdArgs* a, hipStream_t s);
 int vpt_ln_bwd_launch(const VptLnBwdArgs* a, hipStream_t s);

@@ -297,13 +297,14 @@ def frame_affine_backward(x, dy, gain, stats_in, dgain, dbias, per_element=False
     return dx
 
 
-def conv3x3_wgrad(dacc, x):
-    """-> fp32 [Cout, 9, Cin]: sum over frames and pixels of dacc (x) shifted x."""
-    _chk(dacc, torch.bfloat16, "dacc"); _chk(x, torch.bfloat16, "x")
+def conv3x3_wgrad(dacc, x, out=None):
+    """-> fp32 [Cout, 9, Cin]: sum over frames and pixels of dacc (x) shifted x (added to `out` when given)."""
+    _chk(dacc, torch.bfloat16, "dacc"); _chk(x, torch.bfloat16, "x"); _chk(out, torch.float32, "out")
     f, cbo, h, w, _ = dacc.shape
     cbi = x.shape[1]
-    dw = torch.zeros(cbo * 32, 9, cbi * 32, dtype=torch.float32, device=x.device)
-    _call("vpt_conv3x3_wgrad", dict(flops=2.0 * f * h * w * cbo * 32 * 9 * cbi * 32), ptr(dacc), ptr(x), ptr(dw), f, h, w, cbi * 32, cbo * 32, _stream())
+    dw = out if out is not None else torch.zeros(cbo * 32, 9, cbi * 32, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(_native.load().vpt_conv3x3_wgrad_scratch_floats(f, cbi * 32, cbo * 32), dtype=torch.float32, device=x.device)
+    _call("vpt_conv3x3_wgrad", dict(flops=2.0 * f * h * w * cbo * 32 * 9 * cbi * 32), ptr(dacc), ptr(x), ptr(dw), ptr(scratch), f, h, w, cbi * 32, cbo * 32, _stream())
     return dw
 
 
