@@ -24,6 +24,10 @@ for name, hw, cin, cout, use_res in shapes:
     wpk, sa, sg = packing.pack_conv3x3(W.to(dev), torch.ones(cin, device=dev), torch.zeros(cin, device=dev))
     x = torch.relu(torch.randn(f, cin // 32, hw, hw, 32, device=dev)).to(torch.bfloat16)
     res = torch.randn(f, cout // 32, hw, hw, 32, device=dev).to(torch.bfloat16) if use_res else None
+    if os.environ.get("VPT_BENCH_ZERO") == "1":  # DVFS probe: same instruction stream, no operand toggling (MI355X_MICROARCH.md "DVFS give-back")
+        x.zero_(); wpk.zero_()
+        if res is not None:
+            res.zero_()
     xf = x.float().reshape(f, -1).double()
     st_in = torch.stack([xf.sum(1), (xf * xf).sum(1)], 1).contiguous()
     st_out = torch.zeros(f, 2, dtype=torch.float64, device=dev)
