@@ -132,13 +132,15 @@ int vpt_masked_attention_backward(const float* qkvr, const float* kmem, const fl
 /* ---- backward of the IMPALA CNN (behavioural_cloning.py:117-119 obtains these from torch autograd) ---- */
 
 /* Per-element preparation of GN -> conv3x3 -> ReLU (+res) backward: dacc = rstd * dY * [v > 0] (blocked, Cout
- * channels); t12[f] += (sum dz (v - SA), sum dz SG); d_sa / d_sg [9][CoutPad] += sum dz / sum dz (-rstd mu).
+ * channels); t12[f] = (T1, T2) = (sum dz (v - SA), sum dz SG) (optional output); coef[f] = (c0, c1) with
+ * c1 = -rstd^2 T1 / n, c0 = -rstd T2 / n - c1 mu, the statistics terms vpt_conv3x3_dgrad adds as c0 + c1 x;
+ * d_sa / d_sg [9][CoutPad] += sum dz / sum dz (-rstd mu) (accumulated: caller zeroes once per step).
  * stats_in are the statistics of the layer's INPUT (Cin*H*W elements).  With dy = NULL the layer is followed by the
  * max-pool and (dpooled, argmax) are given instead: the pool's backward is applied on the fly.  scratch: fp32
- * [frames][9][Cout] work buffer.  W must be 8, 16, 32 or 64. */
+ * [frames][9*Cout + Cout/32] work buffer.  W must be 8, 16, 32 or 64. */
 int vpt_conv_backward_prepare(const void* dy, const void* dpooled, const uint8_t* argmax, const void* y, const void* res,
                               const double* stats_in, const float* edge_sa, const float* edge_sg, void* dacc, double* t12,
-                              float* d_sa, float* d_sg, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream);
+                              float* coef, float* d_sa, float* d_sg, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream);
 
 /* Input gradient of the layer: dx = conv^T(W', dacc) + skip + coef[f][0] + coef[f][1] * xin, i.e. the implicit-GEMM
  * kernel of vpt_conv3x3_forward on the transposed, spatially flipped weights (wpk_t: [ceil(Cin/128)][Cout/32][9][128][32])

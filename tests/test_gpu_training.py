@@ -285,14 +285,11 @@ def test_conv_layer_backward_dx_and_bias(frames, h, cin, cout, use_res):
     st_in = _stats_of(x.detach()).to(DEV)
     resb = packing.nchw_to_blocked(res).to(DEV) if use_res else None
     yb = ops.conv3x3(xb, wpk, sa, sg, st_in, cout, res=resb)
-    dacc, t12, d_sa, d_sg = ops.conv_backward_prepare(packing.nchw_to_blocked(dY).to(DEV), yb, resb, st_in, sa, sg, cin)
+    dacc, coef, d_sa, d_sg, t12 = ops.conv_backward_prepare(packing.nchw_to_blocked(dY).to(DEV), yb, resb, st_in, sa, sg, cin, want_t12=True)
     n = cin * h * w_
-    mu = (st_in[:, 0] / n)
-    rstd = torch.rsqrt((st_in[:, 1] / n - mu * mu).clamp(min=0) + 1e-5)
-    t1, t2 = t12[:, 0], t12[:, 1]
-    c1 = -(rstd * rstd) * t1 / n
-    c0 = -(rstd / n) * t2 - c1 * mu
-    coef = torch.stack([c0, c1], 1).float().contiguous()
+    from vpt_amd.training import conv_dgrad_coef
+    coef_host = conv_dgrad_coef(st_in, t12, n)     # host restatement of the finish kernel's (c0, c1)
+    assert _l2(coef.cpu(), coef_host.cpu()) < 1e-5
     dx = ops.conv3x3_dgrad(dacc, packing.pack_conv3x3_dgrad(W.detach().to(DEV), gain.detach().to(DEV)), cin, xin=xb, coef=coef)
     torch.cuda.synchronize()
     err = _l2(packing.blocked_to_nchw(dx.cpu(), cin, h, w_), gx)
@@ -335,7 +332,7 @@ def test_conv_layer_param_grads():
     xb, resb = packing.nchw_to_blocked(x).to(DEV), packing.nchw_to_blocked(res).to(DEV)
     st_in = _stats_of(x).to(DEV)
     yb = ops.conv3x3(xb, wpk, sa, sg, st_in, cout, res=resb)
-    dacc, t12, d_sa, d_sg = ops.conv_backward_prepare(packing.nchw_to_blocked(dY).to(DEV), yb, resb, st_in, sa, sg, cin)
+    dacc, coef, d_sa, d_sg = ops.conv_backward_prepare(packing.nchw_to_blocked(dY).to(DEV), yb, resb, st_in, sa, sg, cin)
     dw_raw = ops.conv3x3_wgrad(dacc, xb)
     dW, dgain, dbias = conv_param_grads(dw_raw, d_sa, d_sg, Wd, gd, bd)
     torch.cuda.synchronize()
@@ -358,6 +355,7 @@ def test_conv_first_backward(frames, cout):
     gW, gb = torch.autograd.grad((pooled * dP).sum(), [Wb, b])
     dW, db = ops.conv_first_backward(img.to(DEV), packing.pack_conv_first(W.detach().to(DEV), b.detach().to(DEV)),
                                      packing.nchw_to_blocked(dP).to(DEV), cout)
+    dW = ops.conv_first_grad_to_reference(dW)
     torch.cuda.synchronize()
     eW, eb = _l2(dW.cpu(), gW), _l2(db.cpu(), gb)
     print(f"PARITY conv_first backward: dW {eW:.3e} db {eb:.3e}")
@@ -378,8 +376,8 @@ def test_conv_prepare_fused_pool_backward():
     pooled, am = ops.maxpool(pre, want_argmax=True)
     dp = packing.nchw_to_blocked(torch.randn(f, cout, h // 2, h // 2, generator=g)).to(DEV)
     dpre = ops.maxpool_backward(pre, pooled, dp)
-    ref = ops.conv_backward_prepare(dpre, pre, None, st_in, sa, sg, cin)
-    got = ops.conv_backward_prepare(None, pre, None, st_in, sa, sg, cin, dpooled=dp, argmax=am)
+    ref = ops.conv_backward_prepare(dpre, pre, None, st_in, sa, sg, cin, want_t12=True)
+    got = ops.conv_backward_prepare(None, pre, None, st_in, sa, sg, cin, dpooled=dp, argmax=am, want_t12=True)
     torch.cuda.synchronize()
     assert ((ref[0] != 0) == (got[0] != 0)).all()
     assert _l2(got[0].float().cpu(), ref[0].float().cpu()) < 5e-3      # two bf16 roundings vs one

@@ -25,7 +25,7 @@ SIGNATURES = {
     "vpt_masked_attention_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "vpt_kv_memory_update": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_log_softmax_forward": [_P, _P, _I, _I, _I, _I, _F, _P],
-    "vpt_conv_backward_prepare": [_P] * 13 + [_I, _I, _I, _I, _I, _P],
+    "vpt_conv_backward_prepare": [_P] * 14 + [_I, _I, _I, _I, _I, _P],
     "vpt_conv3x3_dgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_conv_first_backward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_conv3x3_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -60,10 +60,10 @@ int vpt_conv3x3_dgrad(const void* dacc, const void* wpk_t, const void* skip, con
 
 int vpt_conv_backward_prepare(const void* dy, const void* dpooled, const uint8_t* argmax, const void* y, const void* res,
                               const double* stats_in, const float* edge_sa, const float* edge_sg, void* dacc, double* t12,
-                              float* d_sa, float* d_sg, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream) {
+                              float* coef, float* d_sa, float* d_sg, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream) {
   if (Cout & 31) return fail(-1, "vpt_conv_backward_prepare: Cout must be a multiple of 32");
   VptConvBwdPrepArgs a;
-  a.dpooled = (const vpt_bf16*)dpooled; a.argmax = argmax; a.sbuf = scratch; a.wshift = 0;
+  a.dpooled = (const vpt_bf16*)dpooled; a.argmax = argmax; a.sbuf = scratch; a.wshift = 0; a.coef = coef;
   a.dy = (const vpt_bf16*)dy; a.y = (const vpt_bf16*)y; a.res = (const vpt_bf16*)res; a.stats_in = stats_in;
   a.edge_sa = edge_sa; a.edge_sg = edge_sg; a.dacc = (vpt_bf16*)dacc; a.t12 = t12; a.d_sa = d_sa; a.d_sg = d_sg;
   a.frames = frames; a.CB = Cout / 32; a.H = H; a.W = W; a.CoutPad = ((Cout + 127) / 128) * 128;

@@ -338,15 +338,15 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_kernel(VptConvBwdPrepAr
       atomicAdd(&tab_[(2 * 3 + ex) * 32 + oct * 8 + k], bot[k]);
     }
   }
-  // sum dz v -> t12[f].x  (the <SA, S> correction and T2 are added by the finish kernel)
+  // sum dz v of this plane -> sbuf column 9*Cout + cb (the finish kernel adds the planes and the <SA, S> correction)
   tv = wave_sum(tv);
   __shared__ float red_[4];
   if (lane == 0) red_[threadIdx.x >> 6] = tv;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(a.t12 + 2 * f, (double)((red_[0] + red_[1]) + (red_[2] + red_[3])));
   const int Cout = a.CB * 32;
-  for (int i = threadIdx.x; i < 9 * 32; i += 256)
-    a.sbuf[((size_t)f * 9 + (i >> 5)) * Cout + cb * 32 + (i & 31)] = tab_[i];
+  float* srow = a.sbuf + (size_t)f * (9 * Cout + a.CB);
+  if (threadIdx.x == 0) srow[9 * Cout + cb] = (red_[0] + red_[1]) + (red_[2] + red_[3]);
+  for (int i = threadIdx.x; i < 9 * 32; i += 256) srow[(i >> 5) * Cout + cb * 32 + (i & 31)] = tab_[i];
 }
 
 #define FIN_COLS 16  // 256 * 16 >= 9 * Cout  (Cout <= 448)
@@ -368,12 +368,13 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_finish_kernel(VptConvBwdPrep
     float mean, rstd;
     frame_mean_rstd(a.stats_in, f, a.inv_count_in, mean, rstd);
     const float nrm = -rstd * mean;
+    const float* srow = a.sbuf + (size_t)f * (ncol + a.CB);
     float t1c = 0.f, t2c = 0.f;
 #pragma unroll
     for (int j = 0; j < FIN_COLS; ++j) {
       const int i = threadIdx.x + 256 * j;
       if (i < ncol) {
-        const float S = a.sbuf[(size_t)f * ncol + i];
+        const float S = srow[i];
         acc_sa[j] += S;
         acc_sg[j] = fmaf(nrm, S, acc_sg[j]);
         t1c = fmaf(sa[j], S, t1c);
@@ -386,8 +387,15 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_finish_kernel(VptConvBwdPrep
     if ((threadIdx.x & 63) == 0) { red_[w] = t1c; red_[4 + w] = t2c; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      a.t12[2 * f] -= (double)((red_[0] + red_[1]) + (red_[2] + red_[3]));
-      a.t12[2 * f + 1] += (double)((red_[4] + red_[5]) + (red_[6] + red_[7]));
+      double tv = 0.0;
+      for (int cb = 0; cb < a.CB; ++cb) tv += (double)srow[ncol + cb];
+      const double T1 = tv - (double)((red_[0] + red_[1]) + (red_[2] + red_[3]));
+      const double T2 = (double)((red_[4] + red_[5]) + (red_[6] + red_[7]));
+      if (a.t12) { a.t12[2 * f] = T1; a.t12[2 * f + 1] = T2; }
+      // statistics terms of the input gradient: dx += c0 + c1 x,  c1 = -rstd^2 T1 / n,  c0 = -rstd T2 / n - c1 mu
+      const double c1 = -(double)rstd * rstd * T1 * a.inv_count_in;
+      a.coef[2 * f] = (float)(-(double)rstd * T2 * a.inv_count_in - c1 * mean);
+      a.coef[2 * f + 1] = (float)c1;
     }
     __syncthreads();
   }
@@ -404,7 +412,7 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_finish_kernel(VptConvBwdPrep
 
 extern "C" int vpt_conv_bwd_prep_launch(const VptConvBwdPrepArgs* a0, hipStream_t stream) {
   VptConvBwdPrepArgs a = *a0;
-  if (a.frames <= 0 || !a.sbuf) return -1;
+  if (a.frames <= 0 || !a.sbuf || !a.coef) return -1;
   if (a.W < 8 || a.W > 64 || (a.W & (a.W - 1)) || a.CB * 32 * 9 > 256 * FIN_COLS) return -1;  // column-per-thread mapping: W in {8,16,32,64}
   if (!a.dy && (!a.dpooled || !a.argmax || (a.H & 1) || (a.W & 1))) return -1;
   a.wshift = 31 - __builtin_clz((unsigned)a.W);

@@ -135,7 +135,7 @@ struct VptConvBwdPrepArgs {
   const vpt_bf16* dy;      // gradient w.r.t. the layer output (after ReLU and residual add); null -> (dpooled, argmax)
   const vpt_bf16* dpooled; // gradient w.r.t. max_pool(y) [F][CB][H/2][W/2][32]   (fused max-pool backward)
   const uint8_t* argmax;   // window position code kh*3+kw of the maximum, same shape (vpt_pool_kernel)
-  float* sbuf;             // scratch [F][9][Cout] fp32: per-frame edge-class sums of dz
+  float* sbuf;             // scratch [F][9*Cout + Cout/32] fp32: per-frame edge-class sums of dz, then per-plane sum dz v
   int wshift;              // log2(W), filled by the launcher
   const vpt_bf16* y;       // saved layer output
   const vpt_bf16* res;     // saved residual input or null
@@ -143,7 +143,8 @@ struct VptConvBwdPrepArgs {
   const float* edge_sa;    // [9][CoutPad]
   const float* edge_sg;
   vpt_bf16* dacc;          // rstd * dz, blocked like y
-  double* t12;             // [F][2]: T1 = sum dz (v - SA), T2 = sum dz SG   (accumulated)
+  double* t12;             // optional [F][2]: T1 = sum dz (v - SA), T2 = sum dz SG   (written)
+  float* coef;             // [F][2]: (c0, c1) of the input gradient's statistics terms dx += c0 + c1 x   (written)
   float* d_sa;             // [9][CoutPad] accumulated
   float* d_sg;
   int frames, CB, H, W, CoutPad;

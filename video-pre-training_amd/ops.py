@@ -241,25 +241,29 @@ def masked_attention_backward(qkvr, kmem, vmem, memvalid, b_nd, dout, db_nd, bat
     return dqkvr
 
 
-def conv_backward_prepare(dy, y, res, stats_in, edge_sa, edge_sg, cin, dpooled=None, argmax=None):
-    """-> (dacc bf16 blocked, t12 double [F,2], d_sa fp32 [9,CoutPad], d_sg fp32 [9,CoutPad]).
-    dy=None with (dpooled, argmax): the layer feeds a max-pool whose backward is applied on the fly."""
+def conv_backward_prepare(dy, y, res, stats_in, edge_sa, edge_sg, cin, dpooled=None, argmax=None, d_sa=None, d_sg=None, want_t12=False):
+    """-> (dacc bf16 blocked, coef fp32 [F,2], d_sa fp32 [9,CoutPad], d_sg fp32 [9,CoutPad][, t12 double [F,2]]).
+    coef = (c0, c1) of the statistics terms conv3x3_dgrad adds (dx += c0 + c1 x).  d_sa / d_sg are accumulated into when
+    given.  dy=None with (dpooled, argmax): the layer feeds a max-pool whose backward is applied on the fly."""
     for t, nme in ((dy, "dy"), (y, "y"), (res, "res"), (dpooled, "dpooled")):
         _chk(t, torch.bfloat16, nme)
     _chk(argmax, torch.uint8, "argmax")
     _chk(stats_in, torch.float64, "stats_in"); _chk(edge_sa, torch.float32, "edge_sa"); _chk(edge_sg, torch.float32, "edge_sg")
+    _chk(d_sa, torch.float32, "d_sa"); _chk(d_sg, torch.float32, "d_sg")
     if (dy is None) == (dpooled is None or argmax is None):
         raise ValueError("conv_backward_prepare: give either dy or (dpooled, argmax)")
     f, cb, h, w, _ = y.shape
     dev = y.device
     dacc = torch.empty_like(y)
-    t12 = torch.zeros(f, 2, dtype=torch.float64, device=dev)
-    d_sa, d_sg = torch.zeros_like(edge_sa), torch.zeros_like(edge_sg)
-    scratch = torch.empty(f, 9, cb * 32, dtype=torch.float32, device=dev)
+    coef = torch.empty(f, 2, dtype=torch.float32, device=dev)
+    t12 = torch.empty(f, 2, dtype=torch.float64, device=dev) if want_t12 else None
+    if d_sa is None:
+        d_sa, d_sg = torch.zeros_like(edge_sa), torch.zeros_like(edge_sg)
+    scratch = torch.empty(f, 9 * cb * 32 + cb, dtype=torch.float32, device=dev)
     _call("vpt_conv_backward_prepare", dict(bytes=(6.0 if dy is not None else 4.75) * y.numel() + (2.0 * y.numel() if res is not None else 0)),
           ptr(dy), ptr(dpooled), ptr(argmax), ptr(y), ptr(res), ptr(stats_in), ptr(edge_sa), ptr(edge_sg),
-          ptr(dacc), ptr(t12), ptr(d_sa), ptr(d_sg), ptr(scratch), f, h, w, cin, cb * 32, _stream())
-    return dacc, t12, d_sa, d_sg
+          ptr(dacc), ptr(t12), ptr(coef), ptr(d_sa), ptr(d_sg), ptr(scratch), f, h, w, cin, cb * 32, _stream())
+    return (dacc, coef, d_sa, d_sg, t12) if want_t12 else (dacc, coef, d_sa, d_sg)
 
 
 def conv3x3_dgrad(dacc, wpk_t, cin, skip=None, xin=None, coef=None):
@@ -308,12 +312,20 @@ def conv3x3_wgrad(dacc, x, out=None):
     return dw
 
 
-def conv_first_backward(img_u8, wfrag, dpooled, cout):
-    """-> (dW fp32 [cout, 3, 3, 3] in the reference's (o, ch, kh, kw) order, db fp32 [cout])."""
+def conv_first_backward(img_u8, wfrag, dpooled, cout, out=None):
+    """-> (dW fp32 [cout, 27] in (kh, kw, ch) tap order, db fp32 [cout]); accumulated into out=(dW, db) when given.
+    conv_first_grad_to_reference() maps dW to the reference's [cout, 3, 3, 3] (o, ch, kh, kw)."""
     _chk(img_u8, torch.uint8, "img"); _chk(wfrag, torch.bfloat16, "wfrag"); _chk(dpooled, torch.bfloat16, "dpooled")
     f, h, w, _ = img_u8.shape
-    dw = torch.zeros(cout, 27, dtype=torch.float32, device=img_u8.device)
-    db = torch.zeros(cout, dtype=torch.float32, device=img_u8.device)
+    if out is None:
+        out = (torch.zeros(cout, 27, dtype=torch.float32, device=img_u8.device), torch.zeros(cout, dtype=torch.float32, device=img_u8.device))
+    dw, db = out
+    _chk(dw, torch.float32, "dw"); _chk(db, torch.float32, "db")
     _call("vpt_conv_first_backward", dict(flops=2.0 * f * (h // 2) * (w // 2) * cout * 27), ptr(img_u8), ptr(wfrag), ptr(dpooled), ptr(dw), ptr(db),
           f, h, w, cout, _stream())
-    return dw.view(cout, 3, 3, 3).permute(0, 3, 1, 2).contiguous(), db
+    return dw, db
+
+
+def conv_first_grad_to_reference(dw):
+    cout = dw.shape[0]
+    return dw.view(cout, 3, 3, 3).permute(0, 3, 1, 2).contiguous()

@@ -12,7 +12,7 @@ def _ceil_div(a, b):
     return (a + b - 1) // b
 
 
-def pack_conv3x3(weight, gain, bias):
+def pack_conv3x3(weight, gain, bias, tables=True):
     """Conv2d weight [Cout,Cin,3,3] with the preceding GroupNorm(1,Cin) affine (gain, bias [Cin]) folded.
 
     Returns (wpk bf16 [NT][Cin/32][9][128][32], edge_sa fp32 [9][NT*128], edge_sg fp32 [9][NT*128]).
@@ -29,19 +29,32 @@ def pack_conv3x3(weight, gain, bias):
     wp[:cout] = wg
     wpk = wp.view(nt, 128, cin // 32, 32, 9).permute(0, 2, 4, 1, 3).contiguous()
     wpk = swizzle_rows64(wpk)
-    sg_tap = torch.zeros(cp, 3, 3, dtype=torch.float64, device=weight.device)
-    sa_tap = torch.zeros(cp, 3, 3, dtype=torch.float64, device=weight.device)
-    sg_tap[:cout] = wg.double().sum(dim=1)
-    sa_tap[:cout] = (weight.double() * bias.double().view(1, -1, 1, 1)).sum(dim=1)
-    valid = {0: [1, 2], 1: [0, 1, 2], 2: [0, 1]}
-    sa = torch.zeros(9, cp, dtype=torch.float64, device=weight.device)
-    sg = torch.zeros(9, cp, dtype=torch.float64, device=weight.device)
-    for ey in range(3):
-        for ex in range(3):
-            khs, kws = valid[ey], valid[ex]
-            sg[ey * 3 + ex] = sg_tap[:, khs][:, :, kws].sum(dim=(1, 2))
-            sa[ey * 3 + ex] = sa_tap[:, khs][:, :, kws].sum(dim=(1, 2))
-    return wpk, sa.float().contiguous(), sg.float().contiguous()
+    if not tables:
+        return wpk, None, None
+    sg_tap = torch.zeros(cp, 9, dtype=torch.float64, device=weight.device)
+    sa_tap = torch.zeros(cp, 9, dtype=torch.float64, device=weight.device)
+    sg_tap[:cout] = wg.double().sum(dim=1).view(cout, 9)
+    sa_tap[:cout] = (weight.double() * bias.double().view(1, -1, 1, 1)).sum(dim=1).view(cout, 9)
+    m = edge_tap_matrix(weight.device)                    # [9 edge classes, 9 taps]
+    return wpk, (m @ sa_tap.t()).float().contiguous(), (m @ sg_tap.t()).float().contiguous()
+
+
+_EDGE_TAP = {}
+
+
+def edge_tap_matrix(device, dtype=torch.float64):
+    """0/1 matrix [9 edge classes e = 3*ey + ex, 9 taps kh*3 + kw]: the tap reads inside the image for pixels of that class."""
+    key = (str(device), dtype)
+    if key not in _EDGE_TAP:
+        valid = {0: [1, 2], 1: [0, 1, 2], 2: [0, 1]}
+        m = torch.zeros(9, 9, dtype=dtype)
+        for ey in range(3):
+            for ex in range(3):
+                for kh in valid[ey]:
+                    for kw in valid[ex]:
+                        m[ey * 3 + ex, kh * 3 + kw] = 1
+        _EDGE_TAP[key] = m.to(device)
+    return _EDGE_TAP[key]
 
 
 def pack_conv3x3_dgrad(weight, gain):
@@ -49,7 +62,7 @@ def pack_conv3x3_dgrad(weight, gain):
     in the same packed format (a conv with Cin' = Cout, Cout' = Cin, no further gain)."""
     wg = (weight * gain.view(1, -1, 1, 1)).to(torch.bfloat16).float()
     wd = wg.permute(1, 0, 2, 3).flip(2, 3).contiguous()
-    wpk, _, _ = pack_conv3x3(wd, torch.ones(wd.shape[1], device=weight.device), torch.zeros(wd.shape[1], device=weight.device))
+    wpk, _, _ = pack_conv3x3(wd, torch.ones(wd.shape[1], device=weight.device), None, tables=False)
     return wpk
 
 

@@ -310,17 +310,15 @@ class BCTrainer:
         _, sa, sg = w[q]
         cin = x_in.shape[1] * 32
         n = cin * x_in.shape[2] * x_in.shape[3]
-        dacc, t12, d_sa, d_sg = ops.conv_backward_prepare(dy, y, res, s_in, sa, sg, cin, dpooled=pool[0] if pool else None,
-                                                          argmax=pool[1] if pool else None)
-        dw_raw = ops.conv3x3_wgrad(dacc, x_in)
-        if q in acc["raw"]:
-            r = acc["raw"][q]
-            r[0] += dw_raw; r[1] += d_sa; r[2] += d_sg
-        else:
-            acc["raw"][q] = [dw_raw, d_sa, d_sg]
+        r = acc["raw"].get(q)
+        if r is None:   # [dw_raw, d_sa, d_sg]: the kernels accumulate into them across the frame chunks
+            r = acc["raw"][q] = [torch.zeros(y.shape[1] * 32, 9, cin, dtype=torch.float32, device=y.device), torch.zeros_like(sa), torch.zeros_like(sg)]
+        dacc, coef, _, _ = ops.conv_backward_prepare(dy, y, res, s_in, sa, sg, cin, dpooled=pool[0] if pool else None,
+                                                     argmax=pool[1] if pool else None, d_sa=r[1], d_sg=r[2])
+        ops.conv3x3_wgrad(dacc, x_in, out=r[0])
         if not need_dx:
             return None
-        return ops.conv3x3_dgrad(dacc, acc["wt"][q], cin, skip=skip, xin=x_in, coef=conv_dgrad_coef(s_in, t12, n))
+        return ops.conv3x3_dgrad(dacc, acc["wt"][q], cin, skip=skip, xin=x_in, coef=coef)
 
     def _cnn_backward_chunk(self, sv, dd, acc):
         """dd: fp32 [f, 256] gradient w.r.t. the dense layer's pre-activation output for this chunk's frames."""
@@ -355,11 +353,7 @@ class BCTrainer:
             dpooled = ops.frame_affine_backward(rec["pooled"], dx, w[p + "n.g"], rec["s_pool"], dgn, dbn)
             if s == 0:
                 c = cfg["chans"][0]
-                dw, db = ops.conv_first_backward(sv["img"], w[p + "firstconv"], dpooled, c)
-                if "first" in acc:
-                    acc["first"][0] += dw; acc["first"][1] += db
-                else:
-                    acc["first"] = [dw, db]
+                acc["first"] = ops.conv_first_backward(sv["img"], w[p + "firstconv"], dpooled, c, out=acc.get("first"))
             else:
                 dx = self._conv_layer_backward(p + "firstconv", acc, None, rec["pre"], None, rec["x_prev"], rec["s_prev"], None,
                                                pool=(dpooled, rec["argmax"]))
@@ -372,7 +366,8 @@ class BCTrainer:
             dW, dgain, dbias = conv_param_grads(dw_raw, d_sa, d_sg, P[q + ".layer.weight"].float(), P[q + ".norm.weight"].float(),
                                                 P[q + ".norm.bias"].float())
             g[q + ".layer.weight"], g[q + ".norm.weight"], g[q + ".norm.bias"] = dW, dgain, dbias
-        g["net.img_process.cnn.stacks.0.firstconv.layer.weight"], g["net.img_process.cnn.stacks.0.firstconv.layer.bias"] = acc["first"]
+        g["net.img_process.cnn.stacks.0.firstconv.layer.weight"] = ops.conv_first_grad_to_reference(acc["first"][0])
+        g["net.img_process.cnn.stacks.0.firstconv.layer.bias"] = acc["first"][1]
         for s in range(len(cfg["chans"])):
             g[f"net.img_process.cnn.stacks.{s}.n.weight"], g[f"net.img_process.cnn.stacks.{s}.n.bias"] = acc["n"][s]
         pd = "net.img_process.cnn.dense."
@@ -408,18 +403,9 @@ class BCTrainer:
 # ---------------------------------------------------------------------------------------------------------
 # host mapping of the folded-conv gradients to the reference's parameters (small tensors: [Cout, Cin, 3, 3])
 # ---------------------------------------------------------------------------------------------------------
-_VALID_TAPS = {0: [1, 2], 1: [0, 1, 2], 2: [0, 1]}
-
-
 def _tap_sum(tab: torch.Tensor, cout: int) -> torch.Tensor:
     """[9 edge classes, >= cout] -> [cout, 3, 3]: for every tap, the sum over the edge classes in which it is inside the image."""
-    out = torch.zeros(cout, 3, 3, dtype=tab.dtype, device=tab.device)
-    for ey in range(3):
-        for ex in range(3):
-            for kh in _VALID_TAPS[ey]:
-                for kw in _VALID_TAPS[ex]:
-                    out[:, kh, kw] += tab[ey * 3 + ex, :cout]
-    return out
+    return (tab[:, :cout].t() @ packing.edge_tap_matrix(tab.device, tab.dtype)).view(cout, 3, 3)
 
 
 def conv_param_grads(dw_raw: torch.Tensor, d_sa: torch.Tensor, d_sg: torch.Tensor, weight: torch.Tensor,
