@@ -109,6 +109,13 @@ def test_maxpool_and_affine():
     (513, 2048, 8192, True, False, True, 1),
     (256, 4096, 1024, False, True, False, 1),
     (40, 256, 16384, False, False, False, 16),
+    # M <= 8: the acting path's weight-streaming kernel (vpt_gemv.hip)
+    (1, 8763, 2048, True, False, False, 1),
+    (2, 2048, 8192, True, False, True, 1),
+    (3, 4096, 1024, False, True, False, 1),
+    (8, 300, 512, True, True, True, 1),
+    (1, 256, 65536, False, False, False, 16),
+    (5, 256, 16384, False, False, False, 7),
 ])
 def test_linear(m, n, k, bias, relu, res, splitk):
     g = torch.Generator().manual_seed(4)

@@ -148,3 +148,48 @@ def test_policy_full_chunk_t128(pol_1x):
     (pd1, _, _), _ = pol({"img": img1.to(DEV)}, f1.to(DEV), sg)
     torch.cuda.synchronize()
     assert _l2(pd1["buttons"].cpu().numpy(), ref1["buttons"].numpy()) < L2_TOL
+
+
+def test_step_graph_matches_eager(pol_1x):
+    """The captured T = 1 hipGraph (enable_step_graph) must reproduce the eager act() loop step by step, including a
+    `first` reset in the middle of the episode, a state handed in from outside, and a re-capture after a weight update."""
+    pol, cfg, sd = pol_1x
+    n = 7
+    frames = _inputs(77, n, 1).to(DEV)       # [n, 1, 128, 128, 3]: frame i is frames[i] with B = 1
+    firsts = [False, False, False, True, False, False, False]
+
+    def rollout():
+        st = pol.initial_state(1)
+        outs = []
+        for i in range(n):
+            ac, st, res = pol.act({"img": frames[i]}, torch.tensor([firsts[i]], device=DEV), st, stochastic=False, return_pd=True)
+            outs.append((int(ac["buttons"]), int(ac["camera"]), res["pd"]["buttons"].clone(), res["pd"]["camera"].clone(), float(res["vpred"])))
+        torch.cuda.synchronize()
+        return outs, [(m.clone(), (k.clone(), v.clone())) for m, (k, v) in st]
+
+    eager, st_e = rollout()
+    pol.enable_step_graph(1)
+    try:
+        graphed, st_g = rollout()
+        graphed2, _ = rollout()                 # second episode: initial_state copied over the aliased buffers
+        for e, g_, g2 in zip(eager, graphed, graphed2):
+            assert e[0] == g_[0] == g2[0] and e[1] == g_[1] == g2[1]
+            assert torch.allclose(e[2], g_[2], atol=2e-4) and torch.allclose(e[3], g_[3], atol=2e-4) and abs(e[4] - g_[4]) < 1e-3
+            assert torch.allclose(e[2], g2[2], atol=2e-4)
+        for (me, (ke, ve)), (mg, (kg, vg)) in zip(st_e, st_g):
+            assert torch.equal(me, mg) and torch.allclose(ke, kg, atol=1e-4) and torch.allclose(ve, vg, atol=1e-4)
+        # other shapes still take the eager path
+        (pd, _, _), _ = pol({"img": _inputs(78, 2, 3).to(DEV)}, torch.zeros(2, 3, dtype=torch.bool, device=DEV), pol.initial_state(2))
+        assert pd["buttons"].shape == (2, 3, 1, 8641)
+        # a parameter update invalidates the captured weights: the next step re-captures
+        with torch.no_grad():
+            pol.pi_head.buttons.linear_layer.bias[:200].add_(2.0)     # (a uniform shift would cancel in the log-softmax)
+        after, _ = rollout()
+        pol.disable_step_graph()
+        eager_after, _ = rollout()
+        assert torch.allclose(after[-1][2], eager_after[-1][2], atol=2e-4)
+        assert not torch.allclose(after[-1][2], eager[-1][2], atol=1e-3)
+    finally:
+        pol.disable_step_graph()
+        with torch.no_grad():
+            pol.pi_head.buttons.linear_layer.bias[:200].sub_(2.0)

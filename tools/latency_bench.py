@@ -1,0 +1,50 @@
+"""T = 1 acting latency (agent.py:get_action -> policy.act) on one GPU: eager launches vs the captured hipGraph.
+python tools/latency_bench.py [--model 2x] [--steps 200]"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import __graft_entry__ as ge
+ge.build()
+from vpt_amd.lib.policy import MinecraftAgentPolicy
+from vpt_amd.lib.types import minecraft_action_space
+from oracle import vpt_oracle as O  # synthetic weights only
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--model", default="2x"); ap.add_argument("--steps", type=int, default=200)
+a = ap.parse_args()
+pk = O.policy_kwargs_for(a.model); cfg = O.config_from_policy_kwargs(pk, dict(temperature=2.0))
+pol = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0)); pol.load_state_dict(O.synthetic_state_dict(cfg, 0), strict=False); pol = pol.to("cuda")
+g = torch.Generator().manual_seed(1)
+frames = torch.randint(0, 256, (a.steps, 1, 128, 128, 3), generator=g, dtype=torch.uint8).to("cuda")
+first = torch.zeros(1, dtype=torch.bool, device="cuda")
+
+
+def run(n):
+    st = pol.initial_state(1)
+    acts = []
+    for i in range(n):
+        ac, st, _ = pol.act({"img": frames[i]}, first, st, stochastic=False)
+        acts.append(ac)
+    torch.cuda.synchronize()
+    return acts
+
+
+for mode in ("eager", "graph"):
+    if mode == "graph":
+        if not hasattr(pol, "enable_step_graph"):
+            break
+        pol.enable_step_graph()
+    run(10)
+    t0 = time.perf_counter()
+    acts = run(a.steps)
+    dt = (time.perf_counter() - t0) / a.steps
+    print(f"{mode:6s}: {dt*1e3:.3f} ms / step  ({1/dt:.0f} steps/s)   buttons[0..5] = {[int(x['buttons']) for x in acts[:6]]}")
+
+from vpt_amd import ops
+pol.disable_step_graph()
+ops.TIMER.enabled = True; ops.TIMER.reset()
+run(1)
+summ = ops.TIMER.summary()
+print(f"per-kernel GPU time of one eager T=1 step: total {sum(v['ms'] for v in summ.values()):.3f} ms")
+for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
+    print(f"  {k:36s} {v['ms']*1e3:9.1f} us {v['calls']:4d} calls")

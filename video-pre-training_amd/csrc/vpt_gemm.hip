@@ -134,7 +134,10 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
   }
 }
 
+extern "C" int vpt_gemv_launch(const VptGemmArgs* a, hipStream_t stream);
+
 extern "C" int vpt_gemm_launch(const VptGemmArgs* a, hipStream_t stream) {
+  if (a->M > 0 && a->M <= 8) return vpt_gemv_launch(a, stream);   // acting path (T = 1): HBM-bound weight stream, vpt_gemv.hip
   if (a->M <= 0 || a->N <= 0 || (a->K & 63) || a->splitk < 1 || (a->lda & 7)) return -1;
   if (a->splitk > 1 && (!a->atomic_out || a->relu || a->res || a->out_bf16 || a->mask)) return -1;
   const long grid = (long)((a->M + 255) >> 8) * ((a->N + 127) >> 7) * a->splitk;

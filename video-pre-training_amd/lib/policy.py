@@ -165,6 +165,7 @@ class MinecraftAgentPolicy(nn.Module):
         self._engine = PolicyEngine(self._cfg, n_buttons=action_space["buttons"].eltype.n,
                                     n_camera=action_space["camera"].eltype.n)
         self._packed_key = None
+        self._step_graph = None
 
     # ---- engine plumbing --------------------------------------------------------------------
     def _device(self):
@@ -178,6 +179,62 @@ class MinecraftAgentPolicy(nn.Module):
                 raise RuntimeError("MinecraftAgentPolicy (HIP) needs its parameters on the GPU: call .to('cuda')")
             self._engine.pack(params)
             self._packed_key = key
+            if self._step_graph is not None:      # the graph holds the old packed weights' addresses: re-capture lazily
+                self._step_graph = dict(batch=self._step_graph["batch"])
+
+    # ---- T = 1 acting path: one hipGraph replay per environment step ---------------------------
+    def enable_step_graph(self, batch_size: int = 1):
+        """Capture the T = 1 forward for `batch_size` environments into a hipGraph (the ~90 kernel launches of one
+        agent step, agent.py:190-206, become one graph launch).  The recurrent state lives in static buffers
+        that the graph updates in place: the `state_out` returned by a graphed step ALIASES them and is
+        overwritten by the next step (the acting loop only ever keeps the latest state).  Any other state_in
+        (initial_state, a restored snapshot) is copied in.  Other (B, T) shapes keep using eager launches."""
+        self._step_graph = dict(batch=int(batch_size))
+
+    def disable_step_graph(self):
+        self._step_graph = None
+
+    def _capture_step_graph(self):
+        sg, eng, dev = self._step_graph, self._engine, self._device()
+        b, cfg = sg["batch"], self._cfg
+        sg["img"] = torch.zeros(b, 1, *cfg["img_shape"], dtype=torch.uint8, device=dev)
+        sg["first"] = torch.zeros(b, 1, dtype=torch.bool, device=dev)
+        sg["state"] = [(torch.zeros(b, 1, cfg["maxlen"], dtype=torch.bool, device=dev),
+                        (torch.zeros(b, cfg["maxlen"], cfg["hidsize"], dtype=torch.float32, device=dev),
+                         torch.zeros(b, cfg["maxlen"], cfg["hidsize"], dtype=torch.float32, device=dev)))
+                       for _ in range(cfg["n_layers"])]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):           # warm-up outside capture (lazy kernel attributes, allocator pools)
+            for _ in range(2):
+                eng.forward(sg["img"], sg["first"], sg["state"])
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = eng.forward(sg["img"], sg["first"], sg["state"])
+            for (m_in, (k_in, v_in)), (m_out, (k_out, v_out)) in zip(sg["state"], out["state_out"]):
+                m_in.copy_(m_out); k_in.copy_(k_out); v_in.copy_(v_out)
+        for m_in, (k_in, v_in) in sg["state"]:    # the warm-up / capture runs advanced nothing: start from a clean state
+            m_in.zero_(); k_in.zero_(); v_in.zero_()
+        sg["graph"], sg["out"] = graph, out
+
+    def _graphed_forward(self, img, first, state_in):
+        sg = self._step_graph
+        if "graph" not in sg:
+            self._capture_step_graph()
+        sg["img"].copy_(img)
+        sg["first"].copy_(first)
+        for (m_s, (k_s, v_s)), (m, (k, v)) in zip(sg["state"], state_in):
+            if k.data_ptr() != k_s.data_ptr():   # not the aliased state of the previous graphed step
+                k_s.copy_(k); v_s.copy_(v)
+                if m is None:
+                    m_s.zero_()
+                else:
+                    m_s.copy_(m)
+        sg["graph"].replay()
+        out = dict(sg["out"])
+        out["state_out"] = sg["state"]
+        return out
 
     def initial_state(self, batch_size: int):
         """List (one entry per block) of (None, (K, V)) zeros fp32 [B, maxlen, hid] (lib/masked_attention.py:153-159)."""
@@ -200,7 +257,11 @@ class MinecraftAgentPolicy(nn.Module):
         img = obs["img"]
         if img.dtype != torch.uint8:
             raise TypeError("obs['img'] must be uint8 [B,T,128,128,3] (the /255 is fused into the first conv)")
-        out = self._engine.forward(img, first, state_in)
+        sg = self._step_graph
+        if sg is not None and img.shape[0] == sg["batch"] and img.shape[1] == 1:
+            out = self._graphed_forward(img, first, state_in)
+        else:
+            out = self._engine.forward(img, first, state_in)
         pi_logits = {"camera": out["camera"], "buttons": out["buttons"]}
         return (pi_logits, out["vpred"], None), out["state_out"]
 
