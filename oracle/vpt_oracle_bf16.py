@@ -44,7 +44,8 @@ def policy_forward(sd, cfg, img_u8, first, state_in, grad=False, taps=None):
         b, t = img_u8.shape[:2]
         x = img_u8.reshape(b * t, 128, 128, 3).float().permute(0, 3, 1, 2)
         p = "net.img_process.cnn.stacks.0."
-        y = torch.relu(F.conv2d(x, bf(sd[p + "firstconv.layer.weight"]), padding=1) / 255.0 + sd[p + "firstconv.layer.bias"].view(1, -1, 1, 1))
+        # vpt_conv_first.hip: operands = raw bytes (exact in bf16) and bf16(W / 255); bias rides as hi + lo bf16 halves (~fp32)
+        y = torch.relu(F.conv2d(x, bf(sd[p + "firstconv.layer.weight"] / 255.0), padding=1) + sd[p + "firstconv.layer.bias"].view(1, -1, 1, 1))
         cur = None
         for s in range(3):
             p = f"net.img_process.cnn.stacks.{s}."

@@ -64,11 +64,11 @@ def test_conv_first_pack():
                 wk[o, k0:k0 + 8] = frag[0, cs, ks, lane].float()
     assert wk[cout:].abs().max() == 0
     img = torch.randint(0, 256, (1, 8, 8, 3), generator=g, dtype=torch.uint8)
-    # emulate: acc = sum_k wk[o,k] * pix[k], pix[27] = pix[28] = 1, then relu(acc)/255
+    # emulate: acc = sum_k wk[o,k] * pix[k] with wk = W / 255 and pix the raw bytes, pix[27] = pix[28] = 1 (bias hi / lo), then relu
     xpad = F.pad(img.float().permute(0, 3, 1, 2), (1, 1, 1, 1))
     cols = F.unfold(xpad, 3).view(1, 3, 9, 64).permute(0, 2, 1, 3).reshape(1, 27, 64)  # k = tap*3 + ch
     pix = torch.cat([cols, torch.ones(1, 2, 64), torch.zeros(1, 3, 64)], dim=1)
-    out = torch.relu(torch.einsum("ok,bkp->bop", wk[:cout], pix)) / 255.0
+    out = torch.relu(torch.einsum("ok,bkp->bop", wk[:cout], pix))
     ref = torch.relu(F.conv2d(img.float().permute(0, 3, 1, 2) / 255.0, W, b, padding=1)).reshape(1, cout, 64)
     assert (out - ref).abs().max() < 2e-2 * ref.abs().max()
 

@@ -8,9 +8,10 @@
 // Formulation: K = 27 (+2 bias slots) padded to 32 -> two MFMA 32x32x16 k-steps with SWAPPED operands:
 // the weights are the MFMA A operand (rows = output channels, resident in registers for the whole
 // workgroup), the pixels are the B operand (built on the fly from the uint8 tile in LDS; 0..255 are exact
-// in bf16, the 1/255 is applied in fp32 afterwards).  With the swap each lane ends up holding 4 consecutive
+// in bf16; the 1/255 is folded into the packed weights).  With the swap each lane ends up holding 4 consecutive
 // output channels of one pixel, so the conv tile is written to LDS with packed 8-byte stores, and the
-// pool is a packed unsigned-16-bit max over bf16 bit patterns (all values are >= 0 after ReLU).
+// pool is a packed signed-16-bit max over the raw bf16 bit patterns starting from 0, which is max-pool and
+// ReLU in one (positive bf16 patterns order like integers; negative ones are negative integers).
 //
 // One workgroup = 8x8 pooled pixels (17x17 conv pixels, 19x19 input pixels) x 128 output channels.
 #include "vpt_common.h"
@@ -21,11 +22,7 @@
 #define IN_OFF CT_BYTES
 #define IN_BYTES 1088
 
-typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ uint32_t u8_to_bf16_bits(uint32_t b) {
-  return __builtin_bit_cast(uint32_t, (float)b) >> 16;  // exact: 0..255 fit the 8-bit significand
-}
+typedef short i16x8 __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[CT_BYTES + IN_BYTES];
@@ -72,21 +69,21 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
     bf16x8 pf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      uint32_t h[8];
+      float h[8];      // the byte as fp32: exact, so its bf16 is the upper half of the fp32 pattern
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int kA = ks * 16 + e, kB = ks * 16 + 8 + e;     // k for lanes 0-31 / 32-63
         const int offA = kA + 48 * (kA / 9);                   // byte offset of tap (k/9, (k%9)/3), channel k%3
         const int offB = (kB < 27) ? (kB + 48 * (kB / 9)) : 0;
-        const uint32_t byte = ib[hi ? offB : offA];
-        uint32_t bits = u8_to_bf16_bits(byte);
-        if (kB >= 27) {                                        // bias slots (k = 27, 28) carry 1.0, the rest 0
-          const uint32_t special = (kB <= 28) ? 0x3F80u : 0u;
-          bits = hi ? special : bits;
-        }
-        h[e] = bits;
+        float v = (float)ib[hi ? offB : offA];
+        if (kB >= 27) v = hi ? ((kB <= 28) ? 1.0f : 0.0f) : v; // bias slots (k = 27, 28) carry 1.0, the rest 0
+        h[e] = v;
       }
-      u32x4 pk = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+      u32x4 pk;
+      pk.x = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, h[1]), __builtin_bit_cast(uint32_t, h[0]), 0x07060302u);
+      pk.y = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, h[3]), __builtin_bit_cast(uint32_t, h[2]), 0x07060302u);
+      pk.z = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, h[5]), __builtin_bit_cast(uint32_t, h[4]), 0x07060302u);
+      pk.w = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, h[7]), __builtin_bit_cast(uint32_t, h[6]), 0x07060302u);
       pf[ks] = __builtin_bit_cast(bf16x8, pk);
     }
     f32x16 acc[4];
@@ -97,17 +94,17 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) acc[cs] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[cs][ks], pf[ks], acc[cs], 0, 0, 0);
     }
-    const float scale = inimg ? (1.0f / 255.0f) : 0.f;
+    // conv + bias (1/255 is folded into the weights), rounded to bf16 and stored RAW: the ReLU commutes with the
+    // max-pool, so it is applied once per pooled value instead of once per conv value; pixels outside the image -> 0
+    const uint32_t keep = inimg ? 0xffffffffu : 0u;
     if (pv) {
       unsigned char* dst = smem + p * CT_RS + hi * 8;
 #pragma unroll
       for (int cs = 0; cs < 4; ++cs) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const float v0 = fmaxf(acc[cs][4 * g + 0], 0.f) * scale, v1 = fmaxf(acc[cs][4 * g + 1], 0.f) * scale;
-          const float v2 = fmaxf(acc[cs][4 * g + 2], 0.f) * scale, v3 = fmaxf(acc[cs][4 * g + 3], 0.f) * scale;
-          u32x2 pk = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
-          *(u32x2*)(dst + (cs * 32 + g * 8) * 2) = pk;
+          u32x2 pk2 = {pack_bf16x2(acc[cs][4 * g + 0], acc[cs][4 * g + 1]) & keep, pack_bf16x2(acc[cs][4 * g + 2], acc[cs][4 * g + 3]) & keep};
+          *(u32x2*)(dst + (cs * 32 + g * 8) * 2) = pk2;
         }
       }
     }
@@ -123,13 +120,12 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
     const int oct4 = item & 3, pxl = (item >> 2) & 7, pyl = (item >> 5) & 7, cbl = item >> 8;
     const int cg = nt * 128 + cbl * 32 + oct4 * 8;
     const unsigned char* src = smem + ((2 * pyl) * 17 + 2 * pxl) * CT_RS + (cbl * 32 + oct4 * 8) * 2;
-    u16x8 m = *(const u16x8*)src;
+    i16x8 m = {0, 0, 0, 0, 0, 0, 0, 0};    // = ReLU: positive bf16 patterns order like signed 16-bit integers, negative ones stay below 0
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
-        if (dy == 0 && dx == 0) continue;
-        const u16x8 v = *(const u16x8*)(src + (dy * 17 + dx) * CT_RS);
+        const i16x8 v = *(const i16x8*)(src + (dy * 17 + dx) * CT_RS);
         m = __builtin_elementwise_max(m, v);
       }
     if (cg < a.Cout) {

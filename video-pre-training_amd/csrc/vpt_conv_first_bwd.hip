@@ -16,8 +16,6 @@
 #define IN_OFF CT_BYTES
 #define IN_BYTES 1088
 
-__device__ __forceinline__ uint32_t u8_to_bf16_bits_b(uint32_t b) { return __builtin_bit_cast(uint32_t, (float)b) >> 16; }
-
 __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirstBwdArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[CT_BYTES + IN_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -71,22 +69,22 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
       bf16x8 pf[2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        uint32_t h[8];
+        float h[8];      // the byte as fp32: exact, so its bf16 is the upper half of the fp32 pattern
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int kA = ks * 16 + e, kB = ks * 16 + 8 + e;
-          const int offA = kA + 48 * (kA / 9);
-          const int offB = (kB < 27) ? (kB + 48 * (kB / 9)) : 0;
-          const uint32_t byte = ib[hi ? offB : offA];
-          uint32_t bits = u8_to_bf16_bits_b(byte);
-          if (kB >= 27) {
-            const uint32_t special = (kB <= 28) ? 0x3F80u : 0u;
-            bits = hi ? special : bits;
-          }
-          h[e] = bits;
-        }
-        u32x4 pk = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
-        pf[ks] = __builtin_bit_cast(bf16x8, pk);
+      for (int e = 0; e < 8; ++e) {
+        const int kA = ks * 16 + e, kB = ks * 16 + 8 + e;     // k for lanes 0-31 / 32-63
+        const int offA = kA + 48 * (kA / 9);                   // byte offset of tap (k/9, (k%9)/3), channel k%3
+        const int offB = (kB < 27) ? (kB + 48 * (kB / 9)) : 0;
+        float v = (float)ib[hi ? offB : offA];
+        if (kB >= 27) v = hi ? ((kB <= 28) ? 1.0f : 0.0f) : v; // bias slots (k = 27, 28) carry 1.0, the rest 0
+        h[e] = v;
+      }
+      u32x4 pk;
+      pk.x = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, h[1]), __builtin_bit_cast(uint32_t, h[0]), 0x07060302u);
+      pk.y = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, h[3]), __builtin_bit_cast(uint32_t, h[2]), 0x07060302u);
+      pk.z = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, h[5]), __builtin_bit_cast(uint32_t, h[4]), 0x07060302u);
+      pk.w = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, h[7]), __builtin_bit_cast(uint32_t, h[6]), 0x07060302u);
+      pf[ks] = __builtin_bit_cast(bf16x8, pk);
       }
       f32x16 acc[4];
 #pragma unroll
@@ -96,21 +94,22 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) acc[cs] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[cs][ks], pf[ks], acc[cs], 0, 0, 0);
       }
-      const float scale = inimg ? (1.0f / 255.0f) : 0.f;
-      if (pv) {
-        unsigned char* dst = smem + p * CT_RS + hi * 8;
+      // conv + bias (1/255 is folded into the weights), rounded to bf16 and stored RAW: the ReLU commutes with the
+    // max-pool, so it is applied once per pooled value instead of once per conv value; pixels outside the image -> 0
+    const uint32_t keep = inimg ? 0xffffffffu : 0u;
+    if (pv) {
+      unsigned char* dst = smem + p * CT_RS + hi * 8;
 #pragma unroll
-        for (int cs = 0; cs < 4; ++cs)
+      for (int cs = 0; cs < 4; ++cs) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const float v0 = fmaxf(acc[cs][4 * g + 0], 0.f) * scale, v1 = fmaxf(acc[cs][4 * g + 1], 0.f) * scale;
-            const float v2 = fmaxf(acc[cs][4 * g + 2], 0.f) * scale, v3 = fmaxf(acc[cs][4 * g + 3], 0.f) * scale;
-            u32x2 pk = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
-            *(u32x2*)(dst + (cs * 32 + g * 8) * 2) = pk;
-          }
+        for (int g = 0; g < 4; ++g) {
+          u32x2 pk2 = {pack_bf16x2(acc[cs][4 * g + 0], acc[cs][4 * g + 1]) & keep, pack_bf16x2(acc[cs][4 * g + 2], acc[cs][4 * g + 3]) & keep};
+          *(u32x2*)(dst + (cs * 32 + g * 8) * 2) = pk2;
+        }
       }
     }
-    __syncthreads();
+  }
+  __syncthreads();
     // ---- arg-max routing + weight-gradient accumulation ----
     if (ovalid) {
       const vpt_bf16* dP = a.dpooled + ((size_t)(f * CB_out + (og >> 5)) * PH * PW) * 32 + (og & 31);
@@ -119,21 +118,21 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
         const int pyl = pp >> 3, pxl = pp & 7;
         const float d = (float)dP[(size_t)((py0 + pyl) * PW + px0 + pxl) * 32];
         if (d == 0.f) continue;
-        const unsigned short* ct = (const unsigned short*)(smem + ((2 * pyl) * 17 + 2 * pxl) * CT_RS) + oc;
-        unsigned short best = 0;
+        const short* ct = (const short*)(smem + ((2 * pyl) * 17 + 2 * pxl) * CT_RS) + oc;
+        short best = 0;                                        // raw bf16 patterns as signed integers: only values > 0 can win (ReLU gate)
         int bpos = 0;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
           for (int dx = 0; dx < 3; ++dx) {
-            const unsigned short v = ct[(dy * 17 + dx) * (CT_RS / 2)];
-            if (v > best) { best = v; bpos = dy * 17 + dx; }   // strict >: first maximum in scan order (bf16 bits, values >= 0)
+            const short v = ct[(dy * 17 + dx) * (CT_RS / 2)];
+            if (v > best) { best = v; bpos = dy * 17 + dx; }   // strict >: first maximum in scan order
           }
         if (best == 0) continue;                               // ReLU gate (and windows whose maximum is 0)
         const int cpos = (2 * pyl) * 17 + 2 * pxl + bpos;      // conv pixel within the 17x17 tile
         const int cr = cpos / 17, cc = cpos - cr * 17;
         const unsigned char* ib = in + (cr * 19 + cc) * 3;
-        const float ds = d * (1.0f / 255.0f);
+        const float ds = d * (1.0f / 255.0f);                   // d(conv)/dW = img / 255
 #pragma unroll
         for (int k = 0; k < 27; ++k) gw[k] = fmaf(ds, (float)ib[k + 48 * (k / 9)], gw[k]);
         gb += d;

@@ -79,17 +79,16 @@ def swizzle_rows64(t):
 
 def pack_conv_first(weight, bias):
     """Stack-0 firstconv weight [Cout,3,3,3] + bias [Cout] -> MFMA A-operand fragments
-    bf16 [NT][4][2][64][8] (vpt_conv_first.hip).  k = (kh*3+kw)*3 + ch for k < 27; k = 27 / 28 carry the
-    hi / lo bf16 halves of 255*bias (the pixel operand holds 1.0 there; 1/255 is applied after the MFMA)."""
+    bf16 [NT][4][2][64][8] (vpt_conv_first.hip).  k = (kh*3+kw)*3 + ch for k < 27 holds W / 255 (the pixel operand is
+    the raw byte 0..255); k = 27 / 28 carry the hi / lo bf16 halves of the bias (the pixel operand holds 1.0 there)."""
     cout = weight.shape[0]
     assert weight.shape[1:] == (3, 3, 3) and cout % 32 == 0
     nt = _ceil_div(cout, 128)
     cp = nt * 128
     wk = torch.zeros(cp, 32, dtype=torch.float32, device=weight.device)
-    wk[:cout, :27] = weight.permute(0, 2, 3, 1).reshape(cout, 27)
-    b255 = bias * 255.0
-    hi = b255.to(torch.bfloat16).float()
-    lo = (b255 - hi).to(torch.bfloat16).float()
+    wk[:cout, :27] = weight.permute(0, 2, 3, 1).reshape(cout, 27) / 255.0
+    hi = bias.to(torch.bfloat16).float()
+    lo = (bias - hi).to(torch.bfloat16).float()
     wk[:cout, 27] = hi
     wk[:cout, 28] = lo
     # [nt][cs][l31][ks][hi][e] -> [nt][cs][ks][hi][l31][e]
