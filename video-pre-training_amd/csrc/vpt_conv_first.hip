@@ -30,32 +30,57 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
   const int hi = lane >> 5, l31 = lane & 31;
   const int PH = a.H >> 1, PW = a.W >> 1;
   const int tilesX = PW >> 3, tilesY = PH >> 3;
-  int L = xcd_remap(blockIdx.x, gridDim.x);
-  const int nt = L % a.NT; L /= a.NT;
-  const int tx = L % tilesX; L /= tilesX;
-  const int ty = L % tilesY;
-  const int f = L / tilesY;
-  const int py0 = ty * 8, px0 = tx * 8;
-  const int iy0 = 2 * py0 - 2, ix0 = 2 * px0 - 2;
-
-  // ---- uint8 input tile 19 x 19 x 3 (zero outside the image) ----
+  const long T = (long)a.frames * tilesY * tilesX * a.NT;
   unsigned char* in = smem + IN_OFF;
-  const uint8_t* img = a.img + (size_t)f * a.H * a.W * 3;
-  for (int idx = tid; idx < 19 * 57; idx += 256) {
-    const int r = idx / 57, rem = idx - r * 57;
-    const int y = iy0 + r, x = ix0 + rem / 3;
-    unsigned char v = 0;
-    if (y >= 0 && y < a.H && x >= 0 && x < a.W) v = img[((long)y * a.W + ix0) * 3 + rem];
-    in[idx] = v;
-  }
-  // ---- weight fragments: [nt][cs][ks][lane][8] ----
+  const int CB_out = a.Cout >> 5;
+
+  // persistent workgroups (2 per CU): the next tile's 19 x 19 x 3 input bytes are fetched into registers while the
+  // current tile computes, so the global-load latency is off the per-tile critical path
+  unsigned char nxt[5];
+  auto fetch = [&](long tile) {
+    long L = tile / a.NT;
+    const int tx = (int)(L % tilesX); L /= tilesX;
+    const int ty = (int)(L % tilesY);
+    const int f = (int)(L / tilesY);
+    const int iy0 = 2 * (ty * 8) - 2, ix0 = 2 * (tx * 8) - 2;
+    const uint8_t* img = a.img + (size_t)f * a.H * a.W * 3;
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+      const int idx = tid + 256 * m;
+      const int r = idx / 57, rem = idx - r * 57;
+      const int y = iy0 + r, x = ix0 + rem / 3;
+      const bool ok = idx < 19 * 57 && y >= 0 && y < a.H && x >= 0 && x < a.W;
+      const unsigned char v = img[ok ? ((long)y * a.W + ix0) * 3 + rem : 0];
+      nxt[m] = ok ? v : (unsigned char)0;
+    }
+  };
+  // contiguous tile range per workgroup: consecutive tiles belong to the same frame, so the frame statistics are
+  // summed in registers and flushed with one atomic pair per (workgroup, frame)
+  const long per = (T + gridDim.x - 1) / gridDim.x;
+  const long t_begin = blockIdx.x * per, t_end = min(t_begin + per, T);
+  if (t_begin < t_end) fetch(t_begin);
+  int nt_loaded = -1, stat_f = -1;
+  float s_sum = 0.f, s_sq = 0.f;
   bf16x8 wfr[4][2];
+  for (long tile = t_begin; tile < t_end; ++tile) {
+    long L = tile;
+    const int nt = (int)(L % a.NT); L /= a.NT;
+    const int tx = (int)(L % tilesX); L /= tilesX;
+    const int ty = (int)(L % tilesY);
+    const int f = (int)(L / tilesY);
+    const int py0 = ty * 8, px0 = tx * 8;
 #pragma unroll
-  for (int cs = 0; cs < 4; ++cs)
+    for (int m = 0; m < 5; ++m)
+      if (tid + 256 * m < 19 * 57) in[tid + 256 * m] = nxt[m];
+    if (nt != nt_loaded) {   // weight fragments [nt][cs][ks][lane][8] stay in registers across tiles
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-      wfr[cs][ks] = *((const bf16x8*)a.wfrag + ((nt * 4 + cs) * 2 + ks) * 64 + lane);
-  __syncthreads();
+      for (int cs = 0; cs < 4; ++cs)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) wfr[cs][ks] = *((const bf16x8*)a.wfrag + ((nt * 4 + cs) * 2 + ks) * 64 + lane);
+      nt_loaded = nt;
+    }
+    __syncthreads();
+    if (tile + 1 < t_end) fetch(tile + 1);
 
   for (int sub = w; sub < 10; sub += 4) {
     const int p = sub * 32 + l31;
@@ -112,8 +137,10 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
   __syncthreads();
 
   // ---- 3x3 / stride 2 max-pool over the conv tile, store + statistics ----
-  float s_sum = 0.f, s_sq = 0.f;
-  const int CB_out = a.Cout >> 5;
+  if (a.stats_out && f != stat_f) {
+    if (stat_f >= 0) block_stats_atomic(s_sum, s_sq, a.stats_out, stat_f);
+    stat_f = f; s_sum = 0.f; s_sq = 0.f;
+  }
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int item = tid + 256 * it;
@@ -141,20 +168,22 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
       *(u32x4*)(a.y + off) = mv;
     }
   }
-  if (a.stats_out) {
-    s_sum = wave_sum(s_sum);
-    s_sq = wave_sum(s_sq);
-    if (lane == 0) {
-      atomicAdd(a.stats_out + 2 * f, (double)s_sum);
-      atomicAdd(a.stats_out + 2 * f + 1, (double)s_sq);
-    }
+    __syncthreads();   // all pooling reads of the conv tile done before the next tile overwrites it
   }
+  if (a.stats_out && stat_f >= 0) block_stats_atomic(s_sum, s_sq, a.stats_out, stat_f);
 }
 
 extern "C" int vpt_conv_first_launch(const VptConvFirstArgs* a, hipStream_t stream) {
   if ((a->H & 15) || (a->W & 15) || (a->Cout & 31) || a->frames <= 0) return -1;
-  const long grid = (long)a->frames * (a->H >> 4) * (a->W >> 4) * a->NT;
-  if (grid > 0x7fffffffL) return -2;
+  static int num_cu = 0;
+  if (num_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                 ? prop.multiProcessorCount : 256;
+  }
+  long grid = (long)a->frames * (a->H >> 4) * (a->W >> 4) * a->NT;
+  if (grid > 2L * num_cu) grid = 2L * num_cu;
   hipLaunchKernelGGL(vpt_conv_first_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

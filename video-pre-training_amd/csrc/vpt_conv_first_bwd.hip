@@ -41,22 +41,53 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
   float gb = 0.f;
   unsigned char* in = smem + IN_OFF;
 
-  for (long tile = blockIdx.x; tile < T; tile += gridDim.x) {
+  // next tile's input bytes are fetched into registers while the current tile computes (as in the forward kernel)
+  unsigned char nxt[5];
+  auto fetch = [&](long tile) {
+    long L = tile;
+    const int tx = (int)(L % tilesX); L /= tilesX;
+    const int ty = (int)(L % tilesY);
+    const int f = (int)(L / tilesY);
+    const int iy0 = 2 * (ty * 8) - 2, ix0 = 2 * (tx * 8) - 2;
+    const uint8_t* img = a.img + (size_t)f * a.H * a.W * 3;
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+      const int idx = tid + 256 * m;
+      const int r = idx / 57, rem = idx - r * 57;
+      const int y = iy0 + r, x = ix0 + rem / 3;
+      const bool ok = idx < 19 * 57 && y >= 0 && y < a.H && x >= 0 && x < a.W;
+      const unsigned char v = img[ok ? ((long)y * a.W + ix0) * 3 + rem : 0];
+      nxt[m] = ok ? v : (unsigned char)0;
+    }
+  };
+  const long per = (T + gridDim.x - 1) / gridDim.x;
+  const long t_begin = blockIdx.x * per, t_end = min(t_begin + per, T);
+  if (t_begin < t_end) fetch(t_begin);
+
+  for (long tile = t_begin; tile < t_end; ++tile) {
     long L = tile;
     const int tx = (int)(L % tilesX); L /= tilesX;
     const int ty = (int)(L % tilesY);
     const int f = (int)(L / tilesY);
     const int py0 = ty * 8, px0 = tx * 8;
-    const int iy0 = 2 * py0 - 2, ix0 = 2 * px0 - 2;
-    const uint8_t* img = a.img + (size_t)f * a.H * a.W * 3;
-    for (int idx = tid; idx < 19 * 57; idx += 256) {
-      const int r = idx / 57, rem = idx - r * 57;
-      const int y = iy0 + r, x = ix0 + rem / 3;
-      unsigned char v = 0;
-      if (y >= 0 && y < a.H && x >= 0 && x < a.W) v = img[((long)y * a.W + ix0) * 3 + rem];
-      in[idx] = v;
-    }
+#pragma unroll
+    for (int m = 0; m < 5; ++m)
+      if (tid + 256 * m < 19 * 57) in[tid + 256 * m] = nxt[m];
     __syncthreads();
+    if (tile + 1 < t_end) fetch(tile + 1);
+    // this thread's 32 pooled gradients, two bf16 per register, fetched in four groups of 8: group 0 now (its latency
+    // hides behind the recompute), group g + 1 while group g is routed
+    const unsigned short* dP = (const unsigned short*)a.dpooled + ((size_t)(f * CB_out + ((ovalid ? og : 0) >> 5)) * PH * PW) * 32 + ((ovalid ? og : 0) & 31);
+    auto load_group = [&](int g, uint32_t* dst) {
+#pragma unroll
+      for (int q = 0; q < 8; q += 2) {
+        const int pp = half * 32 + g * 8 + q;     // pp and pp + 1 are neighbours in the same pooled row
+        const size_t o = (size_t)((py0 + (pp >> 3)) * PW + px0 + (pp & 7)) * 32;
+        dst[q >> 1] = (uint32_t)dP[o] | ((uint32_t)dP[o + 32] << 16);
+      }
+    };
+    uint32_t cur[4], nx[4];
+    load_group(0, cur);
     // ---- recompute the post-ReLU conv tile (identical to the forward kernel) ----
     for (int sub = w; sub < 10; sub += 4) {
       const int p = sub * 32 + l31;
@@ -112,11 +143,14 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
   __syncthreads();
     // ---- arg-max routing + weight-gradient accumulation ----
     if (ovalid) {
-      const vpt_bf16* dP = a.dpooled + ((size_t)(f * CB_out + (og >> 5)) * PH * PW) * 32 + (og & 31);
-      for (int q = 0; q < 32; ++q) {
-        const int pp = half * 32 + q;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+      if (g < 3) load_group(g + 1, nx);
+#pragma unroll
+      for (int q8 = 0; q8 < 8; ++q8) {
+        const int pp = half * 32 + g * 8 + q8;
         const int pyl = pp >> 3, pxl = pp & 7;
-        const float d = (float)dP[(size_t)((py0 + pyl) * PW + px0 + pxl) * 32];
+        const float d = __builtin_bit_cast(float, (q8 & 1) ? (cur[q8 >> 1] & 0xffff0000u) : (cur[q8 >> 1] << 16));
         if (d == 0.f) continue;
         const short* ct = (const short*)(smem + ((2 * pyl) * 17 + 2 * pxl) * CT_RS) + oc;
         short best = 0;                                        // raw bf16 patterns as signed integers: only values > 0 can win (ReLU gate)
@@ -136,6 +170,10 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
 #pragma unroll
         for (int k = 0; k < 27; ++k) gw[k] = fmaf(ds, (float)ib[k + 48 * (k / 9)], gw[k]);
         gb += d;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cur[k] = nx[k];
+      __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();
