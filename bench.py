@@ -168,7 +168,7 @@ def main():
                 except Exception:
                     traffic = None
             roof = dict(bound="mfma", kernel="vpt_conv3x3_kernel", achieved=round(ach, 1), peak=2500.0, unit="TFLOP/s",
-                        frac=round(ach / 2500.0, 4), traffic=traffic, traffic_unit="HBM bytes per launch (committed PMC pass; algorithmic 1.48e9)", launches=c["calls"],
+                        frac=round(ach / 2500.0, 4), traffic=traffic, traffic_unit="HBM bytes per launch (committed PMC pass; algorithmic 1.55e9)", launches=c["calls"],
                         avg_launch_ms=round(c["ms"] / c["calls"], 4),
                         share_of_step_time=round(c["ms"] / total_ms, 3))
 
