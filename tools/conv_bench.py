@@ -16,6 +16,8 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = "cuda"
 shapes = [("s0.block", 64, 128, 128, True), ("s1.first", 64, 128, 256, False), ("s1.block", 32, 256, 256, True),
           ("s2.first", 32, 256, 256, False), ("s2.block", 16, 256, 256, True)]
+if os.environ.get("VPT_BENCH_SHAPES"):   # "name,hw,cin,cout,res;..." overrides the default list
+    shapes = [(n, int(h), int(ci), int(co), r == "1") for n, h, ci, co, r in (x.split(",") for x in os.environ["VPT_BENCH_SHAPES"].split(";"))]
 g = torch.Generator(device="cpu").manual_seed(0)
 for name, hw, cin, cout, use_res in shapes:
     f = frames * (64 * 64) // (hw * hw) if hw < 64 else frames

@@ -37,6 +37,12 @@
 #define KK_OFF (A_BYTES + 2 * B_BYTES)  // 75072
 #define KK_BYTES (9 * 128 * 4)          // 4608
 #define SMEM_BYTES (KK_OFF + KK_BYTES + 32)  // 79712 (+32: block stats reduction)
+// epilogue staging (overlays the halo / weight buffers after the last step): per wave [res|out tile][xin tile], each
+// 2 channel blocks x 32 pixels x 64 B at an 80-byte pixel pitch (16-byte aligned rows, <= 2-way conflicts on the 8-byte side)
+#define ST_RS 80
+#define ST_N2 (32 * ST_RS)              // 2560
+#define ST_X (2 * ST_N2)                // 5120
+#define ST_WAVE (2 * ST_X)              // 10240 per wave, 40960 per workgroup
 
 // MFMA M-subtile row i (0..31) -> pixel (row 0/1, col 0..15) of a 2x16 patch.  Rows are swapped for columns
 // 4..11 so that each 16-lane ds_read_b128 group {0-3,12-15,20-27} / {4-11,16-19,28-31} stays in one image row.
@@ -155,19 +161,31 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   const int cb0 = nt * 4 + wn * 2;                 // 32-channel block of n2 = 0
   const bool nvalid[2] = {(cb0 + 0) < CB_out, (cb0 + 1) < CB_out};
   const size_t nstep = (size_t)HW * 32;            // next 32-channel block
-  size_t poff[4];
+  // Coalesced side of the epilogue: global accesses are 16 bytes per lane over 16 consecutive pixels x 64 B (one full
+  // 1 KB run per instruction) and pass through a wave-private LDS staging tile; the lane-local side (one pixel, four
+  // consecutive channels per access) only touches LDS.  Going to memory straight from the accumulator layout made
+  // every instruction visit 32 cache lines for 16 useful bytes each -- the L1 line rate, not HBM, was what the
+  // residual / output traffic of the K = 1152 layers was waiting for.
+  const int cq = lane >> 2, cchunk = lane & 3;         // staging role: pixel column of the 2x16 patch, 16-byte chunk
+  int st_lds[2];                                      // LDS offset of (patch row j2, column cq) in l31 order
+  size_t goff[4][2];                                  // global element offset of (m, j2) for channel block cb0
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const int y = ty0 + wm * 8 + 2 * m + sub_row(l31);
-    const int x = tx0 + (l31 & 15);
-    // (waves whose channel blocks lie beyond Cout in a padded N tile use block 0 for the -- ignored -- loads)
-    poff[m] = ((size_t)(f * CB_out + (nvalid[0] ? cb0 : 0)) * HW + (size_t)(y * a.W + x)) * 32 + 4 * hi;
+  for (int j2 = 0; j2 < 2; ++j2) {
+    const int l31q = cq + 16 * ((j2 ^ (cq >> 2) ^ (cq >> 3)) & 1);   // inverse of sub_row(): lane that owns this pixel
+    st_lds[j2] = l31q * ST_RS + cchunk * 16;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int y = ty0 + wm * 8 + 2 * m + j2, x = tx0 + cq;
+      goff[m][j2] = ((size_t)(f * CB_out + (nvalid[0] ? cb0 : 0)) * HW + (size_t)(y * a.W + x)) * 32 + cchunk * 8;
+    }
   }
-  u32x2 rr[4][2][4];
+  const int ll_lds = l31 * ST_RS + 8 * hi;             // lane-local: + n2 * ST_N2 + 16 * g
+  unsigned char* stg = smem + w * ST_WAVE;             // [residual / output tile][xin tile], reused for every m
+  u32x4 rq[4][2][2];
 
   // One K step = one kernel row (3 taps) of one 32-channel block: 48 MFMAs per wave, one barrier.
   // Memory ops are issued in a FIXED order and count per wave -- weight DMA (6), then either the halo of the
-  // next block (6, PRE_A) or the residual (32, PRE_R) -- so the wait before the barrier can be COUNTED:
+  // next block (6, PRE_A) or the residual (16, PRE_R) -- so the wait before the barrier can be COUNTED:
   // vmcnt(N_LATE) retires this step's weight DMA (needed by the next step) while the N_LATE younger loads stay
   // in flight across the barrier and get a second step of MFMAs as cover (a plain __syncthreads() drains
   // vmcnt to 0 at every barrier because an LDS-DMA is pending).  Every load is unconditional (clamped address
@@ -195,8 +213,8 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     if ((PRE_R) && a.res) {                                                                               \
       _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                                    \
         _Pragma("unroll") for (int n2_ = 0; n2_ < 2; ++n2_)                                               \
-          _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                                \
-            rr[m_][n2_][g_] = *(const u32x2*)(a.res + poff[m_] + (nvalid[n2_] ? n2_ : 0) * nstep + 8 * g_); \
+          _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                \
+            rq[m_][n2_][j_] = *(const u32x4*)(a.res + goff[m_][j_] + (nvalid[n2_] ? n2_ : 0) * nstep);    \
     }                                                                                                     \
     const unsigned char* bB0_ = bL0 + buf_ * B_BYTES;                                                     \
     const unsigned char* bB1_ = bL1 + buf_ * B_BYTES;                                                     \
@@ -215,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
       }                                                                                                   \
     }                                                                                                     \
     /* all waves done with the halo / B[buf]; this step's DMA into B[buf^1] has landed */                 \
-    if (PRE_A) WAIT_BARRIER(6); else if ((PRE_R) && a.res) WAIT_BARRIER(32); else WAIT_BARRIER(0);        \
+    if (PRE_A) WAIT_BARRIER(6); else if ((PRE_R) && a.res) WAIT_BARRIER(16); else WAIT_BARRIER(0);        \
     if (WR_A) {                                                                                           \
       _Pragma("unroll") for (int m_ = 0; m_ < 6; ++m_)                                                    \
         if (a_loff[m_] >= 0) *(u32x4*)(smem + a_loff[m_]) = (a_goff[m_] >= 0) ? areg[m_] : zero4;         \
@@ -253,8 +271,10 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
 
   // Operands are SWAPPED in the MFMA (weights = A rows, pixels = B columns), so a lane holds ONE pixel
   // (column l31 of the subtile) and, per accumulator, four groups of 4 consecutive output channels
-  // (rows (r&3) + 8*(r>>2) + 4*hi): the epilogue is lane-local -- 16-byte reads of the constant table,
-  // 8-byte residual loads and 8-byte bf16 stores straight from the accumulator layout, no LDS round trip.
+  // (rows (r&3) + 8*(r>>2) + 4*hi): the arithmetic is lane-local -- 16-byte reads of the constant table, 8-byte
+  // reads of the staged residual / xin, 8-byte writes of the bf16 result back into the staging tile -- and the
+  // staging tile moves to / from memory in full 1 KB runs (see above).  The last step's barrier has retired every
+  // read of the weight / halo buffers, so the staging tiles may overlay them.
   int eoff[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
@@ -266,9 +286,32 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   }
   const float* kk = (const float*)(smem + KK_OFF);
   float s_sum = 0.f, s_sq = 0.f;
+  const bool use_x = a.bwd && a.xin;
+  u32x4 xq[2][2];
+  if (use_x) {
+#pragma unroll
+    for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) xq[n2][j] = *(const u32x4*)(a.xin + goff[0][j] + (nvalid[n2] ? n2 : 0) * nstep);
+  }
 
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
+    // stage the coalesced inputs of this 2x16-pixel subtile
+#pragma unroll
+    for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (a.res) *(u32x4*)(stg + n2 * ST_N2 + st_lds[j]) = rq[m][n2][j];
+        if (use_x) *(u32x4*)(stg + ST_X + n2 * ST_N2 + st_lds[j]) = xq[n2][j];
+      }
+    if (use_x && m < 3) {   // next subtile's xin: in flight while this one is processed
+#pragma unroll
+      for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) xq[n2][j] = *(const u32x4*)(a.xin + goff[m + 1][j] + (nvalid[n2] ? n2 : 0) * nstep);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private tile: in-order LDS queue, no barrier needed
 #pragma unroll
     for (int n2 = 0; n2 < 2; ++n2) {
       if (!nvalid[n2]) continue;
@@ -277,23 +320,34 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
         const f32x4 k4 = *(const f32x4*)(kk + eoff[m] + n2 * 32 + 8 * g);
         float v0 = fmaf(rstd, acc[m][n2][4 * g + 0], k4.x), v1 = fmaf(rstd, acc[m][n2][4 * g + 1], k4.y);
         float v2 = fmaf(rstd, acc[m][n2][4 * g + 2], k4.z), v3 = fmaf(rstd, acc[m][n2][4 * g + 3], k4.w);
+        unsigned char* cell = stg + n2 * ST_N2 + ll_lds + 16 * g;
         if (!a.bwd) {
           v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-        } else if (a.xin) {  // dgrad: + d(mu, rstd)/dx terms of the GroupNorm statistics
-          const u32x2 xi = *(const u32x2*)(a.xin + poff[m] + n2 * nstep + 8 * g);
+        } else if (use_x) {  // dgrad: + d(mu, rstd)/dx terms of the GroupNorm statistics
+          const u32x2 xi = *(const u32x2*)(cell + ST_X);
           v0 += fmaf(c1f, bf16_lo_to_f32(xi.x), c0f); v1 += fmaf(c1f, bf16_hi_to_f32(xi.x), c0f);
           v2 += fmaf(c1f, bf16_lo_to_f32(xi.y), c0f); v3 += fmaf(c1f, bf16_hi_to_f32(xi.y), c0f);
         }
         if (a.res) {
-          v0 += bf16_lo_to_f32(rr[m][n2][g].x); v1 += bf16_hi_to_f32(rr[m][n2][g].x);
-          v2 += bf16_lo_to_f32(rr[m][n2][g].y); v3 += bf16_hi_to_f32(rr[m][n2][g].y);
+          const u32x2 r2 = *(const u32x2*)cell;
+          v0 += bf16_lo_to_f32(r2.x); v1 += bf16_hi_to_f32(r2.x);
+          v2 += bf16_lo_to_f32(r2.y); v3 += bf16_hi_to_f32(r2.y);
         }
         s_sum += (v0 + v1) + (v2 + v3);
         s_sq = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, fmaf(v3, v3, s_sq))));
         const u32x2 pk = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
-        *(u32x2*)(a.y + poff[m] + n2 * nstep + 8 * g) = pk;
+        *(u32x2*)cell = pk;
       }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int n2 = 0; n2 < 2; ++n2) {
+      if (!nvalid[n2]) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        *(u32x4*)(a.y + goff[m][j] + n2 * nstep) = *(const u32x4*)(stg + n2 * ST_N2 + st_lds[j]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile is rewritten by the next subtile
   }
   if (a.stats_out) {
     float* red = (float*)(smem + KK_OFF + KK_BYTES);
