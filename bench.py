@@ -100,15 +100,11 @@ def main():
     from vpt_amd import ops
     from vpt_amd.lib.policy import MinecraftAgentPolicy
     from vpt_amd.lib.types import minecraft_action_space
-    from oracle import vpt_oracle as O  # weights generator + cpu_baseline leg only
+    from vpt_amd import configs   # (oracle/ is only touched by the cpu_baseline leg below)
 
-    pk = O.policy_kwargs_for(args.model)
-    cfg = O.config_from_policy_kwargs(pk, dict(temperature=2.0))
-    sd = O.synthetic_state_dict(cfg, seed=0)
-    pol = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0))
-    pol.load_state_dict(sd, strict=False)
+    pol = MinecraftAgentPolicy(minecraft_action_space(), configs.policy_kwargs_for(args.model), dict(temperature=2.0))
+    configs.randomize_(pol, seed=0)
     pol = pol.to(dev)
-    del sd
 
     B, T = args.batch, args.seq
     g = torch.Generator().manual_seed(1 + rank)

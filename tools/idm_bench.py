@@ -8,16 +8,15 @@ ge.build()
 from vpt_amd import ops
 from vpt_amd.lib.policy import InverseActionPolicy
 from vpt_amd.lib.types import idm_action_space
-from oracle import vpt_oracle as O  # synthetic weights only
+from vpt_amd import configs
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1); ap.add_argument("--seq", type=int, default=128); ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--model", default="4x")
 a = ap.parse_args()
-kw = O.idm_kwargs_for(a.model)
-cfg = O.idm_config_from_kwargs(kw, dict(temperature=2.0))
+kw = configs.idm_kwargs_for(a.model)
 pol = InverseActionPolicy(idm_action_space(), pi_head_kwargs=dict(temperature=2.0), idm_net_kwargs=kw)
-pol.load_state_dict(O.idm_synthetic_state_dict(cfg, seed=0), strict=False)
+configs.randomize_(pol, 0)
 pol = pol.to("cuda")
 g = torch.Generator().manual_seed(1)
 img = torch.randint(0, 256, (a.batch, a.seq, 128, 128, 3), generator=g, dtype=torch.uint8).to("cuda")

@@ -7,13 +7,13 @@ import __graft_entry__ as ge
 ge.build()
 from vpt_amd.lib.policy import MinecraftAgentPolicy
 from vpt_amd.lib.types import minecraft_action_space
-from oracle import vpt_oracle as O  # synthetic weights only
+from vpt_amd import configs
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="2x"); ap.add_argument("--steps", type=int, default=200)
 a = ap.parse_args()
-pk = O.policy_kwargs_for(a.model); cfg = O.config_from_policy_kwargs(pk, dict(temperature=2.0))
-pol = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0)); pol.load_state_dict(O.synthetic_state_dict(cfg, 0), strict=False); pol = pol.to("cuda")
+pk = configs.policy_kwargs_for(a.model)
+pol = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0)); configs.randomize_(pol, 0); pol = pol.to("cuda")
 g = torch.Generator().manual_seed(1)
 frames = torch.randint(0, 256, (a.steps, 1, 128, 128, 3), generator=g, dtype=torch.uint8).to("cuda")
 first = torch.zeros(1, dtype=torch.bool, device="cuda")
