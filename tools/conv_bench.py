@@ -32,7 +32,7 @@ for name, hw, cin, cout, use_res in shapes:
             res.zero_()
     xf = x.float().reshape(f, -1).double()
     st_in = torch.stack([xf.sum(1), (xf * xf).sum(1)], 1).contiguous()
-    st_out = torch.zeros(f, 2, dtype=torch.float64, device=dev)
+    st_out = None if os.environ.get("VPT_BENCH_NOSTATS") == "1" else torch.zeros(f, 2, dtype=torch.float64, device=dev)
     out = torch.empty(f, cout // 32, hw, hw, 32, dtype=torch.bfloat16, device=dev)
     for _ in range(2):
         ops.conv3x3(x, wpk, sa, sg, st_in, cout, res=res, stats_out=st_out, out=out)

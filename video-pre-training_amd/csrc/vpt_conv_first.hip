@@ -59,8 +59,10 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
   const long per = (T + gridDim.x - 1) / gridDim.x;
   const long t_begin = blockIdx.x * per, t_end = min(t_begin + per, T);
   if (t_begin < t_end) fetch(t_begin);
+  // (per tile the sums are fp32 in a fixed order; ACROSS tiles they are added in fp64, so a frame's statistics do not
+  // depend on how the tile list happens to be cut into workgroup ranges, i.e. on the batch size)
   int nt_loaded = -1, stat_f = -1;
-  float s_sum = 0.f, s_sq = 0.f;
+  double d_sum = 0.0, d_sq = 0.0;
   bf16x8 wfr[4][2];
   for (long tile = t_begin; tile < t_end; ++tile) {
     long L = tile;
@@ -138,9 +140,13 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
 
   // ---- 3x3 / stride 2 max-pool over the conv tile, store + statistics ----
   if (a.stats_out && f != stat_f) {
-    if (stat_f >= 0) block_stats_atomic(s_sum, s_sq, a.stats_out, stat_f);
-    stat_f = f; s_sum = 0.f; s_sq = 0.f;
+    if (stat_f >= 0 && lane == 0) {
+      atomicAdd(a.stats_out + 2 * stat_f, d_sum);
+      atomicAdd(a.stats_out + 2 * stat_f + 1, d_sq);
+    }
+    stat_f = f; d_sum = 0.0; d_sq = 0.0;
   }
+  float s_sum = 0.f, s_sq = 0.f;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int item = tid + 256 * it;
@@ -168,9 +174,16 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
       *(u32x4*)(a.y + off) = mv;
     }
   }
+    if (a.stats_out) {
+      d_sum += (double)wave_sum(s_sum);
+      d_sq += (double)wave_sum(s_sq);
+    }
     __syncthreads();   // all pooling reads of the conv tile done before the next tile overwrites it
   }
-  if (a.stats_out && stat_f >= 0) block_stats_atomic(s_sum, s_sq, a.stats_out, stat_f);
+  if (a.stats_out && stat_f >= 0 && lane == 0) {
+    atomicAdd(a.stats_out + 2 * stat_f, d_sum);
+    atomicAdd(a.stats_out + 2 * stat_f + 1, d_sq);
+  }
 }
 
 extern "C" int vpt_conv_first_launch(const VptConvFirstArgs* a, hipStream_t stream) {

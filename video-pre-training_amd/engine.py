@@ -18,6 +18,10 @@ import torch
 
 from . import ops, packing
 
+# split-K of the K = 65536 dense layer (fp32 atomics: the one forward op whose low bits depend on scheduling order;
+# VPT_DENSE_SPLITK=1 makes the forward bit-reproducible at a small cost in parallelism for small batches)
+DENSE_SPLITK = int(os.environ.get("VPT_DENSE_SPLITK", "16"))
+
 
 def config_from_policy_kwargs(policy_kwargs: dict, pi_head_kwargs: Optional[dict] = None) -> dict:
     """The numbers the engine needs, from the reference's ctor kwargs (lib/policy.py:99-190, agent.py:16-38)."""
@@ -195,7 +199,7 @@ class PolicyEngine:
             with ctx:
                 xn = self._cnn_chunk(frames[i:i + self.cnn_chunk])
                 flat = xn.view(xn.shape[0], -1)
-                d32, _ = ops.linear(flat, w["net.img_process.cnn.dense.w"], 256, splitk=16)
+                d32, _ = ops.linear(flat, w["net.img_process.cnn.dense.w"], 256, splitk=DENSE_SPLITK)
                 outs.append(d32)
                 del xn, flat
         if n_streams > 1:
@@ -325,7 +329,7 @@ class IDMEngine(PolicyEngine):
             s0 = torch.zeros(fr.shape[0], 2, dtype=torch.float64, device=fr.device)
             x0 = ops.conv3d_t5(fr, wfrag, bias, self.c3d_out, t, stats_out=s0)
             xn = self._cnn_chunk(None, x0=x0, s_x0=s0)
-            d32, _ = ops.linear(xn.view(xn.shape[0], -1), w["net.img_process.cnn.dense.w"], 256, splitk=16)
+            d32, _ = ops.linear(xn.view(xn.shape[0], -1), w["net.img_process.cnn.dense.w"], 256, splitk=DENSE_SPLITK)
             outs.append(d32)
             del x0, xn
         d = outs[0] if len(outs) == 1 else torch.cat(outs, 0)

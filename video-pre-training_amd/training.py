@@ -23,6 +23,7 @@ import torch.distributed as dist
 
 from . import distributed as D
 from . import ops, packing
+from .engine import DENSE_SPLITK
 
 
 def _round_up(x: int, m: int) -> int:
@@ -103,7 +104,7 @@ class BCTrainer:
                 cnn_saved.append(sv)
             else:
                 xn = eng._cnn_chunk(frames[i:i + eng.cnn_chunk])
-            d32, _ = ops.linear(xn.view(xn.shape[0], -1), w["net.img_process.cnn.dense.w"], 256, splitk=16)
+            d32, _ = ops.linear(xn.view(xn.shape[0], -1), w["net.img_process.cnn.dense.w"], 256, splitk=DENSE_SPLITK)
             outs.append(d32)
             del xn
         d = outs[0] if len(outs) == 1 else torch.cat(outs, 0)                     # [M,256] pre-ReLU dense output
@@ -378,18 +379,28 @@ class BCTrainer:
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def step(self, img_u8, first, state_in, act_buttons, act_camera):
-        """One optimiser step on this rank's shard of the batch.  Returns (global mean loss, state_out)."""
+    def reduced_loss_and_grads(self, img_u8, first, state_in, act_buttons, act_camera):
+        """This rank's shard of the batch -> (global mean loss, gradients of the GLOBAL mean loss summed over ranks, state_out).
+        The loss gradient already carries 1 / global_frames, so the exchange is a plain sum: ONE bucketed all-reduce."""
         world = dist.get_world_size() if dist.is_initialized() else 1
         m_local = img_u8.shape[0] * img_u8.shape[1]
         loss, grads, state_out = self.loss_and_grads(img_u8, first, state_in, act_buttons, act_camera,
                                                      global_frames=m_local * world)
-        names = [n for n in self.trainable if n in grads]
         if world > 1:
-            D.bucketed_all_reduce_([grads[n] for n in names], average=False)   # sum: the 1/global_frames is already inside
+            names = [n for n in self.trainable if n in grads]
+            for n in names:
+                grads[n] = grads[n].contiguous()
+            D.bucketed_all_reduce_([grads[n] for n in names], average=False)
             lt = loss.detach().clone()
             dist.all_reduce(lt)
             loss = lt / world
+        return loss, grads, state_out
+
+    @torch.no_grad()
+    def step(self, img_u8, first, state_in, act_buttons, act_camera):
+        """One optimiser step on this rank's shard of the batch.  Returns (global mean loss, state_out)."""
+        loss, grads, state_out = self.reduced_loss_and_grads(img_u8, first, state_in, act_buttons, act_camera)
+        names = [n for n in self.trainable if n in grads]
         self.step_count += 1
         for n in names:
             gr = grads[n].contiguous().view(-1)
