@@ -170,6 +170,21 @@ int vpt_frame_affine_backward(const void* x, const void* dy, const void* dx_add,
                               const double* stats_in, double* ab, float* dgain, float* dbias,
                               int frames, int C, int HW, int per_element, int pass, void* stream);
 
+/* ---- action codec on the device: int64 / fp64 arrays, one row per action ---- */
+
+/* CameraQuantizer.discretize / undiscretize (lib/actions.py:88-108): n scalars (both camera axes flattened); mu_law = 1
+ * selects the mu-law companding of agent.py:40-45 (maxval 10, binsize 2, mu 10), 0 the linear scheme.  fp64 arithmetic,
+ * round-half-to-even like np.round. */
+int vpt_camera_discretize(const double* xy, long* bins, long n, double maxval, double binsize, double mu, int mu_law, void* stream);
+int vpt_camera_undiscretize(const long* bins, double* xy, long n, double maxval, double binsize, double mu, int mu_law, void* stream);
+
+/* CameraHierarchicalMapping.from_factored / to_factored (lib/action_mapping.py:179-219): buttons int64 [n][20] in
+ * Buttons.ALL order (lib/actions.py:21-33), camera int64 [n][2] bins <-> joint_buttons int64 [n] in 0..8640 and
+ * joint_camera int64 [n] in 0..n_camera_bins^2-1.  Inputs are not validated (the reference raises KeyError on bins
+ * outside the grid). */
+int vpt_action_from_factored(const long* buttons, const long* camera, long* joint_buttons, long* joint_camera, long n, int n_camera_bins, void* stream);
+int vpt_action_to_factored(const long* joint_buttons, const long* joint_camera, long* buttons, long* camera, long n, int n_camera_bins, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,8 @@ _lib = None
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
+_L = ctypes.c_long
+_D = ctypes.c_double
 
 # name -> argtypes, exactly as declared in include/vpt_hip.h
 SIGNATURES = {
@@ -30,6 +32,10 @@ SIGNATURES = {
     "vpt_conv_first_backward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_conv3x3_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_conv3x3_wgrad_scratch_floats": [_I, _I, _I],
+    "vpt_camera_discretize": [_P, _P, _L, _D, _D, _D, _I, _P],
+    "vpt_camera_undiscretize": [_P, _P, _L, _D, _D, _D, _I, _P],
+    "vpt_action_from_factored": [_P, _P, _P, _P, _L, _I, _P],
+    "vpt_action_to_factored": [_P, _P, _P, _P, _L, _I, _P],
     "vpt_maxpool_backward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_frame_affine_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_bc_nll_backward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],

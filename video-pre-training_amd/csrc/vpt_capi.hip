@@ -222,3 +222,20 @@ int vpt_masked_attention_backward(const float* qkvr, const float* kmem, const fl
 }
 
 }  // extern "C"
+
+/* ---- action codec (lib/actions.py, lib/action_mapping.py) ---- */
+int vpt_camera_discretize(const double* xy, long* bins, long n, double maxval, double binsize, double mu, int mu_law, void* stream) {
+  CHECK_LAUNCH(vpt_camera_codec_launch(0, xy, bins, n, maxval, binsize, mu, mu_law, (hipStream_t)stream), "vpt_camera_discretize");
+}
+
+int vpt_camera_undiscretize(const long* bins, double* xy, long n, double maxval, double binsize, double mu, int mu_law, void* stream) {
+  CHECK_LAUNCH(vpt_camera_codec_launch(1, bins, xy, n, maxval, binsize, mu, mu_law, (hipStream_t)stream), "vpt_camera_undiscretize");
+}
+
+int vpt_action_from_factored(const long* buttons, const long* camera, long* joint_buttons, long* joint_camera, long n, int n_camera_bins, void* stream) {
+  CHECK_LAUNCH(vpt_action_mapping_launch(0, buttons, camera, joint_buttons, joint_camera, n, n_camera_bins, (hipStream_t)stream), "vpt_action_from_factored");
+}
+
+int vpt_action_to_factored(const long* joint_buttons, const long* joint_camera, long* buttons, long* camera, long n, int n_camera_bins, void* stream) {
+  CHECK_LAUNCH(vpt_action_mapping_launch(1, joint_buttons, joint_camera, buttons, camera, n, n_camera_bins, (hipStream_t)stream), "vpt_action_to_factored");
+}

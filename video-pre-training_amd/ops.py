@@ -329,3 +329,44 @@ def conv_first_backward(img_u8, wfrag, dpooled, cout, out=None):
 def conv_first_grad_to_reference(dw):
     cout = dw.shape[0]
     return dw.view(cout, 3, 3, 3).permute(0, 3, 1, 2).contiguous()
+
+
+# ---- action codec (lib/actions.py, lib/action_mapping.py on the device) ----------------------------------------
+def camera_discretize(xy, maxval, binsize, mu, mu_law):
+    """fp64 tensor (any shape) -> int64 bins of the same shape."""
+    _chk(xy, torch.float64, "xy")
+    out = torch.empty(xy.shape, dtype=torch.int64, device=xy.device)
+    if xy.numel():
+        _call("vpt_camera_discretize", dict(bytes=16.0 * xy.numel()), ptr(xy), ptr(out), xy.numel(), float(maxval), float(binsize), float(mu), int(bool(mu_law)), _stream())
+    return out
+
+
+def camera_undiscretize(bins, maxval, binsize, mu, mu_law):
+    """int64 bins -> fp64 camera angles."""
+    _chk(bins, torch.int64, "bins")
+    out = torch.empty(bins.shape, dtype=torch.float64, device=bins.device)
+    if bins.numel():
+        _call("vpt_camera_undiscretize", dict(bytes=16.0 * bins.numel()), ptr(bins), ptr(out), bins.numel(), float(maxval), float(binsize), float(mu), int(bool(mu_law)), _stream())
+    return out
+
+
+def action_from_factored(buttons, camera, n_camera_bins=11):
+    """buttons int64 [N,20], camera int64 [N,2] -> (joint buttons int64 [N], joint camera int64 [N])."""
+    _chk(buttons, torch.int64, "buttons"); _chk(camera, torch.int64, "camera")
+    n = buttons.shape[0]
+    jb = torch.empty(n, dtype=torch.int64, device=buttons.device)
+    jc = torch.empty(n, dtype=torch.int64, device=buttons.device)
+    if n:
+        _call("vpt_action_from_factored", dict(bytes=192.0 * n), ptr(buttons), ptr(camera), ptr(jb), ptr(jc), n, int(n_camera_bins), _stream())
+    return jb, jc
+
+
+def action_to_factored(joint_buttons, joint_camera, n_camera_bins=11):
+    """joint indices int64 [N] -> (buttons int64 [N,20], camera int64 [N,2])."""
+    _chk(joint_buttons, torch.int64, "joint_buttons"); _chk(joint_camera, torch.int64, "joint_camera")
+    n = joint_buttons.shape[0]
+    b = torch.empty(n, 20, dtype=torch.int64, device=joint_buttons.device)
+    c = torch.empty(n, 2, dtype=torch.int64, device=joint_buttons.device)
+    if n:
+        _call("vpt_action_to_factored", dict(bytes=192.0 * n), ptr(joint_buttons), ptr(joint_camera), ptr(b), ptr(c), n, int(n_camera_bins), _stream())
+    return b, c
