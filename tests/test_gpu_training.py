@@ -397,3 +397,40 @@ def test_conv_prepare_fused_pool_backward():
     rstd = torch.rsqrt(x.reshape(f, -1).double().var(1, unbiased=False) + 1e-5).float()
     exact = gpre * (pre_n.detach() > 0) * rstd.view(f, 1, 1, 1)
     assert _l2(packing.blocked_to_nchw(got[0].cpu(), cout, h, h), exact) < 3e-3
+
+
+def test_trainer_checkpoint_resume(trainer_1x, tmp_path):
+    """Policy weights (.weights format) + BCTrainer.state_dict() restore a run: the resumed step equals the uninterrupted
+    one up to the order of the fp32 atomics inside the backward (same inputs, same Adam moments and step count)."""
+    import copy
+    pol, cfg, sd = trainer_1x
+    g = torch.Generator().manual_seed(41)
+    b, t = 2, 3
+    img = torch.randint(0, 256, (b, t, 128, 128, 3), generator=g, dtype=torch.uint8).to(DEV)
+    first = torch.zeros(b, t, dtype=torch.bool, device=DEV)
+    ab, ac = torch.randint(0, 8641, (b, t), generator=g).to(DEV), torch.randint(0, 121, (b, t), generator=g).to(DEV)
+    start = copy.deepcopy(pol.state_dict())
+    try:
+        tr = BCTrainer(pol, train_cnn=True)
+        st = pol.initial_state(b)
+        for _ in range(2):
+            _, st = tr.step(img, first, st, ab, ac)
+        torch.save(pol.state_dict(), tmp_path / "w.weights")
+        torch.save(tr.state_dict(), tmp_path / "opt.pt")
+        st_saved = [(m.clone(), (k.clone(), v.clone())) for m, (k, v) in st]
+        loss_a, _ = tr.step(img, first, st, ab, ac)
+        after_a = {k: v.detach().clone() for k, v in pol.named_parameters()}
+        # resume in a fresh trainer
+        pol.load_state_dict(torch.load(tmp_path / "w.weights"), strict=False)
+        tr2 = BCTrainer(pol, train_cnn=True, lr=1.0)          # hyper-parameters come from the checkpoint
+        tr2.load_state_dict(torch.load(tmp_path / "opt.pt"))
+        assert tr2.step_count == 2 and tr2.lr == tr.lr
+        loss_b, _ = tr2.step(img, first, st_saved, ab, ac)
+        torch.cuda.synchronize()
+        assert abs(loss_a - loss_b) < 1e-5
+        for k, v in pol.named_parameters():
+            assert torch.allclose(v.detach(), after_a[k], rtol=0, atol=2e-6), (k, float((v.detach() - after_a[k]).abs().max()))
+        moved = max(float((after_a[k] - start[k].to(DEV)).abs().max()) for k in after_a)
+        assert moved > 1e-4                                     # (the three steps did change the weights: lr 1.81e-4 each)
+    finally:
+        pol.load_state_dict(start, strict=False)

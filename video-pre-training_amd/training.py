@@ -72,6 +72,23 @@ class BCTrainer:
         self.m = {n: torch.zeros_like(self.params[n], dtype=torch.float32) for n in self.trainable}
         self.v = {n: torch.zeros_like(self.params[n], dtype=torch.float32) for n in self.trainable}
 
+    # ---- checkpoint / resume ---------------------------------------------------
+    def state_dict(self) -> dict:
+        """Optimizer state next to the policy's own `.weights` state_dict (behavioural_cloning.py:131-132 saves only the
+        latter): Adam moments keyed by the reference's parameter names, the step count and the hyper-parameters."""
+        return dict(step=self.step_count, lr=self.lr, weight_decay=self.wd, betas=tuple(self.betas), eps=self.eps,
+                    train_cnn=self.train_cnn, exp_avg={n: t.detach().clone() for n, t in self.m.items()},
+                    exp_avg_sq={n: t.detach().clone() for n, t in self.v.items()})
+
+    def load_state_dict(self, sd: dict):
+        if set(sd["exp_avg"]) != set(self.m):
+            raise KeyError(f"optimizer state does not match the trainable parameters: {sorted(set(sd['exp_avg']) ^ set(self.m))[:4]} ...")
+        self.step_count = int(sd["step"])
+        self.lr, self.wd, self.betas, self.eps = sd["lr"], sd["weight_decay"], tuple(sd["betas"]), sd["eps"]
+        for n in self.m:
+            self.m[n].copy_(sd["exp_avg"][n])
+            self.v[n].copy_(sd["exp_avg_sq"][n])
+
     def _is_trainable(self, name: str) -> bool:
         if name.startswith("net.img_process.cnn.") and not self.train_cnn:
             return False            # train_cnn=False: fine-tune the trunk and heads only
