@@ -66,7 +66,8 @@ int vpt_frame_affine_forward(const void* x, void* y, const float* gain, const fl
 /* C[M,N] = A[M,K] W[N,K]^T (+bias) (ReLU) (+res): every nn.Linear on the path (lib/util.py:58-82,
  * lib/xf.py:251-254, lib/action_head.py:164, lib/scaled_mse_head.py:35).  A bf16 [M][lda]; wpk bf16
  * [ceil(N/128)][K/32][128][32]; bias fp32[N] or NULL; res fp32 [M][ldr] or NULL; out_f32 [M][ldc] and/or
- * out_bf16 [M][ldcb].  splitk > 1 accumulates into a caller-zeroed out_f32 with atomics (no ReLU/res).
+ * out_bf16 [M][ldcb].  splitk > 1 (no ReLU/res): out_f32 is a caller-zeroed [splitk][M][ldc] buffer, split s writes its
+ * partial product to slice s and the caller sums the slices -- no atomics, so the result is bit-reproducible.
  * mask (optional, bf16 [M][ldm]) zeroes outputs where mask <= 0 before the residual add: the ReLU backward of
  * the BC step's dgrad GEMMs.  The same entry point serves forward, dgrad (W^T packed) and wgrad (A = dY^T). */
 int vpt_linear_forward(const void* A, const void* wpk, const float* bias, const float* res,

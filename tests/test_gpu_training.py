@@ -434,3 +434,42 @@ def test_trainer_checkpoint_resume(trainer_1x, tmp_path):
         assert moved > 1e-4                                     # (the three steps did change the weights: lr 1.81e-4 each)
     finally:
         pol.load_state_dict(start, strict=False)
+
+
+def test_bc_gradients_independent_of_cnn_chunking(trainer_1x):
+    """The CNN forward / backward runs in frame chunks (1024 by default) whose weight-gradient pieces are accumulated
+    in place: ragged chunks must give the same gradients as one chunk (frames are independent, the statistics are
+    fp64 across tiles, the split-K dense layer sums its slices in a fixed order).  Chunks of 10 frames keep the dense
+    layer on the GEMM kernel in both runs (M <= 8 rows would take the GEMV kernel, whose fp32 summation order over
+    K = 65536 differs in the last bits)."""
+    pol, cfg, sd = trainer_1x
+    tr = BCTrainer(pol, train_cnn=True)
+    b, t = 3, 10                                    # 30 frames: one chunk vs chunks of 10, 10, 10
+    g = torch.Generator().manual_seed(51)
+    img = torch.randint(0, 256, (b, t, 128, 128, 3), generator=g, dtype=torch.uint8).to(DEV)
+    first = torch.zeros(b, t, dtype=torch.bool, device=DEV)
+    ab, ac = torch.randint(0, 8641, (b, t), generator=g).to(DEV), torch.randint(0, 121, (b, t), generator=g).to(DEV)
+    eng = pol._engine
+    saved = eng.cnn_chunk
+    try:
+        eng.cnn_chunk = 1024
+        l1, g1, _ = tr.loss_and_grads(img, first, pol.initial_state(b), ab, ac)
+        g1 = {k: v.clone() for k, v in g1.items()}
+        eng.cnn_chunk = 10                      # 10, 10, 10
+        l2, g2, _ = tr.loss_and_grads(img, first, pol.initial_state(b), ab, ac)
+        (pd1, _, _), _ = pol({"img": img}, first, pol.initial_state(b))          # inference path, ragged chunks too
+        eng.cnn_chunk = 1024
+        (pd2, _, _), _ = pol({"img": img}, first, pol.initial_state(b))
+        torch.cuda.synchronize()
+    finally:
+        eng.cnn_chunk = saved
+    assert abs(float(l1) - float(l2)) < 1e-5
+    assert torch.equal(pd1["buttons"], pd2["buttons"])
+    worst = 0.0
+    for k, v in g1.items():
+        if float(v.norm()) == 0:
+            continue
+        e = _l2(g2[k].float().cpu(), v.float().cpu())
+        worst = max(worst, e)
+        assert e < 1e-4, (k, e)
+    print(f"PARITY BC gradients, 3 CNN chunks vs 1: worst rel-L2 {worst:.2e}")

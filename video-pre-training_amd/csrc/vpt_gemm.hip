@@ -120,8 +120,8 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
         const int row = m0 + wm * 128 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         if (row >= a.M) continue;
         float v = acc[m][n2][r] + bv;
-        if (a.atomic_out) {
-          atomicAdd(a.out_f32 + (size_t)row * a.ldc + col, v);
+        if (a.atomic_out) {   // split-K: this split's partial product goes to its own [M][ldc] slice (deterministic; the caller sums)
+          a.out_f32[((size_t)split * a.M + row) * a.ldc + col] = v;
         } else {
           if (a.relu) v = fmaxf(v, 0.f);
           if (a.mask && !((float)a.mask[(size_t)row * a.ldm + col] > 0.f)) v = 0.f;  // ReLU backward: gate by the saved activation

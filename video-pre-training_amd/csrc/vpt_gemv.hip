@@ -1,6 +1,6 @@
 // Skinny linear layer for the acting path (M = B*T <= 8 rows, agent.py:190-206): out[m][n] = sum_k A[m][k] W[n][k]
 // with the same fused epilogue as vpt_gemm_kernel (bias, ReLU, gate mask, fp32 residual, fp32 / bf16 outputs, or
-// split-K atomics).  At M = 1 the layer is a stream of the weight matrix (2 bytes per MAC): HBM-bound, so the job is
+// split-K partial slices).  At M = 1 the layer is a stream of the weight matrix (2 bytes per MAC): HBM-bound, so the job is
 // to keep many 16-byte loads in flight on every CU rather than to feed the MFMA -- a 256 x 128 GEMM tile would
 // leave 1 row of 256 busy and put N/128 workgroups on a 256-CU chip.
 //
@@ -55,8 +55,8 @@ __global__ __launch_bounds__(256) void vpt_gemv_kernel(VptGemmArgs a) {
     if (m < a.M && col < a.N) {
       float v = (part_[0][r][m] + part_[1][r][m]) + (part_[2][r][m] + part_[3][r][m]);
       if (a.bias && split == 0) v += a.bias[col];
-      if (a.atomic_out) {
-        atomicAdd(a.out_f32 + (size_t)m * a.ldc + col, v);
+      if (a.atomic_out) {   // split-K: own [M][ldc] slice per split, summed by the caller (deterministic)
+        a.out_f32[((size_t)split * a.M + m) * a.ldc + col] = v;
       } else {
         if (a.relu) v = fmaxf(v, 0.f);
         if (a.mask && !((float)a.mask[(size_t)m * a.ldm + col] > 0.f)) v = 0.f;

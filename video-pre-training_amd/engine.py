@@ -18,8 +18,7 @@ import torch
 
 from . import ops, packing
 
-# split-K of the K = 65536 dense layer (fp32 atomics: the one forward op whose low bits depend on scheduling order;
-# VPT_DENSE_SPLITK=1 makes the forward bit-reproducible at a small cost in parallelism for small batches)
+# split-K of the K = 65536 dense layer (per-split partial slices summed in a fixed order: deterministic)
 DENSE_SPLITK = int(os.environ.get("VPT_DENSE_SPLITK", "16"))
 
 

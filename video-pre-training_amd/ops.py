@@ -116,14 +116,16 @@ def linear(a_bf16, wpk, n, bias=None, res=None, relu=False, out_f32=True, out_bf
     m, k = a_bf16.shape
     dev = a_bf16.device
     o32 = None
-    if out_f32:
-        o32 = torch.zeros(m, n, dtype=torch.float32, device=dev) if splitk > 1 else torch.empty(m, n, dtype=torch.float32, device=dev)
+    if out_f32:   # split-K: one [m, n] slice per split (zeroed: a split without k-steps writes nothing), summed below
+        o32 = torch.zeros(splitk, m, n, dtype=torch.float32, device=dev) if splitk > 1 else torch.empty(m, n, dtype=torch.float32, device=dev)
     o16, ld16 = None, n
     if out_bf16:
         ld16 = out_bf16_ld or n
         o16 = torch.zeros(m, ld16, dtype=torch.bfloat16, device=dev) if ld16 > n else torch.empty(m, n, dtype=torch.bfloat16, device=dev)
     _call("vpt_linear_forward", dict(flops=2.0 * m * n * k, bytes=2.0 * (m * k + n * k) + 4.0 * m * n), ptr(a_bf16), ptr(wpk), ptr(bias), ptr(res), ptr(o32), ptr(o16),
           m, n, k, k, n, n, ld16, 1 if relu else 0, splitk, ptr(mask), mask.shape[1] if mask is not None else 0, _stream())
+    if splitk > 1 and o32 is not None:
+        o32 = o32.sum(0)           # fixed summation order: the result does not depend on scheduling
     return o32, o16
 
 
