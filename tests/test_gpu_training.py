@@ -187,8 +187,10 @@ def test_bc_gradients_vs_oracle(trainer_1x, train_cnn):
 
 @pytest.mark.parametrize("train_cnn", [False, True])
 def test_bc_step_reduces_loss(trainer_1x, train_cnn):
+    """A few Adam steps on a fixed batch from the seeded weights (restored first: the fixture is shared) lower the loss."""
     pol, cfg, sd = trainer_1x
-    tr = BCTrainer(pol, lr=3e-4, weight_decay=0.0, train_cnn=train_cnn)
+    pol.load_state_dict(sd, strict=False)
+    tr = BCTrainer(pol, lr=1e-4, weight_decay=0.0, train_cnn=train_cnn)
     b, t = 2, 4
     g = torch.Generator().manual_seed(6)
     img = torch.randint(0, 256, (b, t, 128, 128, 3), generator=g, dtype=torch.uint8).to(DEV)
@@ -196,12 +198,15 @@ def test_bc_step_reduces_loss(trainer_1x, train_cnn):
     ab = torch.randint(0, 8641, (b, t), generator=g).to(DEV)
     ac = torch.randint(0, 121, (b, t), generator=g).to(DEV)
     losses = []
-    for _ in range(4):
-        loss, _ = tr.step(img, first, pol.initial_state(b), ab, ac)
-        losses.append(loss)
-    torch.cuda.synchronize()
-    print("BC losses on a fixed batch:", losses)
-    assert losses[-1] < losses[0] - 0.05
+    try:
+        for _ in range(6):
+            loss, _ = tr.step(img, first, pol.initial_state(b), ab, ac)
+            losses.append(loss)
+        torch.cuda.synchronize()
+    finally:
+        pol.load_state_dict(sd, strict=False)
+    print("BC losses on a fixed batch:", [round(l, 3) for l in losses])
+    assert losses[-1] < losses[0] - 0.2 and all(b_ < a_ + 0.05 for a_, b_ in zip(losses, losses[1:]))
 
 
 # ---------------------------------------------------------------------------------------------------------
