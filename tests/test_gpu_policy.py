@@ -193,3 +193,31 @@ def test_step_graph_matches_eager(pol_1x):
         pol.disable_step_graph()
         with torch.no_grad():
             pol.pi_head.buttons.linear_layer.bias[:200].sub_(2.0)
+
+
+@pytest.mark.parametrize("b,ts,firsts", [
+    (3, (1, 1, 1), ([False, True, False], [False, False, False], [True, False, False])),   # the acting shape, three envs, resets
+    (1, (129, 2), ([False], [False])),                                                     # one frame more than the memory
+    (2, (257, 64), ([True, False], [False, True])),                                        # > 2 memories long, then a reset
+])
+def test_policy_vs_oracle_ragged_shapes(pol_1x, b, ts, firsts):
+    """Chunk lengths that are not multiples of anything in the kernels (query tile 32, memory 128), several chunks with
+    the state carried, `first` raised on different sequences at different chunks."""
+    pol, cfg, sd = pol_1x
+    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
+    so, sg = O.initial_state(cfg, b), pol.initial_state(b)
+    for i, (t, first0) in enumerate(zip(ts, firsts)):
+        img = _inputs(100 + 7 * i + t, b, t)
+        first = torch.zeros(b, t, dtype=torch.bool)
+        first[:, 0] = torch.tensor(first0)
+        ref = O.policy_forward(sd, cfg, img, first, so)
+        so = ref["state_out"]
+        (pd, vpred, _), sg = pol({"img": img.to(DEV)}, first.to(DEV), sg)
+        torch.cuda.synchronize()
+        for k in ("buttons", "camera"):
+            e, l = _rel(pd[k].cpu().numpy(), ref[k].numpy()), _l2(pd[k].cpu().numpy(), ref[k].numpy())
+            assert e < TOL and l < L2_TOL, (k, t, e, l)
+        assert float((vpred.cpu() - ref["vpred"]).abs().max()) < 0.25
+        for (m1, (k1, v1)), (m2, (k2, v2)) in zip(sg, so):
+            assert torch.equal(m1.cpu(), m2)
+            assert _l2(k1.cpu().numpy(), k2.numpy()) < KV_TOL and _l2(v1.cpu().numpy(), v2.numpy()) < KV_TOL
