@@ -401,8 +401,21 @@ class BCTrainer:
         The loss gradient already carries 1 / global_frames, so the exchange is a plain sum: ONE bucketed all-reduce."""
         world = dist.get_world_size() if dist.is_initialized() else 1
         m_local = img_u8.shape[0] * img_u8.shape[1]
-        loss, grads, state_out = self.loss_and_grads(img_u8, first, state_in, act_buttons, act_camera,
-                                                     global_frames=m_local * world)
+        err = None
+        try:
+            loss, grads, state_out = self.loss_and_grads(img_u8, first, state_in, act_buttons, act_camera,
+                                                         global_frames=m_local * world)
+        except Exception as e:          # e.g. out of memory on one rank
+            if world == 1:
+                raise
+            err = e
+        if world > 1:
+            # The local forward / backward has no collective in it; agree on its outcome BEFORE the gradient exchange so
+            # that one failing rank makes every rank raise instead of leaving the others blocked in the all-reduce.
+            ok = torch.tensor([0.0 if err is not None else 1.0], device=img_u8.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) == 0.0:
+                raise RuntimeError(f"BC step failed on {'this' if err is not None else 'another'} rank: {err!r}")
         if world > 1:
             names = [n for n in self.trainable if n in grads]
             for n in names:
