@@ -196,7 +196,7 @@ def main():
             bc = dict(ms_per_step=round(1e3 * bc_el / args.bc_steps, 2), frames_per_s=round(world * B * T * args.bc_steps / bc_el, 1),
                       steps=args.bc_steps, warmup=args.bc_warmup, global_batch=world * B, seq_len=T, trained="all parameters (CNN + trunk + heads)",
                       optimizer="Adam lr 1.81e-4 wd 0.039428 (behavioural_cloning.py:38-40)",
-                      allreduce=("one bucketed RCCL all-reduce of the fp32 gradients per step" if distributed else "none (1 GPU)"),
+                      allreduce=("bucketed RCCL all-reduce of the fp32 gradients, trunk + heads overlapped with the CNN backward" if distributed else "none (1 GPU)"),
                       loss_first=round(losses[0], 4), loss_last=round(losses[-1], 4),
                       peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1))
         except Exception as e:  # the forward line must survive a failure of the training leg

@@ -81,3 +81,47 @@ def test_two_rank_bc_step_matches_single_process():
     print(f"PARITY 2-rank all-reduced BC gradients vs single process: worst rel-L2 {max(errs):.3e}, mean {sum(errs) / len(errs):.3e}")
     for k in r0["params"]:
         assert torch.equal(r0["params"][k], r1["params"][k]), k     # replicas stay bit-identical after the step
+
+
+def _failing_worker(rank, world, port, out_dir, where):
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    ge.build()
+    from vpt_amd import distributed as D
+    from vpt_amd.training import BCTrainer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pol = _make()
+        tr = BCTrainer(pol, train_cnn=True, weight_decay=0.0)
+        if rank == 1:      # a local failure on ONE rank, before or after the early (trunk) gradient exchange has started
+            def boom(*a, **k):
+                raise MemoryError("synthetic out-of-memory on rank 1")
+            if where == "late":
+                tr._cnn_backward_begin = boom
+            else:
+                tr._cnn_forward_saving = boom
+        img, first, ab, ac = _batch()
+        b0, b1 = D.shard_range(img.shape[0], rank, world)
+        sl = slice(b0, b1)
+        try:
+            tr.step(img[sl].cuda(), first[sl].cuda(), pol.initial_state(b1 - b0), ab[sl].cuda(), ac[sl].cuda())
+            outcome = "no error"
+        except RuntimeError as e:
+            outcome = str(e)
+        with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+            f.write(outcome)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("where", ["early", "late"])
+def test_failure_on_one_rank_raises_on_all_ranks(where):
+    """A rank that fails locally must not leave the other rank blocked in the gradient all-reduce: it still joins every
+    collective (with zeros) and all ranks raise together."""
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_failing_worker, args=(2, 29541 if where == "early" else 29542, d, where), nprocs=2, join=True)
+        r0, r1 = open(os.path.join(d, "rank0.txt")).read(), open(os.path.join(d, "rank1.txt")).read()
+    assert "failed on another rank" in r0, r0
+    assert "failed on this rank" in r1 and "synthetic out-of-memory" in r1, r1

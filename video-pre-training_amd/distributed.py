@@ -39,14 +39,12 @@ def max_over_ranks(value: float, device="cpu") -> float:
     return float(t.item())
 
 
-def bucketed_all_reduce_(tensors: Sequence[torch.Tensor], bucket_bytes: int = 64 << 20, average: bool = True) -> int:
-    """Sum (or average) `tensors` in place across ranks in flat buckets of ~bucket_bytes: the gradient
-    exchange of the data-parallel BC step (994 MB fp32 for the 2x model, SURVEY.md §8e).  Returns the number
-    of collectives issued.  64 MB buckets keep each of the 7 xGMI links busy without serialising behind one
-    giant tensor; the reduce is asynchronous per bucket and waited at the end."""
+def bucketed_all_reduce_start(tensors: Sequence[torch.Tensor], bucket_bytes: int = 64 << 20):
+    """Launch the (sum) all-reduce of `tensors` in flat buckets of ~bucket_bytes asynchronously; returns the pending list
+    for bucketed_all_reduce_finish.  The collectives are ordered after the work already enqueued on the current stream
+    and run on the backend's own stream, i.e. concurrently with whatever the caller enqueues next."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return 0
-    world = dist.get_world_size()
+        return []
     buckets: List[List[torch.Tensor]] = [[]]
     size = 0
     for t in tensors:
@@ -62,13 +60,29 @@ def bucketed_all_reduce_(tensors: Sequence[torch.Tensor], bucket_bytes: int = 64
             continue
         flat = torch.cat([t.reshape(-1) for t in bucket])
         works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, bucket))
+    return works
+
+
+def bucketed_all_reduce_finish(works, scale: float = 1.0) -> int:
+    """Wait for the pending buckets and scatter the reduced values back into the original tensors (x scale)."""
     for work, flat, bucket in works:
         work.wait()
-        if average:
-            flat.div_(world)
+        if scale != 1.0:
+            flat.mul_(scale)
         off = 0
         for t in bucket:
             n = t.numel()
             t.copy_(flat[off:off + n].view_as(t))
             off += n
     return len(works)
+
+
+def bucketed_all_reduce_(tensors: Sequence[torch.Tensor], bucket_bytes: int = 64 << 20, average: bool = True) -> int:
+    """Sum (or average) `tensors` in place across ranks in flat buckets of ~bucket_bytes: the gradient
+    exchange of the data-parallel BC step (994 MB fp32 for the 2x model, SURVEY.md §8e).  Returns the number
+    of collectives issued.  64 MB buckets keep each of the 7 xGMI links busy without serialising behind one
+    giant tensor; the reduce is asynchronous per bucket and waited at the end."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    works = bucketed_all_reduce_start(tensors, bucket_bytes)
+    return bucketed_all_reduce_finish(works, 1.0 / dist.get_world_size() if average else 1.0)

@@ -98,9 +98,12 @@ class BCTrainer:
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def loss_and_grads(self, img_u8, first, state_in, act_buttons, act_camera, global_frames: Optional[int] = None, debug: Optional[dict] = None):
+    def loss_and_grads(self, img_u8, first, state_in, act_buttons, act_camera, global_frames: Optional[int] = None, debug: Optional[dict] = None,
+                       on_trunk_grads=None):
         """Forward (saving activations) + backward.  Returns (loss of this rank's frames, grads dict, state_out).
-        global_frames: number of frames in the global (all-rank) batch the mean runs over (default: local)."""
+        global_frames: number of frames in the global (all-rank) batch the mean runs over (default: local).
+        on_trunk_grads(g): called once the gradients of everything behind the CNN (88 % of the parameters) are final and
+        before the CNN's backward starts -- the data-parallel step starts their all-reduce there."""
         pol, eng = self.policy, self.engine
         pol._ensure_packed()
         cfg, w = eng.cfg, eng.w
@@ -238,6 +241,8 @@ class BCTrainer:
         ddn, _, g[pl + "layer.weight"] = linear_backward(dx16, hid, dn, P[pl + "layer.weight"])
         g[pl + "norm.weight"], g[pl + "norm.bias"] = zeros(256), zeros(256)
         dd = ops.layernorm_backward(d, P[pl + "norm.weight"], ddn, g[pl + "norm.weight"], g[pl + "norm.bias"], relu_in=True)
+        if on_trunk_grads is not None:
+            on_trunk_grads(g)
         if self.train_cnn:
             acc = self._cnn_backward_begin(P)
             for ci, i in enumerate(range(0, m, eng.cnn_chunk)):
@@ -398,33 +403,45 @@ class BCTrainer:
     @torch.no_grad()
     def reduced_loss_and_grads(self, img_u8, first, state_in, act_buttons, act_camera):
         """This rank's shard of the batch -> (global mean loss, gradients of the GLOBAL mean loss summed over ranks, state_out).
-        The loss gradient already carries 1 / global_frames, so the exchange is a plain sum: ONE bucketed all-reduce."""
+        The loss gradient already carries 1 / global_frames, so the exchange is a plain sum, in two bucketed all-reduces:
+        the trunk + head gradients (final before the CNN backward starts) travel over RCCL WHILE the CNN backward -- two
+        thirds of the step's compute -- runs; the CNN's own gradients (a tenth of the bytes) follow at the end.  A rank
+        that fails locally (e.g. out of memory) still joins every collective with zeros and reports it in the final
+        (loss, healthy-rank count) reduction, so all ranks raise together instead of blocking in an all-reduce."""
         world = dist.get_world_size() if dist.is_initialized() else 1
         m_local = img_u8.shape[0] * img_u8.shape[1]
-        err = None
+        if world == 1:
+            return self.loss_and_grads(img_u8, first, state_in, act_buttons, act_camera, global_frames=m_local)
+        dev = img_u8.device
+        early = [n for n in self.trainable if not n.startswith("net.img_process.cnn.")]   # final before the CNN backward
+        late = [n for n in self.trainable if n.startswith("net.img_process.cnn.")]
+        pending, state = [], dict(early_sent=False)
+
+        def start_trunk_exchange(g):
+            for n in early:
+                g[n] = g[n].contiguous()
+            pending.extend(D.bucketed_all_reduce_start([g[n] for n in early]))
+            state["early_sent"] = True
+
+        err, loss, grads, state_out = None, None, None, None
         try:
             loss, grads, state_out = self.loss_and_grads(img_u8, first, state_in, act_buttons, act_camera,
-                                                         global_frames=m_local * world)
-        except Exception as e:          # e.g. out of memory on one rank
-            if world == 1:
-                raise
-            err = e
-        if world > 1:
-            # The local forward / backward has no collective in it; agree on its outcome BEFORE the gradient exchange so
-            # that one failing rank makes every rank raise instead of leaving the others blocked in the all-reduce.
-            ok = torch.tensor([0.0 if err is not None else 1.0], device=img_u8.device)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if float(ok.item()) == 0.0:
-                raise RuntimeError(f"BC step failed on {'this' if err is not None else 'another'} rank: {err!r}")
-        if world > 1:
-            names = [n for n in self.trainable if n in grads]
-            for n in names:
+                                                         global_frames=m_local * world, on_trunk_grads=start_trunk_exchange)
+            for n in late:
                 grads[n] = grads[n].contiguous()
-            D.bucketed_all_reduce_([grads[n] for n in names], average=False)
-            lt = loss.detach().clone()
-            dist.all_reduce(lt)
-            loss = lt / world
-        return loss, grads, state_out
+            pending.extend(D.bucketed_all_reduce_start([grads[n] for n in late]))
+        except Exception as e:          # e.g. out of memory on this rank: still take part in every collective (with zeros of
+            err = e                     # the same shapes) so that the other ranks are not left blocked, then fail everywhere
+            zeros = lambda names: [torch.zeros_like(self.params[n], dtype=torch.float32) for n in names]
+            if not state["early_sent"]:
+                pending.extend(D.bucketed_all_reduce_start(zeros(early)))
+            pending.extend(D.bucketed_all_reduce_start(zeros(late)))
+        D.bucketed_all_reduce_finish(pending)
+        tail = torch.tensor([0.0 if err is not None else float(loss), 0.0 if err is not None else 1.0], device=dev)
+        dist.all_reduce(tail)           # (sum of losses, number of healthy ranks)
+        if float(tail[1].item()) != world:
+            raise RuntimeError(f"BC step failed on {'this' if err is not None else 'another'} rank: {err!r}")
+        return tail[0] / world, grads, state_out
 
     @torch.no_grad()
     def step(self, img_u8, first, state_in, act_buttons, act_camera):
