@@ -13,9 +13,9 @@ train_cnn=True, the reference's behaviour (behavioural_cloning.py:57-63 trains e
 dense layer GEMMs, per-element / per-channel affine backward, max-pool routing, the folded GroupNorm convolutions
 (vpt_conv_bwd_prep_kernel -> vpt_conv3x3_kernel in dgrad mode + vpt_conv_wgrad_kernel -> conv_param_grads) and the
 fused first conv (vpt_conv_first_bwd_kernel).  train_cnn=False freezes `net.img_process.cnn.*` and fine-tunes the
-trunk and heads only (71 % of the 2x model's parameters).  Data parallelism: one process per GPU, sequences sharded by rank, ONE
-bucketed RCCL all-reduce of the gradients per step (distributed.bucketed_all_reduce_), averaged inside the
-fused Adam (grad_scale = 1 / world)."""
+trunk and heads only (71 % of the 2x model's parameters).  Data parallelism: one process per GPU, sequences sharded by rank, the
+gradients summed over RCCL in buckets -- trunk + heads while the CNN backward runs, the CNN's at the end
+(BCTrainer.reduced_loss_and_grads); the 1 / global_frames factor is already in the loss gradient."""
 from typing import Dict, List, Optional
 
 import torch
