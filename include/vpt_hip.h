@@ -75,6 +75,11 @@ int vpt_linear_forward(const void* A, const void* wpk, const float* bias, const 
                        int lda, int ldr, int ldc, int ldcb, int relu, int splitk, const void* mask, int ldm,
                        void* stream);
 
+/* Second stage of a split-K linear: out = epilogue(sum_s part[s][M][N]) with the same epilogue options as
+ * vpt_linear_forward (part = the [splitk][M][N] buffer a vpt_linear_forward call with splitk > 1 filled). */
+int vpt_linear_splitk_epilogue(const float* part, int splitk, const float* bias, const float* res, float* out_f32, void* out_bf16,
+                               int M, int N, int ldr, int ldc, int ldcb, int relu, const void* mask, int ldm, void* stream);
+
 /* nn.LayerNorm over the last dim with optional ReLU on the input (lib/util.py:61-62,169; lib/policy.py:188,211-214). */
 int vpt_layernorm_forward(const float* x, const float* gain, const float* bias, float* out_f32, void* out_bf16,
                           int M, int D, int relu_in, void* stream);

@@ -109,6 +109,10 @@ def test_maxpool_and_affine():
     (513, 2048, 8192, True, False, True, 1),
     (256, 4096, 1024, False, True, False, 1),
     (40, 256, 16384, False, False, False, 16),
+    # 8 < M <= 512 with few N tiles: automatic split-K + epilogue kernel (one IDM window)
+    (128, 4096, 4096, True, True, True, 1),
+    (128, 640, 16384, True, False, False, 1),
+    (300, 1000, 2048, False, True, False, 1),
     # M <= 8: the acting path's weight-streaming kernel (vpt_gemv.hip)
     (1, 8763, 2048, True, False, False, 1),
     (2, 2048, 8192, True, False, True, 1),

@@ -141,6 +141,15 @@ int vpt_linear_forward(const void* A, const void* wpk, const float* bias, const 
   CHECK_LAUNCH(vpt_gemm_launch(&a, (hipStream_t)stream), "vpt_linear_forward");
 }
 
+int vpt_linear_splitk_epilogue(const float* part, int splitk, const float* bias, const float* res, float* out_f32, void* out_bf16,
+                               int M, int N, int ldr, int ldc, int ldcb, int relu, const void* mask, int ldm, void* stream) {
+  VptGemmArgs a;
+  a.A = nullptr; a.wpk = nullptr; a.bias = bias; a.res = res; a.out_f32 = out_f32; a.out_bf16 = (vpt_bf16*)out_bf16;
+  a.M = M; a.N = N; a.K = 0; a.lda = 0; a.ldr = ldr; a.ldc = ldc; a.ldcb = ldcb; a.relu = relu; a.splitk = splitk; a.atomic_out = 0;
+  a.mask = (const vpt_bf16*)mask; a.ldm = ldm;
+  CHECK_LAUNCH(vpt_splitk_epilogue_launch(part, splitk, &a, (hipStream_t)stream), "vpt_linear_splitk_epilogue");
+}
+
 int vpt_layernorm_forward(const float* x, const float* gain, const float* bias, float* out_f32, void* out_bf16,
                           int M, int D, int relu_in, void* stream) {
   VptLayerNormArgs a;

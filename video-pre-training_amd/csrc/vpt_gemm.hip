@@ -166,6 +166,31 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
   }
 }
 
+// Second stage of a split-K linear: out = epilogue( sum_s part[s] ) with the GEMM's full epilogue (bias, ReLU, gate mask,
+// fp32 residual, fp32 / bf16 outputs).  Fixed summation order -> deterministic.  Used for mid-size M (e.g. one
+// 128-frame IDM window), where the 256 x 128 tiling alone would put only N/128 workgroups on 256 CUs.
+__global__ __launch_bounds__(256) void vpt_splitk_epilogue_kernel(const float* __restrict__ part, int splitk, VptGemmArgs a) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)a.M * a.N;
+  if (i >= total) return;
+  const int row = (int)(i / a.N), col = (int)(i - (long)row * a.N);
+  float v = 0.f;
+  for (int sp = 0; sp < splitk; ++sp) v += part[(size_t)sp * total + i];
+  if (a.bias) v += a.bias[col];
+  if (a.relu) v = fmaxf(v, 0.f);
+  if (a.mask && !((float)a.mask[(size_t)row * a.ldm + col] > 0.f)) v = 0.f;
+  if (a.res) v += a.res[(size_t)row * a.ldr + col];
+  if (a.out_f32) a.out_f32[(size_t)row * a.ldc + col] = v;
+  if (a.out_bf16) a.out_bf16[(size_t)row * a.ldcb + col] = (vpt_bf16)v;
+}
+
+extern "C" int vpt_splitk_epilogue_launch(const float* part, int splitk, const VptGemmArgs* a, hipStream_t stream) {
+  if (a->M <= 0 || a->N <= 0 || splitk < 1 || !part) return -1;
+  const long total = (long)a->M * a->N;
+  hipLaunchKernelGGL(vpt_splitk_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, part, splitk, *a);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 extern "C" int vpt_gemv_launch(const VptGemmArgs* a, hipStream_t stream);
 
 extern "C" int vpt_gemm_launch(const VptGemmArgs* a, hipStream_t stream) {

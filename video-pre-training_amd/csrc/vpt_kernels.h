@@ -232,6 +232,7 @@ int vpt_affine_bwd_launch(const VptAffineBwdArgs* a, int pass, hipStream_t s);
 int vpt_pool_bwd_launch(const VptPoolBwdArgs* a, hipStream_t s);
 int vpt_conv_bwd_prep_launch(const VptConvBwdPrepArgs* a, hipStream_t s);
 int vpt_conv_first_bwd_launch(const VptConvFirstBwdArgs* a, hipStream_t s);
+int vpt_splitk_epilogue_launch(const float* part, int splitk, const VptGemmArgs* a, hipStream_t s);
 int vpt_camera_codec_launch(int decode, const void* in, void* out, long n, double maxval, double binsize, double mu, int mu_law, hipStream_t s);
 int vpt_action_mapping_launch(int to_factored, const long* a, const long* b, long* oa, long* ob, long n, int n_camera_bins, hipStream_t s);
 int vpt_conv_wgrad_groups(int frames, int Cin, int Cout);

@@ -115,12 +115,30 @@ def linear(a_bf16, wpk, n, bias=None, res=None, relu=False, out_f32=True, out_bf
     _chk(res, torch.float32, "res"); _chk(mask, torch.bfloat16, "mask")
     m, k = a_bf16.shape
     dev = a_bf16.device
+    ld16 = (out_bf16_ld or n) if out_bf16 else n
+    # Mid-size M (e.g. one 128-frame IDM window): the 256 x 128 tiling alone gives N/128 workgroups for 256 CUs, so cut K
+    # as well and finish with the epilogue kernel (fixed summation order: deterministic).
+    auto_sk = 1
+    if splitk == 1 and 8 < m <= 512 and k >= 2048:
+        tiles = ((m + 255) // 256) * ((n + 127) // 128)
+        if tiles < 128:
+            auto_sk = max(1, min(16, k // 512, 256 // tiles))
+    if auto_sk > 1:
+        part = torch.zeros(auto_sk, m, n, dtype=torch.float32, device=dev)
+        _call("vpt_linear_forward", dict(flops=2.0 * m * n * k, bytes=2.0 * (m * k + n * k) + 4.0 * m * n), ptr(a_bf16), ptr(wpk), None, None, ptr(part), None,
+              m, n, k, k, n, n, n, 0, auto_sk, None, 0, _stream())
+        o32 = torch.empty(m, n, dtype=torch.float32, device=dev) if out_f32 else None
+        o16 = None
+        if out_bf16:
+            o16 = torch.zeros(m, ld16, dtype=torch.bfloat16, device=dev) if ld16 > n else torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+        _call("vpt_linear_splitk_epilogue", dict(bytes=4.0 * (auto_sk + 1) * m * n), ptr(part), auto_sk, ptr(bias), ptr(res), ptr(o32), ptr(o16),
+              m, n, n, n, ld16, 1 if relu else 0, ptr(mask), mask.shape[1] if mask is not None else 0, _stream())
+        return o32, o16
     o32 = None
     if out_f32:   # split-K: one [m, n] slice per split (zeroed: a split without k-steps writes nothing), summed below
         o32 = torch.zeros(splitk, m, n, dtype=torch.float32, device=dev) if splitk > 1 else torch.empty(m, n, dtype=torch.float32, device=dev)
-    o16, ld16 = None, n
+    o16 = None
     if out_bf16:
-        ld16 = out_bf16_ld or n
         o16 = torch.zeros(m, ld16, dtype=torch.bfloat16, device=dev) if ld16 > n else torch.empty(m, n, dtype=torch.bfloat16, device=dev)
     _call("vpt_linear_forward", dict(flops=2.0 * m * n * k, bytes=2.0 * (m * k + n * k) + 4.0 * m * n), ptr(a_bf16), ptr(wpk), ptr(bias), ptr(res), ptr(o32), ptr(o16),
           m, n, k, k, n, n, ld16, 1 if relu else 0, splitk, ptr(mask), mask.shape[1] if mask is not None else 0, _stream())
