@@ -75,6 +75,11 @@ int vpt_linear_forward(const void* A, const void* wpk, const float* bias, const 
                        int lda, int ldr, int ldc, int ldcb, int relu, int splitk, const void* mask, int ldm,
                        void* stream);
 
+/* Weight gradient of a linear layer without transposed copies: dw[n][k] (+)= sum_m dy[m][n] * x[m][k]; dy bf16 [M][ldy],
+ * x bf16 [M][ldx] (both row-major over the M frames / tokens), dw fp32 [N][ldw]; N, K, ldy, ldx multiples of 8.
+ * Replaces autograd's dW = dY^T X for every nn.Linear of the BC step (behavioural_cloning.py:117-119). */
+int vpt_linear_wgrad(const void* dy, const void* x, float* dw, int M, int N, int K, int ldy, int ldx, int ldw, int accumulate, void* stream);
+
 /* Second stage of a split-K linear: out = epilogue(sum_s part[s][M][N]) with the same epilogue options as
  * vpt_linear_forward (part = the [splitk][M][N] buffer a vpt_linear_forward call with splitk > 1 filled). */
 int vpt_linear_splitk_epilogue(const float* part, int splitk, const float* bias, const float* res, float* out_f32, void* out_bf16,

@@ -255,3 +255,18 @@ def test_adam_step_matches_torch():
     ops.adam_step_(p3, gsum * 0.125, m3, v3, 1, lr=1e-3)
     torch.cuda.synchronize()
     assert torch.allclose(p2, p3, atol=1e-7)
+
+
+@pytest.mark.parametrize("m,n,k,accumulate", [(300, 256, 192, False), (1000, 8768, 2048, False), (64, 65536, 256, True), (8192, 2048, 2048, False)])
+def test_linear_wgrad_tn(m, n, k, accumulate):
+    """dW = dY^T X from the row-major activations (vpt_gemm_tn_kernel, LDS transpose reads) against torch."""
+    g = torch.Generator().manual_seed(9)
+    dy = torch.randn(m, n, generator=g).to(torch.bfloat16)
+    x = torch.randn(m, k, generator=g).to(torch.bfloat16)
+    ref = dy.float().t() @ x.float()
+    base = torch.randn(n, k, generator=g) if accumulate else None
+    out = ops.linear_wgrad(dy.to(DEV), x.to(DEV), n, out=base.to(DEV).clone() if accumulate else None)
+    torch.cuda.synchronize()
+    if accumulate:
+        ref = ref + base
+    assert _relerr(out.cpu(), ref) < 2e-3, _relerr(out.cpu(), ref)

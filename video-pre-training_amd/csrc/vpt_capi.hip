@@ -141,6 +141,13 @@ int vpt_linear_forward(const void* A, const void* wpk, const float* bias, const 
   CHECK_LAUNCH(vpt_gemm_launch(&a, (hipStream_t)stream), "vpt_linear_forward");
 }
 
+int vpt_linear_wgrad(const void* dy, const void* x, float* dw, int M, int N, int K, int ldy, int ldx, int ldw, int accumulate, void* stream) {
+  VptGemmTnArgs a;
+  a.A = (const vpt_bf16*)dy; a.B = (const vpt_bf16*)x; a.C = dw; a.M = M; a.N1 = N; a.N2 = K; a.lda = ldy; a.ldb = ldx; a.ldc = ldw;
+  a.accumulate = accumulate;
+  CHECK_LAUNCH(vpt_gemm_tn_launch(&a, (hipStream_t)stream), "vpt_linear_wgrad");
+}
+
 int vpt_linear_splitk_epilogue(const float* part, int splitk, const float* bias, const float* res, float* out_f32, void* out_bf16,
                                int M, int N, int ldr, int ldc, int ldcb, int relu, const void* mask, int ldm, void* stream) {
   VptGemmArgs a;

@@ -166,6 +166,127 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight-gradient GEMM in the "TN" form:  C[n1][n2] (+)= sum_m A[m][n1] * B[m][n2]  with A, B bf16 ROW-major over the
+// reduction index m (frames / tokens) -- exactly how dY [M][N] and X [M][K] lie in memory, so dW = dY^T X needs no
+// transposed copies of the activations.  The k-contiguous MFMA fragments come from gfx950's LDS transpose read
+// (ds_read_b64_tr_b16: 16 lanes read a [4 m][16 n] block of the row-major tile, each receives one column's 4 m's), the
+// trick of vpt_conv_wgrad.hip.  Tile 256 (n1) x 128 (n2), k-step 64 m-rows, 4 waves of 128 x 64, register-staged
+// prefetch; LDS row pitches 576 B / 320 B (= 16 banks mod 64: the four rows of a transpose read land on disjoint banks).
+#define TA_RS 576
+#define TA_BYTES (64 * TA_RS)   // 36864
+#define TB_RS 320
+#define TB_BYTES (64 * TB_RS)   // 20480
+typedef __attribute__((address_space(3))) bf16x4 gemm_lds_bf16x4;
+
+__device__ __forceinline__ bf16x8 tn_frag(const unsigned char* p, int row_stride) {   // 8 consecutive m of this lane's column
+  const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((gemm_lds_bf16x4*)(p));
+  const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((gemm_lds_bf16x4*)(p + 4 * row_stride));
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256, 2) void vpt_gemm_tn_kernel(VptGemmTnArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[TA_BYTES + TB_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int t1 = (a.N1 + 255) >> 8, t2 = (a.N2 + 127) >> 7;
+  int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int j2 = L % t2; L /= t2;
+  const int j1 = L;
+  const int c1 = j1 * 256, c2 = j2 * 128;
+  const int nsteps = (a.M + 63) >> 6;
+
+  // staging: A tile = 64 rows x 512 B = 2048 chunks of 16 B (8 per thread), B tile = 64 x 256 B = 1024 chunks (4 per thread)
+  u32x4 areg[8], breg[4];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  auto load = [&](int s) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int q = tid + 256 * i, r = q >> 5, c = (q & 31) * 8;
+      const int m = s * 64 + r, col = c1 + c;
+      areg[i] = (m < a.M && col < a.N1) ? *(const u32x4*)(a.A + (size_t)m * a.lda + col) : zero4;   // N1, N2 multiples of 8
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = tid + 256 * i, r = q >> 4, c = (q & 15) * 8;
+      const int m = s * 64 + r, col = c2 + c;
+      breg[i] = (m < a.M && col < a.N2) ? *(const u32x4*)(a.B + (size_t)m * a.ldb + col) : zero4;
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int q = tid + 256 * i;
+      *(u32x4*)(smem + (q >> 5) * TA_RS + (q & 31) * 16) = areg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = tid + 256 * i;
+      *(u32x4*)(smem + TA_BYTES + (q >> 4) * TB_RS + (q & 15) * 16) = breg[i];
+    }
+  };
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  // per-lane part of a fragment address: 16-lane group g reads m-rows 8*(g>>1) + (i>>2) (+4), columns 16*(g&1) + 4*(i&3)..+3
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int colb = (16 * (g16 & 1) + 4 * (i16 & 3)) * 2, rowl = 8 * (g16 >> 1) + (i16 >> 2);
+  const unsigned char* aL = smem + rowl * TA_RS + (wm * 128) * 2 + colb;
+  const unsigned char* bL = smem + TA_BYTES + rowl * TB_RS + (wn * 64) * 2 + colb;
+
+  load(0);
+  store();
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const bool more = s + 1 < nsteps;
+    if (more) load(s + 1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 af[4], bfr[2];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) af[m] = tn_frag(aL + kk * 16 * TA_RS + m * 64, TA_RS);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) bfr[n] = tn_frag(bL + kk * 16 * TB_RS + n * 64, TB_RS);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) store();
+    __syncthreads();
+  }
+  // epilogue: lane = column (n2), 16 rows (n1) per accumulator; optional accumulate into the existing output
+  const int rbase = c1 + wm * 128 + 4 * hi;
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int col = c2 + wn * 64 + n * 32 + l31;
+    if (col >= a.N2) continue;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      float* o = a.C + (size_t)(rbase + m * 32) * a.ldc + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        if (rbase + m * 32 + dr < a.N1) o[dr * a.ldc] = a.accumulate ? o[dr * a.ldc] + acc[m][n][r] : acc[m][n][r];
+      }
+    }
+  }
+}
+
+extern "C" int vpt_gemm_tn_launch(const VptGemmTnArgs* a, hipStream_t stream) {
+  if (a->M <= 0 || a->N1 <= 0 || a->N2 <= 0 || (a->N1 & 7) || (a->N2 & 7) || (a->lda & 7) || (a->ldb & 7)) return -1;
+  const long grid = (long)((a->N1 + 255) >> 8) * ((a->N2 + 127) >> 7);
+  if (grid > 0x7fffffffL) return -2;
+  hipLaunchKernelGGL(vpt_gemm_tn_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *a);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 // Second stage of a split-K linear: out = epilogue( sum_s part[s] ) with the GEMM's full epilogue (bias, ReLU, gate mask,
 // fp32 residual, fp32 / bf16 outputs).  Fixed summation order -> deterministic.  Used for mid-size M (e.g. one
 // 128-frame IDM window), where the 256 x 128 tiling alone would put only N/128 workgroups on 256 CUs.

@@ -74,6 +74,13 @@ struct VptGemmArgs {
   int ldm;
 };
 
+struct VptGemmTnArgs {     // C[n1][n2] (+)= sum_m A[m][n1] * B[m][n2]
+  const vpt_bf16* A;       // [M][lda]
+  const vpt_bf16* B;       // [M][ldb]
+  float* C;                // [N1][ldc]
+  int M, N1, N2, lda, ldb, ldc, accumulate;
+};
+
 struct VptLayerNormArgs {
   const float* x;          // [M][D]
   const float* gain;
@@ -232,6 +239,7 @@ int vpt_affine_bwd_launch(const VptAffineBwdArgs* a, int pass, hipStream_t s);
 int vpt_pool_bwd_launch(const VptPoolBwdArgs* a, hipStream_t s);
 int vpt_conv_bwd_prep_launch(const VptConvBwdPrepArgs* a, hipStream_t s);
 int vpt_conv_first_bwd_launch(const VptConvFirstBwdArgs* a, hipStream_t s);
+int vpt_gemm_tn_launch(const VptGemmTnArgs* a, hipStream_t s);
 int vpt_splitk_epilogue_launch(const float* part, int splitk, const VptGemmArgs* a, hipStream_t s);
 int vpt_camera_codec_launch(int decode, const void* in, void* out, long n, double maxval, double binsize, double mu, int mu_law, hipStream_t s);
 int vpt_action_mapping_launch(int to_factored, const long* a, const long* b, long* oa, long* ob, long n, int n_camera_bins, hipStream_t s);

@@ -147,6 +147,16 @@ def linear(a_bf16, wpk, n, bias=None, res=None, relu=False, out_f32=True, out_bf
     return o32, o16
 
 
+def linear_wgrad(dy16, x16, n, out=None):
+    """dW [n, K] fp32 = dy16[:, :n]^T @ x16 (sum over the M rows), straight from the row-major activations; added to `out` when given."""
+    _chk(dy16, torch.bfloat16, "dy"); _chk(x16, torch.bfloat16, "x"); _chk(out, torch.float32, "out")
+    m, k = x16.shape
+    assert dy16.shape[0] == m and n % 8 == 0 and k % 8 == 0
+    dw = out if out is not None else torch.empty(n, k, dtype=torch.float32, device=x16.device)
+    _call("vpt_linear_wgrad", dict(flops=2.0 * m * n * k), ptr(dy16), ptr(x16), ptr(dw), m, n, k, dy16.shape[1], k, k, 1 if out is not None else 0, _stream())
+    return dw
+
+
 def layernorm(x, gain, bias, relu_in=False, out_f32=False, out_bf16=True):
     _chk(x, torch.float32, "x"); _chk(gain, torch.float32, "gain"); _chk(bias, torch.float32, "bias")
     m, d = x.shape

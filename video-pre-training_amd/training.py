@@ -37,7 +37,7 @@ def linear_backward(dy16: torch.Tensor, n: int, x16: Optional[torch.Tensor], wei
     dy16: bf16 [M, Np] (Np >= n, Np % 64 == 0, padding zero); x16: bf16 [M, K]; weight fp32 [n, K].
     Returns (dx fp32 or None, dx bf16 or None, dW fp32 [n, K] or None).
     dgrad:  dx = dy W      -> GEMM(A = dy, weights = W^T packed), optional ReLU gate `mask` and skip-sum `res`;
-    wgrad:  dW = dy^T x    -> GEMM(A = dy^T [n, M], weights = x^T packed), reduction over the M frames."""
+    wgrad:  dW = dy^T x    -> the TN GEMM (ops.linear_wgrad): both operands row-major over the M frames, no transposes."""
     m, np_ = dy16.shape
     k = weight.shape[1]
     dev = dy16.device
@@ -48,14 +48,8 @@ def linear_backward(dy16: torch.Tensor, n: int, x16: Optional[torch.Tensor], wei
         dx32, dx16 = ops.linear(dy16, packing.pack_linear(wt), k, res=res, mask=mask, out_f32=dx_f32,
                                 out_bf16=dx_bf16_ld is not None, out_bf16_ld=dx_bf16_ld)
         del wt
-    if need_dw:
-        mp = _round_up(m, 64)
-        a = torch.zeros(n, mp, dtype=torch.bfloat16, device=dev)
-        a[:, :m] = dy16[:, :n].t()
-        xt = torch.zeros(k, mp, dtype=torch.bfloat16, device=dev)
-        xt[:, :m] = x16.t()
-        dw, _ = ops.linear(a, packing.pack_linear(xt), k)
-        del a, xt
+    if need_dw:       # dW = dy^T x straight from the row-major activations (vpt_gemm_tn_kernel: LDS transpose reads, no copies)
+        dw = ops.linear_wgrad(dy16, x16, np_)[:n]
     return dx32, dx16, dw
 
 
@@ -355,13 +349,8 @@ class BCTrainer:
         dd16 = ops.gate_cast(dd, 256)
         _, dxn = ops.linear(dd16, acc["dense_wt"], k, out_f32=False, out_bf16=True)
         xn = ops.frame_affine(x_last, w[pd + "g"], w[pd + "b"], s_last, per_element=True)
-        fp = _round_up(f, 64)
-        xt = torch.zeros(k, fp, dtype=torch.bfloat16, device=dd.device)
-        xt[:, :f] = xn.view(f, k).t()
-        ddt = torch.zeros(256, fp, dtype=torch.bfloat16, device=dd.device)
-        ddt[:, :f] = dd16.t()
-        acc["dense_dwT"], _ = ops.linear(xt, packing.pack_linear(ddt), 256, res=acc["dense_dwT"])
-        del xt, xn, ddt
+        ops.linear_wgrad(xn.view(f, k), dd16, k, out=acc["dense_dwT"])      # dWd^T [K, 256] += xn^T dd
+        del xn
         dx = ops.frame_affine_backward(x_last, dxn.view_as(x_last), w[pd + "g"], s_last, acc["dense_dg"], acc["dense_db"], per_element=True)
         del dxn
         for s in reversed(range(len(cfg["chans"]))):
