@@ -21,14 +21,48 @@ def bf(t):
     return t.to(torch.bfloat16).float()
 
 
-def conv_fold(sd, pfx, x_bf, res=None):
+def f16(t):
+    return t.to(torch.float16).float()
+
+
+def bf_split(t):
+    """hi + lo bf16 halves (what a 2- or 3-pass split-operand MFMA sees): ~16 mantissa bits."""
+    hi = bf(t)
+    return hi + bf(t - hi)
+
+
+def f16_split(t):
+    hi = f16(t)
+    return hi + f16(t - hi)
+
+
+def exact(t):
+    return t
+
+
+ROUNDERS = {"fp32": exact, "bf16": bf, "fp16": f16, "bf16x2": bf_split, "fp16x2": f16_split}
+
+
+class Rounding:
+    """Where the pipeline rounds: MFMA weight operands (w), CNN activations as stored between kernels and fed to the
+    MFMAs (a), transformer-trunk GEMM operands / stored activations (t).  Default = what the bf16 kernels do."""
+
+    def __init__(self, w="bf16", a="bf16", t="bf16"):
+        self.names = (w, a, t)
+        self.w, self.a, self.t = ROUNDERS[w], ROUNDERS[a], ROUNDERS[t]
+
+
+DEFAULT_ROUNDING = Rounding()
+
+
+def conv_fold(sd, pfx, x_bf, res=None, rnd=DEFAULT_ROUNDING):
     """vpt_conv3x3_kernel: raw bf16 activations through conv(bf16(W*gain)), GroupNorm applied as the epilogue fold."""
     g, b, W = sd[pfx + "norm.weight"], sd[pfx + "norm.bias"], sd[pfx + "layer.weight"]
     n = x_bf.shape[0]
     flat = x_bf.reshape(n, -1)
     mu = flat.mean(1)
     rstd = torch.rsqrt(flat.var(1, unbiased=False) + O.NORM_EPS)
-    Wg = bf(W * g.view(1, -1, 1, 1))
+    Wg = rnd.w(W * g.view(1, -1, 1, 1))
     acc = F.conv2d(x_bf, Wg, padding=1)
     ones = torch.ones(1, x_bf.shape[1], *x_bf.shape[2:])
     sg = F.conv2d(ones, Wg, padding=1)
@@ -36,34 +70,35 @@ def conv_fold(sd, pfx, x_bf, res=None):
     out = torch.relu(rstd.view(-1, 1, 1, 1) * acc - (rstd * mu).view(-1, 1, 1, 1) * sg + sa)
     if res is not None:
         out = out + res
-    return bf(out)
+    return rnd.a(out)
 
 
-def policy_forward(sd, cfg, img_u8, first, state_in, grad=False, taps=None):
+def policy_forward(sd, cfg, img_u8, first, state_in, grad=False, taps=None, rnd=DEFAULT_ROUNDING):
+    bw, ba, bt = rnd.w, rnd.a, rnd.t
     with torch.set_grad_enabled(grad):
         b, t = img_u8.shape[:2]
         x = img_u8.reshape(b * t, 128, 128, 3).float().permute(0, 3, 1, 2)
         p = "net.img_process.cnn.stacks.0."
         # vpt_conv_first.hip: operands = raw bytes (exact in bf16) and bf16(W / 255); bias rides as hi + lo bf16 halves (~fp32)
-        y = torch.relu(F.conv2d(x, bf(sd[p + "firstconv.layer.weight"] / 255.0), padding=1) + sd[p + "firstconv.layer.bias"].view(1, -1, 1, 1))
+        y = torch.relu(F.conv2d(x, bw(sd[p + "firstconv.layer.weight"] / 255.0), padding=1) + sd[p + "firstconv.layer.bias"].view(1, -1, 1, 1))
         cur = None
         for s in range(3):
             p = f"net.img_process.cnn.stacks.{s}."
             if s > 0:
-                y = conv_fold(sd, p + "firstconv.", cur)
-            y = bf(F.max_pool2d(bf(y), 3, 2, 1))
-            cur = bf(O.group_norm_1(y, sd[p + "n.weight"], sd[p + "n.bias"]))
+                y = conv_fold(sd, p + "firstconv.", cur, rnd=rnd)
+            y = ba(F.max_pool2d(ba(y), 3, 2, 1))
+            cur = ba(O.group_norm_1(y, sd[p + "n.weight"], sd[p + "n.bias"]))
             for blk in range(2):
                 q = f"{p}blocks.{blk}."
-                h = conv_fold(sd, q + "conv0.", cur)
-                cur = conv_fold(sd, q + "conv1.", h, res=cur)
+                h = conv_fold(sd, q + "conv0.", cur, rnd=rnd)
+                cur = conv_fold(sd, q + "conv1.", h, res=cur, rnd=rnd)
         flat = cur.reshape(b * t, -1)
         p = "net.img_process.cnn.dense."
-        xn = bf(O.layer_norm(flat, sd[p + "norm.weight"], sd[p + "norm.bias"]))
-        d = xn @ bf(sd[p + "layer.weight"]).t()
+        xn = ba(O.layer_norm(flat, sd[p + "norm.weight"], sd[p + "norm.bias"]))
+        d = xn @ bw(sd[p + "layer.weight"]).t()
         p = "net.img_process.linear."
-        dn = bf(O.layer_norm(torch.relu(d), sd[p + "norm.weight"], sd[p + "norm.bias"]))
-        x = torch.relu(dn @ bf(sd[p + "layer.weight"]).t()).reshape(b, t, -1)
+        dn = bt(O.layer_norm(torch.relu(d), sd[p + "norm.weight"], sd[p + "norm.bias"]))
+        x = torch.relu(dn @ bw(sd[p + "layer.weight"]).t()).reshape(b, t, -1)
         if taps is not None:
             taps["img_process"] = x
         first_b = first[:, 0]
@@ -74,43 +109,45 @@ def policy_forward(sd, cfg, img_u8, first, state_in, grad=False, taps=None):
             p = f"net.recurrent_layer.blocks.{l}."
             o = p + "r.orc_block."
             x1 = O.layer_norm(x, sd[p + "pre_r_ln.weight"], sd[p + "pre_r_ln.bias"])
-            x1b = bf(x1)
+            x1b = bt(x1)
             sm, (km, vm) = state_in[l]
-            q = x1b @ bf(sd[o + "q_layer.weight"]).t() + sd[o + "q_layer.bias"]
-            k = x1b @ bf(sd[o + "k_layer.weight"]).t()
-            v = x1b @ bf(sd[o + "v_layer.weight"]).t()
-            r = x1b @ bf(sd[o + "r_layer.weight"]).t() + sd[o + "r_layer.bias"]
+            q = x1b @ bw(sd[o + "q_layer.weight"]).t() + sd[o + "q_layer.bias"]
+            k = x1b @ bw(sd[o + "k_layer.weight"]).t()
+            v = x1b @ bw(sd[o + "v_layer.weight"]).t()
+            r = x1b @ bw(sd[o + "r_layer.weight"]).t() + sd[o + "r_layer.bias"]
             kf, vf = torch.cat([km, k], 1), torch.cat([vm, v], 1)
             split = lambda z: z.reshape(b, z.shape[1], heads, dh).permute(0, 2, 1, 3)
             lg = split(q) @ split(kf).transpose(-1, -2) / dh
             vis, nm = O.band_visibility(t, maxlen, first_b, sm)
             lg = lg + (~vis).float().unsqueeze(1) * O.NEG_MASK + O.rel_pos_bias(r.reshape(b, t, heads, -1), sd[o + "b_nd"], t, maxlen)
-            a = bf((torch.softmax(lg, -1) @ split(vf)).permute(0, 2, 1, 3).reshape(b, t, hid))
-            x2 = x1 + a @ bf(sd[o + "proj_layer.weight"]).t() + sd[o + "proj_layer.bias"]
-            hb = bf(O.layer_norm(x2, sd[p + "mlp0.norm.weight"], sd[p + "mlp0.norm.bias"]))
-            h2 = bf(torch.relu(hb @ bf(sd[p + "mlp0.layer.weight"]).t()))
-            x = x2 + h2 @ bf(sd[p + "mlp1.layer.weight"]).t() + sd[p + "mlp1.layer.bias"]
+            a = bt((torch.softmax(lg, -1) @ split(vf)).permute(0, 2, 1, 3).reshape(b, t, hid))
+            x2 = x1 + a @ bw(sd[o + "proj_layer.weight"]).t() + sd[o + "proj_layer.bias"]
+            hb = bt(O.layer_norm(x2, sd[p + "mlp0.norm.weight"], sd[p + "mlp0.norm.bias"]))
+            h2 = bt(torch.relu(hb @ bw(sd[p + "mlp0.layer.weight"]).t()))
+            x = x2 + h2 @ bw(sd[p + "mlp1.layer.weight"]).t() + sd[p + "mlp1.layer.bias"]
             state_out.append((nm, (kf[:, -maxlen:], vf[:, -maxlen:])))
             if taps is not None:
                 taps[f"block{l}"] = x
-        xb = bf(O.layer_norm(torch.relu(x), sd["net.lastlayer.norm.weight"], sd["net.lastlayer.norm.bias"]))
-        y = torch.relu(xb @ bf(sd["net.lastlayer.layer.weight"]).t())
+        xb = bt(O.layer_norm(torch.relu(x), sd["net.lastlayer.norm.weight"], sd["net.lastlayer.norm.bias"]))
+        y = torch.relu(xb @ bw(sd["net.lastlayer.layer.weight"]).t())
         if taps is not None:
             taps["y"] = y
         lat = O.layer_norm(y, sd["net.final_ln.weight"], sd["net.final_ln.bias"])
-        latb = bf(lat)
-        out = {"latent": lat, "state_out": state_out}
+        latb = bt(lat)
+        out = {"latent": lat, "state_out": state_out,
+               # value head: column 8762 of the fused heads GEMM (same operand rounding as the policy heads)
+               "vpred": latb @ bw(sd["value_head.linear.weight"]).t() + sd["value_head.linear.bias"]}
         for hname in ("buttons", "camera"):
-            z = latb @ bf(sd[f"pi_head.{hname}.linear_layer.weight"]).t() + sd[f"pi_head.{hname}.linear_layer.bias"]
+            z = latb @ bw(sd[f"pi_head.{hname}.linear_layer.weight"]).t() + sd[f"pi_head.{hname}.linear_layer.bias"]
             out[hname] = torch.log_softmax(z / cfg["temperature"], -1).unsqueeze(-2)
         return out
 
 
-def bc_loss_and_grads(sd, cfg, img_u8, first, state_in, act_buttons, act_camera):
+def bc_loss_and_grads(sd, cfg, img_u8, first, state_in, act_buttons, act_camera, rnd=DEFAULT_ROUNDING):
     """As vpt_oracle.bc_loss_and_grads, through the bf16-emulating forward."""
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point}
     state_det = [(m, (k.detach(), v.detach())) for m, (k, v) in state_in]
-    out = policy_forward(leaves, cfg, img_u8, first, state_det, grad=True)
+    out = policy_forward(leaves, cfg, img_u8, first, state_det, grad=True, rnd=rnd)
     lp = out["buttons"][:, :, 0].gather(-1, act_buttons.unsqueeze(-1)).squeeze(-1) \
         + out["camera"][:, :, 0].gather(-1, act_camera.unsqueeze(-1)).squeeze(-1)
     loss = -lp.mean()

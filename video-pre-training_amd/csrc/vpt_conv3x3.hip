@@ -36,7 +36,7 @@
 #define B_BYTES (3 * 128 * 64)          // 24576 per buffer (unpadded, swizzled)
 #define KK_OFF (A_BYTES + 2 * B_BYTES)  // 75072
 #define KK_BYTES (9 * 128 * 4)          // 4608
-#define SMEM_BYTES (KK_OFF + KK_BYTES + 32)  // 79712 (+32: block stats reduction)
+#define SMEM_BYTES (KK_OFF + KK_BYTES + 48)  // 79728 (+32: block stats reduction, +16: priority flag)
 // epilogue staging (overlays the halo / weight buffers after the last step): per wave [res|out tile][xin tile], each
 // 2 channel blocks x 32 pixels x 64 B at an 80-byte pixel pitch (16-byte aligned rows, <= 2-way conflicts on the 8-byte side)
 #define ST_RS 80
@@ -48,21 +48,30 @@
 // 4..11 so that each 16-lane ds_read_b128 group {0-3,12-15,20-27} / {4-11,16-19,28-31} stays in one image row.
 __device__ __forceinline__ int sub_row(int i) { return ((i >> 4) ^ (i >> 2) ^ (i >> 3)) & 1; }
 
+// One word per CU (key = XCC id | SE | SH | CU from the hardware id registers): 1 while a high-priority workgroup is resident.
+// Speed only -- results never depend on it (experiment switch VPT_CONV_PRIO, off by default).
+__device__ int vpt_conv_cu_prio[4096];
+
+// COUNTED: the wait in front of each step's barrier is a counted s_waitcnt that retires the weight DMA only and leaves the
+// younger halo / residual prefetch loads in flight across the barrier (a plain __syncthreads() drains vmcnt to 0 because an
+// LDS-DMA is pending).
 template <bool COUNTED>
 __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
+  int prio_key = -1;
+  long long t_trace[3];
+  if (a.trace && tid == 0) t_trace[0] = wall_clock64();
+  if ((a.prio_level > 0 || a.trace) && tid == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID: cu_id[11:8] sh_id[12] se_id[15:13]
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_REG_XCC_ID[3:0]
+    prio_key = (int)(((xcc & 15u) << 8) | ((hw >> 8) & 0xffu));
+    *(int*)(smem + KK_OFF + KK_BYTES + 32) = (a.prio_level > 0 && atomicCAS(&vpt_conv_cu_prio[prio_key], 0, 1) == 0) ? 1 : 0;
+  }
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;
   const int hi = lane >> 5, l31 = lane & 31;
 
-  // De-phase the two workgroups that share a CU: the second wave of resident workgroups (blocks 256..511 with
-  // 2 per CU on 256 CUs) starts half a tile later, and every later workgroup inherits the phase of the slot it
-  // fills -- so one half of the chip is in its HBM-bound prologue/epilogue while the other half issues MFMAs.
-  if (a.stagger_ticks > 0 && blockIdx.x >= a.stagger_first && blockIdx.x < 2 * a.stagger_first) {
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < a.stagger_ticks) __builtin_amdgcn_s_sleep(64);
-  }
   const int tilesX = a.W >> 4, tilesY = a.H >> 4;
   int L = xcd_remap(blockIdx.x, gridDim.x);
   const int nt = L % a.NT; L /= a.NT;
@@ -72,28 +81,28 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   const int tx0 = tx * 16, ty0 = ty * 16;
   const int NCB = a.Cin >> 5;
   const int HW = a.H * a.W;
-  const int nsteps = NCB * 3;
 
   // ---- halo staging map: chunk q -> (pixel P = 8*(q>>5) + (q&7), part = (q>>3)&3) ----
-  int a_goff[6], a_loff[6];
+  int a_loff[6];            // LDS byte offset, -1: no chunk (beyond the 324 halo pixels)
+  unsigned a_gbyte[6];      // byte offset inside one channel-block plane (clamped to 0 outside the image)
+  unsigned a_inside = 0;    // bit m: chunk m lies inside the image (else literal zeros: the conv pads the NORMALISED tensor)
 #pragma unroll
   for (int m = 0; m < 6; ++m) {
     const int q = tid + 256 * m;
     const int P = ((q >> 5) << 3) + (q & 7), part = (q >> 3) & 3;
+    a_loff[m] = -1;
+    a_gbyte[m] = 0u;
     if (P < 324) {
       const int hy = P / 18, hx = P - hy * 18;
       const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
       a_loff[m] = P * A_RS + part * 16;
-      a_goff[m] = (y >= 0 && y < a.H && x >= 0 && x < a.W) ? (y * a.W + x) * 32 + part * 8 : -1;
-    } else {
-      a_loff[m] = -1;
-      a_goff[m] = -1;
+      if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
+        a_gbyte[m] = (unsigned)((y * a.W + x) * 32 + part * 8) * 2u;
+        a_inside |= 1u << m;
+      }
     }
   }
   const bf16_t* xplane = a.x + (size_t)f * NCB * HW * 32;
-  unsigned a_gbyte[6];  // clamped byte offset inside one channel block (32-bit: scalar base + vector offset loads)
-#pragma unroll
-  for (int m = 0; m < 6; ++m) a_gbyte[m] = (a_goff[m] >= 0) ? (unsigned)a_goff[m] * 2u : 0u;
   // weight DMA: wave w moves pieces (4*m + w), m = 0..5, of the 24 KB step tile; lane = 16-byte chunk
   const bf16_t* wbase = a.wpk + (size_t)nt * NCB * 9 * 4096 + (size_t)(w * 64 + lane) * 8;
   unsigned char* bdst = smem + A_BYTES + w * 1024;
@@ -137,10 +146,13 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
       if (idx < 9 * 128) kk[idx] = ksa[k] - rstd * mean * ksg[k];
     }
   }
-#pragma unroll
-  for (int m = 0; m < 6; ++m)
-    if (a_loff[m] >= 0) *(u32x4*)(smem + a_loff[m]) = (a_goff[m] >= 0) ? areg[m] : zero4;
+#define WRITE_HALO()                                                                                      \
+  _Pragma("unroll") for (int m_ = 0; m_ < 6; ++m_)                                                        \
+    if (a_loff[m_] >= 0) *(u32x4*)(smem + a_loff[m_]) = ((a_inside >> m_) & 1u) ? areg[m_] : zero4
+  WRITE_HALO();
   __syncthreads();
+  const int high_prio = a.prio_level > 0 ? __builtin_amdgcn_readfirstlane(*(const int*)(smem + KK_OFF + KK_BYTES + 32)) : 0;
+  if (high_prio) __builtin_amdgcn_s_setprio(2);
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -156,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   const unsigned char* bL0 = smem + A_BYTES + (wn * 64 + l31) * 64 + (((0 + hi) ^ bsw) << 4);  // ks = 0
   const unsigned char* bL1 = smem + A_BYTES + (wn * 64 + l31) * 64 + (((2 + hi) ^ bsw) << 4);  // ks = 1
 
-  // epilogue addressing (needed early: the residual is requested at the start of the last channel block)
+  // epilogue addressing (needed early: the residual is requested during the last channel block)
   const int CB_out = a.Cout >> 5;
   const int cb0 = nt * 4 + wn * 2;                 // 32-channel block of n2 = 0
   const bool nvalid[2] = {(cb0 + 0) < CB_out, (cb0 + 1) < CB_out};
@@ -168,28 +180,68 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   // residual / output traffic of the K = 1152 layers was waiting for.
   const int cq = lane >> 2, cchunk = lane & 3;         // staging role: pixel column of the 2x16 patch, 16-byte chunk
   int st_lds[2];                                      // LDS offset of (patch row j2, column cq) in l31 order
-  size_t goff[4][2];                                  // global element offset of (m, j2) for channel block cb0
+  size_t goff0[2];                                    // global element offset of (m = 0, j2) for channel block cb0
+  const size_t gm = (size_t)(2 * a.W) * 32;           // + m * gm: two image rows further down
 #pragma unroll
   for (int j2 = 0; j2 < 2; ++j2) {
     const int l31q = cq + 16 * ((j2 ^ (cq >> 2) ^ (cq >> 3)) & 1);   // inverse of sub_row(): lane that owns this pixel
     st_lds[j2] = l31q * ST_RS + cchunk * 16;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int y = ty0 + wm * 8 + 2 * m + j2, x = tx0 + cq;
-      goff[m][j2] = ((size_t)(f * CB_out + (nvalid[0] ? cb0 : 0)) * HW + (size_t)(y * a.W + x)) * 32 + cchunk * 8;
-    }
+    const int y = ty0 + wm * 8 + j2, x = tx0 + cq;
+    goff0[j2] = ((size_t)(f * CB_out + (nvalid[0] ? cb0 : 0)) * HW + (size_t)(y * a.W + x)) * 32 + cchunk * 8;
   }
   const int ll_lds = l31 * ST_RS + 8 * hi;             // lane-local: + n2 * ST_N2 + 16 * g
   unsigned char* stg = smem + w * ST_WAVE;             // [residual / output tile][xin tile], reused for every m
   u32x4 rq[4][2][2];
+#define LOAD_RES(m_)                                                                                      \
+  _Pragma("unroll") for (int n2_ = 0; n2_ < 2; ++n2_)                                                     \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                      \
+      rq[m_][n2_][j_] = *(const u32x4*)(a.res + goff0[j_] + (m_) * gm + (nvalid[n2_] ? n2_ : 0) * nstep)
 
-  // One K step = one kernel row (3 taps) of one 32-channel block: 48 MFMAs per wave, one barrier.
-  // Memory ops are issued in a FIXED order and count per wave -- weight DMA (6), then either the halo of the
-  // next block (6, PRE_A) or the residual (16, PRE_R) -- so the wait before the barrier can be COUNTED:
-  // vmcnt(N_LATE) retires this step's weight DMA (needed by the next step) while the N_LATE younger loads stay
-  // in flight across the barrier and get a second step of MFMAs as cover (a plain __syncthreads() drains
-  // vmcnt to 0 at every barrier because an LDS-DMA is pending).  Every load is unconditional (clamped address
-  // + select) so that the count is exact.
+  // ---- main loop ----------------------------------------------------------------------------------------------------
+  // One K step = one kernel row (3 taps) of one 32-channel block = 6 groups (tap dx, 16-channel half ks) of 8 MFMAs per
+  // wave.  Round-1 profile: 55 % of the wave cycles were SQ_WAIT_INST_ANY -- every group read its six fragments into the
+  // registers the previous group's MFMAs had just released and then waited lgkmcnt(0), so the matrix pipe drained for one
+  // LDS round trip per 8 MFMAs (one workgroup per CU alone reached 85 % of two).  Now the schedule is explicit, one
+  // instruction pair at a time, pinned with sched_barrier (left alone, the scheduler sinks every fragment read next to
+  // its first use to save registers):
+  //   - two fragment register sets; while group g's MFMAs issue, the fragments of group g+1 are requested, one
+  //     pair of ds_read_b128 behind each of the first three MFMAs, in the order the next group consumes them;
+  //   - the two remaining slots of each group carry the step's global traffic: the weight DMA of the next step
+  //     (6 x global_load_lds, groups 0-2) and the halo of the next channel block / the residual (groups 3-4), so no
+  //     MFMA ever queues behind a burst of memory instructions;
+  //   - the step's barrier sits in front of the LAST group's MFMAs: every wave then holds its last fragments of the
+  //     step in registers, the next step's weights (requested >= 24 MFMAs earlier) have landed, so the next step's
+  //     first fragments are requested behind the barrier and arrive under group 5's MFMAs.
+  bf16x8 fa[2][4], fb[2][2];
+  const bf16_t* resp = a.res ? a.res : a.y;   // no residual: the prefetch still runs (exact counted waits), result unused
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define MM(set_, m_, n_) acc[m_][n_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set_][n_], fa[set_][m_], acc[m_][n_], 0, 0, 0)
+#define FA_LD(set_, dy_, g_, m_) \
+  fa[set_][m_] = *(const bf16x8*)(aL + ((dy_) * 18 + ((g_) >> 1)) * A_RS + (m_) * (2 * 18 * A_RS) + ((g_) & 1) * 32)
+#define FB_LD(set_, g_, n_, boff_) \
+  fb[set_][n_] = *(const bf16x8*)((((g_) & 1) ? bL1 : bL0) + (boff_) + ((g_) >> 1) * (128 * 64) + (n_) * (32 * 64))
+  // MFMAs of register set `set_`; fragments of group (ndy_, ng_) go to the other set; X0 / X1: the two free slots
+#define GROUP(set_, ndy_, ng_, nboff_, X0, X1)                                                            \
+  do {                                                                                                    \
+    MM(set_, 0, 0); FB_LD(1 - (set_), ng_, 0, nboff_); FA_LD(1 - (set_), ndy_, ng_, 0); SB();             \
+    MM(set_, 0, 1); FB_LD(1 - (set_), ng_, 1, nboff_); FA_LD(1 - (set_), ndy_, ng_, 1); SB();             \
+    MM(set_, 1, 0); FA_LD(1 - (set_), ndy_, ng_, 2); FA_LD(1 - (set_), ndy_, ng_, 3); SB();               \
+    MM(set_, 1, 1); SB();                                                                                 \
+    MM(set_, 2, 0); X0; SB();                                                                             \
+    MM(set_, 2, 1); SB();                                                                                 \
+    MM(set_, 3, 0); X1; SB();                                                                             \
+    MM(set_, 3, 1); SB();                                                                                 \
+  } while (0)
+#define GROUP_TAIL(set_)                                                                                  \
+  do {                                                                                                    \
+    _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_) { MM(set_, m_, 0); MM(set_, m_, 1); }                \
+  } while (0)
+#define GLDS(m_)                                                                                          \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp_ + (m_) * 2048),    \
+                                   (__attribute__((address_space(3))) void*)(bd_ + (m_) * 4096), 16, 0, 0)
+#define XA(m_) areg[m_] = *(const u32x4*)((const char*)xplane + (cbo_ + a_gbyte[m_]))
+#define XR(m_, n2_, j_) rq[m_][n2_][j_] = *(const u32x4*)(resp + goff0[j_] + (m_) * gm + (nvalid[n2_] ? n2_ : 0) * nstep)
+#define NOP_() ((void)0)
 #define WAIT_BARRIER(n_late_)                                                                             \
   do {                                                                                                    \
     if constexpr (COUNTED) {                                                                              \
@@ -199,64 +251,87 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     } else {                                                                                              \
       __syncthreads();                                                                                    \
     }                                                                                                     \
+    SB();                                                                                                 \
   } while (0)
-#define CONV_STEP(cb_, dy_, PRE_A, WR_A, PRE_R)                                                           \
+  // Memory ops are issued in a FIXED order and count per wave -- weight DMA (6), then either the halo of the next block
+  // (6, PRE_A) or the residual of subtiles 0 / 1 (8, PRE_R) -- so the counted wait in front of the barrier is exact: it
+  // retires the DMA and leaves the younger loads in flight across the barrier.
+#define CONV_STEP(cb_, dy_, NEXT_DY, PRE_A, WR_A, PRE_R, LAST)                                            \
   do {                                                                                                    \
     const int s_ = (cb_) * 3 + (dy_);                                                                     \
-    const int buf_ = s_ & 1;                                                                              \
-    if (s_ + 1 < nsteps) ISSUE_B(s_ + 1, buf_ ^ 1);                                                       \
+    const int boff_ = (s_ & 1) * B_BYTES, noff_ = B_BYTES - boff_;                                        \
+    const bf16_t* wp_ = wbase + (size_t)(s_ + 1) * 12288;                                                 \
+    unsigned char* bd_ = bdst + noff_;                                                                    \
+    const unsigned cbo_ = (unsigned)((cb_) + 1) * (unsigned)HW * 64u; /* bytes; uniform */                \
+    if (LAST) {                                                                                           \
+      GROUP(0, dy_, 1, boff_, NOP_(), NOP_());                                                            \
+      GROUP(1, dy_, 2, boff_, NOP_(), NOP_());                                                            \
+      GROUP(0, dy_, 3, boff_, NOP_(), NOP_());                                                            \
+    } else {                                                                                              \
+      GROUP(0, dy_, 1, boff_, GLDS(0), GLDS(1));                                                          \
+      GROUP(1, dy_, 2, boff_, GLDS(2), GLDS(3));                                                          \
+      GROUP(0, dy_, 3, boff_, GLDS(4), GLDS(5));                                                          \
+    }                                                                                                     \
     if (PRE_A) {                                                                                          \
-      const unsigned cbo_ = (unsigned)((cb_) + 1) * (unsigned)HW * 64u; /* bytes; uniform */              \
-      _Pragma("unroll") for (int m_ = 0; m_ < 6; ++m_)                                                    \
-        areg[m_] = *(const u32x4*)((const char*)xplane + (cbo_ + a_gbyte[m_]));                           \
-    }                                                                                                     \
-    if ((PRE_R) && a.res) {                                                                               \
-      _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                                    \
-        _Pragma("unroll") for (int n2_ = 0; n2_ < 2; ++n2_)                                               \
-          _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                \
-            rq[m_][n2_][j_] = *(const u32x4*)(a.res + goff[m_][j_] + (nvalid[n2_] ? n2_ : 0) * nstep);    \
-    }                                                                                                     \
-    const unsigned char* bB0_ = bL0 + buf_ * B_BYTES;                                                     \
-    const unsigned char* bB1_ = bL1 + buf_ * B_BYTES;                                                     \
-    _Pragma("unroll") for (int dx_ = 0; dx_ < 3; ++dx_) {                                                 \
-      _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                               \
-        bf16x8 fa_[4], fb_[2];                                                                            \
-        _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                                  \
-          fa_[m_] = *(const bf16x8*)(aL + ((dy_) * 18 + dx_) * A_RS + m_ * (2 * 18 * A_RS) + ks_ * 32);   \
-        _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_)                                                  \
-          fb_[n_] = *(const bf16x8*)((ks_ ? bB1_ : bB0_) + dx_ * (128 * 64) + n_ * (32 * 64));            \
-        if (a.ablate & 64) __builtin_amdgcn_s_setprio(1);                                                 \
-        _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                                  \
-          _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_)                                                \
-            acc[m_][n_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb_[n_], fa_[m_], acc[m_][n_], 0, 0, 0); \
-        if (a.ablate & 64) __builtin_amdgcn_s_setprio(0);                                                 \
-      }                                                                                                   \
-    }                                                                                                     \
-    /* all waves done with the halo / B[buf]; this step's DMA into B[buf^1] has landed */                 \
-    if (PRE_A) WAIT_BARRIER(6); else if ((PRE_R) && a.res) WAIT_BARRIER(16); else WAIT_BARRIER(0);        \
-    if (WR_A) {                                                                                           \
-      _Pragma("unroll") for (int m_ = 0; m_ < 6; ++m_)                                                    \
-        if (a_loff[m_] >= 0) *(u32x4*)(smem + a_loff[m_]) = (a_goff[m_] >= 0) ? areg[m_] : zero4;         \
+      GROUP(1, dy_, 4, boff_, do { XA(0); XA(1); } while (0), do { XA(2); } while (0));                   \
+      GROUP(0, dy_, 5, boff_, do { XA(3); XA(4); } while (0), do { XA(5); } while (0));                   \
+      WAIT_BARRIER(6);                                                                                    \
+    } else if (PRE_R) {                                                                                   \
+      GROUP(1, dy_, 4, boff_, do { XR(0, 0, 0); XR(0, 0, 1); } while (0), do { XR(0, 1, 0); XR(0, 1, 1); } while (0)); \
+      GROUP(0, dy_, 5, boff_, do { XR(1, 0, 0); XR(1, 0, 1); } while (0), do { XR(1, 1, 0); XR(1, 1, 1); } while (0)); \
+      WAIT_BARRIER(8);                                                                                    \
+    } else {                                                                                              \
+      GROUP(1, dy_, 4, boff_, NOP_(), NOP_());                                                            \
+      GROUP(0, dy_, 5, boff_, NOP_(), NOP_());                                                            \
       WAIT_BARRIER(0);                                                                                    \
+    }                                                                                                     \
+    if (WR_A) {   /* the halo of the next channel block replaces the current one: second barrier before its first read */ \
+      _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_) {                                                  \
+        if (a_loff[m_] >= 0) *(u32x4*)(smem + a_loff[m_]) = ((a_inside >> m_) & 1u) ? areg[m_] : zero4;   \
+        if (m_ + 4 < 6 && a_loff[m_ + 4] >= 0) *(u32x4*)(smem + a_loff[m_ + 4]) = ((a_inside >> (m_ + 4)) & 1u) ? areg[m_ + 4] : zero4; \
+        SB(); MM(1, m_, 0); SB();                                                                         \
+      }                                                                                                   \
+      WAIT_BARRIER(0);                                                                                    \
+      MM(1, 0, 1); FB_LD(0, 0, 0, noff_); SB();                                                           \
+      MM(1, 1, 1); FA_LD(0, 0, 0, 0); SB();                                                               \
+      MM(1, 2, 1); FB_LD(0, 0, 1, noff_); FA_LD(0, 0, 0, 1); SB();                                        \
+      MM(1, 3, 1); FA_LD(0, 0, 0, 2); FA_LD(0, 0, 0, 3); SB();                                            \
+    } else if (LAST) {                                                                                    \
+      GROUP_TAIL(1);                                                                                      \
+    } else {                                                                                              \
+      GROUP(1, NEXT_DY, 0, noff_, NOP_(), NOP_());                                                        \
     }                                                                                                     \
   } while (0)
 
+  if (a.trace && tid == 0) t_trace[1] = wall_clock64();
   if (a.ablate != 2) {
+    FB_LD(0, 0, 0, 0); FA_LD(0, 0, 0, 0); FB_LD(0, 0, 1, 0); FA_LD(0, 0, 0, 1); FA_LD(0, 0, 0, 2); FA_LD(0, 0, 0, 3);
+    SB();
     for (int cb = 0; cb + 1 < NCB; ++cb) {
-      CONV_STEP(cb, 0, true, false, false);
-      CONV_STEP(cb, 1, false, false, false);
-      CONV_STEP(cb, 2, false, true, false);
+      CONV_STEP(cb, 0, 1, true, false, false, false);
+      CONV_STEP(cb, 1, 2, false, false, false, false);
+      CONV_STEP(cb, 2, 0, false, true, false, false);
     }
-    // last channel block: no further halo -> request the residual instead, two steps ahead of its use
-    CONV_STEP(NCB - 1, 0, false, false, true);
-    CONV_STEP(NCB - 1, 1, false, false, false);
-    CONV_STEP(NCB - 1, 2, false, false, false);
+    // last channel block: no further halo -> request the residual of the first two subtiles instead
+    CONV_STEP(NCB - 1, 0, 1, false, false, true, false);
+    CONV_STEP(NCB - 1, 1, 2, false, false, false, false);
+    CONV_STEP(NCB - 1, 2, 0, false, false, false, true);
+  } else {
+    __syncthreads();
   }
 #undef CONV_STEP
 #undef WAIT_BARRIER
-
+#undef GROUP
+#undef GROUP_TAIL
+#undef GLDS
+#undef XA
+#undef XR
+#undef MM
+#undef FA_LD
+#undef FB_LD
 
   // ---------------- epilogue ----------------
+  if (a.trace && tid == 0) t_trace[2] = wall_clock64();
   if (a.ablate == 1) {  // profiling: keep the accumulators live, skip the epilogue
     float t = 0.f;
 #pragma unroll
@@ -266,8 +341,15 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) t += acc[m][n][r];
     if (t == 12345.678f) a.y[0] = (vpt_bf16)t;
+    if (prio_key >= 0 && high_prio) atomicExch(&vpt_conv_cu_prio[prio_key], 0);
     return;
   }
+  // the fragment registers are dead: the residual of subtiles 2 / 3 travels while subtiles 0 / 1 are processed
+  if (a.res) {
+    if (a.ablate == 2) { LOAD_RES(0); LOAD_RES(1); }
+    LOAD_RES(2); LOAD_RES(3);
+  }
+  SB();
 
   // Operands are SWAPPED in the MFMA (weights = A rows, pixels = B columns), so a lane holds ONE pixel
   // (column l31 of the subtile) and, per accumulator, four groups of 4 consecutive output channels
@@ -292,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
 #pragma unroll
     for (int n2 = 0; n2 < 2; ++n2)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) xq[n2][j] = *(const u32x4*)(a.xin + goff[0][j] + (nvalid[n2] ? n2 : 0) * nstep);
+      for (int j = 0; j < 2; ++j) xq[n2][j] = *(const u32x4*)(a.xin + goff0[j] + (nvalid[n2] ? n2 : 0) * nstep);
   }
 
 #pragma unroll
@@ -309,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
 #pragma unroll
       for (int n2 = 0; n2 < 2; ++n2)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) xq[n2][j] = *(const u32x4*)(a.xin + goff[m + 1][j] + (nvalid[n2] ? n2 : 0) * nstep);
+        for (int j = 0; j < 2; ++j) xq[n2][j] = *(const u32x4*)(a.xin + goff0[j] + (m + 1) * gm + (nvalid[n2] ? n2 : 0) * nstep);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private tile: in-order LDS queue, no barrier needed
 #pragma unroll
@@ -345,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
       if (!nvalid[n2]) continue;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        *(u32x4*)(a.y + goff[m][j] + n2 * nstep) = *(const u32x4*)(stg + n2 * ST_N2 + st_lds[j]);
+        *(u32x4*)(a.y + goff0[j] + m * gm + n2 * nstep) = *(const u32x4*)(stg + n2 * ST_N2 + st_lds[j]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile is rewritten by the next subtile
   }
@@ -360,34 +442,42 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
       atomicAdd(a.stats_out + 2 * f + 1, (double)((red[4] + red[5]) + (red[6] + red[7])));
     }
   }
+  if (prio_key >= 0 && high_prio) atomicExch(&vpt_conv_cu_prio[prio_key], 0);
+  if (a.trace && tid == 0) {   // profiling (vpt_conv3x3_set_trace): 100 MHz timestamps of the tile's phases
+    long long* t = a.trace + (size_t)blockIdx.x * 6;
+    t[0] = t_trace[0]; t[1] = t_trace[1]; t[2] = t_trace[2]; t[3] = wall_clock64(); t[4] = prio_key; t[5] = high_prio;
+  }
 }
 
+static long long* g_conv_trace = nullptr;
+extern "C" void vpt_conv3x3_set_trace(void* buf) { g_conv_trace = (long long*)buf; }  // profiling: [grid][6] int64, or null
+
 extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream) {
-  static int ablate = -1, stagger_pct = 0, num_cu = 256;
+  static int ablate = -1, prio_level = 0, extra_lds = 0;
   if (ablate < 0) {
     const char* e = getenv("VPT_CONV_ABLATE");
     ablate = e ? atoi(e) : 0;
-    const char* g = getenv("VPT_CONV_STAGGER_PCT");  // start delay of the 2nd resident workgroup, % of the tile's MFMA time
-    stagger_pct = g ? atoi(g) : 0;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      num_cu = prop.multiProcessorCount;
+    const char* pr = getenv("VPT_CONV_PRIO");       // 0 = equal priorities, 1..3 = s_setprio level of the first workgroup on a CU
+    prio_level = pr ? atoi(pr) : 0;
+    const char* xl = getenv("VPT_CONV_EXTRA_LDS");  // profiling: dynamic LDS bytes (> 2 KB forces one workgroup per CU)
+    extra_lds = xl ? atoi(xl) : 0;
+    if (extra_lds > 0) {
+      hipFuncSetAttribute((const void*)vpt_conv3x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds);
+      hipFuncSetAttribute((const void*)vpt_conv3x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds);
+    }
   }
   VptConv3x3Args a_copy = *a_in;
   a_copy.ablate = ablate;
+  a_copy.prio_level = prio_level;
+  a_copy.trace = g_conv_trace;
   if (!a_copy.bwd && !a_copy.stats_in) return -1;
-  // one tile = (Cin/32)*3 steps of 48 MFMAs/wave, two waves per SIMD: ~ nsteps * 3072 cycles at ~2 GHz;
-  // wall_clock64 ticks at 100 MHz
-  a_copy.stagger_first = num_cu;
-  a_copy.stagger_ticks = (int)((long)(a_in->Cin / 32) * 3 * 3072 / 20 * stagger_pct / 100);
   const VptConv3x3Args* a = &a_copy;
   if ((a->H & 15) || (a->W & 15) || (a->Cin & 31) || (a->Cout & 31) || a->frames <= 0) return -1;
   const long grid = (long)a->frames * (a->H >> 4) * (a->W >> 4) * a->NT;
   if (grid > 0x7fffffffL) return -2;
   static int counted = -1;
   if (counted < 0) { const char* e = getenv("VPT_CONV_COUNTED"); counted = e ? atoi(e) : 0; }
-  if (counted) hipLaunchKernelGGL(vpt_conv3x3_kernel<true>, dim3((unsigned)grid), dim3(256), 0, stream, *a);
-  else hipLaunchKernelGGL(vpt_conv3x3_kernel<false>, dim3((unsigned)grid), dim3(256), 0, stream, *a);
+  if (counted) hipLaunchKernelGGL(vpt_conv3x3_kernel<true>, dim3((unsigned)grid), dim3(256), extra_lds, stream, *a);
+  else hipLaunchKernelGGL(vpt_conv3x3_kernel<false>, dim3((unsigned)grid), dim3(256), extra_lds, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

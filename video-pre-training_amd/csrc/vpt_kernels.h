@@ -18,7 +18,8 @@ struct VptConv3x3Args {
   int frames, H, W, Cin, Cout, CoutPad, NT;
   double inv_count_in;     // 1 / (Cin*H*W)
   int ablate;              // profiling only (env VPT_CONV_ABLATE)
-  int stagger_first, stagger_ticks;  // de-phasing of co-resident workgroups (set by the launcher)
+  long long* trace;        // profiling only: per-workgroup phase timestamps (vpt_conv3x3_set_trace)
+  int prio_level;          // > 0: first workgroup on a CU runs at this s_setprio level (anti-phasing, set by the launcher)
   // dgrad mode (bwd != 0): no GroupNorm fold, no ReLU; out = conv + res + coef[f][0] + coef[f][1] * xin
   int bwd;
   const vpt_bf16* xin;     // the forward layer's input x (same shape as this call's output)
