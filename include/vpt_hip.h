@@ -25,6 +25,10 @@ extern "C" {
 
 /* Library / build identification: returns "vpt_hip <version> gfx950". */
 const char* vpt_version(void);
+/* "bf16" (libvpt_hip.so, the default) or "fp16" (libvpt_hip_f16.so: the same sources built with -DVPT_OPERAND_F16): the format
+ * of every 16-bit buffer this library reads or writes -- activations, packed weights, MFMA operands.  Same ABI, same
+ * MFMA rate; the fp16 build is the parity mode (8x finer operand rounding; lib/policy.py: precision="fp16"). */
+const char* vpt_operand_format(void);
 /* Human-readable reason for the most recent non-zero return on this thread. */
 const char* vpt_last_error(void);
 

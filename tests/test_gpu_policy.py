@@ -1,12 +1,9 @@
 """End-to-end parity of the HIP policy (through the reference's MinecraftAgentPolicy API) against the golden
-vectors of the live reference and against the oracle.  Needs an MI355X.
+vectors of the live reference and against the oracle, in BOTH precision modes.  Needs an MI355X.
 
-Tolerance: the conv / linear kernels take bf16 operands with fp32 accumulation; statistics, softmax, the
-residual stream of the transformer and the KV memory stay fp32.  A CPU emulation of exactly these rounding
-points predicts, for the synthetic 1x weights: log-prob relative-L2 error ~1e-3
-(max|d|/max|ref| ~4e-3) and ~3.5e-2 relative-L2 on the K/V memory (error grows ~0.15 %/layer through the 14
-normalised CNN layers).  Bounds used here: log-probs rel-L2 < 3e-3 and max|d|/max|ref| < 1e-2; K/V memory
-rel-L2 < 6e-2; masks exact."""
+What is gated and why is in tests/parity.py: log-probs as returned AND centred logits, latent, value (relative), KV
+memory, and exact deterministic actions outside the noise band.  precision="fp16" is held to the north star's 1e-3 on the
+log-probs; "bf16" (the benchmarked default) to bounds calibrated by the CPU emulator of its rounding points."""
 import numpy as np
 import pytest
 import torch
@@ -17,12 +14,9 @@ import vpt_amd  # noqa: E402,F401
 from vpt_amd.lib.policy import MinecraftAgentPolicy  # noqa: E402
 from vpt_amd.lib.types import minecraft_action_space  # noqa: E402
 from oracle import vpt_oracle as O  # noqa: E402
+from tests import parity as P  # noqa: E402
 
 DEV = "cuda"
-TOL = 1e-2      # max|d| / max|ref| on log-probs
-L2_TOL = 3e-3   # relative L2 on log-probs
-KV_TOL = 6e-2   # relative L2 on the K/V memory rows written by the chunk
-V_TOL = 0.25    # absolute, on the raw value-head output (std ~1.3 with the synthetic weights; latent rel. error ~3e-2)
 
 
 def _inputs(seed, b, t):
@@ -30,30 +24,30 @@ def _inputs(seed, b, t):
     return torch.randint(0, 256, (b, t, 128, 128, 3), generator=g, dtype=torch.uint8)
 
 
-@pytest.fixture(scope="module")
-def pol_1x():
+@pytest.fixture(scope="module", params=["bf16", "fp16"])
+def pol_1x(request):
     pk = O.policy_kwargs_for("1x")
     cfg = O.config_from_policy_kwargs(pk, dict(temperature=2.0))
     sd = O.synthetic_state_dict(cfg, seed=0)
-    pol = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0))
+    pol = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0), precision=request.param)
     pol.load_state_dict(sd, strict=False)
     return pol.to(DEV), cfg, sd
 
 
 def _rel(a, ref):
-    return float(np.abs(a - ref).max() / np.abs(ref).max())
+    return P.rel_max(a, ref)
 
 
 def _l2(a, ref):
-    return float(np.linalg.norm((a - ref).ravel()) / max(np.linalg.norm(ref.ravel()), 1e-30))
+    return P.rel_l2(a, ref)
 
 
 def test_policy_chunks_vs_golden(pol_1x, golden_1x):
     pol, cfg, sd = pol_1x
+    mode, B = pol.precision, P.BOUNDS[pol.precision]
     G = golden_1x
     b = 2
     state = pol.initial_state(b)
-    report = {}
     for tag, t, first0 in [("A", 4, [False, True]), ("B", 3, [False, False]), ("C", 1, [False, False])]:
         img = _inputs(100 + ord(tag), b, t)
         first = torch.zeros(b, t, dtype=torch.bool)
@@ -62,26 +56,55 @@ def test_policy_chunks_vs_golden(pol_1x, golden_1x):
         torch.cuda.synchronize()
         assert pd["buttons"].shape == (b, t, 1, 8641) and pd["camera"].shape == (b, t, 1, 121) and vpred.shape == (b, t, 1)
         assert list(pd.keys()) == ["camera", "buttons"]
-        report[tag] = (_rel(pd["buttons"].cpu().numpy(), G[f"{tag}_buttons"]), _rel(pd["camera"].cpu().numpy(), G[f"{tag}_camera"]),
-                       float(np.abs(vpred.cpu().numpy() - G[f"{tag}_vpred"]).max()),
-                       _l2(pd["buttons"].cpu().numpy(), G[f"{tag}_buttons"]), _l2(pd["camera"].cpu().numpy(), G[f"{tag}_camera"]))
-        for l, (m, (k, v)) in enumerate(state):
-            assert m.dtype == torch.bool and m.shape == (b, 1, 128)
-            assert np.array_equal(m.cpu().numpy(), G[f"{tag}_mask{l}"])
+        m = P.policy_metrics(dict(buttons=pd["buttons"], camera=pd["camera"], vpred=vpred),
+                             dict(buttons=G[f"{tag}_buttons"], camera=G[f"{tag}_camera"], vpred=G[f"{tag}_vpred"]))
+        print(f"PARITY[{mode}] vs golden chunk {tag}: {P.fmt(m)}")
+        P.check(m, mode, f"golden chunk {tag}")
+        for l, (mk, (k, v)) in enumerate(state):
+            assert mk.dtype == torch.bool and mk.shape == (b, 1, 128)
+            assert np.array_equal(mk.cpu().numpy(), G[f"{tag}_mask{l}"])
             assert k.dtype == torch.float32 and k.shape == (b, 128, 1024)
-            assert _l2(k[:, -t:].cpu().numpy(), G[f"{tag}_Ktail{l}"][:, -t:]) < KV_TOL
-            assert _l2(v[:, -t:].cpu().numpy(), G[f"{tag}_Vtail{l}"][:, -t:]) < KV_TOL
+            assert _l2(k[:, -t:], G[f"{tag}_Ktail{l}"][:, -t:]) < B["kv_l2"]
+            assert _l2(v[:, -t:], G[f"{tag}_Vtail{l}"][:, -t:]) < B["kv_l2"]
         assert torch.allclose(pd["buttons"].exp().sum(-1).cpu(), torch.ones(b, t, 1), atol=1e-3)
-    print("PARITY vs golden (max/max buttons, max/max camera, |dv|, relL2 buttons, relL2 camera) per chunk:", report)
-    for tag, (eb, ec, ev, lb, lc) in report.items():
-        assert eb < TOL and ec < TOL and ev < V_TOL and lb < L2_TOL and lc < L2_TOL, report
-    # act(): API shapes/dtypes + agreement of the deterministic action with the reference where the
-    # reference's top-2 margin exceeds the bf16 noise (bit-exactness is only defined away from near-ties)
+    # act(): API shapes / dtypes; log_prob of the deterministic action against the reference's
     img = _inputs(999, b, 1)[:, 0]
     ac, state2, res = pol.act({"img": img.to(DEV)}, torch.zeros(b, dtype=torch.bool, device=DEV), state, stochastic=False)
     assert ac["buttons"].dtype == torch.int64 and ac["buttons"].shape == (b, 1)
     assert res["log_prob"].shape == (b,) and res["vpred"].shape == (b, 1)
-    assert np.abs(res["log_prob"].cpu().numpy() - G["act_log_prob"]).max() < 0.1
+    assert np.abs(res["log_prob"].cpu().numpy() - G["act_log_prob"]).max() < (0.02 if mode == "fp16" else 0.1)
+
+
+def test_deterministic_actions_equal_reference(pol_1x):
+    """act(stochastic=False) over 64 frames with carried state: integer action indices must EQUAL the oracle's argmax
+    wherever the oracle's top-2 margin exceeds 4x the measured max log-prob error of the head (a16: lib/action_head.py:195-197)."""
+    pol, cfg, sd = pol_1x
+    mode = pol.precision
+    b, t = 4, 16
+    img = _inputs(555, b, t)
+    first = torch.zeros(b, t, dtype=torch.bool)
+    ref = O.policy_forward(sd, cfg, img, first, O.initial_state(cfg, b))
+    st = pol.initial_state(b)
+    acts = {"buttons": [], "camera": []}
+    pds = {"buttons": [], "camera": []}
+    for i in range(t):
+        ac, st, res = pol.act({"img": img[:, i].to(DEV)}, first[:, i].to(DEV), st, stochastic=False, return_pd=True)
+        for h in acts:
+            acts[h].append(ac[h].cpu()); pds[h].append(res["pd"][h].cpu())
+    torch.cuda.synchronize()
+    for h in acts:
+        got = torch.stack(acts[h], 1)[:, :, 0]              # [b, t]
+        logp = torch.stack(pds[h], 1)                        # [b, t, 1, n]
+        m = P.head_metrics(logp, ref[h])
+        want = ref[h].argmax(-1)[:, :, 0]
+        err = m["max_abs_err"]
+        top2 = ref[h].topk(2, -1).values[:, :, 0]
+        safe = (top2[..., 0] - top2[..., 1]) > 4 * err
+        print(f"ACTIONS[{mode}] {h}: agree {float((got == want).float().mean()):.3f} overall, {int(safe.sum())}/{safe.numel()} positions outside "
+              f"the noise band (4 x {err:.2e}), mismatches there: {int(((got != want) & safe).sum())}")
+        assert bool((got[safe] == want[safe]).all())
+        if mode == "fp16":
+            assert float(safe.float().mean()) > 0.5, "fp16 mode should resolve most positions"
 
 
 def test_policy_vs_oracle_long_chunk(pol_1x):
@@ -98,17 +121,13 @@ def test_policy_vs_oracle_long_chunk(pol_1x):
         so = ref["state_out"]
         (pd, vpred, _), sg = pol({"img": img.to(DEV)}, first.to(DEV), sg)
         torch.cuda.synchronize()
-        eb = _rel(pd["buttons"].cpu().numpy(), ref["buttons"].numpy())
-        ec = _rel(pd["camera"].cpu().numpy(), ref["camera"].numpy())
-        agree = (pd["buttons"].argmax(-1).cpu() == ref["buttons"].argmax(-1)).float().mean().item()
-        lb = _l2(pd["buttons"].cpu().numpy(), ref["buttons"].numpy())
-        lc = _l2(pd["camera"].cpu().numpy(), ref["camera"].numpy())
-        print(f"PARITY vs oracle t={t}: max/max buttons {eb:.3e} camera {ec:.3e}; relL2 buttons {lb:.3e} camera {lc:.3e}; "
-              f"argmax agreement {agree:.3f}")
-        assert eb < TOL and ec < TOL and lb < L2_TOL and lc < L2_TOL
+        B = P.BOUNDS[pol.precision]
+        m = P.policy_metrics(dict(buttons=pd["buttons"], camera=pd["camera"], vpred=vpred), ref)
+        print(f"PARITY[{pol.precision}] vs oracle t={t}: {P.fmt(m)}")
+        P.check(m, pol.precision, f"long chunk t={t}")
         for (m1, (k1, v1)), (m2, (k2, v2)) in zip(sg, so):
             assert torch.equal(m1.cpu(), m2)
-            assert _l2(k1.cpu().numpy(), k2.numpy()) < KV_TOL and _l2(v1.cpu().numpy(), v2.numpy()) < KV_TOL
+            assert _l2(k1, k2) < B["kv_l2"] and _l2(v1, v2) < B["kv_l2"]
 
 
 def test_first_resets_memory(pol_1x):
@@ -135,19 +154,19 @@ def test_policy_full_chunk_t128(pol_1x):
     ref = O.policy_forward(sd, cfg, img, first, O.initial_state(cfg, b))
     (pd, vpred, _), sg = pol({"img": img.to(DEV)}, first.to(DEV), pol.initial_state(b))
     torch.cuda.synchronize()
-    lb = _l2(pd["buttons"].cpu().numpy(), ref["buttons"].numpy())
-    lc = _l2(pd["camera"].cpu().numpy(), ref["camera"].numpy())
-    print(f"PARITY vs oracle t=128: relL2 buttons {lb:.3e} camera {lc:.3e}")
-    assert lb < L2_TOL and lc < L2_TOL
+    B = P.BOUNDS[pol.precision]
+    m = P.policy_metrics(dict(buttons=pd["buttons"], camera=pd["camera"], vpred=vpred), ref)
+    print(f"PARITY[{pol.precision}] vs oracle t=128: {P.fmt(m)}")
+    P.check(m, pol.precision, "t=128")
     for (m1, (k1, v1)), (m2, (k2, v2)) in zip(sg, ref["state_out"]):
         assert torch.equal(m1.cpu(), m2) and bool(m2.all())
-        assert _l2(k1.cpu().numpy(), k2.numpy()) < KV_TOL
+        assert _l2(k1, k2) < B["kv_l2"]
     img1 = _inputs(42, b, 1)
     f1 = torch.zeros(b, 1, dtype=torch.bool)
     ref1 = O.policy_forward(sd, cfg, img1, f1, ref["state_out"])
     (pd1, _, _), _ = pol({"img": img1.to(DEV)}, f1.to(DEV), sg)
     torch.cuda.synchronize()
-    assert _l2(pd1["buttons"].cpu().numpy(), ref1["buttons"].numpy()) < L2_TOL
+    assert _l2(pd1["buttons"], ref1["buttons"]) < B["lp_l2"]
 
 
 def test_step_graph_matches_eager(pol_1x):
@@ -214,10 +233,8 @@ def test_policy_vs_oracle_ragged_shapes(pol_1x, b, ts, firsts):
         so = ref["state_out"]
         (pd, vpred, _), sg = pol({"img": img.to(DEV)}, first.to(DEV), sg)
         torch.cuda.synchronize()
-        for k in ("buttons", "camera"):
-            e, l = _rel(pd[k].cpu().numpy(), ref[k].numpy()), _l2(pd[k].cpu().numpy(), ref[k].numpy())
-            assert e < TOL and l < L2_TOL, (k, t, e, l)
-        assert float((vpred.cpu() - ref["vpred"]).abs().max()) < 0.25
+        B = P.BOUNDS[pol.precision]
+        P.check(P.policy_metrics(dict(buttons=pd["buttons"], camera=pd["camera"], vpred=vpred), ref), pol.precision, f"ragged t={t}")
         for (m1, (k1, v1)), (m2, (k2, v2)) in zip(sg, so):
             assert torch.equal(m1.cpu(), m2)
-            assert _l2(k1.cpu().numpy(), k2.numpy()) < KV_TOL and _l2(v1.cpu().numpy(), v2.numpy()) < KV_TOL
+            assert _l2(k1, k2) < B["kv_l2"] and _l2(v1, v2) < B["kv_l2"]

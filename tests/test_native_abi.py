@@ -43,7 +43,17 @@ def test_version_and_error_strings(lib):
 def test_missing_library_fails_loudly(monkeypatch):
     import vpt_amd  # noqa: F401
     from vpt_amd import _native
-    monkeypatch.setattr(_native, "_lib", None)
-    monkeypatch.setattr(_native, "_LIB_PATH", "/nonexistent/libvpt_hip.so")
-    with pytest.raises(_native.NativeLibraryError):
-        _native.load()
+    monkeypatch.setattr(_native, "_libs", {})
+    monkeypatch.setattr(_native, "_LIB_PATHS", {"bf16": "/nonexistent/libvpt_hip.so", "fp16": "/nonexistent/libvpt_hip_f16.so"})
+    for fmt in ("bf16", "fp16"):
+        with pytest.raises(_native.NativeLibraryError):
+            _native.load(fmt)
+
+
+def test_both_operand_formats_built_with_the_same_abi(lib):
+    """libvpt_hip_f16.so (precision="fp16") is the same sources built with -DVPT_OPERAND_F16: identical export list."""
+    from vpt_amd import _native
+    f16 = _native.load("fp16")
+    assert lib.vpt_operand_format() == b"bf16" and f16.vpt_operand_format() == b"fp16"
+    for name in _native.SIGNATURES:
+        assert hasattr(f16, name), name

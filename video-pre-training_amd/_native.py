@@ -7,7 +7,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libvpt_hip.so")
-_lib = None
+# one library per 16-bit operand format (vpt_operand_format()): same sources, same ABI
+_LIB_PATHS = {"bf16": _LIB_PATH, "fp16": os.path.join(_HERE, "libvpt_hip_f16.so")}
+_libs = {}
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -57,31 +59,34 @@ def lib_path():
     return _LIB_PATH
 
 
-def load():
-    """Load (once) and type the shared library.  Raises NativeLibraryError if it is missing."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def load(fmt: str = "bf16"):
+    """Load (once) and type the shared library for one operand format.  Raises NativeLibraryError if it is missing."""
+    if fmt in _libs:
+        return _libs[fmt]
     # PyTorch-ROCm ships its own libamdhip64.so; load it FIRST so that libvpt_hip.so binds to the same HIP
     # runtime instance torch uses (two runtimes in one process cannot share streams or device pointers).
     import torch  # noqa: F401
-    if not os.path.exists(_LIB_PATH):
+    path = _LIB_PATHS[fmt]
+    if not os.path.exists(path):
         raise NativeLibraryError(
-            f"{_LIB_PATH} is missing: run `python __graft_entry__.py` (build()) first; there is no CPU fallback")
-    lib = ctypes.CDLL(_LIB_PATH)
+            f"{path} is missing: run `python __graft_entry__.py` (build()) first; there is no CPU fallback")
+    lib = ctypes.CDLL(path)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = _I
     lib.vpt_version.restype = ctypes.c_char_p
+    lib.vpt_operand_format.restype = ctypes.c_char_p
     lib.vpt_conv3x3_wgrad_scratch_floats.restype = ctypes.c_long
     lib.vpt_last_error.restype = ctypes.c_char_p
-    _lib = lib
+    if lib.vpt_operand_format().decode() != fmt:
+        raise NativeLibraryError(f"{path} reports operand format {lib.vpt_operand_format().decode()}, expected {fmt}")
+    _libs[fmt] = lib
     return lib
 
 
-def call(name, *args):
-    lib = load()
+def call(name, *args, fmt: str = "bf16"):
+    lib = load(fmt)
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed: {lib.vpt_last_error().decode()}")

@@ -19,7 +19,7 @@
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vpt_nll_bwd_kernel(VptNllBwdArgs a) {
   const int row = blockIdx.x, tid = threadIdx.x;
-  vpt_bf16* dz = a.dz + (size_t)row * a.ldz;
+  vpt_op16* dz = a.dz + (size_t)row * a.ldz;
   const float* lb = a.lp_buttons + (size_t)row * a.nb;
   const float* lc = a.lp_camera + (size_t)row * a.nc;
   const long ab = a.act_buttons[row], ac = a.act_camera[row];
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void vpt_nll_bwd_kernel(VptNllBwdArgs a) {
     float g = 0.f;
     if (i < a.nb) g = (expf(lb[i]) - (i == ab ? 1.f : 0.f)) * a.scale;
     else if (i < a.nb + a.nc) g = (expf(lc[i - a.nb]) - ((i - a.nb) == ac ? 1.f : 0.f)) * a.scale;
-    dz[i] = (vpt_bf16)g;
+    dz[i] = (vpt_op16)g;
   }
 }
 
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void vpt_gate_cast_kernel(VptGateCastArgs a) {
       v = a.x[(size_t)row * a.ldx + col];
       if (a.mask && !((float)a.mask[(size_t)row * a.ldm + col] > 0.f)) v = 0.f;
     }
-    a.out[i] = (vpt_bf16)v;
+    a.out[i] = (vpt_op16)v;
   }
 }
 

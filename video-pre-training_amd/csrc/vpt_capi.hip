@@ -1,6 +1,7 @@
 // C ABI (include/vpt_hip.h) on top of the per-kernel launchers.  Plain pointers and sizes only.
 #include "../../include/vpt_hip.h"
 #include "vpt_kernels.h"
+#include "vpt_common.h"
 #include <stdio.h>
 #include <math.h>
 
@@ -14,13 +15,14 @@ static int fail(int code, const char* what) {
 
 extern "C" {
 
-const char* vpt_version(void) { return "vpt_hip 0.1 gfx950"; }
+const char* vpt_version(void) { return "vpt_hip 0.2 gfx950"; }
+const char* vpt_operand_format(void) { return VPT_OPERAND_NAME; }
 const char* vpt_last_error(void) { return g_err; }
 
 int vpt_conv_first_forward(const uint8_t* img, const void* wfrag, void* y, double* stats_out,
                            int frames, int H, int W, int Cout, void* stream) {
   VptConvFirstArgs a;
-  a.img = img; a.wfrag = (const vpt_bf16*)wfrag; a.y = (vpt_bf16*)y; a.stats_out = stats_out;
+  a.img = img; a.wfrag = (const vpt_op16*)wfrag; a.y = (vpt_op16*)y; a.stats_out = stats_out;
   a.frames = frames; a.H = H; a.W = W; a.Cout = Cout; a.NT = (Cout + 127) / 128;
   CHECK_LAUNCH(vpt_conv_first_launch(&a, (hipStream_t)stream), "vpt_conv_first_forward");
 }
@@ -28,7 +30,7 @@ int vpt_conv_first_forward(const uint8_t* img, const void* wfrag, void* y, doubl
 int vpt_conv3d_t5_forward(const uint8_t* img, const void* wfrag, const float* bias, void* y, double* stats_out,
                           int frames, int T, int H, int W, int Cout, void* stream) {
   VptConv3dArgs a;
-  a.img = img; a.wfrag = (const vpt_bf16*)wfrag; a.bias = bias; a.y = (vpt_bf16*)y; a.stats_out = stats_out;
+  a.img = img; a.wfrag = (const vpt_op16*)wfrag; a.bias = bias; a.y = (vpt_op16*)y; a.stats_out = stats_out;
   a.frames = frames; a.T = T; a.H = H; a.W = W; a.Cout = Cout; a.NT = (Cout + 127) / 128;
   CHECK_LAUNCH(vpt_conv3d_launch(&a, (hipStream_t)stream), "vpt_conv3d_t5_forward");
 }
@@ -38,8 +40,8 @@ int vpt_conv3x3_forward(const void* x, const void* wpk, const float* edge_sa, co
                         int frames, int H, int W, int Cin, int Cout, void* stream) {
   if (!stats_in) return fail(-1, "vpt_conv3x3_forward: stats_in is required");
   VptConv3x3Args a;
-  a.x = (const vpt_bf16*)x; a.wpk = (const vpt_bf16*)wpk; a.edge_sa = edge_sa; a.edge_sg = edge_sg;
-  a.stats_in = stats_in; a.res = (const vpt_bf16*)res; a.y = (vpt_bf16*)y; a.stats_out = stats_out;
+  a.x = (const vpt_op16*)x; a.wpk = (const vpt_op16*)wpk; a.edge_sa = edge_sa; a.edge_sg = edge_sg;
+  a.stats_in = stats_in; a.res = (const vpt_op16*)res; a.y = (vpt_op16*)y; a.stats_out = stats_out;
   a.frames = frames; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.NT = (Cout + 127) / 128; a.CoutPad = a.NT * 128;
   a.inv_count_in = 1.0 / ((double)Cin * H * W);
@@ -50,11 +52,11 @@ int vpt_conv3x3_forward(const void* x, const void* wpk, const float* edge_sa, co
 int vpt_conv3x3_dgrad(const void* dacc, const void* wpk_t, const void* skip, const void* xin, const float* coef, void* dx,
                       int frames, int H, int W, int Cout, int Cin, void* stream) {
   VptConv3x3Args a;
-  a.x = (const vpt_bf16*)dacc; a.wpk = (const vpt_bf16*)wpk_t; a.edge_sa = nullptr; a.edge_sg = nullptr;
-  a.stats_in = nullptr; a.res = (const vpt_bf16*)skip; a.y = (vpt_bf16*)dx; a.stats_out = nullptr;
+  a.x = (const vpt_op16*)dacc; a.wpk = (const vpt_op16*)wpk_t; a.edge_sa = nullptr; a.edge_sg = nullptr;
+  a.stats_in = nullptr; a.res = (const vpt_op16*)skip; a.y = (vpt_op16*)dx; a.stats_out = nullptr;
   a.frames = frames; a.H = H; a.W = W; a.Cin = Cout; a.Cout = Cin;   // roles swap in the transposed convolution
   a.NT = (Cin + 127) / 128; a.CoutPad = a.NT * 128; a.inv_count_in = 1.0;
-  a.bwd = 1; a.xin = (const vpt_bf16*)xin; a.coef = coef;
+  a.bwd = 1; a.xin = (const vpt_op16*)xin; a.coef = coef;
   CHECK_LAUNCH(vpt_conv3x3_launch(&a, (hipStream_t)stream), "vpt_conv3x3_dgrad");
 }
 
@@ -63,9 +65,9 @@ int vpt_conv_backward_prepare(const void* dy, const void* dpooled, const uint8_t
                               float* coef, float* d_sa, float* d_sg, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream) {
   if (Cout & 31) return fail(-1, "vpt_conv_backward_prepare: Cout must be a multiple of 32");
   VptConvBwdPrepArgs a;
-  a.dpooled = (const vpt_bf16*)dpooled; a.argmax = argmax; a.sbuf = scratch; a.wshift = 0; a.coef = coef;
-  a.dy = (const vpt_bf16*)dy; a.y = (const vpt_bf16*)y; a.res = (const vpt_bf16*)res; a.stats_in = stats_in;
-  a.edge_sa = edge_sa; a.edge_sg = edge_sg; a.dacc = (vpt_bf16*)dacc; a.t12 = t12; a.d_sa = d_sa; a.d_sg = d_sg;
+  a.dpooled = (const vpt_op16*)dpooled; a.argmax = argmax; a.sbuf = scratch; a.wshift = 0; a.coef = coef;
+  a.dy = (const vpt_op16*)dy; a.y = (const vpt_op16*)y; a.res = (const vpt_op16*)res; a.stats_in = stats_in;
+  a.edge_sa = edge_sa; a.edge_sg = edge_sg; a.dacc = (vpt_op16*)dacc; a.t12 = t12; a.d_sa = d_sa; a.d_sg = d_sg;
   a.frames = frames; a.CB = Cout / 32; a.H = H; a.W = W; a.CoutPad = ((Cout + 127) / 128) * 128;
   a.inv_count_in = 1.0 / ((double)Cin * H * W);
   CHECK_LAUNCH(vpt_conv_bwd_prep_launch(&a, (hipStream_t)stream), "vpt_conv_backward_prepare");
@@ -74,7 +76,7 @@ int vpt_conv_backward_prepare(const void* dy, const void* dpooled, const uint8_t
 int vpt_conv_first_backward(const uint8_t* img, const void* wfrag, const void* dpooled, float* dw, float* db,
                             int frames, int H, int W, int Cout, void* stream) {
   VptConvFirstBwdArgs a;
-  a.img = img; a.wfrag = (const vpt_bf16*)wfrag; a.dpooled = (const vpt_bf16*)dpooled; a.dw = dw; a.db = db;
+  a.img = img; a.wfrag = (const vpt_op16*)wfrag; a.dpooled = (const vpt_op16*)dpooled; a.dw = dw; a.db = db;
   a.frames = frames; a.H = H; a.W = W; a.Cout = Cout;
   CHECK_LAUNCH(vpt_conv_first_bwd_launch(&a, (hipStream_t)stream), "vpt_conv_first_backward");
 }
@@ -85,7 +87,7 @@ long vpt_conv3x3_wgrad_scratch_floats(int frames, int Cin, int Cout) {
 
 int vpt_conv3x3_wgrad(const void* dacc, const void* x, float* dw, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream) {
   VptConvWgradArgs a;
-  a.dacc = (const vpt_bf16*)dacc; a.x = (const vpt_bf16*)x; a.dw = dw; a.partial = scratch;
+  a.dacc = (const vpt_op16*)dacc; a.x = (const vpt_op16*)x; a.dw = dw; a.partial = scratch;
   a.frames = frames; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.OT = 0; a.frames_per_wg = 0;
   CHECK_LAUNCH(vpt_conv_wgrad_launch(&a, (hipStream_t)stream), "vpt_conv3x3_wgrad");
 }
@@ -93,8 +95,8 @@ int vpt_conv3x3_wgrad(const void* dacc, const void* x, float* dw, float* scratch
 int vpt_maxpool_backward(const void* pre, const void* pooled, const void* dpooled, void* dpre,
                          int frames, int C, int H, int W, void* stream) {
   VptPoolBwdArgs a;
-  a.pre = (const vpt_bf16*)pre; a.pooled = (const vpt_bf16*)pooled; a.dpooled = (const vpt_bf16*)dpooled;
-  a.dpre = (vpt_bf16*)dpre; a.frames = frames; a.CB = C / 32; a.H = H; a.W = W;
+  a.pre = (const vpt_op16*)pre; a.pooled = (const vpt_op16*)pooled; a.dpooled = (const vpt_op16*)dpooled;
+  a.dpre = (vpt_op16*)dpre; a.frames = frames; a.CB = C / 32; a.H = H; a.W = W;
   CHECK_LAUNCH(vpt_pool_bwd_launch(&a, (hipStream_t)stream), "vpt_maxpool_backward");
 }
 
@@ -102,7 +104,7 @@ int vpt_frame_affine_backward(const void* x, const void* dy, const void* dx_add,
                               const double* stats_in, double* ab, float* dgain, float* dbias,
                               int frames, int C, int HW, int per_element, int pass, void* stream) {
   VptAffineBwdArgs a;
-  a.x = (const vpt_bf16*)x; a.dy = (const vpt_bf16*)dy; a.dx_add = (const vpt_bf16*)dx_add; a.dx = (vpt_bf16*)dx;
+  a.x = (const vpt_op16*)x; a.dy = (const vpt_op16*)dy; a.dx_add = (const vpt_op16*)dx_add; a.dx = (vpt_op16*)dx;
   a.gain = gain; a.stats_in = stats_in; a.ab = ab; a.dgain = dgain; a.dbias = dbias;
   a.frames = frames; a.CB = C / 32; a.HW = HW; a.per_element = per_element; a.inv_count = 1.0 / ((double)C * HW);
   CHECK_LAUNCH(vpt_affine_bwd_launch(&a, pass, (hipStream_t)stream), "vpt_frame_affine_backward");
@@ -111,7 +113,7 @@ int vpt_frame_affine_backward(const void* x, const void* dy, const void* dx_add,
 int vpt_maxpool_forward(const void* x, void* y, double* stats_out, uint8_t* argmax, int frames, int C, int H, int W, void* stream) {
   if (C & 31) return fail(-1, "vpt_maxpool_forward: C must be a multiple of 32");
   VptPoolArgs a;
-  a.x = (const vpt_bf16*)x; a.y = (vpt_bf16*)y; a.stats_out = stats_out; a.argmax = argmax;
+  a.x = (const vpt_op16*)x; a.y = (vpt_op16*)y; a.stats_out = stats_out; a.argmax = argmax;
   a.frames = frames; a.CB = C / 32; a.H = H; a.W = W;
   CHECK_LAUNCH(vpt_pool_launch(&a, (hipStream_t)stream), "vpt_maxpool_forward");
 }
@@ -121,7 +123,7 @@ int vpt_frame_affine_forward(const void* x, void* y, const float* gain, const fl
                              int frames, int C, int HW, int per_element, void* stream) {
   if (C & 31) return fail(-1, "vpt_frame_affine_forward: C must be a multiple of 32");
   VptAffineArgs a;
-  a.x = (const vpt_bf16*)x; a.y = (vpt_bf16*)y; a.gain = gain; a.bias = bias;
+  a.x = (const vpt_op16*)x; a.y = (vpt_op16*)y; a.gain = gain; a.bias = bias;
   a.stats_in = stats_in; a.stats_out = stats_out;
   a.frames = frames; a.CB = C / 32; a.HW = HW; a.per_element = per_element;
   a.inv_count = 1.0 / ((double)C * HW);
@@ -133,9 +135,9 @@ int vpt_linear_forward(const void* A, const void* wpk, const float* bias, const 
                        int lda, int ldr, int ldc, int ldcb, int relu, int splitk, const void* mask, int ldm,
                        void* stream) {
   VptGemmArgs a;
-  a.mask = (const vpt_bf16*)mask; a.ldm = ldm;
-  a.A = (const vpt_bf16*)A; a.wpk = (const vpt_bf16*)wpk; a.bias = bias; a.res = res;
-  a.out_f32 = out_f32; a.out_bf16 = (vpt_bf16*)out_bf16;
+  a.mask = (const vpt_op16*)mask; a.ldm = ldm;
+  a.A = (const vpt_op16*)A; a.wpk = (const vpt_op16*)wpk; a.bias = bias; a.res = res;
+  a.out_f32 = out_f32; a.out_bf16 = (vpt_op16*)out_bf16;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldr = ldr; a.ldc = ldc; a.ldcb = ldcb;
   a.relu = relu; a.splitk = splitk < 1 ? 1 : splitk; a.atomic_out = a.splitk > 1;
   CHECK_LAUNCH(vpt_gemm_launch(&a, (hipStream_t)stream), "vpt_linear_forward");
@@ -143,7 +145,7 @@ int vpt_linear_forward(const void* A, const void* wpk, const float* bias, const 
 
 int vpt_linear_wgrad(const void* dy, const void* x, float* dw, int M, int N, int K, int ldy, int ldx, int ldw, int accumulate, void* stream) {
   VptGemmTnArgs a;
-  a.A = (const vpt_bf16*)dy; a.B = (const vpt_bf16*)x; a.C = dw; a.M = M; a.N1 = N; a.N2 = K; a.lda = ldy; a.ldb = ldx; a.ldc = ldw;
+  a.A = (const vpt_op16*)dy; a.B = (const vpt_op16*)x; a.C = dw; a.M = M; a.N1 = N; a.N2 = K; a.lda = ldy; a.ldb = ldx; a.ldc = ldw;
   a.accumulate = accumulate;
   CHECK_LAUNCH(vpt_gemm_tn_launch(&a, (hipStream_t)stream), "vpt_linear_wgrad");
 }
@@ -151,16 +153,16 @@ int vpt_linear_wgrad(const void* dy, const void* x, float* dw, int M, int N, int
 int vpt_linear_splitk_epilogue(const float* part, int splitk, const float* bias, const float* res, float* out_f32, void* out_bf16,
                                int M, int N, int ldr, int ldc, int ldcb, int relu, const void* mask, int ldm, void* stream) {
   VptGemmArgs a;
-  a.A = nullptr; a.wpk = nullptr; a.bias = bias; a.res = res; a.out_f32 = out_f32; a.out_bf16 = (vpt_bf16*)out_bf16;
+  a.A = nullptr; a.wpk = nullptr; a.bias = bias; a.res = res; a.out_f32 = out_f32; a.out_bf16 = (vpt_op16*)out_bf16;
   a.M = M; a.N = N; a.K = 0; a.lda = 0; a.ldr = ldr; a.ldc = ldc; a.ldcb = ldcb; a.relu = relu; a.splitk = splitk; a.atomic_out = 0;
-  a.mask = (const vpt_bf16*)mask; a.ldm = ldm;
+  a.mask = (const vpt_op16*)mask; a.ldm = ldm;
   CHECK_LAUNCH(vpt_splitk_epilogue_launch(part, splitk, &a, (hipStream_t)stream), "vpt_linear_splitk_epilogue");
 }
 
 int vpt_layernorm_forward(const float* x, const float* gain, const float* bias, float* out_f32, void* out_bf16,
                           int M, int D, int relu_in, void* stream) {
   VptLayerNormArgs a;
-  a.x = x; a.gain = gain; a.bias = bias; a.out_f32 = out_f32; a.out_bf16 = (vpt_bf16*)out_bf16;
+  a.x = x; a.gain = gain; a.bias = bias; a.out_f32 = out_f32; a.out_bf16 = (vpt_op16*)out_bf16;
   a.M = M; a.D = D; a.relu_in = relu_in;
   CHECK_LAUNCH(vpt_layernorm_launch(&a, (hipStream_t)stream), "vpt_layernorm_forward");
 }
@@ -169,7 +171,7 @@ int vpt_masked_attention_forward(const float* qkvr, const float* kmem, const flo
                                  const float* b_nd, void* out, int B, int t, int heads, int hid, int ld,
                                  int maxlen, int causal, void* stream) {
   VptAttnArgs a;
-  a.qkvr = qkvr; a.kmem = kmem; a.vmem = vmem; a.memvalid = memvalid; a.b_nd = b_nd; a.out = (vpt_bf16*)out;
+  a.qkvr = qkvr; a.kmem = kmem; a.vmem = vmem; a.memvalid = memvalid; a.b_nd = b_nd; a.out = (vpt_op16*)out;
   a.B = B; a.t = t; a.heads = heads; a.hid = hid; a.ld = ld; a.maxlen = maxlen; a.causal = causal;
   CHECK_LAUNCH(vpt_attn_launch(&a, (hipStream_t)stream), "vpt_masked_attention_forward");
 }
@@ -204,7 +206,7 @@ int vpt_bc_nll_backward(const float* lp_buttons, const float* lp_camera, const i
                         const int64_t* act_camera, void* dz, int M, int nb, int nc, int ldz, float scale, void* stream) {
   VptNllBwdArgs a;
   a.lp_buttons = lp_buttons; a.lp_camera = lp_camera; a.act_buttons = (const long*)act_buttons;
-  a.act_camera = (const long*)act_camera; a.dz = (vpt_bf16*)dz; a.M = M; a.nb = nb; a.nc = nc; a.ldz = ldz; a.scale = scale;
+  a.act_camera = (const long*)act_camera; a.dz = (vpt_op16*)dz; a.M = M; a.nb = nb; a.nc = nc; a.ldz = ldz; a.scale = scale;
   CHECK_LAUNCH(vpt_nll_bwd_launch(&a, (hipStream_t)stream), "vpt_bc_nll_backward");
 }
 
@@ -218,13 +220,13 @@ int vpt_layernorm_backward(const float* x, const float* gain, const float* dy, c
 
 int vpt_gate_cast_bf16(const float* x, const void* mask, void* out, int M, int N, int ldx, int ldm, int ldo, void* stream) {
   VptGateCastArgs a;
-  a.x = x; a.mask = (const vpt_bf16*)mask; a.out = (vpt_bf16*)out; a.M = M; a.N = N; a.ldx = ldx; a.ldm = ldm; a.ldo = ldo;
+  a.x = x; a.mask = (const vpt_op16*)mask; a.out = (vpt_op16*)out; a.M = M; a.N = N; a.ldx = ldx; a.ldm = ldm; a.ldo = ldo;
   CHECK_LAUNCH(vpt_gate_cast_launch(&a, (hipStream_t)stream), "vpt_gate_cast_bf16");
 }
 
 int vpt_column_sum(const void* x_bf16, float* out, int M, int N, int ld, void* stream) {
   VptColsumArgs a;
-  a.x = (const vpt_bf16*)x_bf16; a.out = out; a.M = M; a.N = N; a.ld = ld;
+  a.x = (const vpt_op16*)x_bf16; a.out = out; a.M = M; a.N = N; a.ld = ld;
   CHECK_LAUNCH(vpt_colsum_launch(&a, (hipStream_t)stream), "vpt_column_sum");
 }
 

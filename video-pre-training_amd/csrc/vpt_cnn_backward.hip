@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void vpt_pool_bwd_kernel(VptPoolBwdArgs a) {
   const int x = r % a.W; r /= a.W;
   const int y = r % a.H;
   const int cb = r / a.H;
-  const vpt_bf16* pre = a.pre + ((size_t)(f * a.CB + cb) * a.H * a.W) * 32 + oct * 8;
+  const vpt_op16* pre = a.pre + ((size_t)(f * a.CB + cb) * a.H * a.W) * 32 + oct * 8;
   const size_t pplane = ((size_t)(f * a.CB + cb) * PH * PW) * 32 + oct * 8;
   const u16x8 mine = *(const u16x8*)(pre + (size_t)(y * a.W + x) * 32);
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -3,10 +3,29 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef __bf16 bf16_t;
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// ---- the 16-bit MFMA operand / activation storage type ------------------------------------------------
+// Default: bfloat16 (north star: "MFMA bf16 tiles").  Built a second time with -DVPT_OPERAND_F16 (libvpt_hip_f16.so,
+// PolicyEngine(precision="fp16")) every 16-bit operand is IEEE half instead: same MFMA rate
+// (v_mfma_f32_32x32x16_f16), same bytes, 8x finer rounding -- the parity mode of DESIGN.md "Precision".
+#ifdef VPT_OPERAND_F16
+typedef _Float16 op16_t;
+typedef _Float16 op16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 op16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 op16x8 __attribute__((ext_vector_type(8)));
+#define VPT_MFMA_32X32X16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+typedef __fp16 tr16x4 __attribute__((ext_vector_type(4)));   // element type the f16 transpose-read builtin is declared with
+#define VPT_DS_READ_TR16_B64 __builtin_amdgcn_ds_read_tr16_b64_v4f16
+#define VPT_OPERAND_NAME "fp16"
+#else
+typedef __bf16 op16_t;
+typedef __bf16 op16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 op16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 op16x8 __attribute__((ext_vector_type(8)));
+#define VPT_MFMA_32X32X16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+typedef __bf16 tr16x4 __attribute__((ext_vector_type(4)));
+#define VPT_DS_READ_TR16_B64 __builtin_amdgcn_ds_read_tr16_b64_v4bf16
+#define VPT_OPERAND_NAME "bf16"
+#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -15,26 +34,42 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 #define VPT_NORM_EPS 1e-5f
 
-// ---- bf16 <-> f32 -------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+// ---- 16-bit operand <-> f32 --------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pack_op16x2(float lo, float hi) {
   f32x2 v = {lo, hi};
-  bf16x2 b = __builtin_convertvector(v, bf16x2);  // v_cvt_pk_bf16_f32 (RNE)
+  op16x2 b = __builtin_convertvector(v, op16x2);  // round to nearest even
   return __builtin_bit_cast(uint32_t, b);
 }
-__device__ __forceinline__ float bf16_lo_to_f32(uint32_t packed) { return __builtin_bit_cast(float, packed << 16); }
-__device__ __forceinline__ float bf16_hi_to_f32(uint32_t packed) { return __builtin_bit_cast(float, packed & 0xffff0000u); }
+#ifdef VPT_OPERAND_F16
+__device__ __forceinline__ float op16_lo_to_f32(uint32_t packed) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(packed & 0xffffu)); }
+__device__ __forceinline__ float op16_hi_to_f32(uint32_t packed) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(packed >> 16)); }
+// two values that are exact in the operand format (bytes 0..255, 0.0, 1.0): any rounding mode will do
+__device__ __forceinline__ uint32_t pack_op16x2_exact(float lo, float hi) { return pack_op16x2(lo, hi); }
+#else
+__device__ __forceinline__ float op16_lo_to_f32(uint32_t packed) { return __builtin_bit_cast(float, packed << 16); }
+__device__ __forceinline__ float op16_hi_to_f32(uint32_t packed) { return __builtin_bit_cast(float, packed & 0xffff0000u); }
+// exact values: the bf16 is the upper half of the fp32 pattern (one v_perm_b32 per pair)
+__device__ __forceinline__ uint32_t pack_op16x2_exact(float lo, float hi) {
+  return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x07060302u);
+}
+#endif
 
-// 8 bf16 (one 16-byte chunk) -> 8 floats
+// LDS transpose read (ds_read_b64_tr_b16): 4 consecutive 16-bit elements of this lane's column
+__device__ __forceinline__ op16x4 lds_tr16_read(const unsigned char* p) {
+  return __builtin_bit_cast(op16x4, VPT_DS_READ_TR16_B64((__attribute__((address_space(3))) tr16x4*)(p)));
+}
+
+// 8 operands (one 16-byte chunk) -> 8 floats
 __device__ __forceinline__ void unpack8(const u32x4& c, float* f) {
-  f[0] = bf16_lo_to_f32(c.x); f[1] = bf16_hi_to_f32(c.x);
-  f[2] = bf16_lo_to_f32(c.y); f[3] = bf16_hi_to_f32(c.y);
-  f[4] = bf16_lo_to_f32(c.z); f[5] = bf16_hi_to_f32(c.z);
-  f[6] = bf16_lo_to_f32(c.w); f[7] = bf16_hi_to_f32(c.w);
+  f[0] = op16_lo_to_f32(c.x); f[1] = op16_hi_to_f32(c.x);
+  f[2] = op16_lo_to_f32(c.y); f[3] = op16_hi_to_f32(c.y);
+  f[4] = op16_lo_to_f32(c.z); f[5] = op16_hi_to_f32(c.z);
+  f[6] = op16_lo_to_f32(c.w); f[7] = op16_hi_to_f32(c.w);
 }
 __device__ __forceinline__ u32x4 pack8(const float* f) {
   u32x4 c;
-  c.x = pack_bf16x2(f[0], f[1]); c.y = pack_bf16x2(f[2], f[3]);
-  c.z = pack_bf16x2(f[4], f[5]); c.w = pack_bf16x2(f[6], f[7]);
+  c.x = pack_op16x2(f[0], f[1]); c.y = pack_op16x2(f[2], f[3]);
+  c.z = pack_op16x2(f[4], f[5]); c.w = pack_op16x2(f[6], f[7]);
   return c;
 }
 

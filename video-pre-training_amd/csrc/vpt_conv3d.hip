@@ -37,9 +37,9 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3d_t5_kernel(VptConv3dArgs a) 
     *(u32x4*)(in + dt * 768 + c16 * 16) = v;
   }
   if (tid < 128) bias_s[tid] = a.bias[nt * 128 + tid];
-  bf16x8 wfr[4];
+  op16x8 wfr[4];
 #pragma unroll
-  for (int cs = 0; cs < 4; ++cs) wfr[cs] = *((const bf16x8*)a.wfrag + (nt * 4 + cs) * 64 + lane);
+  for (int cs = 0; cs < 4; ++cs) wfr[cs] = *((const op16x8*)a.wfrag + (nt * 4 + cs) * 64 + lane);
   __syncthreads();
 
   const int CB_out = a.Cout >> 5;
@@ -47,17 +47,17 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3d_t5_kernel(VptConv3dArgs a) 
 #pragma unroll
   for (int sub = 0; sub < 2; ++sub) {
     const int pl = w * 64 + sub * 32 + l31;  // pixel within the chunk
-    uint32_t h[8];
+    float h[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int kA = e, kB = 8 + e;  // k for lanes 0-31 / 32-63; k = dt*3 + ch, k = 15 is padding
       const int offA = (kA / 3) * 768 + (kA % 3), offB = (kB < 15) ? (kB / 3) * 768 + (kB % 3) : 0;
-      uint32_t bits = __builtin_bit_cast(uint32_t, (float)in[pl * 3 + (hi ? offB : offA)]) >> 16;
-      if (kB >= 15) bits = hi ? 0u : bits;
-      h[e] = bits;
+      float v = (float)in[pl * 3 + (hi ? offB : offA)];   // a byte: exact in either 16-bit operand format
+      if (kB >= 15) v = hi ? 0.f : v;
+      h[e] = v;
     }
-    const u32x4 pk = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
-    const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+    const u32x4 pk = {pack_op16x2_exact(h[0], h[1]), pack_op16x2_exact(h[2], h[3]), pack_op16x2_exact(h[4], h[5]), pack_op16x2_exact(h[6], h[7])};
+    const op16x8 pf = __builtin_bit_cast(op16x8, pk);
     const size_t pbase = ((size_t)f * CB_out + nt * 4) * HW * 32 + (size_t)(p0 + pl) * 32 + 4 * hi;
 #pragma unroll
     for (int cs = 0; cs < 4; ++cs) {
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3d_t5_kernel(VptConv3dArgs a) 
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[cs], pf, acc, 0, 0, 0);
+      acc = VPT_MFMA_32X32X16(wfr[cs], pf, acc, 0, 0, 0);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 b4 = *(const f32x4*)(bias_s + cs * 32 + 8 * g + 4 * hi);
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3d_t5_kernel(VptConv3dArgs a) 
         const float v3 = fmaxf(fmaf(acc[4 * g + 3], 1.0f / 255.0f, b4.w), 0.f);
         s_sum += (v0 + v1) + (v2 + v3);
         s_sq = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, fmaf(v3, v3, s_sq))));
-        const u32x2 o = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+        const u32x2 o = {pack_op16x2(v0, v1), pack_op16x2(v2, v3)};
         *(u32x2*)(a.y + pbase + (size_t)cs * HW * 32 + 8 * g) = o;
       }
     }

@@ -36,7 +36,7 @@
 #define B_BYTES (3 * 128 * 64)          // 24576 per buffer (unpadded, swizzled)
 #define KK_OFF (A_BYTES + 2 * B_BYTES)  // 75072
 #define KK_BYTES (9 * 128 * 4)          // 4608
-#define SMEM_BYTES (KK_OFF + KK_BYTES + 48)  // 79728 (+32: block stats reduction, +16: priority flag)
+#define SMEM_BYTES (KK_OFF + KK_BYTES + 32)  // 79712 (+32: block stats reduction)
 // epilogue staging (overlays the halo / weight buffers after the last step): per wave [res|out tile][xin tile], each
 // 2 channel blocks x 32 pixels x 64 B at an 80-byte pixel pitch (16-byte aligned rows, <= 2-way conflicts on the 8-byte side)
 #define ST_RS 80
@@ -48,9 +48,6 @@
 // 4..11 so that each 16-lane ds_read_b128 group {0-3,12-15,20-27} / {4-11,16-19,28-31} stays in one image row.
 __device__ __forceinline__ int sub_row(int i) { return ((i >> 4) ^ (i >> 2) ^ (i >> 3)) & 1; }
 
-// One word per CU (key = XCC id | SE | SH | CU from the hardware id registers): 1 while a high-priority workgroup is resident.
-// Speed only -- results never depend on it (experiment switch VPT_CONV_PRIO, off by default).
-__device__ int vpt_conv_cu_prio[4096];
 
 // COUNTED: the wait in front of each step's barrier is a counted s_waitcnt that retires the weight DMA only and leaves the
 // younger halo / residual prefetch loads in flight across the barrier (a plain __syncthreads() drains vmcnt to 0 because an
@@ -59,14 +56,14 @@ template <bool COUNTED>
 __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
-  int prio_key = -1;
+  // profiling (vpt_conv3x3_set_trace): CU id + 100 MHz timestamps of the tile's phases
+  int cu_key = -1;
   long long t_trace[3];
-  if (a.trace && tid == 0) t_trace[0] = wall_clock64();
-  if ((a.prio_level > 0 || a.trace) && tid == 0) {
+  if (a.trace && tid == 0) {
+    t_trace[0] = wall_clock64();
     const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID: cu_id[11:8] sh_id[12] se_id[15:13]
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_REG_XCC_ID[3:0]
-    prio_key = (int)(((xcc & 15u) << 8) | ((hw >> 8) & 0xffu));
-    *(int*)(smem + KK_OFF + KK_BYTES + 32) = (a.prio_level > 0 && atomicCAS(&vpt_conv_cu_prio[prio_key], 0, 1) == 0) ? 1 : 0;
+    cu_key = (int)(((xcc & 15u) << 8) | ((hw >> 8) & 0xffu));
   }
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;
@@ -102,14 +99,14 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
       }
     }
   }
-  const bf16_t* xplane = a.x + (size_t)f * NCB * HW * 32;
+  const op16_t* xplane = a.x + (size_t)f * NCB * HW * 32;
   // weight DMA: wave w moves pieces (4*m + w), m = 0..5, of the 24 KB step tile; lane = 16-byte chunk
-  const bf16_t* wbase = a.wpk + (size_t)nt * NCB * 9 * 4096 + (size_t)(w * 64 + lane) * 8;
+  const op16_t* wbase = a.wpk + (size_t)nt * NCB * 9 * 4096 + (size_t)(w * 64 + lane) * 8;
   unsigned char* bdst = smem + A_BYTES + w * 1024;
 
 #define ISSUE_B(step_, buf_)                                                                              \
   do {                                                                                                    \
-    const bf16_t* wp_ = wbase + (size_t)(step_) * 12288;                                                  \
+    const op16_t* wp_ = wbase + (size_t)(step_) * 12288;                                                  \
     _Pragma("unroll") for (int m_ = 0; m_ < 6; ++m_)                                                      \
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp_ + m_ * 2048),  \
                                        (__attribute__((address_space(3))) void*)(bdst + (buf_) * B_BYTES + m_ * 4096), \
@@ -151,8 +148,6 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     if (a_loff[m_] >= 0) *(u32x4*)(smem + a_loff[m_]) = ((a_inside >> m_) & 1u) ? areg[m_] : zero4
   WRITE_HALO();
   __syncthreads();
-  const int high_prio = a.prio_level > 0 ? __builtin_amdgcn_readfirstlane(*(const int*)(smem + KK_OFF + KK_BYTES + 32)) : 0;
-  if (high_prio) __builtin_amdgcn_s_setprio(2);
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -212,14 +207,14 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   //   - the step's barrier sits in front of the LAST group's MFMAs: every wave then holds its last fragments of the
   //     step in registers, the next step's weights (requested >= 24 MFMAs earlier) have landed, so the next step's
   //     first fragments are requested behind the barrier and arrive under group 5's MFMAs.
-  bf16x8 fa[2][4], fb[2][2];
-  const bf16_t* resp = a.res ? a.res : a.y;   // no residual: the prefetch still runs (exact counted waits), result unused
+  op16x8 fa[2][4], fb[2][2];
+  const op16_t* resp = a.res ? a.res : a.y;   // no residual: the prefetch still runs (exact counted waits), result unused
 #define SB() __builtin_amdgcn_sched_barrier(0)
-#define MM(set_, m_, n_) acc[m_][n_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set_][n_], fa[set_][m_], acc[m_][n_], 0, 0, 0)
+#define MM(set_, m_, n_) acc[m_][n_] = VPT_MFMA_32X32X16(fb[set_][n_], fa[set_][m_], acc[m_][n_], 0, 0, 0)
 #define FA_LD(set_, dy_, g_, m_) \
-  fa[set_][m_] = *(const bf16x8*)(aL + ((dy_) * 18 + ((g_) >> 1)) * A_RS + (m_) * (2 * 18 * A_RS) + ((g_) & 1) * 32)
+  fa[set_][m_] = *(const op16x8*)(aL + ((dy_) * 18 + ((g_) >> 1)) * A_RS + (m_) * (2 * 18 * A_RS) + ((g_) & 1) * 32)
 #define FB_LD(set_, g_, n_, boff_) \
-  fb[set_][n_] = *(const bf16x8*)((((g_) & 1) ? bL1 : bL0) + (boff_) + ((g_) >> 1) * (128 * 64) + (n_) * (32 * 64))
+  fb[set_][n_] = *(const op16x8*)((((g_) & 1) ? bL1 : bL0) + (boff_) + ((g_) >> 1) * (128 * 64) + (n_) * (32 * 64))
   // MFMAs of register set `set_`; fragments of group (ndy_, ng_) go to the other set; X0 / X1: the two free slots
 #define GROUP(set_, ndy_, ng_, nboff_, X0, X1)                                                            \
   do {                                                                                                    \
@@ -260,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   do {                                                                                                    \
     const int s_ = (cb_) * 3 + (dy_);                                                                     \
     const int boff_ = (s_ & 1) * B_BYTES, noff_ = B_BYTES - boff_;                                        \
-    const bf16_t* wp_ = wbase + (size_t)(s_ + 1) * 12288;                                                 \
+    const op16_t* wp_ = wbase + (size_t)(s_ + 1) * 12288;                                                 \
     unsigned char* bd_ = bdst + noff_;                                                                    \
     const unsigned cbo_ = (unsigned)((cb_) + 1) * (unsigned)HW * 64u; /* bytes; uniform */                \
     if (LAST) {                                                                                           \
@@ -340,8 +335,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
       for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) t += acc[m][n][r];
-    if (t == 12345.678f) a.y[0] = (vpt_bf16)t;
-    if (prio_key >= 0 && high_prio) atomicExch(&vpt_conv_cu_prio[prio_key], 0);
+    if (t == 12345.678f) a.y[0] = (vpt_op16)t;
     return;
   }
   // the fragment registers are dead: the residual of subtiles 2 / 3 travels while subtiles 0 / 1 are processed
@@ -407,17 +401,17 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
           v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
         } else if (use_x) {  // dgrad: + d(mu, rstd)/dx terms of the GroupNorm statistics
           const u32x2 xi = *(const u32x2*)(cell + ST_X);
-          v0 += fmaf(c1f, bf16_lo_to_f32(xi.x), c0f); v1 += fmaf(c1f, bf16_hi_to_f32(xi.x), c0f);
-          v2 += fmaf(c1f, bf16_lo_to_f32(xi.y), c0f); v3 += fmaf(c1f, bf16_hi_to_f32(xi.y), c0f);
+          v0 += fmaf(c1f, op16_lo_to_f32(xi.x), c0f); v1 += fmaf(c1f, op16_hi_to_f32(xi.x), c0f);
+          v2 += fmaf(c1f, op16_lo_to_f32(xi.y), c0f); v3 += fmaf(c1f, op16_hi_to_f32(xi.y), c0f);
         }
         if (a.res) {
           const u32x2 r2 = *(const u32x2*)cell;
-          v0 += bf16_lo_to_f32(r2.x); v1 += bf16_hi_to_f32(r2.x);
-          v2 += bf16_lo_to_f32(r2.y); v3 += bf16_hi_to_f32(r2.y);
+          v0 += op16_lo_to_f32(r2.x); v1 += op16_hi_to_f32(r2.x);
+          v2 += op16_lo_to_f32(r2.y); v3 += op16_hi_to_f32(r2.y);
         }
         s_sum += (v0 + v1) + (v2 + v3);
         s_sq = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, fmaf(v3, v3, s_sq))));
-        const u32x2 pk = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+        const u32x2 pk = {pack_op16x2(v0, v1), pack_op16x2(v2, v3)};
         *(u32x2*)cell = pk;
       }
     }
@@ -442,10 +436,9 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
       atomicAdd(a.stats_out + 2 * f + 1, (double)((red[4] + red[5]) + (red[6] + red[7])));
     }
   }
-  if (prio_key >= 0 && high_prio) atomicExch(&vpt_conv_cu_prio[prio_key], 0);
-  if (a.trace && tid == 0) {   // profiling (vpt_conv3x3_set_trace): 100 MHz timestamps of the tile's phases
+  if (a.trace && tid == 0) {
     long long* t = a.trace + (size_t)blockIdx.x * 6;
-    t[0] = t_trace[0]; t[1] = t_trace[1]; t[2] = t_trace[2]; t[3] = wall_clock64(); t[4] = prio_key; t[5] = high_prio;
+    t[0] = t_trace[0]; t[1] = t_trace[1]; t[2] = t_trace[2]; t[3] = wall_clock64(); t[4] = cu_key; t[5] = 0;
   }
 }
 
@@ -453,12 +446,10 @@ static long long* g_conv_trace = nullptr;
 extern "C" void vpt_conv3x3_set_trace(void* buf) { g_conv_trace = (long long*)buf; }  // profiling: [grid][6] int64, or null
 
 extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream) {
-  static int ablate = -1, prio_level = 0, extra_lds = 0;
+  static int ablate = -1, extra_lds = 0;
   if (ablate < 0) {
     const char* e = getenv("VPT_CONV_ABLATE");
     ablate = e ? atoi(e) : 0;
-    const char* pr = getenv("VPT_CONV_PRIO");       // 0 = equal priorities, 1..3 = s_setprio level of the first workgroup on a CU
-    prio_level = pr ? atoi(pr) : 0;
     const char* xl = getenv("VPT_CONV_EXTRA_LDS");  // profiling: dynamic LDS bytes (> 2 KB forces one workgroup per CU)
     extra_lds = xl ? atoi(xl) : 0;
     if (extra_lds > 0) {
@@ -468,15 +459,13 @@ extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream
   }
   VptConv3x3Args a_copy = *a_in;
   a_copy.ablate = ablate;
-  a_copy.prio_level = prio_level;
   a_copy.trace = g_conv_trace;
-  if (!a_copy.bwd && !a_copy.stats_in) return -1;
   const VptConv3x3Args* a = &a_copy;
   if ((a->H & 15) || (a->W & 15) || (a->Cin & 31) || (a->Cout & 31) || a->frames <= 0) return -1;
   const long grid = (long)a->frames * (a->H >> 4) * (a->W >> 4) * a->NT;
   if (grid > 0x7fffffffL) return -2;
   static int counted = -1;
-  if (counted < 0) { const char* e = getenv("VPT_CONV_COUNTED"); counted = e ? atoi(e) : 0; }
+  if (counted < 0) { const char* e = getenv("VPT_CONV_COUNTED"); counted = e ? atoi(e) : 1; }
   if (counted) hipLaunchKernelGGL(vpt_conv3x3_kernel<true>, dim3((unsigned)grid), dim3(256), extra_lds, stream, *a);
   else hipLaunchKernelGGL(vpt_conv3x3_kernel<false>, dim3((unsigned)grid), dim3(256), extra_lds, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -3;

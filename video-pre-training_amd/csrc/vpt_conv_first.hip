@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
   // depend on how the tile list happens to be cut into workgroup ranges, i.e. on the batch size)
   int nt_loaded = -1, stat_f = -1;
   double d_sum = 0.0, d_sq = 0.0;
-  bf16x8 wfr[4][2];
+  op16x8 wfr[4][2];
   for (long tile = t_begin; tile < t_end; ++tile) {
     long L = tile;
     const int nt = (int)(L % a.NT); L /= a.NT;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
 #pragma unroll
       for (int cs = 0; cs < 4; ++cs)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) wfr[cs][ks] = *((const bf16x8*)a.wfrag + ((nt * 4 + cs) * 2 + ks) * 64 + lane);
+        for (int ks = 0; ks < 2; ++ks) wfr[cs][ks] = *((const op16x8*)a.wfrag + ((nt * 4 + cs) * 2 + ks) * 64 + lane);
       nt_loaded = nt;
     }
     __syncthreads();
@@ -93,10 +93,10 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
     const bool inimg = pv && gy >= 0 && gx >= 0 && gy < a.H && gx < a.W;
     const unsigned char* ib = in + (cr * 19 + cc) * 3;
 
-    bf16x8 pf[2];
+    op16x8 pf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      float h[8];      // the byte as fp32: exact, so its bf16 is the upper half of the fp32 pattern
+      float h[8];      // the byte as fp32: exact in either 16-bit operand format
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int kA = ks * 16 + e, kB = ks * 16 + 8 + e;     // k for lanes 0-31 / 32-63
@@ -107,11 +107,11 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
         h[e] = v;
       }
       u32x4 pk;
-      pk.x = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, h[1]), __builtin_bit_cast(uint32_t, h[0]), 0x07060302u);
-      pk.y = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, h[3]), __builtin_bit_cast(uint32_t, h[2]), 0x07060302u);
-      pk.z = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, h[5]), __builtin_bit_cast(uint32_t, h[4]), 0x07060302u);
-      pk.w = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, h[7]), __builtin_bit_cast(uint32_t, h[6]), 0x07060302u);
-      pf[ks] = __builtin_bit_cast(bf16x8, pk);
+      pk.x = pack_op16x2_exact(h[0], h[1]);
+      pk.y = pack_op16x2_exact(h[2], h[3]);
+      pk.z = pack_op16x2_exact(h[4], h[5]);
+      pk.w = pack_op16x2_exact(h[6], h[7]);
+      pf[ks] = __builtin_bit_cast(op16x8, pk);
     }
     f32x16 acc[4];
 #pragma unroll
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[cs][r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) acc[cs] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[cs][ks], pf[ks], acc[cs], 0, 0, 0);
+      for (int ks = 0; ks < 2; ++ks) acc[cs] = VPT_MFMA_32X32X16(wfr[cs][ks], pf[ks], acc[cs], 0, 0, 0);
     }
     // conv + bias (1/255 is folded into the weights), rounded to bf16 and stored RAW: the ReLU commutes with the
     // max-pool, so it is applied once per pooled value instead of once per conv value; pixels outside the image -> 0
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
       for (int cs = 0; cs < 4; ++cs) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          u32x2 pk2 = {pack_bf16x2(acc[cs][4 * g + 0], acc[cs][4 * g + 1]) & keep, pack_bf16x2(acc[cs][4 * g + 2], acc[cs][4 * g + 3]) & keep};
+          u32x2 pk2 = {pack_op16x2(acc[cs][4 * g + 0], acc[cs][4 * g + 1]) & keep, pack_op16x2(acc[cs][4 * g + 2], acc[cs][4 * g + 3]) & keep};
           *(u32x2*)(dst + (cs * 32 + g * 8) * 2) = pk2;
         }
       }

@@ -26,11 +26,11 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
   const int nt = blockIdx.y;
   const int CB_out = a.Cout >> 5;
 
-  bf16x8 wfr[4][2];
+  op16x8 wfr[4][2];
 #pragma unroll
   for (int cs = 0; cs < 4; ++cs)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) wfr[cs][ks] = *((const bf16x8*)a.wfrag + ((nt * 4 + cs) * 2 + ks) * 64 + lane);
+    for (int ks = 0; ks < 2; ++ks) wfr[cs][ks] = *((const op16x8*)a.wfrag + ((nt * 4 + cs) * 2 + ks) * 64 + lane);
 
   const int oc = tid & 127, half = tid >> 7;   // backward role: output channel within the N tile, pooled-pixel half
   const int og = nt * 128 + oc;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
       const int gy = 2 * py0 - 1 + cr, gx = 2 * px0 - 1 + cc;
       const bool inimg = pv && gy >= 0 && gx >= 0 && gy < a.H && gx < a.W;
       const unsigned char* ib = in + (cr * 19 + cc) * 3;
-      bf16x8 pf[2];
+      op16x8 pf[2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         float h[8];      // the byte as fp32: exact, so its bf16 is the upper half of the fp32 pattern
@@ -111,11 +111,11 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
         h[e] = v;
       }
       u32x4 pk;
-      pk.x = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, h[1]), __builtin_bit_cast(uint32_t, h[0]), 0x07060302u);
-      pk.y = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, h[3]), __builtin_bit_cast(uint32_t, h[2]), 0x07060302u);
-      pk.z = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, h[5]), __builtin_bit_cast(uint32_t, h[4]), 0x07060302u);
-      pk.w = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, h[7]), __builtin_bit_cast(uint32_t, h[6]), 0x07060302u);
-      pf[ks] = __builtin_bit_cast(bf16x8, pk);
+      pk.x = pack_op16x2_exact(h[0], h[1]);
+      pk.y = pack_op16x2_exact(h[2], h[3]);
+      pk.z = pack_op16x2_exact(h[4], h[5]);
+      pk.w = pack_op16x2_exact(h[6], h[7]);
+      pf[ks] = __builtin_bit_cast(op16x8, pk);
       }
       f32x16 acc[4];
 #pragma unroll
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[cs][r] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) acc[cs] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[cs][ks], pf[ks], acc[cs], 0, 0, 0);
+        for (int ks = 0; ks < 2; ++ks) acc[cs] = VPT_MFMA_32X32X16(wfr[cs][ks], pf[ks], acc[cs], 0, 0, 0);
       }
       // conv + bias (1/255 is folded into the weights), rounded to bf16 and stored RAW: the ReLU commutes with the
     // max-pool, so it is applied once per pooled value instead of once per conv value; pixels outside the image -> 0
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
       for (int cs = 0; cs < 4; ++cs) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          u32x2 pk2 = {pack_bf16x2(acc[cs][4 * g + 0], acc[cs][4 * g + 1]) & keep, pack_bf16x2(acc[cs][4 * g + 2], acc[cs][4 * g + 3]) & keep};
+          u32x2 pk2 = {pack_op16x2(acc[cs][4 * g + 0], acc[cs][4 * g + 1]) & keep, pack_op16x2(acc[cs][4 * g + 2], acc[cs][4 * g + 3]) & keep};
           *(u32x2*)(dst + (cs * 32 + g * 8) * 2) = pk2;
         }
       }
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
       for (int q8 = 0; q8 < 8; ++q8) {
         const int pp = half * 32 + g * 8 + q8;
         const int pyl = pp >> 3, pxl = pp & 7;
-        const float d = __builtin_bit_cast(float, (q8 & 1) ? (cur[q8 >> 1] & 0xffff0000u) : (cur[q8 >> 1] << 16));
+        const float d = (q8 & 1) ? op16_hi_to_f32(cur[q8 >> 1]) : op16_lo_to_f32(cur[q8 >> 1]);
         if (d == 0.f) continue;
         const short* ct = (const short*)(smem + ((2 * pyl) * 17 + 2 * pxl) * CT_RS) + oc;
         short best = 0;                                        // raw bf16 patterns as signed integers: only values > 0 can win (ReLU gate)

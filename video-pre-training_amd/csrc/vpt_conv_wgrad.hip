@@ -20,11 +20,9 @@
 #include "vpt_common.h"
 #include "vpt_kernels.h"
 
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {  // 8 pixels of this lane's channel: two 4-pixel transposes
-  const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
-  const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 256));
+__device__ __forceinline__ op16x8 tr_frag(const unsigned char* p) {  // 8 pixels of this lane's channel: two 4-pixel transposes
+  const op16x4 a = lds_tr16_read(p);
+  const op16x4 b = lds_tr16_read(p + 256);
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
@@ -127,7 +125,7 @@ __global__ __launch_bounds__(512, 1) void vpt_conv_wgrad_kernel(VptConvWgradArgs
     for (int ks = 0; ks < 4; ++ks) {
       const int q0 = ks * 16;
       const int r = q0 / W, x0 = q0 % W;
-      bf16x8 af[3], bfr[3];
+      op16x8 af[3], bfr[3];
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) af[dx] = tr_frag(dA + (r * DP + x0 - dx + 2) * 64);
 #pragma unroll
@@ -136,7 +134,7 @@ __global__ __launch_bounds__(512, 1) void vpt_conv_wgrad_kernel(VptConvWgradArgs
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx)
-          acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[dx], bfr[dy], acc[dy * 3 + dx], 0, 0, 0);
+          acc[dy * 3 + dx] = VPT_MFMA_32X32X16(af[dx], bfr[dy], acc[dy * 3 + dx], 0, 0, 0);
     }
     store_step((s + 1) & 1);
     __syncthreads();

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void vpt_pool_kernel(VptPoolArgs a) {
     const int px = r % PW; r /= PW;
     const int py = r % PH;
     const int cb = r / PH;
-    const vpt_bf16* plane = a.x + ((size_t)(f * a.CB + cb) * a.H * a.W) * 32 + oct * 8;
+    const vpt_op16* plane = a.x + ((size_t)(f * a.CB + cb) * a.H * a.W) * 32 + oct * 8;
     u16x8 m = {0, 0, 0, 0, 0, 0, 0, 0};
     u16x8 am = {15, 15, 15, 15, 15, 15, 15, 15};
 #pragma unroll

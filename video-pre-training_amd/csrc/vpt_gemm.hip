@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
 
   // staging maps
   const int arow = tid >> 3, apart = tid & 7;
-  const vpt_bf16* aptr[8];
+  const vpt_op16* aptr[8];
   bool avalid[8];
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
     aptr[m] = a.A + (size_t)(avalid[m] ? grow : 0) * a.lda + apart * 8;
   }
   unsigned char* ast = smem + arow * GA_RS + apart * 16;
-  const vpt_bf16* wbase = a.wpk + (size_t)nt * (a.K >> 5) * 4096 + tid * 8;
+  const vpt_op16* wbase = a.wpk + (size_t)nt * (a.K >> 5) * 4096 + tid * 8;
   unsigned char* bst = smem + GA_BYTES + (tid >> 2) * GB_RS + (tid & 3) * 16;
 
   u32x4 areg[8], breg[4];
@@ -85,17 +85,17 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
     }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      bf16x8 af[4], bf[2];
+      op16x8 af[4], bf[2];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) af[m] = *(const bf16x8*)(aL + m * (32 * GA_RS) + kk * 32);
+      for (int m = 0; m < 4; ++m) af[m] = *(const op16x8*)(aL + m * (32 * GA_RS) + kk * 32);
 #pragma unroll
       for (int n = 0; n < 2; ++n)
-        bf[n] = *(const bf16x8*)(bL + (kk >> 1) * (128 * GB_RS) + n * (32 * GB_RS) + (kk & 1) * 32);
+        bf[n] = *(const op16x8*)(bL + (kk >> 1) * (128 * GB_RS) + n * (32 * GB_RS) + (kk & 1) * 32);
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
+          acc[m][n] = VPT_MFMA_32X32X16(af[m], bf[n], acc[m][n], 0, 0, 0);
     }
     __syncthreads();
     if (more) {
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
         for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
       }
       if (a.mask) {         // ReLU backward: gate by the saved activation
-        const vpt_bf16* mk = a.mask + (size_t)row0 * a.ldm + col;
+        const vpt_op16* mk = a.mask + (size_t)row0 * a.ldm + col;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (ok[r] && !((float)mk[((r & 3) + 8 * (r >> 2)) * a.ldm] > 0.f)) v[r] = 0.f;
@@ -157,10 +157,10 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
           if (ok[r]) o[((r & 3) + 8 * (r >> 2)) * a.ldc] = v[r];
       }
       if (a.out_bf16) {
-        vpt_bf16* o = a.out_bf16 + (size_t)row0 * a.ldcb + col;
+        vpt_op16* o = a.out_bf16 + (size_t)row0 * a.ldcb + col;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (ok[r]) o[((r & 3) + 8 * (r >> 2)) * a.ldcb] = (vpt_bf16)v[r];
+          if (ok[r]) o[((r & 3) + 8 * (r >> 2)) * a.ldcb] = (vpt_op16)v[r];
       }
     }
   }
@@ -177,11 +177,9 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
 #define TA_BYTES (64 * TA_RS)   // 36864
 #define TB_RS 320
 #define TB_BYTES (64 * TB_RS)   // 20480
-typedef __attribute__((address_space(3))) bf16x4 gemm_lds_bf16x4;
-
-__device__ __forceinline__ bf16x8 tn_frag(const unsigned char* p, int row_stride) {   // 8 consecutive m of this lane's column
-  const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((gemm_lds_bf16x4*)(p));
-  const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((gemm_lds_bf16x4*)(p + 4 * row_stride));
+__device__ __forceinline__ op16x8 tn_frag(const unsigned char* p, int row_stride) {   // 8 consecutive m of this lane's column
+  const op16x4 a = lds_tr16_read(p);
+  const op16x4 b = lds_tr16_read(p + 4 * row_stride);
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
@@ -247,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_tn_kernel(VptGemmTnArgs a) {
     if (more) load(s + 1);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      bf16x8 af[4], bfr[2];
+      op16x8 af[4], bfr[2];
 #pragma unroll
       for (int m = 0; m < 4; ++m) af[m] = tn_frag(aL + kk * 16 * TA_RS + m * 64, TA_RS);
 #pragma unroll
@@ -255,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_tn_kernel(VptGemmTnArgs a) {
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+        for (int n = 0; n < 2; ++n) acc[m][n] = VPT_MFMA_32X32X16(af[m], bfr[n], acc[m][n], 0, 0, 0);
     }
     __syncthreads();
     if (more) store();
@@ -302,7 +300,7 @@ __global__ __launch_bounds__(256) void vpt_splitk_epilogue_kernel(const float* _
   if (a.mask && !((float)a.mask[(size_t)row * a.ldm + col] > 0.f)) v = 0.f;
   if (a.res) v += a.res[(size_t)row * a.ldr + col];
   if (a.out_f32) a.out_f32[(size_t)row * a.ldc + col] = v;
-  if (a.out_bf16) a.out_bf16[(size_t)row * a.ldcb + col] = (vpt_bf16)v;
+  if (a.out_bf16) a.out_bf16[(size_t)row * a.ldcb + col] = (vpt_op16)v;
 }
 
 extern "C" int vpt_splitk_epilogue_launch(const float* part, int splitk, const VptGemmArgs* a, hipStream_t stream) {

@@ -22,8 +22,8 @@ __global__ __launch_bounds__(256) void vpt_gemv_kernel(VptGemmArgs a) {
   const int kbs = a.K >> 5;
   const int per = (kbs + a.splitk - 1) / a.splitk;
   const int kb0 = split * per, kb1 = min(kb0 + per, kbs);
-  const vpt_bf16* wp = a.wpk + ((size_t)nt * kbs * 128 + rin + row) * 32 + chunk * 8;
-  const vpt_bf16* ap = a.A + chunk * 8;
+  const vpt_op16* wp = a.wpk + ((size_t)nt * kbs * 128 + rin + row) * 32 + chunk * 8;
+  const vpt_op16* ap = a.A + chunk * 8;
   float acc[MR];
 #pragma unroll
   for (int m = 0; m < MR; ++m) acc[m] = 0.f;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void vpt_gemv_kernel(VptGemmArgs a) {
         if (a.mask && !((float)a.mask[(size_t)m * a.ldm + col] > 0.f)) v = 0.f;
         if (a.res) v += a.res[(size_t)m * a.ldr + col];
         if (a.out_f32) a.out_f32[(size_t)m * a.ldc + col] = v;
-        if (a.out_bf16) a.out_bf16[(size_t)m * a.ldcb + col] = (vpt_bf16)v;
+        if (a.out_bf16) a.out_bf16[(size_t)m * a.ldcb + col] = (vpt_op16)v;
       }
     }
   }

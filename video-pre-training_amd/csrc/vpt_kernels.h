@@ -4,56 +4,59 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef __bf16 vpt_bf16;
+#ifdef VPT_OPERAND_F16
+typedef _Float16 vpt_op16;   // precision mode "fp16" (see vpt_common.h)
+#else
+typedef __bf16 vpt_op16;
+#endif
 
 struct VptConv3x3Args {
-  const vpt_bf16* x;       // [F][Cin/32][H][W][32]
-  const vpt_bf16* wpk;     // [NT][Cin/32][9][128][32], GroupNorm gain folded
+  const vpt_op16* x;       // [F][Cin/32][H][W][32]
+  const vpt_op16* wpk;     // [NT][Cin/32][9][128][32], GroupNorm gain folded
   const float* edge_sa;    // [9][CoutPad]
   const float* edge_sg;    // [9][CoutPad]
   const double* stats_in;  // [F][2]  sum / sumsq of x
-  const vpt_bf16* res;     // optional residual, same layout as y
-  vpt_bf16* y;             // [F][Cout/32][H][W][32]
+  const vpt_op16* res;     // optional residual, same layout as y
+  vpt_op16* y;             // [F][Cout/32][H][W][32]
   double* stats_out;       // optional [F][2], accumulated (caller zeroes)
   int frames, H, W, Cin, Cout, CoutPad, NT;
   double inv_count_in;     // 1 / (Cin*H*W)
   int ablate;              // profiling only (env VPT_CONV_ABLATE)
   long long* trace;        // profiling only: per-workgroup phase timestamps (vpt_conv3x3_set_trace)
-  int prio_level;          // > 0: first workgroup on a CU runs at this s_setprio level (anti-phasing, set by the launcher)
   // dgrad mode (bwd != 0): no GroupNorm fold, no ReLU; out = conv + res + coef[f][0] + coef[f][1] * xin
   int bwd;
-  const vpt_bf16* xin;     // the forward layer's input x (same shape as this call's output)
+  const vpt_op16* xin;     // the forward layer's input x (same shape as this call's output)
   const float* coef;       // [F][2]
 };
 
 struct VptConvFirstArgs {
   const uint8_t* img;      // [F][H][W][3]
-  const vpt_bf16* wfrag;   // [NT][4][2][64][8]  MFMA A-operand fragments (bias folded in k=27,28)
-  vpt_bf16* y;             // pooled output [F][Cout/32][H/2][W/2][32]
+  const vpt_op16* wfrag;   // [NT][4][2][64][8]  MFMA A-operand fragments (bias folded in k=27,28)
+  vpt_op16* y;             // pooled output [F][Cout/32][H/2][W/2][32]
   double* stats_out;       // [F][2]
   int frames, H, W, Cout, NT;
 };
 
 struct VptConv3dArgs {
   const uint8_t* img;      // [B*T][H][W][3]
-  const vpt_bf16* wfrag;   // [NT][4][64][8]  MFMA A-operand fragments, k = dt*3 + ch (15 used)
+  const vpt_op16* wfrag;   // [NT][4][64][8]  MFMA A-operand fragments, k = dt*3 + ch (15 used)
   const float* bias;       // [NT*128]
-  vpt_bf16* y;             // [B*T][Cout/32][H][W][32]
+  vpt_op16* y;             // [B*T][Cout/32][H][W][32]
   double* stats_out;       // [B*T][2]
   int frames, T, H, W, Cout, NT;
 };
 
 struct VptPoolArgs {
-  const vpt_bf16* x;       // [F][CB][H][W][32]  (non-negative values: post-ReLU)
-  vpt_bf16* y;             // [F][CB][H/2][W/2][32]
+  const vpt_op16* x;       // [F][CB][H][W][32]  (non-negative values: post-ReLU)
+  vpt_op16* y;             // [F][CB][H/2][W/2][32]
   double* stats_out;       // [F][2]
   uint8_t* argmax;         // optional [F][CB][H/2][W/2][32]: window position code kh*3+kw of the first maximum (15: window all zero)
   int frames, CB, H, W;
 };
 
 struct VptAffineArgs {     // y = (x - mean_f) * rstd_f * g[idx] + b[idx]
-  const vpt_bf16* x;
-  vpt_bf16* y;
+  const vpt_op16* x;
+  vpt_op16* y;
   const float* gain;       // per channel [C] (per_element=0) or per position [C*H*W] in blocked order (=1)
   const float* bias;
   const double* stats_in;  // [F][2]
@@ -63,21 +66,21 @@ struct VptAffineArgs {     // y = (x - mean_f) * rstd_f * g[idx] + b[idx]
 };
 
 struct VptGemmArgs {
-  const vpt_bf16* A;       // [M][lda] bf16 row-major
-  const vpt_bf16* wpk;     // [NT][K/32][128][32]
+  const vpt_op16* A;       // [M][lda] bf16 row-major
+  const vpt_op16* wpk;     // [NT][K/32][128][32]
   const float* bias;       // [N] or null
   const float* res;        // [M][ldr] fp32 or null
   float* out_f32;          // [M][ldc] or null
-  vpt_bf16* out_bf16;      // [M][ldcb] or null
+  vpt_op16* out_bf16;      // [M][ldcb] or null
   int M, N, K, lda, ldr, ldc, ldcb;
   int relu, splitk, atomic_out;
-  const vpt_bf16* mask;    // optional [M][ldm]: output is zeroed where mask <= 0 (ReLU backward)
+  const vpt_op16* mask;    // optional [M][ldm]: output is zeroed where mask <= 0 (ReLU backward)
   int ldm;
 };
 
 struct VptGemmTnArgs {     // C[n1][n2] (+)= sum_m A[m][n1] * B[m][n2]
-  const vpt_bf16* A;       // [M][lda]
-  const vpt_bf16* B;       // [M][ldb]
+  const vpt_op16* A;       // [M][lda]
+  const vpt_op16* B;       // [M][ldb]
   float* C;                // [N1][ldc]
   int M, N1, N2, lda, ldb, ldc, accumulate;
 };
@@ -87,7 +90,7 @@ struct VptLayerNormArgs {
   const float* gain;
   const float* bias;
   float* out_f32;          // optional [M][D]
-  vpt_bf16* out_bf16;      // optional [M][D]
+  vpt_op16* out_bf16;      // optional [M][D]
   int M, D, relu_in;
 };
 
@@ -97,7 +100,7 @@ struct VptAttnArgs {
   const float* vmem;
   const uint8_t* memvalid; // [B][maxlen]  state_mask & !first
   const float* b_nd;       // [10][maxlen]
-  vpt_bf16* out;           // [B*t][hid]
+  vpt_op16* out;           // [B*t][hid]
   int B, t, heads, hid, ld, maxlen, causal;
 };
 
@@ -118,10 +121,10 @@ struct VptLogSoftmaxArgs {
 };
 
 struct VptAffineBwdArgs {
-  const vpt_bf16* x;       // the affine's INPUT, blocked
-  const vpt_bf16* dy;      // gradient w.r.t. its output
-  const vpt_bf16* dx_add;  // optional, added to dx (pass 2)
-  vpt_bf16* dx;            // pass 2 output
+  const vpt_op16* x;       // the affine's INPUT, blocked
+  const vpt_op16* dy;      // gradient w.r.t. its output
+  const vpt_op16* dx_add;  // optional, added to dx (pass 2)
+  vpt_op16* dx;            // pass 2 output
   const float* gain;
   const double* stats_in;  // statistics of x
   double* ab;              // [F][2] sum dy g, sum dy g xhat (pass 1 accumulates, pass 2 reads)
@@ -132,25 +135,25 @@ struct VptAffineBwdArgs {
 };
 
 struct VptPoolBwdArgs {
-  const vpt_bf16* pre;     // pre-pool tensor [F][CB][H][W][32]
-  const vpt_bf16* pooled;  // [F][CB][H/2][W/2][32]
-  const vpt_bf16* dpooled;
-  vpt_bf16* dpre;
+  const vpt_op16* pre;     // pre-pool tensor [F][CB][H][W][32]
+  const vpt_op16* pooled;  // [F][CB][H/2][W/2][32]
+  const vpt_op16* dpooled;
+  vpt_op16* dpre;
   int frames, CB, H, W;
 };
 
 struct VptConvBwdPrepArgs {
-  const vpt_bf16* dy;      // gradient w.r.t. the layer output (after ReLU and residual add); null -> (dpooled, argmax)
-  const vpt_bf16* dpooled; // gradient w.r.t. max_pool(y) [F][CB][H/2][W/2][32]   (fused max-pool backward)
+  const vpt_op16* dy;      // gradient w.r.t. the layer output (after ReLU and residual add); null -> (dpooled, argmax)
+  const vpt_op16* dpooled; // gradient w.r.t. max_pool(y) [F][CB][H/2][W/2][32]   (fused max-pool backward)
   const uint8_t* argmax;   // window position code kh*3+kw of the maximum, same shape (vpt_pool_kernel)
   float* sbuf;             // scratch [F][9*Cout + Cout/32] fp32: per-frame edge-class sums of dz, then per-plane sum dz v
   int wshift;              // log2(W), filled by the launcher
-  const vpt_bf16* y;       // saved layer output
-  const vpt_bf16* res;     // saved residual input or null
+  const vpt_op16* y;       // saved layer output
+  const vpt_op16* res;     // saved residual input or null
   const double* stats_in;  // statistics of the conv's INPUT x
   const float* edge_sa;    // [9][CoutPad]
   const float* edge_sg;
-  vpt_bf16* dacc;          // rstd * dz, blocked like y
+  vpt_op16* dacc;          // rstd * dz, blocked like y
   double* t12;             // optional [F][2]: T1 = sum dz (v - SA), T2 = sum dz SG   (written)
   float* coef;             // [F][2]: (c0, c1) of the input gradient's statistics terms dx += c0 + c1 x   (written)
   float* d_sa;             // [9][CoutPad] accumulated
@@ -161,16 +164,16 @@ struct VptConvBwdPrepArgs {
 
 struct VptConvFirstBwdArgs {
   const uint8_t* img;      // [F][H][W][3]
-  const vpt_bf16* wfrag;   // forward weight fragments (the pre-pool tile is recomputed)
-  const vpt_bf16* dpooled; // gradient w.r.t. the pooled output [F][Cout/32][H/2][W/2][32]
+  const vpt_op16* wfrag;   // forward weight fragments (the pre-pool tile is recomputed)
+  const vpt_op16* dpooled; // gradient w.r.t. the pooled output [F][Cout/32][H/2][W/2][32]
   float* dw;               // [Cout][27] in (kh, kw, ch) order, accumulated
   float* db;               // [Cout] accumulated
   int frames, H, W, Cout;
 };
 
 struct VptConvWgradArgs {
-  const vpt_bf16* dacc;    // [F][Cout/32][H][W][32]
-  const vpt_bf16* x;       // [F][Cin/32][H][W][32]
+  const vpt_op16* dacc;    // [F][Cout/32][H][W][32]
+  const vpt_op16* x;       // [F][Cin/32][H][W][32]
   float* dw;               // [Cout][9][Cin] accumulated (caller zeroes)
   float* partial;          // scratch [vpt_conv_wgrad_groups()][Cout][9][Cin]
   int frames, H, W, Cin, Cout;
@@ -182,15 +185,15 @@ struct VptNllBwdArgs {
   const float* lp_camera;  // [M][nc]
   const long* act_buttons; // [M]
   const long* act_camera;  // [M]
-  vpt_bf16* dz;            // [M][ldz]: d loss / d (pre-softmax logits), columns nb+nc.. zero
+  vpt_op16* dz;            // [M][ldz]: d loss / d (pre-softmax logits), columns nb+nc.. zero
   int M, nb, nc, ldz;
   float scale;             // 1 / (frames in the global batch * temperature)
 };
 
 struct VptGateCastArgs {
   const float* x;          // [M][ldx]
-  const vpt_bf16* mask;    // optional [M][ldm]
-  vpt_bf16* out;           // [M][ldo]
+  const vpt_op16* mask;    // optional [M][ldm]
+  vpt_op16* out;           // [M][ldo]
   int M, N, ldx, ldm, ldo;
 };
 
@@ -206,7 +209,7 @@ struct VptLnBwdArgs {
 };
 
 struct VptColsumArgs {
-  const vpt_bf16* x;       // [M][ld]
+  const vpt_op16* x;       // [M][ld]
   float* out;              // [N] accumulated (caller zeroes)
   int M, N, ld;
 };

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void vpt_layernorm_kernel(VptLayerNormArgs a) 
     y.w = fmaf((v.w - mean) * rstd, g.w, b.w);
     if (a.out_f32) *(f32x4*)(a.out_f32 + (size_t)row * a.D + 4 * i) = y;
     if (a.out_bf16) {
-      u32x2 p = {pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w)};
+      u32x2 p = {pack_op16x2(y.x, y.y), pack_op16x2(y.z, y.w)};
       *(u32x2*)(a.out_bf16 + (size_t)row * a.D + 4 * i) = p;
     }
   }
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void vpt_attn_kernel(VptAttnArgs a) {
       const float sc = Sc[qi];
 #pragma unroll
       for (int i = 0; i < 16; ++i) o[i] *= sc;
-      vpt_bf16* dst = a.out + (tok0 + q0 + qi) * hid + h * ATT_DH + dg * 16;
+      vpt_op16* dst = a.out + (tok0 + q0 + qi) * hid + h * ATT_DH + dg * 16;
       *(u32x4*)dst = pack8(o);
       *(u32x4*)(dst + 8) = pack8(o + 8);
     }

@@ -71,9 +71,29 @@ class _NullCtx:
         return False
 
 
+PRECISIONS = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+
+def resolve_precision(precision: Optional[str]) -> str:
+    """precision=None -> env VPT_PRECISION -> "bf16" (the benchmarked default; "fp16" = the parity mode, same speed)."""
+    p = precision or os.environ.get("VPT_PRECISION", "bf16")
+    if p not in PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(PRECISIONS)}, got {p!r}")
+    return p
+
+
 class PolicyEngine:
-    def __init__(self, cfg: dict, n_buttons: int, n_camera: int, cnn_chunk: int = 1024, cnn_streams: int = 3):
+    """precision: format of every 16-bit MFMA operand / stored CNN activation.  "bf16" (default, what bench.py
+    measures) or "fp16": the same kernels built with IEEE-half operands (libvpt_hip_f16.so) -- same MFMA rate and
+    bytes, 8x finer rounding: log-probs within 2.5e-4 of the fp32 reference instead of 1.8e-3
+    (profiles/r02_precision_sweep_1x.md).  Accumulation, statistics, softmax, residual stream and KV memory are fp32
+    in both.  The BC step (training.py) supports bf16 only."""
+
+    def __init__(self, cfg: dict, n_buttons: int, n_camera: int, cnn_chunk: int = 1024, cnn_streams: int = 3,
+                 precision: Optional[str] = None):
         check_supported(cfg)
+        self.precision = resolve_precision(precision)
+        self.dtype = PRECISIONS[self.precision]
         self.cfg = cfg
         self.n_buttons, self.n_camera = n_buttons, n_camera
         self.cnn_chunk = int(os.environ.get("VPT_CNN_CHUNK", cnn_chunk))
@@ -92,24 +112,23 @@ class PolicyEngine:
         for s, c in enumerate(cfg["chans"]):
             p = f"net.img_process.cnn.stacks.{s}."
             if s == 0:
-                w[p + "firstconv"] = packing.pack_conv_first(f32(sd[p + "firstconv.layer.weight"]), f32(sd[p + "firstconv.layer.bias"]))
+                w[p + "firstconv"] = packing.pack_conv_first(f32(sd[p + "firstconv.layer.weight"]), f32(sd[p + "firstconv.layer.bias"]), dtype=self.dtype)
             else:
-                w[p + "firstconv"] = packing.pack_conv3x3(f32(sd[p + "firstconv.layer.weight"]),
-                                                          f32(sd[p + "firstconv.norm.weight"]), f32(sd[p + "firstconv.norm.bias"]))
+                w[p + "firstconv"] = packing.pack_conv3x3(f32(sd[p + "firstconv.layer.weight"]), f32(sd[p + "firstconv.norm.weight"]), f32(sd[p + "firstconv.norm.bias"]), dtype=self.dtype)
             w[p + "n.g"], w[p + "n.b"] = f32(sd[p + "n.weight"]), f32(sd[p + "n.bias"])
             for b in range(2):
                 for cv in range(2):
                     q = f"{p}blocks.{b}.conv{cv}"
-                    w[q] = packing.pack_conv3x3(f32(sd[q + ".layer.weight"]), f32(sd[q + ".norm.weight"]), f32(sd[q + ".norm.bias"]))
+                    w[q] = packing.pack_conv3x3(f32(sd[q + ".layer.weight"]), f32(sd[q + ".norm.weight"]), f32(sd[q + ".norm.bias"]), dtype=self.dtype)
             cin = c
         c2 = cfg["chans"][-1]
         p = "net.img_process.cnn.dense."
         w[p + "g"] = packing.chw_to_blocked_vector(f32(sd[p + "norm.weight"]), c2, 16, 16)
         w[p + "b"] = packing.chw_to_blocked_vector(f32(sd[p + "norm.bias"]), c2, 16, 16)
-        w[p + "w"] = packing.pack_linear(packing.chw_to_blocked_columns(f32(sd[p + "layer.weight"]), c2, 16, 16))
+        w[p + "w"] = packing.pack_linear(packing.chw_to_blocked_columns(f32(sd[p + "layer.weight"]), c2, 16, 16), dtype=self.dtype)
         p = "net.img_process.linear."
         w[p + "g"], w[p + "b"] = f32(sd[p + "norm.weight"]), f32(sd[p + "norm.bias"])
-        w[p + "w"] = packing.pack_linear(f32(sd[p + "layer.weight"]))
+        w[p + "w"] = packing.pack_linear(f32(sd[p + "layer.weight"]), dtype=self.dtype)
         hid = cfg["hidsize"]
         for l in range(cfg["n_layers"]):
             p = f"net.recurrent_layer.blocks.{l}."
@@ -119,21 +138,21 @@ class PolicyEngine:
                             f32(sd[o + "v_layer.weight"]), f32(sd[o + "r_layer.weight"])], dim=0)
             nr = sd[o + "r_layer.weight"].shape[0]
             bq = torch.cat([f32(sd[o + "q_layer.bias"]), torch.zeros(2 * hid, device=wq.device), f32(sd[o + "r_layer.bias"])])
-            w[p + "qkvr.w"], w[p + "qkvr.b"] = packing.pack_linear(wq), bq.contiguous()
+            w[p + "qkvr.w"], w[p + "qkvr.b"] = packing.pack_linear(wq, dtype=self.dtype), bq.contiguous()
             w[p + "b_nd"] = f32(sd[o + "b_nd"])
-            w[p + "proj.w"], w[p + "proj.b"] = packing.pack_linear(f32(sd[o + "proj_layer.weight"])), f32(sd[o + "proj_layer.bias"])
+            w[p + "proj.w"], w[p + "proj.b"] = packing.pack_linear(f32(sd[o + "proj_layer.weight"]), dtype=self.dtype), f32(sd[o + "proj_layer.bias"])
             w[p + "ln2.g"], w[p + "ln2.b"] = f32(sd[p + "mlp0.norm.weight"]), f32(sd[p + "mlp0.norm.bias"])
-            w[p + "mlp0.w"] = packing.pack_linear(f32(sd[p + "mlp0.layer.weight"]))
-            w[p + "mlp1.w"], w[p + "mlp1.b"] = packing.pack_linear(f32(sd[p + "mlp1.layer.weight"])), f32(sd[p + "mlp1.layer.bias"])
+            w[p + "mlp0.w"] = packing.pack_linear(f32(sd[p + "mlp0.layer.weight"]), dtype=self.dtype)
+            w[p + "mlp1.w"], w[p + "mlp1.b"] = packing.pack_linear(f32(sd[p + "mlp1.layer.weight"]), dtype=self.dtype), f32(sd[p + "mlp1.layer.bias"])
             self.n_qkvr = 3 * hid + nr
         w["last.g"], w["last.b"] = f32(sd["net.lastlayer.norm.weight"]), f32(sd["net.lastlayer.norm.bias"])
-        w["last.w"] = packing.pack_linear(f32(sd["net.lastlayer.layer.weight"]))
+        w["last.w"] = packing.pack_linear(f32(sd["net.lastlayer.layer.weight"]), dtype=self.dtype)
         w["final.g"], w["final.b"] = f32(sd["net.final_ln.weight"]), f32(sd["net.final_ln.bias"])
         wh = torch.cat([f32(sd["pi_head.buttons.linear_layer.weight"]), f32(sd["pi_head.camera.linear_layer.weight"]),
                         f32(sd["value_head.linear.weight"])], dim=0)
         bh = torch.cat([f32(sd["pi_head.buttons.linear_layer.bias"]), f32(sd["pi_head.camera.linear_layer.bias"]),
                         f32(sd["value_head.linear.bias"])])
-        w["heads.w"], w["heads.b"] = packing.pack_linear(wh), bh.contiguous()
+        w["heads.w"], w["heads.b"] = packing.pack_linear(wh, dtype=self.dtype), bh.contiguous()
         self.w = w
         self.packed = True
 
@@ -206,7 +225,7 @@ class PolicyEngine:
                 main.wait_stream(st)
         d = outs[0] if len(outs) == 1 else torch.cat(outs, 0)
         p = "net.img_process.linear."
-        _, dn = ops.layernorm(d, w[p + "g"], w[p + "b"], relu_in=True)
+        _, dn = ops.layernorm(d, w[p + "g"], w[p + "b"], relu_in=True, dtype=self.dtype)
         x, _ = ops.linear(dn, w[p + "w"], cfg["hidsize"], relu=True)
         return x
 
@@ -228,21 +247,21 @@ class PolicyEngine:
             if state_mask is None:
                 state_mask = torch.zeros(bsz, 1, maxlen, dtype=torch.bool, device=x.device)
             memvalid = (state_mask & not_first).reshape(bsz, maxlen).to(torch.uint8).contiguous()
-            x1, x1b = ops.layernorm(x, w[p + "ln1.g"], w[p + "ln1.b"], out_f32=True)
+            x1, x1b = ops.layernorm(x, w[p + "ln1.g"], w[p + "ln1.b"], out_f32=True, dtype=self.dtype)
             qkvr, _ = ops.linear(x1b, w[p + "qkvr.w"], self.n_qkvr, bias=w[p + "qkvr.b"])
-            att = ops.masked_attention(qkvr, kmem.contiguous(), vmem.contiguous(), memvalid, w[p + "b_nd"], bsz, t, heads, hid)
+            att = ops.masked_attention(qkvr, kmem.contiguous(), vmem.contiguous(), memvalid, w[p + "b_nd"], bsz, t, heads, hid, dtype=self.dtype)
             kout, vout = ops.kv_memory_update(qkvr, kmem.contiguous(), vmem.contiguous(), bsz, t, hid)
             x2, _ = ops.linear(att, w[p + "proj.w"], hid, bias=w[p + "proj.b"], res=x1)
-            _, hb = ops.layernorm(x2, w[p + "ln2.g"], w[p + "ln2.b"])
+            _, hb = ops.layernorm(x2, w[p + "ln2.g"], w[p + "ln2.b"], dtype=self.dtype)
             _, h2 = ops.linear(hb, w[p + "mlp0.w"], hid * cfg["pointwise_ratio"], relu=True, out_f32=False, out_bf16=True)
             x, _ = ops.linear(h2, w[p + "mlp1.w"], hid, bias=w[p + "mlp1.b"], res=x2)
             new_mask = torch.cat([state_mask[:, :, t:] & not_first,
                                   torch.ones(bsz, 1, min(t, maxlen), dtype=torch.bool, device=x.device)], dim=-1)
             state_out.append((new_mask, (kout, vout)))
 
-        _, xb = ops.layernorm(x, w["last.g"], w["last.b"], relu_in=True)
+        _, xb = ops.layernorm(x, w["last.g"], w["last.b"], relu_in=True, dtype=self.dtype)
         y, _ = ops.linear(xb, w["last.w"], hid, relu=True)
-        latent, lb = ops.layernorm(y, w["final.g"], w["final.b"], out_f32=True)
+        latent, lb = ops.layernorm(y, w["final.g"], w["final.b"], out_f32=True, dtype=self.dtype)
         nb, nc = self.n_buttons, self.n_camera
         logits, _ = ops.linear(lb, w["heads.w"], nb + nc + 1, bias=w["heads.b"])
         temp = cfg["temperature"]
@@ -257,8 +276,10 @@ class IDMEngine(PolicyEngine):
     with a normed first conv, transformer blocks with mask "none" and no memory, ReLU, final_ln (the reference
     computes `lastlayer` and discards it, lib/policy.py:390-391 -- so it is not computed here), two heads."""
 
-    def __init__(self, cfg: dict, button_shape, camera_shape, cnn_chunk: int = 128):
+    def __init__(self, cfg: dict, button_shape, camera_shape, cnn_chunk: int = 128, precision: Optional[str] = None):
         check_supported(cfg, idm=True)
+        self.precision = resolve_precision(precision)
+        self.dtype = PRECISIONS[self.precision]
         self.cfg = cfg
         self.button_shape, self.camera_shape = tuple(button_shape), tuple(camera_shape)  # (20, 2), (2, 11)
         self.cnn_chunk = cnn_chunk
@@ -271,25 +292,24 @@ class IDMEngine(PolicyEngine):
     def pack(self, sd):
         cfg, w = self.cfg, {}
         f32 = lambda t: t.detach().float().contiguous()
-        w["conv3d"] = packing.pack_conv3d_t5(f32(sd["net.conv3d_layer.layer.weight"]), f32(sd["net.conv3d_layer.layer.bias"]))
+        w["conv3d"] = packing.pack_conv3d_t5(f32(sd["net.conv3d_layer.layer.weight"]), f32(sd["net.conv3d_layer.layer.bias"]), dtype=self.dtype)
         self.c3d_out = sd["net.conv3d_layer.layer.weight"].shape[0]
         for s, c in enumerate(cfg["chans"]):
             p = f"net.img_process.cnn.stacks.{s}."
-            w[p + "firstconv"] = packing.pack_conv3x3(f32(sd[p + "firstconv.layer.weight"]),
-                                                      f32(sd[p + "firstconv.norm.weight"]), f32(sd[p + "firstconv.norm.bias"]))
+            w[p + "firstconv"] = packing.pack_conv3x3(f32(sd[p + "firstconv.layer.weight"]), f32(sd[p + "firstconv.norm.weight"]), f32(sd[p + "firstconv.norm.bias"]), dtype=self.dtype)
             w[p + "n.g"], w[p + "n.b"] = f32(sd[p + "n.weight"]), f32(sd[p + "n.bias"])
             for b in range(2):
                 for cv in range(2):
                     q = f"{p}blocks.{b}.conv{cv}"
-                    w[q] = packing.pack_conv3x3(f32(sd[q + ".layer.weight"]), f32(sd[q + ".norm.weight"]), f32(sd[q + ".norm.bias"]))
+                    w[q] = packing.pack_conv3x3(f32(sd[q + ".layer.weight"]), f32(sd[q + ".norm.weight"]), f32(sd[q + ".norm.bias"]), dtype=self.dtype)
         c2 = cfg["chans"][-1]
         p = "net.img_process.cnn.dense."
         w[p + "g"] = packing.chw_to_blocked_vector(f32(sd[p + "norm.weight"]), c2, 16, 16)
         w[p + "b"] = packing.chw_to_blocked_vector(f32(sd[p + "norm.bias"]), c2, 16, 16)
-        w[p + "w"] = packing.pack_linear(packing.chw_to_blocked_columns(f32(sd[p + "layer.weight"]), c2, 16, 16))
+        w[p + "w"] = packing.pack_linear(packing.chw_to_blocked_columns(f32(sd[p + "layer.weight"]), c2, 16, 16), dtype=self.dtype)
         p = "net.img_process.linear."
         w[p + "g"], w[p + "b"] = f32(sd[p + "norm.weight"]), f32(sd[p + "norm.bias"])
-        w[p + "w"] = packing.pack_linear(f32(sd[p + "layer.weight"]))
+        w[p + "w"] = packing.pack_linear(f32(sd[p + "layer.weight"]), dtype=self.dtype)
         hid = cfg["hidsize"]
         for l in range(cfg["n_layers"]):
             p = f"net.recurrent_layer.blocks.{l}."
@@ -297,14 +317,14 @@ class IDMEngine(PolicyEngine):
             w[p + "ln1.g"], w[p + "ln1.b"] = f32(sd[p + "pre_r_ln.weight"]), f32(sd[p + "pre_r_ln.bias"])
             wq = torch.cat([f32(sd[o + "q_layer.weight"]), f32(sd[o + "k_layer.weight"]), f32(sd[o + "v_layer.weight"])], dim=0)
             bq = torch.cat([f32(sd[o + "q_layer.bias"]), torch.zeros(2 * hid, device=wq.device)])
-            w[p + "qkv.w"], w[p + "qkv.b"] = packing.pack_linear(wq), bq.contiguous()
-            w[p + "proj.w"], w[p + "proj.b"] = packing.pack_linear(f32(sd[o + "proj_layer.weight"])), f32(sd[o + "proj_layer.bias"])
+            w[p + "qkv.w"], w[p + "qkv.b"] = packing.pack_linear(wq, dtype=self.dtype), bq.contiguous()
+            w[p + "proj.w"], w[p + "proj.b"] = packing.pack_linear(f32(sd[o + "proj_layer.weight"]), dtype=self.dtype), f32(sd[o + "proj_layer.bias"])
             w[p + "ln2.g"], w[p + "ln2.b"] = f32(sd[p + "mlp0.norm.weight"]), f32(sd[p + "mlp0.norm.bias"])
-            w[p + "mlp0.w"] = packing.pack_linear(f32(sd[p + "mlp0.layer.weight"]))
-            w[p + "mlp1.w"], w[p + "mlp1.b"] = packing.pack_linear(f32(sd[p + "mlp1.layer.weight"])), f32(sd[p + "mlp1.layer.bias"])
+            w[p + "mlp0.w"] = packing.pack_linear(f32(sd[p + "mlp0.layer.weight"]), dtype=self.dtype)
+            w[p + "mlp1.w"], w[p + "mlp1.b"] = packing.pack_linear(f32(sd[p + "mlp1.layer.weight"]), dtype=self.dtype), f32(sd[p + "mlp1.layer.bias"])
         w["final.g"], w["final.b"] = f32(sd["net.final_ln.weight"]), f32(sd["net.final_ln.bias"])
         for h in ("buttons", "camera"):
-            w[h + ".w"] = packing.pack_linear(f32(sd[f"pi_head.{h}.linear_layer.weight"]))
+            w[h + ".w"] = packing.pack_linear(f32(sd[f"pi_head.{h}.linear_layer.weight"]), dtype=self.dtype)
             w[h + ".b"] = f32(sd[f"pi_head.{h}.linear_layer.bias"])
         self.w = w
         self.packed = True
@@ -333,18 +353,18 @@ class IDMEngine(PolicyEngine):
             del x0, xn
         d = outs[0] if len(outs) == 1 else torch.cat(outs, 0)
         p = "net.img_process.linear."
-        _, dn = ops.layernorm(d, w[p + "g"], w[p + "b"], relu_in=True)
+        _, dn = ops.layernorm(d, w[p + "g"], w[p + "b"], relu_in=True, dtype=self.dtype)
         x, _ = ops.linear(dn, w[p + "w"], hid, relu=True)
         for l in range(cfg["n_layers"]):
             p = f"net.recurrent_layer.blocks.{l}."
-            x1, x1b = ops.layernorm(x, w[p + "ln1.g"], w[p + "ln1.b"], out_f32=True)
+            x1, x1b = ops.layernorm(x, w[p + "ln1.g"], w[p + "ln1.b"], out_f32=True, dtype=self.dtype)
             qkv, _ = ops.linear(x1b, w[p + "qkv.w"], 3 * hid, bias=w[p + "qkv.b"])
-            att = ops.full_attention(qkv, bsz, t, heads, hid)
+            att = ops.full_attention(qkv, bsz, t, heads, hid, dtype=self.dtype)
             x2, _ = ops.linear(att, w[p + "proj.w"], hid, bias=w[p + "proj.b"], res=x1)
-            _, hb = ops.layernorm(x2, w[p + "ln2.g"], w[p + "ln2.b"])
+            _, hb = ops.layernorm(x2, w[p + "ln2.g"], w[p + "ln2.b"], dtype=self.dtype)
             _, h2 = ops.linear(hb, w[p + "mlp0.w"], hid * cfg["pointwise_ratio"], relu=True, out_f32=False, out_bf16=True)
             x, _ = ops.linear(h2, w[p + "mlp1.w"], hid, bias=w[p + "mlp1.b"], res=x2)
-        latent, lb = ops.layernorm(x, w["final.g"], w["final.b"], relu_in=True, out_f32=True)
+        latent, lb = ops.layernorm(x, w["final.g"], w["final.b"], relu_in=True, out_f32=True, dtype=self.dtype)
         out = {}
         temp = cfg["temperature"]
         for h, shape in (("buttons", self.button_shape), ("camera", self.camera_shape)):

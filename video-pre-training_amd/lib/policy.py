@@ -39,10 +39,6 @@ def _fan_in_(w: torch.Tensor, scale: float):
     return w
 
 
-class _ImgPreprocess(_Node):
-    pass
-
-
 class MinecraftPolicy(nn.Module):
     """Parameter container with the key names of lib/policy.py:83-224 (transformer recurrence only)."""
 
@@ -155,7 +151,11 @@ class ScaledMSEHead(nn.Module):
 
 
 class MinecraftAgentPolicy(nn.Module):
-    def __init__(self, action_space, policy_kwargs, pi_head_kwargs):
+    """`precision` (not a reference argument; also env VPT_PRECISION or set_precision()): "bf16" -- the default and the
+    benchmarked mode -- or "fp16", the parity mode: the same kernels with IEEE-half MFMA operands, same speed, 8x finer
+    operand rounding (engine.PolicyEngine)."""
+
+    def __init__(self, action_space, policy_kwargs, pi_head_kwargs, precision: Optional[str] = None):
         super().__init__()
         self.net = MinecraftPolicy(**policy_kwargs)
         self.action_space = action_space
@@ -163,9 +163,23 @@ class MinecraftAgentPolicy(nn.Module):
         self.pi_head = make_action_head(self.action_space, self.net.output_latent_size(), **pi_head_kwargs)
         self._cfg = config_from_policy_kwargs(policy_kwargs, pi_head_kwargs)
         self._engine = PolicyEngine(self._cfg, n_buttons=action_space["buttons"].eltype.n,
-                                    n_camera=action_space["camera"].eltype.n)
+                                    n_camera=action_space["camera"].eltype.n, precision=precision)
         self._packed_key = None
         self._step_graph = None
+
+    @property
+    def precision(self) -> str:
+        return self._engine.precision
+
+    def set_precision(self, precision: str):
+        """Switch the operand format ("bf16" / "fp16"); weights are re-packed on the next forward."""
+        if precision != self._engine.precision:
+            self._engine = PolicyEngine(self._cfg, n_buttons=self._engine.n_buttons, n_camera=self._engine.n_camera,
+                                        precision=precision)
+            self._packed_key = None
+            if self._step_graph is not None:
+                self._step_graph = dict(batch=self._step_graph["batch"])
+        return self
 
     # ---- engine plumbing --------------------------------------------------------------------
     def _device(self):
@@ -325,7 +339,7 @@ class InverseActionNet(MinecraftPolicy):
 class InverseActionPolicy(nn.Module):
     """lib/policy.py:406-467 over the HIP engine: same constructor, `initial_state`, `forward`, `predict`."""
 
-    def __init__(self, action_space, pi_head_kwargs=None, idm_net_kwargs=None):
+    def __init__(self, action_space, pi_head_kwargs=None, idm_net_kwargs=None, precision: Optional[str] = None):
         super().__init__()
         self.action_space = action_space
         self.net = InverseActionNet(**idm_net_kwargs)
@@ -333,8 +347,18 @@ class InverseActionPolicy(nn.Module):
         self.pi_head = make_action_head(self.action_space, self.net.output_latent_size(), **pi_head_kwargs)
         self._cfg = config_from_policy_kwargs(idm_net_kwargs, pi_head_kwargs)
         bt, ct = action_space["buttons"], action_space["camera"]
-        self._engine = IDMEngine(self._cfg, (bt.size, bt.eltype.n), (ct.size, ct.eltype.n))
+        self._engine = IDMEngine(self._cfg, (bt.size, bt.eltype.n), (ct.size, ct.eltype.n), precision=precision)
         self._packed_key = None
+
+    @property
+    def precision(self) -> str:
+        return self._engine.precision
+
+    def set_precision(self, precision: str):
+        if precision != self._engine.precision:
+            self._engine = IDMEngine(self._cfg, self._engine.button_shape, self._engine.camera_shape, precision=precision)
+            self._packed_key = None
+        return self
 
     def _device(self):
         return next(self.parameters()).device

@@ -41,15 +41,36 @@ class KernelTimer:
 TIMER = KernelTimer()
 
 
-def _call(name, meta, *args):
+def _call(name, meta, *args, fmt="bf16"):
     if TIMER.enabled:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        _native.call(name, *args)
+        _native.call(name, *args, fmt=fmt)
         b.record()
         TIMER.records.append((name, a, b, meta or {}))
     else:
-        _native.call(name, *args)
+        _native.call(name, *args, fmt=fmt)
+
+
+# The 16-bit operand format of a call (bf16: libvpt_hip.so, fp16: libvpt_hip_f16.so, see include/vpt_hip.h
+# vpt_operand_format) is the dtype of its 16-bit tensors; every 16-bit tensor of one call must agree.
+OP16 = "op16"
+_FMT = {torch.bfloat16: "bf16", torch.float16: "fp16"}
+
+
+def _fmt(*tensors, dtype=None):
+    """-> (torch dtype, library format) of the 16-bit tensors among `tensors` (or of `dtype` when there are none)."""
+    dt = dtype
+    for t in tensors:
+        if t is not None and t.dtype in _FMT:
+            if dt is not None and t.dtype != dt:
+                raise TypeError(f"mixed 16-bit operand formats in one call: {dt} and {t.dtype}")
+            dt = t.dtype
+    if dt is None:
+        dt = torch.bfloat16
+    if dt not in _FMT:
+        raise TypeError(f"16-bit operand dtype must be bfloat16 or float16, got {dt}")
+    return dt, _FMT[dt]
 
 
 def _chk(t, dtype, name):
@@ -57,7 +78,10 @@ def _chk(t, dtype, name):
         return
     if not t.is_cuda:
         raise RuntimeError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
-    if t.dtype != dtype:
+    if dtype is OP16:
+        if t.dtype not in _FMT:
+            raise TypeError(f"{name}: expected a 16-bit operand tensor (bfloat16 / float16), got {t.dtype}")
+    elif t.dtype != dtype:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
     if not t.is_contiguous():
         raise ValueError(f"{name}: tensor must be contiguous")
@@ -65,44 +89,47 @@ def _chk(t, dtype, name):
 
 def conv_first(img_u8, wfrag, cout, stats_out=None):
     """img_u8 [F,H,W,3] uint8 -> pooled blocked bf16 [F, cout/32, H/2, W/2, 32]."""
-    _chk(img_u8, torch.uint8, "img"); _chk(wfrag, torch.bfloat16, "wfrag"); _chk(stats_out, torch.float64, "stats_out")
+    _chk(img_u8, torch.uint8, "img"); _chk(wfrag, OP16, "wfrag"); _chk(stats_out, torch.float64, "stats_out")
     f, h, w, _ = img_u8.shape
-    y = torch.empty(f, cout // 32, h // 2, w // 2, 32, dtype=torch.bfloat16, device=img_u8.device)
-    _call("vpt_conv_first_forward", dict(flops=2.0 * f * h * w * cout * 27, bytes=f * (h * w * 3 + h * w * cout // 2)), ptr(img_u8), ptr(wfrag), ptr(y), ptr(stats_out), f, h, w, cout, _stream())
+    dt, fmt = _fmt(wfrag)
+    y = torch.empty(f, cout // 32, h // 2, w // 2, 32, dtype=dt, device=img_u8.device)
+    _call("vpt_conv_first_forward", dict(flops=2.0 * f * h * w * cout * 27, bytes=f * (h * w * 3 + h * w * cout // 2)), ptr(img_u8), ptr(wfrag), ptr(y), ptr(stats_out), f, h, w, cout, _stream(), fmt=fmt)
     return y
 
 
 def conv3x3(x, wpk, edge_sa, edge_sg, stats_in, cout, res=None, stats_out=None, out=None):
     """x blocked bf16 [F,Cin/32,H,W,32] -> blocked bf16 [F,cout/32,H,W,32] (GN fold + ReLU [+res])."""
-    _chk(x, torch.bfloat16, "x"); _chk(wpk, torch.bfloat16, "wpk"); _chk(edge_sa, torch.float32, "edge_sa")
+    _chk(x, OP16, "x"); _chk(wpk, OP16, "wpk"); _chk(edge_sa, torch.float32, "edge_sa")
     _chk(edge_sg, torch.float32, "edge_sg"); _chk(stats_in, torch.float64, "stats_in")
-    _chk(res, torch.bfloat16, "res"); _chk(stats_out, torch.float64, "stats_out")
+    _chk(res, OP16, "res"); _chk(stats_out, torch.float64, "stats_out")
     f, cb, h, w, _ = x.shape
+    dt, fmt = _fmt(x, wpk, res, out)
     if out is None:
-        out = torch.empty(f, cout // 32, h, w, 32, dtype=torch.bfloat16, device=x.device)
+        out = torch.empty(f, cout // 32, h, w, 32, dtype=dt, device=x.device)
     _call("vpt_conv3x3_forward", dict(flops=2.0 * f * h * w * cout * 9 * cb * 32, bytes=2.0 * f * h * w * (cb * 32 + cout * (2 if res is not None else 1))), ptr(x), ptr(wpk), ptr(edge_sa), ptr(edge_sg), ptr(stats_in), ptr(res),
-                 ptr(out), ptr(stats_out), f, h, w, cb * 32, cout, _stream())
+                 ptr(out), ptr(stats_out), f, h, w, cb * 32, cout, _stream(), fmt=fmt)
     return out
 
 
 def maxpool(x, stats_out=None, want_argmax=False):
     """-> pooled, or (pooled, argmax uint8) with want_argmax (training: vpt_conv_backward_prepare routes through it)."""
-    _chk(x, torch.bfloat16, "x"); _chk(stats_out, torch.float64, "stats_out")
+    _chk(x, OP16, "x"); _chk(stats_out, torch.float64, "stats_out")
     f, cb, h, w, _ = x.shape
-    y = torch.empty(f, cb, h // 2, w // 2, 32, dtype=torch.bfloat16, device=x.device)
+    dt, fmt = _fmt(x)
+    y = torch.empty(f, cb, h // 2, w // 2, 32, dtype=dt, device=x.device)
     am = torch.empty(f, cb, h // 2, w // 2, 32, dtype=torch.uint8, device=x.device) if want_argmax else None
-    _call("vpt_maxpool_forward", dict(bytes=2.0 * f * cb * 32 * h * w * 1.25), ptr(x), ptr(y), ptr(stats_out), ptr(am), f, cb * 32, h, w, _stream())
+    _call("vpt_maxpool_forward", dict(bytes=2.0 * f * cb * 32 * h * w * 1.25), ptr(x), ptr(y), ptr(stats_out), ptr(am), f, cb * 32, h, w, _stream(), fmt=fmt)
     return (y, am) if want_argmax else y
 
 
 def frame_affine(x, gain, bias, stats_in, stats_out=None, per_element=False, out=None):
-    _chk(x, torch.bfloat16, "x"); _chk(gain, torch.float32, "gain"); _chk(bias, torch.float32, "bias")
+    _chk(x, OP16, "x"); _chk(gain, torch.float32, "gain"); _chk(bias, torch.float32, "bias")
     _chk(stats_in, torch.float64, "stats_in"); _chk(stats_out, torch.float64, "stats_out")
     f, cb, h, w, _ = x.shape
     if out is None:
         out = torch.empty_like(x)
     _call("vpt_frame_affine_forward", dict(bytes=4.0 * f * cb * 32 * h * w), ptr(x), ptr(out), ptr(gain), ptr(bias), ptr(stats_in), ptr(stats_out),
-                 f, cb * 32, h * w, 1 if per_element else 0, _stream())
+                 f, cb * 32, h * w, 1 if per_element else 0, _stream(), fmt=_fmt(x, out)[1])
     return out
 
 
@@ -111,10 +138,11 @@ def linear(a_bf16, wpk, n, bias=None, res=None, relu=False, out_f32=True, out_bf
     """a [M,K] bf16 (row stride = K) x packed weight -> ([M,n] fp32 or None, [M,ld] bf16 or None).
     mask: optional bf16 [M, >=n] gate (output zeroed where mask <= 0).  out_bf16_ld: row stride of the bf16
     output (>= n, extra columns zero) so it can feed the next GEMM as an A operand with K padded to 64."""
-    _chk(a_bf16, torch.bfloat16, "A"); _chk(wpk, torch.bfloat16, "wpk"); _chk(bias, torch.float32, "bias")
-    _chk(res, torch.float32, "res"); _chk(mask, torch.bfloat16, "mask")
+    _chk(a_bf16, OP16, "A"); _chk(wpk, OP16, "wpk"); _chk(bias, torch.float32, "bias")
+    _chk(res, torch.float32, "res"); _chk(mask, OP16, "mask")
     m, k = a_bf16.shape
     dev = a_bf16.device
+    dt, fmt = _fmt(a_bf16, wpk, mask)
     ld16 = (out_bf16_ld or n) if out_bf16 else n
     # Mid-size M (e.g. one 128-frame IDM window): the 256 x 128 tiling alone gives N/128 workgroups for 256 CUs, so cut K
     # as well and finish with the epilogue kernel (fixed summation order: deterministic).
@@ -126,22 +154,22 @@ def linear(a_bf16, wpk, n, bias=None, res=None, relu=False, out_f32=True, out_bf
     if auto_sk > 1:
         part = torch.zeros(auto_sk, m, n, dtype=torch.float32, device=dev)
         _call("vpt_linear_forward", dict(flops=2.0 * m * n * k, bytes=2.0 * (m * k + n * k) + 4.0 * m * n), ptr(a_bf16), ptr(wpk), None, None, ptr(part), None,
-              m, n, k, k, n, n, n, 0, auto_sk, None, 0, _stream())
+              m, n, k, k, n, n, n, 0, auto_sk, None, 0, _stream(), fmt=fmt)
         o32 = torch.empty(m, n, dtype=torch.float32, device=dev) if out_f32 else None
         o16 = None
         if out_bf16:
-            o16 = torch.zeros(m, ld16, dtype=torch.bfloat16, device=dev) if ld16 > n else torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+            o16 = torch.zeros(m, ld16, dtype=dt, device=dev) if ld16 > n else torch.empty(m, n, dtype=dt, device=dev)
         _call("vpt_linear_splitk_epilogue", dict(bytes=4.0 * (auto_sk + 1) * m * n), ptr(part), auto_sk, ptr(bias), ptr(res), ptr(o32), ptr(o16),
-              m, n, n, n, ld16, 1 if relu else 0, ptr(mask), mask.shape[1] if mask is not None else 0, _stream())
+              m, n, n, n, ld16, 1 if relu else 0, ptr(mask), mask.shape[1] if mask is not None else 0, _stream(), fmt=fmt)
         return o32, o16
     o32 = None
     if out_f32:   # split-K: one [m, n] slice per split (zeroed: a split without k-steps writes nothing), summed below
         o32 = torch.zeros(splitk, m, n, dtype=torch.float32, device=dev) if splitk > 1 else torch.empty(m, n, dtype=torch.float32, device=dev)
     o16 = None
     if out_bf16:
-        o16 = torch.zeros(m, ld16, dtype=torch.bfloat16, device=dev) if ld16 > n else torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+        o16 = torch.zeros(m, ld16, dtype=dt, device=dev) if ld16 > n else torch.empty(m, n, dtype=dt, device=dev)
     _call("vpt_linear_forward", dict(flops=2.0 * m * n * k, bytes=2.0 * (m * k + n * k) + 4.0 * m * n), ptr(a_bf16), ptr(wpk), ptr(bias), ptr(res), ptr(o32), ptr(o16),
-          m, n, k, k, n, n, ld16, 1 if relu else 0, splitk, ptr(mask), mask.shape[1] if mask is not None else 0, _stream())
+          m, n, k, k, n, n, ld16, 1 if relu else 0, splitk, ptr(mask), mask.shape[1] if mask is not None else 0, _stream(), fmt=fmt)
     if splitk > 1 and o32 is not None:
         o32 = o32.sum(0)           # fixed summation order: the result does not depend on scheduling
     return o32, o16
@@ -149,50 +177,55 @@ def linear(a_bf16, wpk, n, bias=None, res=None, relu=False, out_f32=True, out_bf
 
 def linear_wgrad(dy16, x16, n, out=None):
     """dW [n, K] fp32 = dy16[:, :n]^T @ x16 (sum over the M rows), straight from the row-major activations; added to `out` when given."""
-    _chk(dy16, torch.bfloat16, "dy"); _chk(x16, torch.bfloat16, "x"); _chk(out, torch.float32, "out")
+    _chk(dy16, OP16, "dy"); _chk(x16, OP16, "x"); _chk(out, torch.float32, "out")
     m, k = x16.shape
     assert dy16.shape[0] == m and n % 8 == 0 and k % 8 == 0
     dw = out if out is not None else torch.empty(n, k, dtype=torch.float32, device=x16.device)
-    _call("vpt_linear_wgrad", dict(flops=2.0 * m * n * k), ptr(dy16), ptr(x16), ptr(dw), m, n, k, dy16.shape[1], k, k, 1 if out is not None else 0, _stream())
+    _call("vpt_linear_wgrad", dict(flops=2.0 * m * n * k), ptr(dy16), ptr(x16), ptr(dw), m, n, k, dy16.shape[1], k, k, 1 if out is not None else 0, _stream(), fmt=_fmt(dy16, x16)[1])
     return dw
 
 
-def layernorm(x, gain, bias, relu_in=False, out_f32=False, out_bf16=True):
+def layernorm(x, gain, bias, relu_in=False, out_f32=False, out_bf16=True, dtype=torch.bfloat16):
+    """dtype: format of the 16-bit output (the A operand of the next GEMM)."""
     _chk(x, torch.float32, "x"); _chk(gain, torch.float32, "gain"); _chk(bias, torch.float32, "bias")
     m, d = x.shape
     o32 = torch.empty_like(x) if out_f32 else None
-    o16 = torch.empty(m, d, dtype=torch.bfloat16, device=x.device) if out_bf16 else None
-    _call("vpt_layernorm_forward", dict(bytes=6.0 * m * d), ptr(x), ptr(gain), ptr(bias), ptr(o32), ptr(o16), m, d, 1 if relu_in else 0, _stream())
+    dt, fmt = _fmt(dtype=dtype)
+    o16 = torch.empty(m, d, dtype=dt, device=x.device) if out_bf16 else None
+    _call("vpt_layernorm_forward", dict(bytes=6.0 * m * d), ptr(x), ptr(gain), ptr(bias), ptr(o32), ptr(o16), m, d, 1 if relu_in else 0, _stream(), fmt=fmt)
     return o32, o16
 
 
 def conv3d_t5(img_u8, wfrag, bias, cout, t, stats_out=None):
     """img_u8 [F = B*t, H, W, 3] uint8 -> blocked bf16 [F, cout/32, H, W, 32] (IDM temporal conv + ReLU)."""
-    _chk(img_u8, torch.uint8, "img"); _chk(wfrag, torch.bfloat16, "wfrag"); _chk(bias, torch.float32, "bias")
+    _chk(img_u8, torch.uint8, "img"); _chk(wfrag, OP16, "wfrag"); _chk(bias, torch.float32, "bias")
     _chk(stats_out, torch.float64, "stats_out")
     f, h, w, _ = img_u8.shape
-    y = torch.empty(f, cout // 32, h, w, 32, dtype=torch.bfloat16, device=img_u8.device)
+    dt, fmt = _fmt(wfrag)
+    y = torch.empty(f, cout // 32, h, w, 32, dtype=dt, device=img_u8.device)
     _call("vpt_conv3d_t5_forward", dict(flops=2.0 * f * h * w * cout * 15, bytes=f * h * w * (3 + 2 * cout)),
-          ptr(img_u8), ptr(wfrag), ptr(bias), ptr(y), ptr(stats_out), f, t, h, w, cout, _stream())
+          ptr(img_u8), ptr(wfrag), ptr(bias), ptr(y), ptr(stats_out), f, t, h, w, cout, _stream(), fmt=fmt)
     return y
 
 
-def full_attention(qkv, batch, t, heads, hid):
+def full_attention(qkv, batch, t, heads, hid, dtype=torch.bfloat16):
     """Mask "none", no memory (IDM): every query attends to all t rows of its chunk.  qkv [B*t, 3*hid] fp32."""
     _chk(qkv, torch.float32, "qkv")
-    out = torch.empty(batch * t, hid, dtype=torch.bfloat16, device=qkv.device)
+    dt, fmt = _fmt(dtype=dtype)
+    out = torch.empty(batch * t, hid, dtype=dt, device=qkv.device)
     _call("vpt_masked_attention_forward", dict(flops=4.0 * batch * t * t * hid), ptr(qkv), None, None, None, None, ptr(out),
-          batch, t, heads, hid, qkv.shape[1], 0, 0, _stream())
+          batch, t, heads, hid, qkv.shape[1], 0, 0, _stream(), fmt=fmt)
     return out
 
 
-def masked_attention(qkvr, kmem, vmem, memvalid, b_nd, batch, t, heads, hid):
+def masked_attention(qkvr, kmem, vmem, memvalid, b_nd, batch, t, heads, hid, dtype=torch.bfloat16):
     _chk(qkvr, torch.float32, "qkvr"); _chk(kmem, torch.float32, "kmem"); _chk(vmem, torch.float32, "vmem")
     _chk(memvalid, torch.uint8, "memvalid"); _chk(b_nd, torch.float32, "b_nd")
     maxlen = kmem.shape[1]
-    out = torch.empty(batch * t, hid, dtype=torch.bfloat16, device=qkvr.device)
+    dt, fmt = _fmt(dtype=dtype)
+    out = torch.empty(batch * t, hid, dtype=dt, device=qkvr.device)
     _call("vpt_masked_attention_forward", dict(flops=4.0 * batch * t * (t + maxlen) * hid), ptr(qkvr), ptr(kmem), ptr(vmem), ptr(memvalid), ptr(b_nd), ptr(out),
-                 batch, t, heads, hid, qkvr.shape[1], maxlen, 1, _stream())
+                 batch, t, heads, hid, qkvr.shape[1], maxlen, 1, _stream(), fmt=fmt)
     return out
 
 
@@ -249,7 +282,7 @@ def layernorm_backward(x, gain, dy, dgain, dbias, relu_in=False, dx_add=None):
 
 def gate_cast(x, ldo, mask=None):
     """fp32 [M, N] -> bf16 [M, ldo] (zero padded), zeroed where mask <= 0."""
-    _chk(x, torch.float32, "x"); _chk(mask, torch.bfloat16, "mask")
+    _chk(x, torch.float32, "x"); _chk(mask, OP16, "mask")
     m, n = x.shape
     out = torch.empty(m, ldo, dtype=torch.bfloat16, device=x.device)
     _call("vpt_gate_cast_bf16", dict(bytes=6.0 * m * ldo), ptr(x), ptr(mask), ptr(out), m, n, n, mask.shape[1] if mask is not None else 0, ldo, _stream())
@@ -257,7 +290,7 @@ def gate_cast(x, ldo, mask=None):
 
 
 def column_sum_(out, x_bf16, n):
-    _chk(x_bf16, torch.bfloat16, "x"); _chk(out, torch.float32, "out")
+    _chk(x_bf16, OP16, "x"); _chk(out, torch.float32, "out")
     _call("vpt_column_sum", dict(bytes=2.0 * x_bf16.numel()), ptr(x_bf16), ptr(out), x_bf16.shape[0], n, x_bf16.shape[1], _stream())
 
 
@@ -276,7 +309,7 @@ def conv_backward_prepare(dy, y, res, stats_in, edge_sa, edge_sg, cin, dpooled=N
     coef = (c0, c1) of the statistics terms conv3x3_dgrad adds (dx += c0 + c1 x).  d_sa / d_sg are accumulated into when
     given.  dy=None with (dpooled, argmax): the layer feeds a max-pool whose backward is applied on the fly."""
     for t, nme in ((dy, "dy"), (y, "y"), (res, "res"), (dpooled, "dpooled")):
-        _chk(t, torch.bfloat16, nme)
+        _chk(t, OP16, nme)
     _chk(argmax, torch.uint8, "argmax")
     _chk(stats_in, torch.float64, "stats_in"); _chk(edge_sa, torch.float32, "edge_sa"); _chk(edge_sg, torch.float32, "edge_sg")
     _chk(d_sa, torch.float32, "d_sa"); _chk(d_sg, torch.float32, "d_sg")
@@ -298,8 +331,8 @@ def conv_backward_prepare(dy, y, res, stats_in, edge_sa, edge_sg, cin, dpooled=N
 
 def conv3x3_dgrad(dacc, wpk_t, cin, skip=None, xin=None, coef=None):
     """dacc blocked [F,Cout/32,H,W,32] -> dx blocked [F,cin/32,H,W,32] (transposed conv + skip + c0 + c1*xin)."""
-    _chk(dacc, torch.bfloat16, "dacc"); _chk(wpk_t, torch.bfloat16, "wpk_t"); _chk(skip, torch.bfloat16, "skip")
-    _chk(xin, torch.bfloat16, "xin"); _chk(coef, torch.float32, "coef")
+    _chk(dacc, OP16, "dacc"); _chk(wpk_t, OP16, "wpk_t"); _chk(skip, OP16, "skip")
+    _chk(xin, OP16, "xin"); _chk(coef, torch.float32, "coef")
     f, cb, h, w, _ = dacc.shape
     dx = torch.empty(f, cin // 32, h, w, 32, dtype=torch.bfloat16, device=dacc.device)
     _call("vpt_conv3x3_dgrad", dict(flops=2.0 * f * h * w * cin * 9 * cb * 32), ptr(dacc), ptr(wpk_t), ptr(skip), ptr(xin), ptr(coef), ptr(dx),
@@ -309,7 +342,7 @@ def conv3x3_dgrad(dacc, wpk_t, cin, skip=None, xin=None, coef=None):
 
 def maxpool_backward(pre, pooled, dpooled):
     for t, nme in ((pre, "pre"), (pooled, "pooled"), (dpooled, "dpooled")):
-        _chk(t, torch.bfloat16, nme)
+        _chk(t, OP16, nme)
     f, cb, h, w, _ = pre.shape
     dpre = torch.empty_like(pre)
     _call("vpt_maxpool_backward", dict(bytes=5.0 * pre.numel()), ptr(pre), ptr(pooled), ptr(dpooled), ptr(dpre), f, cb * 32, h, w, _stream())
@@ -318,7 +351,7 @@ def maxpool_backward(pre, pooled, dpooled):
 
 def frame_affine_backward(x, dy, gain, stats_in, dgain, dbias, per_element=False, dx_add=None):
     """Backward of frame_affine: returns dx (bf16 blocked); dgain / dbias accumulated in place."""
-    _chk(x, torch.bfloat16, "x"); _chk(dy, torch.bfloat16, "dy"); _chk(dx_add, torch.bfloat16, "dx_add")
+    _chk(x, OP16, "x"); _chk(dy, OP16, "dy"); _chk(dx_add, OP16, "dx_add")
     _chk(gain, torch.float32, "gain"); _chk(stats_in, torch.float64, "stats_in"); _chk(dgain, torch.float32, "dgain"); _chk(dbias, torch.float32, "dbias")
     f, cb, h, w, _ = x.shape
     ab = torch.zeros(f, 2, dtype=torch.float64, device=x.device)
@@ -333,7 +366,7 @@ def frame_affine_backward(x, dy, gain, stats_in, dgain, dbias, per_element=False
 
 def conv3x3_wgrad(dacc, x, out=None):
     """-> fp32 [Cout, 9, Cin]: sum over frames and pixels of dacc (x) shifted x (added to `out` when given)."""
-    _chk(dacc, torch.bfloat16, "dacc"); _chk(x, torch.bfloat16, "x"); _chk(out, torch.float32, "out")
+    _chk(dacc, OP16, "dacc"); _chk(x, OP16, "x"); _chk(out, torch.float32, "out")
     f, cbo, h, w, _ = dacc.shape
     cbi = x.shape[1]
     dw = out if out is not None else torch.zeros(cbo * 32, 9, cbi * 32, dtype=torch.float32, device=x.device)
@@ -345,7 +378,7 @@ def conv3x3_wgrad(dacc, x, out=None):
 def conv_first_backward(img_u8, wfrag, dpooled, cout, out=None):
     """-> (dW fp32 [cout, 27] in (kh, kw, ch) tap order, db fp32 [cout]); accumulated into out=(dW, db) when given.
     conv_first_grad_to_reference() maps dW to the reference's [cout, 3, 3, 3] (o, ch, kh, kw)."""
-    _chk(img_u8, torch.uint8, "img"); _chk(wfrag, torch.bfloat16, "wfrag"); _chk(dpooled, torch.bfloat16, "dpooled")
+    _chk(img_u8, torch.uint8, "img"); _chk(wfrag, OP16, "wfrag"); _chk(dpooled, OP16, "dpooled")
     f, h, w, _ = img_u8.shape
     if out is None:
         out = (torch.zeros(cout, 27, dtype=torch.float32, device=img_u8.device), torch.zeros(cout, dtype=torch.float32, device=img_u8.device))

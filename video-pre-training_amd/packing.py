@@ -12,7 +12,7 @@ def _ceil_div(a, b):
     return (a + b - 1) // b
 
 
-def pack_conv3x3(weight, gain, bias, tables=True):
+def pack_conv3x3(weight, gain, bias, tables=True, dtype=torch.bfloat16):
     """Conv2d weight [Cout,Cin,3,3] with the preceding GroupNorm(1,Cin) affine (gain, bias [Cin]) folded.
 
     Returns (wpk bf16 [NT][Cin/32][9][128][32], edge_sa fp32 [9][NT*128], edge_sg fp32 [9][NT*128]).
@@ -24,8 +24,8 @@ def pack_conv3x3(weight, gain, bias, tables=True):
     assert cin % 32 == 0 and cout % 32 == 0
     nt = _ceil_div(cout, 128)
     cp = nt * 128
-    wg = (weight * gain.view(1, -1, 1, 1)).to(torch.bfloat16)
-    wp = torch.zeros(cp, cin, 3, 3, dtype=torch.bfloat16, device=weight.device)
+    wg = (weight * gain.view(1, -1, 1, 1)).to(dtype)
+    wp = torch.zeros(cp, cin, 3, 3, dtype=dtype, device=weight.device)
     wp[:cout] = wg
     wpk = wp.view(nt, 128, cin // 32, 32, 9).permute(0, 2, 4, 1, 3).contiguous()
     wpk = swizzle_rows64(wpk)
@@ -77,7 +77,7 @@ def swizzle_rows64(t):
     return torch.gather(v, -2, idx).reshape(t.shape).contiguous()
 
 
-def pack_conv_first(weight, bias):
+def pack_conv_first(weight, bias, dtype=torch.bfloat16):
     """Stack-0 firstconv weight [Cout,3,3,3] + bias [Cout] -> MFMA A-operand fragments
     bf16 [NT][4][2][64][8] (vpt_conv_first.hip).  k = (kh*3+kw)*3 + ch for k < 27 holds W / 255 (the pixel operand is
     the raw byte 0..255); k = 27 / 28 carry the hi / lo bf16 halves of the bias (the pixel operand holds 1.0 there)."""
@@ -87,16 +87,16 @@ def pack_conv_first(weight, bias):
     cp = nt * 128
     wk = torch.zeros(cp, 32, dtype=torch.float32, device=weight.device)
     wk[:cout, :27] = weight.permute(0, 2, 3, 1).reshape(cout, 27) / 255.0
-    hi = bias.to(torch.bfloat16).float()
-    lo = (bias - hi).to(torch.bfloat16).float()
+    hi = bias.to(dtype).float()
+    lo = (bias - hi).to(dtype).float()
     wk[:cout, 27] = hi
     wk[:cout, 28] = lo
     # [nt][cs][l31][ks][hi][e] -> [nt][cs][ks][hi][l31][e]
     frag = wk.view(nt, 4, 32, 2, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous().view(nt, 4, 2, 64, 8)
-    return frag.to(torch.bfloat16).contiguous()
+    return frag.to(dtype).contiguous()
 
 
-def pack_conv3d_t5(weight, bias):
+def pack_conv3d_t5(weight, bias, dtype=torch.bfloat16):
     """IDM Conv3d weight [O,3,5,1,1] + bias [O] -> (MFMA A-operand fragments bf16 [NT][4][64][8], bias fp32 [NT*128]).
     k = dt*3 + ch for k < 15 (dt = temporal tap 0..4), k = 15 is zero padding (vpt_conv3d.hip)."""
     o = weight.shape[0]
@@ -108,16 +108,16 @@ def pack_conv3d_t5(weight, bias):
     frag = wk.view(nt, 4, 32, 2, 8).permute(0, 1, 3, 2, 4).contiguous().view(nt, 4, 64, 8)
     bp = torch.zeros(cp, dtype=torch.float32, device=weight.device)
     bp[:o] = bias
-    return frag.to(torch.bfloat16).contiguous(), bp
+    return frag.to(dtype).contiguous(), bp
 
 
-def pack_linear(weight):
+def pack_linear(weight, dtype=torch.bfloat16):
     """nn.Linear weight [N,K] -> bf16 [ceil(N/128)][K/32][128][32] (vpt_gemm.hip B operand)."""
     n, k = weight.shape
     assert k % 64 == 0
     nt = _ceil_div(n, 128)
-    wp = torch.zeros(nt * 128, k, dtype=torch.bfloat16, device=weight.device)
-    wp[:n] = weight.to(torch.bfloat16)
+    wp = torch.zeros(nt * 128, k, dtype=dtype, device=weight.device)
+    wp[:n] = weight.to(dtype)
     return wp.view(nt, 128, k // 32, 32).permute(0, 2, 1, 3).contiguous()
 
 

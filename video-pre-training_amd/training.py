@@ -59,6 +59,8 @@ class BCTrainer:
         self.train_cnn = bool(train_cnn)
         self.policy = policy
         self.engine = policy._engine
+        if self.engine.precision != "bf16":
+            raise NotImplementedError("BCTrainer: the hand-written backward supports precision='bf16' only (fp16 gradients would need loss scaling)")
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.step_count = 0
         self.params: Dict[str, torch.nn.Parameter] = dict(policy.named_parameters())
