@@ -63,7 +63,10 @@ def policy_metrics(out, ref):
         for k, v in head_metrics(out[h], ref[h]).items():
             m[f"{h}.{k}"] = v
     if "vpred" in out and "vpred" in ref and out["vpred"] is not None:
-        m["v_rel"] = rel_max(out["vpred"], ref["vpred"])
+        # raw value-head output (O(1) with the synthetic heads): error relative to max(1, max|v|) so that a handful of
+        # small values (T = 1..4) does not turn a 0.1 absolute error into a "100 %" one
+        v, vr = _np(out["vpred"]), _np(ref["vpred"])
+        m["v_rel"] = float(np.abs(v - vr).max() / max(1.0, np.abs(vr).max()))
     if "latent" in out and "latent" in ref:
         m["latent_l2"] = rel_l2(out["latent"], ref["latent"])
     return m
