@@ -125,6 +125,14 @@ int vpt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int vpt_bc_nll_backward(const float* lp_buttons, const float* lp_camera, const int64_t* act_buttons,
                         const int64_t* act_camera, void* dz, int M, int nb, int nc, int ldz, float scale, void* stream);
 
+/* The same boundary for an ARBITRARY incoming gradient -- what torch autograd hands to the outputs of
+ * MinecraftAgentPolicy.forward / get_output_for_observation (lib/policy.py:252-305) when the caller writes its own loss, as
+ * behavioural_cloning.py:101-119 does: g_buttons / g_camera = d loss / d log-prob ([M][nb] / [M][nc], either may be NULL),
+ * g_value = d loss / d (raw value-head output) ([M], may be NULL).  dz = (g - exp(lp) * rowsum(g)) / temperature per head,
+ * the value column passes through; bf16 [M][ldz], ldz >= nb + nc + 1, padding zero. */
+int vpt_heads_logprob_backward(const float* lp_buttons, const float* lp_camera, const float* g_buttons, const float* g_camera,
+                               const float* g_value, void* dz, int M, int nb, int nc, int ldz, float temperature, void* stream);
+
 /* nn.LayerNorm backward (optionally through a ReLU on the LayerNorm's input): dx = dx_add + dLN(x, dy);
  * dgain / dbias are accumulated with atomics (caller zeroes). */
 int vpt_layernorm_backward(const float* x, const float* gain, const float* dy, const float* dx_add, float* dx,

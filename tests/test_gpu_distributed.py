@@ -21,16 +21,16 @@ def _make(seed=0):
     return pol.to("cuda")
 
 
-def _batch():
+def _batch(b=4):
     g = torch.Generator().manual_seed(33)
-    b, t = 4, 5
+    t = 5
     img = torch.randint(0, 256, (b, t, 128, 128, 3), generator=g, dtype=torch.uint8)
     first = torch.zeros(b, t, dtype=torch.bool)
     first[1, 0] = True
     return img, first, torch.randint(0, 8641, (b, t), generator=g), torch.randint(0, 121, (b, t), generator=g)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, b=4):
     import torch.distributed as dist
     import __graft_entry__ as ge
     ge.build()
@@ -41,7 +41,7 @@ def _worker(rank, world, port, out_dir):
     try:
         pol = _make()
         tr = BCTrainer(pol, train_cnn=True, weight_decay=0.0)
-        img, first, ab, ac = _batch()
+        img, first, ab, ac = _batch(b)
         b0, b1 = D.shard_range(img.shape[0], rank, world)
         sl = slice(b0, b1)
         args = (img[sl].cuda(), first[sl].cuda(), pol.initial_state(b1 - b0), ab[sl].cuda(), ac[sl].cuda())
@@ -54,17 +54,18 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_rank_bc_step_matches_single_process():
+@pytest.mark.parametrize("b", [4, 5])   # 5 sequences on 2 ranks: shards of 3 and 2 (the mean runs over the true global count)
+def test_two_rank_bc_step_matches_single_process(b):
     import torch.multiprocessing as mp
     from vpt_amd.training import BCTrainer
     pol = _make()
     tr = BCTrainer(pol, train_cnn=True, weight_decay=0.0)
-    img, first, ab, ac = _batch()
-    loss1, grads1, _ = tr.reduced_loss_and_grads(img.cuda(), first.cuda(), pol.initial_state(4), ab.cuda(), ac.cuda())
+    img, first, ab, ac = _batch(b)
+    loss1, grads1, _ = tr.reduced_loss_and_grads(img.cuda(), first.cuda(), pol.initial_state(b), ab.cuda(), ac.cuda())
     torch.cuda.synchronize()
     grads1 = {k: v.cpu() for k, v in grads1.items()}
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(2, 29533, d), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, 29533 + b, d, b), nprocs=2, join=True)
         r0, r1 = torch.load(os.path.join(d, "rank0.pt")), torch.load(os.path.join(d, "rank1.pt"))
     assert abs(r0["loss"] - float(loss1)) < 1e-4 and abs(r0["loss"] - r1["loss"]) < 1e-6
     # Same frames, same kernels: every per-frame quantity (incl. the GroupNorm statistics, whose cross-tile sums are fp64)

@@ -478,3 +478,107 @@ def test_bc_gradients_independent_of_cnn_chunking(trainer_1x):
         worst = max(worst, e)
         assert e < 1e-4, (k, e)
     print(f"PARITY BC gradients, 3 CNN chunks vs 1: worst rel-L2 {worst:.2e}")
+
+
+def test_heads_logprob_backward_matches_autograd():
+    """vpt_heads_logprob_backward: d/dz of log_softmax(z / T) for ARBITRARY incoming gradients (the autograd boundary)."""
+    g = torch.Generator().manual_seed(11)
+    m, nb, nc, temp = 5, 8641, 121, 2.0
+    zb = (torch.randn(m, nb, generator=g) * 2).requires_grad_(True)
+    zc = (torch.randn(m, nc, generator=g) * 2).requires_grad_(True)
+    lb, lc = torch.log_softmax(zb / temp, -1), torch.log_softmax(zc / temp, -1)
+    gb_in, gc_in, gv_in = torch.randn(m, nb, generator=g), torch.randn(m, nc, generator=g), torch.randn(m, generator=g)
+    gb, gc = torch.autograd.grad((lb * gb_in).sum() + (lc * gc_in).sum(), [zb, zc])
+    dz = ops.heads_logprob_backward(lb.detach().to(DEV), lc.detach().to(DEV), gb_in.to(DEV), gc_in.to(DEV), gv_in.to(DEV), 8768, temp)
+    torch.cuda.synchronize()
+    dz = dz.cpu().float()
+    assert _l2(dz[:, :nb], gb) < 6e-3 and _l2(dz[:, nb:nb + nc], gc) < 6e-3
+    assert _l2(dz[:, nb + nc], gv_in) < 6e-3 and float(dz[:, nb + nc + 1:].abs().max()) == 0.0
+    dz2 = ops.heads_logprob_backward(lb.detach().to(DEV), lc.detach().to(DEV), None, gc_in.to(DEV), None, 8768, temp).cpu().float()
+    assert float(dz2[:, :nb].abs().max()) == 0.0 and _l2(dz2[:, nb:nb + nc], gc) < 6e-3
+
+
+def test_reference_bc_loop_runs_unchanged():
+    """The statements of behavioural_cloning.py:57-67,99-122, literally, on the HIP policy: get_output_for_observation ->
+    get_logprob_of_action -> detach the state -> (-log_prob / BATCH_SIZE).backward() x 8 -> (no-op) clip -> th.optim.Adam.step().
+    The accumulated param.grad must equal BCTrainer's hand-driven gradients of the same 8 frames (same kernels) and point
+    where the fp32 oracle's autograd points; Adam must move the weights."""
+    th = torch
+    from vpt_amd.lib.tree_util import tree_map
+    pk = O.policy_kwargs_for("1x")
+    cfg = O.config_from_policy_kwargs(pk, dict(temperature=2.0))
+    sd = O.synthetic_state_dict(cfg, seed=0)
+    policy = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0))
+    policy.load_state_dict(sd, strict=False)
+    policy = policy.to(DEV)
+    BATCH_SIZE, LEARNING_RATE, WEIGHT_DECAY, MAX_GRAD_NORM = 8, 0.000181, 0.039428, 5.0
+    g = torch.Generator().manual_seed(77)
+    images = torch.randint(0, 256, (BATCH_SIZE, 128, 128, 3), generator=g, dtype=torch.uint8)
+    a_b, a_c = torch.randint(0, 8641, (BATCH_SIZE,), generator=g), torch.randint(0, 121, (BATCH_SIZE,), generator=g)
+
+    # ---- behavioural_cloning.py:57-67 ----
+    trainable_parameters = policy.parameters()
+    optimizer = th.optim.Adam(trainable_parameters, lr=LEARNING_RATE, weight_decay=WEIGHT_DECAY)
+    dummy_first = th.from_numpy(np.array((False,))).to(DEV)
+    episode_hidden_states = {}
+    before = {n: p.detach().clone() for n, p in policy.named_parameters()}
+    # ---- behavioural_cloning.py:86-122 (one batch; every sample from episode 0) ----
+    batch_loss = 0
+    for i in range(BATCH_SIZE):
+        episode_id = 0
+        agent_action = {"buttons": a_b[i].reshape(1, 1).to(DEV), "camera": a_c[i].reshape(1, 1).to(DEV)}   # agent._env_action_to_agent
+        agent_obs = {"img": images[i:i + 1].to(DEV)}                                                       # agent._env_obs_to_agent
+        if episode_id not in episode_hidden_states:
+            episode_hidden_states[episode_id] = policy.initial_state(1)
+        agent_state = episode_hidden_states[episode_id]
+        pi_distribution, v_prediction, new_agent_state = policy.get_output_for_observation(agent_obs, agent_state, dummy_first)
+        log_prob = policy.get_logprob_of_action(pi_distribution, agent_action)
+        new_agent_state = tree_map(lambda x: x.detach(), new_agent_state)
+        episode_hidden_states[episode_id] = new_agent_state
+        loss = -log_prob / BATCH_SIZE
+        batch_loss += loss.item()
+        loss.backward()
+    th.nn.utils.clip_grad_norm_(trainable_parameters, MAX_GRAD_NORM)       # exhausted generator: a no-op, as in the reference
+    grads_loop = {n: p.grad.detach().clone() for n, p in policy.named_parameters() if p.grad is not None}
+    optimizer.step()
+    optimizer.zero_grad()
+    torch.cuda.synchronize()
+
+    assert "value_head.linear.weight" not in grads_loop          # no gradient under the BC loss, as in the reference (SURVEY §4)
+    moved = sum(int(not torch.equal(before[n], p.detach())) for n, p in policy.named_parameters() if n in grads_loop)
+    assert moved == len(grads_loop) and len(grads_loop) >= 129
+
+    # (1) same kernels driven by hand: BCTrainer on the same 8 frames, T = 1 each, state carried
+    pol2 = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0))
+    pol2.load_state_dict(sd, strict=False)
+    pol2 = pol2.to(DEV)
+    tr = BCTrainer(pol2, train_cnn=True, optimizer_state=False)
+    st, acc, loss_sum = pol2.initial_state(1), {}, 0.0
+    so, acc_ref, loss_ref = O.initial_state(cfg, 1), {}, 0.0
+    first = torch.zeros(1, 1, dtype=torch.bool)
+    for i in range(BATCH_SIZE):
+        l, gr, st = tr.loss_and_grads(images[i:i + 1, None].to(DEV), first.to(DEV), st, a_b[i].reshape(1, 1).to(DEV), a_c[i].reshape(1, 1).to(DEV))
+        loss_sum += float(l) / BATCH_SIZE
+        for n, v in gr.items():
+            acc[n] = acc.get(n, 0) + v.reshape(before[n].shape) / BATCH_SIZE
+        # (2) the fp32 oracle's autograd (the reference's gradients, tests/golden/make_golden_bc.py pins it)
+        lr_, gr_, so = O.bc_loss_and_grads(sd, cfg, images[i:i + 1, None], first, so, a_b[i].reshape(1, 1), a_c[i].reshape(1, 1))
+        loss_ref += lr_ / BATCH_SIZE
+        for n, v in gr_.items():
+            acc_ref[n] = acc_ref.get(n, 0) + v / BATCH_SIZE
+    torch.cuda.synchronize()
+    assert abs(batch_loss - loss_sum) < 1e-4 and abs(batch_loss - loss_ref) < 2e-2
+    worst, worst_cos = 0.0, 1.0
+    for n, gl in grads_loop.items():
+        if float(acc[n].norm()) == 0.0:
+            continue
+        e = _l2(gl, acc[n])
+        worst = max(worst, e)
+        assert e < 1e-3, (n, e)                      # autograd boundary == hand-driven trainer (fp32 summation order only)
+        ref = acc_ref[n]
+        if float(ref.norm()) > 0:
+            cos = float((gl.cpu() * ref).sum() / (gl.cpu().norm() * ref.norm()))
+            worst_cos = min(worst_cos, cos)
+            assert cos > 0.7, (n, cos)               # bf16 ReLU-gate flips: see test_bc_gradients_vs_oracle for the calibrated bounds
+    print(f"PARITY reference BC loop: param.grad vs BCTrainer worst rel-L2 {worst:.2e}; worst cosine vs fp32 oracle autograd {worst_cos:.3f}; "
+          f"loss {batch_loss:.4f} (trainer {loss_sum:.4f}, oracle {loss_ref:.4f})")

@@ -1,5 +1,4 @@
 #!/bin/bash
 out=gpurun_out/r02_tests; mkdir -p $out
-timeout 2400 python -m pytest tests/test_gpu_configs.py tests/test_gpu_idm.py -x -q -s -m gpu --durations=10 > $out/configs.log 2>&1; echo "rc=$?" >> $out/configs.log
-grep -E "PARITY|ACTIONS|passed|failed|Error|error|rc=|s call" $out/configs.log | cut -c1-330 | tail -50
-timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; echo "smoke rc=$?"; tail -6 $out/smoke.log | cut -c1-300
+timeout 2400 python -m pytest tests/test_gpu_training.py tests/test_gpu_distributed.py -x -q -s -m gpu --durations=5 > $out/training.log 2>&1; echo "rc=$?" >> $out/training.log
+grep -E "PARITY|passed|failed|Error|error|rc=|s call" $out/training.log | cut -c1-330 | tail -40

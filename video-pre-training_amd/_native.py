@@ -43,6 +43,7 @@ SIGNATURES = {
     "vpt_maxpool_backward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_frame_affine_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_bc_nll_backward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "vpt_heads_logprob_backward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "vpt_layernorm_backward": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "vpt_gate_cast_bf16": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_column_sum": [_P, _P, _I, _I, _I, _P],

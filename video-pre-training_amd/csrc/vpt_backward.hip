@@ -38,6 +38,41 @@ extern "C" int vpt_nll_bwd_launch(const VptNllBwdArgs* a, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Backward of lp = log_softmax(z / T) for an ARBITRARY incoming gradient g = dL/dlp (what torch autograd hands to the
+// policy's outputs, lib/policy.py:271-305): dz = (g - exp(lp) * sum_j g_j) / T per head; the value column passes through.
+// One workgroup per row; the row sums by wave shuffles + LDS.
+__global__ __launch_bounds__(256) void vpt_heads_bwd_kernel(VptHeadsBwdArgs a) {
+  __shared__ float red[8];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* lb = a.lp_buttons + (size_t)row * a.nb;
+  const float* lc = a.lp_camera + (size_t)row * a.nc;
+  const float* gb = a.g_buttons ? a.g_buttons + (size_t)row * a.nb : nullptr;
+  const float* gc = a.g_camera ? a.g_camera + (size_t)row * a.nc : nullptr;
+  float sb = 0.f, sc = 0.f;
+  if (gb) for (int i = tid; i < a.nb; i += 256) sb += gb[i];
+  if (gc) for (int i = tid; i < a.nc; i += 256) sc += gc[i];
+  sb = wave_sum(sb); sc = wave_sum(sc);
+  if ((tid & 63) == 0) { red[tid >> 6] = sb; red[4 + (tid >> 6)] = sc; }
+  __syncthreads();
+  sb = (red[0] + red[1]) + (red[2] + red[3]);
+  sc = (red[4] + red[5]) + (red[6] + red[7]);
+  vpt_op16* dz = a.dz + (size_t)row * a.ldz;
+  for (int i = tid; i < a.ldz; i += 256) {
+    float g = 0.f;
+    if (i < a.nb) { if (gb) g = (gb[i] - expf(lb[i]) * sb) * a.inv_temp; }
+    else if (i < a.nb + a.nc) { if (gc) g = (gc[i - a.nb] - expf(lc[i - a.nb]) * sc) * a.inv_temp; }
+    else if (i == a.nb + a.nc && a.g_value) g = a.g_value[row];
+    dz[i] = (vpt_op16)g;
+  }
+}
+
+extern "C" int vpt_heads_bwd_launch(const VptHeadsBwdArgs* a, hipStream_t stream) {
+  if (a->M <= 0 || a->ldz < a->nb + a->nc + 1) return -1;
+  hipLaunchKernelGGL(vpt_heads_bwd_kernel, dim3(a->M), dim3(256), 0, stream, *a);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// ------------------------------------------------------------------------------------------------
 // out_bf16[M][ldo] = (mask > 0 ? x : 0), columns >= N zero: ReLU gate + cast + K-padding of a GEMM A operand
 __global__ __launch_bounds__(256) void vpt_gate_cast_kernel(VptGateCastArgs a) {
   const size_t total = (size_t)a.M * a.ldo;

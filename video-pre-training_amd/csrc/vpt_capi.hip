@@ -210,6 +210,15 @@ int vpt_bc_nll_backward(const float* lp_buttons, const float* lp_camera, const i
   CHECK_LAUNCH(vpt_nll_bwd_launch(&a, (hipStream_t)stream), "vpt_bc_nll_backward");
 }
 
+int vpt_heads_logprob_backward(const float* lp_buttons, const float* lp_camera, const float* g_buttons, const float* g_camera,
+                               const float* g_value, void* dz, int M, int nb, int nc, int ldz, float temperature, void* stream) {
+  if (!(temperature > 0.f)) return fail(-1, "vpt_heads_logprob_backward: temperature must be positive");
+  VptHeadsBwdArgs a;
+  a.lp_buttons = lp_buttons; a.lp_camera = lp_camera; a.g_buttons = g_buttons; a.g_camera = g_camera; a.g_value = g_value;
+  a.dz = (vpt_op16*)dz; a.M = M; a.nb = nb; a.nc = nc; a.ldz = ldz; a.inv_temp = 1.0f / temperature;
+  CHECK_LAUNCH(vpt_heads_bwd_launch(&a, (hipStream_t)stream), "vpt_heads_logprob_backward");
+}
+
 int vpt_layernorm_backward(const float* x, const float* gain, const float* dy, const float* dx_add, float* dx,
                            float* dgain, float* dbias, int M, int D, int relu_in, void* stream) {
   VptLnBwdArgs a;

@@ -190,6 +190,17 @@ struct VptNllBwdArgs {
   float scale;             // 1 / (frames in the global batch * temperature)
 };
 
+struct VptHeadsBwdArgs {   // generic backward of the two log-softmax heads + the value column (autograd boundary)
+  const float* lp_buttons; // [M][nb] log-probabilities (forward output)
+  const float* lp_camera;  // [M][nc]
+  const float* g_buttons;  // optional [M][nb]: incoming d loss / d log-prob
+  const float* g_camera;   // optional [M][nc]
+  const float* g_value;    // optional [M]: incoming d loss / d (raw value-head output)
+  vpt_op16* dz;            // [M][ldz]: d loss / d (fused head logits), padding columns zero
+  int M, nb, nc, ldz;
+  float inv_temp;          // 1 / temperature
+};
+
 struct VptGateCastArgs {
   const float* x;          // [M][ldx]
   const vpt_op16* mask;    // optional [M][ldm]
@@ -250,6 +261,7 @@ int vpt_action_mapping_launch(int to_factored, const long* a, const long* b, lon
 int vpt_conv_wgrad_groups(int frames, int Cin, int Cout);
 int vpt_conv_wgrad_launch(const VptConvWgradArgs* a, hipStream_t s);
 int vpt_nll_bwd_launch(const VptNllBwdArgs* a, hipStream_t s);
+int vpt_heads_bwd_launch(const VptHeadsBwdArgs* a, hipStream_t s);
 int vpt_ln_bwd_launch(const VptLnBwdArgs* a, hipStream_t s);
 int vpt_gate_cast_launch(const VptGateCastArgs* a, hipStream_t s);
 int vpt_colsum_launch(const VptColsumArgs* a, hipStream_t s);

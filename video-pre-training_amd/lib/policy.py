@@ -150,6 +150,49 @@ class ScaledMSEHead(nn.Module):
         return self.normalizer.denormalize(x)
 
 
+class _PolicyForwardFn(torch.autograd.Function):
+    """The differentiable boundary: MinecraftAgentPolicy.forward as ONE autograd node whose backward is the hand-written
+    HIP backward of training.py (every layer, CNN included).  That is what lets the reference's own training loop --
+    `get_output_for_observation` -> `get_logprob_of_action` -> `loss.backward()` -> `torch.optim.Adam.step()`
+    (behavioural_cloning.py:99-122) -- run unchanged: autograd accumulates the returned gradients into `param.grad` exactly
+    as it does for the reference's module tree.  The recurrent state is returned non-differentiable (the reference's loop
+    detaches it, behavioural_cloning.py:111; gradients never cross chunk boundaries)."""
+
+    @staticmethod
+    def forward(ctx, policy, grad_engine, img, first, state_in, names, *params):
+        S = grad_engine.forward_saving(img, first, state_in)
+        bsz, t = S["bsz"], S["t"]
+        nb, nc = grad_engine.engine.n_buttons, grad_engine.engine.n_camera
+        ctx.S, ctx.grad_engine, ctx.names = S, grad_engine, names
+        ctx.param_shapes = [p.shape for p in params]
+        lp_b = S["lp_b"].view(bsz, t, 1, nb)
+        lp_c = S["lp_c"].view(bsz, t, 1, nc)
+        vpred = S["logits"][:, nb + nc:nb + nc + 1].reshape(bsz, t, 1).clone()
+        flat = []
+        for m, (k, v) in S["state_out"]:
+            flat += [m, k, v]
+        ctx.mark_non_differentiable(*flat)
+        ctx.set_materialize_grads(False)     # an output the loss does not use arrives as None: no value-head gradient under the BC loss
+        return (lp_b, lp_c, vpred, *flat)
+
+    @staticmethod
+    def backward(ctx, g_b, g_c, g_v, *g_state):
+        from .. import ops
+        S, eng = ctx.S, ctx.grad_engine
+        if S is None:
+            raise RuntimeError("the policy's activations were already consumed by a backward pass (retain_graph is not supported)")
+        ctx.S = None
+        m = S["m"]
+        flat2 = lambda g_, n_: None if g_ is None else g_.reshape(m, n_).float().contiguous()
+        nb, nc = eng.engine.n_buttons, eng.engine.n_camera
+        gv = None if g_v is None else g_v.reshape(m).float().contiguous()
+        with torch.no_grad():
+            dz = ops.heads_logprob_backward(S["lp_b"], S["lp_c"], flat2(g_b, nb), flat2(g_c, nc), gv, S["ldz"], eng.engine.cfg["temperature"])
+            g = eng.backward_from(S, dz, value_grads=gv is not None)
+        grads = tuple(g[n].reshape(shape) if n in g else None for n, shape in zip(ctx.names, ctx.param_shapes))
+        return (None, None, None, None, None, None) + grads
+
+
 class MinecraftAgentPolicy(nn.Module):
     """`precision` (not a reference argument; also env VPT_PRECISION or set_precision()): "bf16" -- the default and the
     benchmarked mode -- or "fp16", the parity mode: the same kernels with IEEE-half MFMA operands, same speed, 8x finer
@@ -166,6 +209,7 @@ class MinecraftAgentPolicy(nn.Module):
                                     n_camera=action_space["camera"].eltype.n, precision=precision)
         self._packed_key = None
         self._step_graph = None
+        self._grad_engines = {}
 
     @property
     def precision(self) -> str:
@@ -174,6 +218,7 @@ class MinecraftAgentPolicy(nn.Module):
     def set_precision(self, precision: str):
         """Switch the operand format ("bf16" / "fp16"); weights are re-packed on the next forward."""
         if precision != self._engine.precision:
+            self._grad_engines = {}
             self._engine = PolicyEngine(self._cfg, n_buttons=self._engine.n_buttons, n_camera=self._engine.n_camera,
                                         precision=precision)
             self._packed_key = None
@@ -271,6 +316,8 @@ class MinecraftAgentPolicy(nn.Module):
         img = obs["img"]
         if img.dtype != torch.uint8:
             raise TypeError("obs['img'] must be uint8 [B,T,128,128,3] (the /255 is fused into the first conv)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_differentiable(img, first, state_in)
         sg = self._step_graph
         if sg is not None and img.shape[0] == sg["batch"] and img.shape[1] == 1:
             out = self._graphed_forward(img, first, state_in)
@@ -278,6 +325,25 @@ class MinecraftAgentPolicy(nn.Module):
             out = self._engine.forward(img, first, state_in)
         pi_logits = {"camera": out["camera"], "buttons": out["buttons"]}
         return (pi_logits, out["vpred"], None), out["state_out"]
+
+    def _forward_differentiable(self, img, first, state_in):
+        """Gradient-enabled call (the reference's get_output_for_observation is, lib/policy.py:287-305): same kernels, every
+        activation kept for the backward, outputs attached to the autograd graph through _PolicyForwardFn."""
+        from ..training import BCTrainer
+        if self._engine.precision != "bf16":
+            raise NotImplementedError("gradients are implemented for precision='bf16' only: wrap inference in torch.no_grad() "
+                                      "(policy.act / policy.v already are) or call set_precision('bf16') before training")
+        named = [(n, p) for n, p in self.named_parameters()]
+        train_cnn = any(p.requires_grad for n, p in named if n.startswith("net.img_process.cnn."))
+        eng = self._grad_engines.get(train_cnn)
+        if eng is None:
+            eng = self._grad_engines[train_cnn] = BCTrainer(self, train_cnn=train_cnn, optimizer_state=False)
+        names = [n for n, _ in named]
+        out = _PolicyForwardFn.apply(self, eng, img, first, state_in, names, *[p for _, p in named])
+        lp_b, lp_c, vpred = out[:3]
+        flat = out[3:]
+        state_out = [(flat[3 * l], (flat[3 * l + 1], flat[3 * l + 2])) for l in range(self._cfg["n_layers"])]
+        return ({"camera": lp_c, "buttons": lp_b}, vpred, None), state_out
 
     def get_logprob_of_action(self, pd, action):
         ac = tree_map(lambda x: x.unsqueeze(1), action)

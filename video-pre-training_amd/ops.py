@@ -270,6 +270,19 @@ def nll_backward(lp_buttons, lp_camera, act_buttons, act_camera, ldz, scale):
     return dz
 
 
+def heads_logprob_backward(lp_buttons, lp_camera, g_buttons, g_camera, g_value, ldz, temperature):
+    """bf16 [M, ldz] gradient w.r.t. the fused head logits for arbitrary incoming gradients of the two log-prob tensors and of the
+    raw value output (any of them None = zero).  The autograd boundary of lib/policy.py uses this; the BC fast path uses nll_backward."""
+    _chk(lp_buttons, torch.float32, "lp_buttons"); _chk(lp_camera, torch.float32, "lp_camera")
+    _chk(g_buttons, torch.float32, "g_buttons"); _chk(g_camera, torch.float32, "g_camera"); _chk(g_value, torch.float32, "g_value")
+    m, nb = lp_buttons.shape
+    nc = lp_camera.shape[1]
+    dz = torch.empty(m, ldz, dtype=torch.bfloat16, device=lp_buttons.device)
+    _call("vpt_heads_logprob_backward", dict(bytes=10.0 * m * ldz), ptr(lp_buttons), ptr(lp_camera), ptr(g_buttons), ptr(g_camera), ptr(g_value),
+          ptr(dz), m, nb, nc, ldz, ctypes.c_float(temperature), _stream())
+    return dz
+
+
 def layernorm_backward(x, gain, dy, dgain, dbias, relu_in=False, dx_add=None):
     for t, nme in ((x, "x"), (gain, "gain"), (dy, "dy"), (dgain, "dgain"), (dbias, "dbias"), (dx_add, "dx_add")):
         _chk(t, torch.float32, nme)

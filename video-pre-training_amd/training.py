@@ -55,7 +55,10 @@ def linear_backward(dy16: torch.Tensor, n: int, x16: Optional[torch.Tensor], wei
 
 class BCTrainer:
     def __init__(self, policy, lr: float = 0.000181, weight_decay: float = 0.039428, betas=(0.9, 0.999), eps: float = 1e-8,
-                 train_cnn: bool = False):
+                 train_cnn: bool = True, optimizer_state: bool = True):
+        """train_cnn=True (default, as the reference: behavioural_cloning.py:57-63 optimises policy.parameters(), i.e. every
+        parameter) or False to freeze `net.img_process.cnn.*` and fine-tune trunk + heads only (no CNN activations kept).
+        optimizer_state=False: gradients only (the autograd boundary of lib/policy.py), no Adam moments allocated."""
         self.train_cnn = bool(train_cnn)
         self.policy = policy
         self.engine = policy._engine
@@ -65,8 +68,8 @@ class BCTrainer:
         self.step_count = 0
         self.params: Dict[str, torch.nn.Parameter] = dict(policy.named_parameters())
         self.trainable = [n for n in self.params if self._is_trainable(n)]
-        self.m = {n: torch.zeros_like(self.params[n], dtype=torch.float32) for n in self.trainable}
-        self.v = {n: torch.zeros_like(self.params[n], dtype=torch.float32) for n in self.trainable}
+        self.m = {n: torch.zeros_like(self.params[n], dtype=torch.float32) for n in self.trainable} if optimizer_state else {}
+        self.v = {n: torch.zeros_like(self.params[n], dtype=torch.float32) for n in self.trainable} if optimizer_state else {}
 
     # ---- checkpoint / resume ---------------------------------------------------
     def state_dict(self) -> dict:
@@ -100,10 +103,23 @@ class BCTrainer:
         global_frames: number of frames in the global (all-rank) batch the mean runs over (default: local).
         on_trunk_grads(g): called once the gradients of everything behind the CNN (88 % of the parameters) are final and
         before the CNN's backward starts -- the data-parallel step starts their all-reduce there."""
+        S = self.forward_saving(img_u8, first, state_in)
+        m = S["m"]
+        ab = act_buttons.reshape(m).to(torch.int64).contiguous()
+        ac = act_camera.reshape(m).to(torch.int64).contiguous()
+        loss = -(S["lp_b"].gather(1, ab[:, None]) + S["lp_c"].gather(1, ac[:, None])).mean()
+        gf = global_frames or m
+        dz = ops.nll_backward(S["lp_b"], S["lp_c"], ab, ac, S["ldz"], 1.0 / (gf * self.engine.cfg["temperature"]))
+        g = self.backward_from(S, dz, on_trunk_grads=on_trunk_grads, debug=debug)
+        return loss, g, S["state_out"]
+
+    @torch.no_grad()
+    def forward_saving(self, img_u8, first, state_in) -> dict:
+        """The policy forward with every activation the backward needs kept alive.  Returns the saved-state dict S:
+        S["lp_b"] / S["lp_c"] fp32 [M, n] log-probs, S["logits"] fp32 [M, nb+nc+1] (last column: raw value), S["state_out"]."""
         pol, eng = self.policy, self.engine
         pol._ensure_packed()
         cfg, w = eng.cfg, eng.w
-        P = {n: p.detach() for n, p in self.params.items()}
         bsz, t = img_u8.shape[:2]
         m = bsz * t
         hid, heads, maxlen = cfg["hidsize"], cfg["heads"], cfg["maxlen"]
@@ -159,17 +175,27 @@ class BCTrainer:
         temp = cfg["temperature"]
         lp_b = ops.log_softmax_cols(logits, 0, nb, temp)
         lp_c = ops.log_softmax_cols(logits, nb, nc, temp)
-        ab = act_buttons.reshape(m).to(torch.int64).contiguous()
-        ac = act_camera.reshape(m).to(torch.int64).contiguous()
-        loss = -(lp_b.gather(1, ab[:, None]) + lp_c.gather(1, ac[:, None])).mean()
+        return dict(m=m, bsz=bsz, t=t, dev=dev, d=d, dn=dn, x_lin16=x_lin16, saved=saved, x_trunk=x_trunk, xb=xb, y=y, y16=y16, lb=lb,
+                    logits=logits, lp_b=lp_b, lp_c=lp_c, cnn_saved=cnn_saved, state_out=state_out, ldz=_round_up(nb + nc + 1, 64))
 
-        # ---------------- backward ----------------
+    @torch.no_grad()
+    def backward_from(self, S: dict, dz: torch.Tensor, on_trunk_grads=None, debug: Optional[dict] = None, value_grads: bool = False):
+        """Backward of everything below the head logits.  dz: bf16 [M, ldz] = d loss / d (fused head logits).
+        Consumes S (the CNN activations are released chunk by chunk).  value_grads: also return the value head's gradients
+        (non-zero only when dz's value column is)."""
+        pol, eng = self.policy, self.engine
+        cfg, w = eng.cfg, eng.w
+        P = {n: p.detach() for n, p in self.params.items()}
+        m, bsz, t, dev = S["m"], S["bsz"], S["t"], S["dev"]
+        hid, heads, maxlen = cfg["hidsize"], cfg["heads"], cfg["maxlen"]
+        ratio = cfg["pointwise_ratio"]
+        nb, nc = eng.n_buttons, eng.n_camera
+        d, dn, x_lin16, saved, x_trunk, xb, y, y16, lb = (S[k] for k in ("d", "dn", "x_lin16", "saved", "x_trunk", "xb", "y", "y16", "lb"))
+        cnn_saved = S["cnn_saved"]
+        pl = "net.img_process.linear."
         g: Dict[str, torch.Tensor] = {}
         zeros = lambda n_: torch.zeros(n_, dtype=torch.float32, device=dev)
-        gf = global_frames or m
         nh = nb + nc + 1
-        ldz = _round_up(nh, 64)
-        dz = ops.nll_backward(lp_b, lp_c, ab, ac, ldz, 1.0 / (gf * temp))
         # heads (fused [buttons; camera; value] GEMM): dlat, dW, db
         wh = torch.cat([P["pi_head.buttons.linear_layer.weight"], P["pi_head.camera.linear_layer.weight"],
                         P["value_head.linear.weight"]], 0)
@@ -180,6 +206,8 @@ class BCTrainer:
         ops.column_sum_(dbh, dz, nh)
         g["pi_head.buttons.linear_layer.weight"], g["pi_head.camera.linear_layer.weight"] = dwh[:nb], dwh[nb:nb + nc]
         g["pi_head.buttons.linear_layer.bias"], g["pi_head.camera.linear_layer.bias"] = dbh[:nb], dbh[nb:nb + nc]
+        if value_grads:
+            g["value_head.linear.weight"], g["value_head.linear.bias"] = dwh[nb + nc:nh].clone(), dbh[nb + nc:nh].clone()
         del dz, dwh
         # final_ln
         g["net.final_ln.weight"], g["net.final_ln.bias"] = zeros(hid), zeros(hid)
@@ -245,7 +273,7 @@ class BCTrainer:
                 self._cnn_backward_chunk(cnn_saved[ci], dd[i:i + eng.cnn_chunk].contiguous(), acc)
                 cnn_saved[ci] = None
             self._cnn_backward_finish(acc, P, g)
-        return loss, g, state_out
+        return g
 
     # ------------------------------------------------------------------------------------------
     # IMPALA CNN: forward that keeps every activation (6.2 MB / frame on the 2x model: a 64 x 128 batch is 50 GB of
@@ -404,6 +432,11 @@ class BCTrainer:
         if world == 1:
             return self.loss_and_grads(img_u8, first, state_in, act_buttons, act_camera, global_frames=m_local)
         dev = img_u8.device
+        # Shards may differ by one sequence when B % world != 0 (distributed.shard_range): the mean runs over the TRUE global
+        # frame count, and the reported loss is the frame-weighted mean of the ranks' losses.
+        count = torch.tensor([float(m_local)], dtype=torch.float64, device=dev)
+        dist.all_reduce(count)
+        m_global = int(round(float(count.item())))
         early = [n for n in self.trainable if not n.startswith("net.img_process.cnn.")]   # final before the CNN backward
         late = [n for n in self.trainable if n.startswith("net.img_process.cnn.")]
         pending, state = [], dict(early_sent=False)
@@ -417,7 +450,7 @@ class BCTrainer:
         err, loss, grads, state_out = None, None, None, None
         try:
             loss, grads, state_out = self.loss_and_grads(img_u8, first, state_in, act_buttons, act_camera,
-                                                         global_frames=m_local * world, on_trunk_grads=start_trunk_exchange)
+                                                         global_frames=m_global, on_trunk_grads=start_trunk_exchange)
             for n in late:
                 grads[n] = grads[n].contiguous()
             pending.extend(D.bucketed_all_reduce_start([grads[n] for n in late]))
@@ -428,11 +461,11 @@ class BCTrainer:
                 pending.extend(D.bucketed_all_reduce_start(zeros(early)))
             pending.extend(D.bucketed_all_reduce_start(zeros(late)))
         D.bucketed_all_reduce_finish(pending)
-        tail = torch.tensor([0.0 if err is not None else float(loss), 0.0 if err is not None else 1.0], device=dev)
-        dist.all_reduce(tail)           # (sum of losses, number of healthy ranks)
+        tail = torch.tensor([0.0 if err is not None else float(loss) * m_local, 0.0 if err is not None else 1.0], device=dev)
+        dist.all_reduce(tail)           # (sum over ranks of loss x local frames, number of healthy ranks)
         if float(tail[1].item()) != world:
             raise RuntimeError(f"BC step failed on {'this' if err is not None else 'another'} rank: {err!r}")
-        return tail[0] / world, grads, state_out
+        return tail[0] / m_global, grads, state_out
 
     @torch.no_grad()
     def step(self, img_u8, first, state_in, act_buttons, act_camera):
