@@ -14,8 +14,11 @@ Extra objects on the line:
   roofline     : dominant kernel (vpt_conv3x3_kernel, 72 % of the forward FLOPs): algorithmic FLOPs of all
                  its launches in one step / their summed HIP-event durations, vs the 2.5 PFLOP/s dense bf16
                  MFMA peak (MI355X_MICROARCH.md).  `e2e_frac` = frames/s x 15.1016 GFLOP / peak.
-  cpu_baseline : the CPU oracle (fp32 port of the reference forward; the reference itself cannot travel to
-                 the GPU box) timed on the host cores on a bounded sample of the same workload.
+  cpu_baseline : the UNMODIFIED reference (packaged by oracle/make_ref.py into the git-ignored oracle/_ref/, which travels
+                 to the GPU box) timed on 8 host cores on a bounded sample (B=1, T=16) of the same workload, plus
+                 BASELINE.json configs[0] (1x); kind "port" (the oracle) only if the archive is missing.
+  parity       : log-prob / centred-logit / value errors of the bf16 default and of the fp16 parity mode vs the oracle.
+  fp16_mode    : frames/s of the same workload with precision="fp16".
 """
 import argparse
 import json
@@ -32,34 +35,108 @@ FLOP_PER_FRAME = {"1x": 3.8235e9, "2x": 15.1016e9, "3x": 33.8409e9}  # BASELINE.
 MFMA_BF16_PEAK = 2.5e15
 
 
-def cpu_baseline(model: str, seconds_budget: float = 25.0):
-    """Oracle forward on the host cores: B=1, T=16 frames of the same synthetic distribution."""
-    from oracle import vpt_oracle as O
+def _host_threads(limit):
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 32))  # torch CPU ops stop scaling (and oversubscribe) far below 256 logical cores
+    return max(1, min(avail, limit))
+
+
+def _median_time(fn, budget_s, max_reps=5):
+    fn()  # warm-up
+    times, t_start = [], time.time()
+    while len(times) < max_reps and (not times or time.time() - t_start < budget_s):
+        t0 = time.time()
+        fn()
+        times.append(time.time() - t0)
+    times.sort()
+    return times[len(times) // 2], len(times)
+
+
+def cpu_baseline(model: str):
+    """the UNMODIFIED reference (oracle/_ref/vpt_reference.zip, packaged by oracle/make_ref.py) on the host
+    cores, fp32, torch.set_num_threads(8), B=1 T=16 of the same synthetic frames, median of 5 after 1 warm-up -- for the
+    benchmarked model AND for BASELINE.json configs[0] (1x).  Falls back to the oracle port when the archive is absent."""
+    from oracle import vpt_oracle as O
+    from oracle import make_ref
+    cores = _host_threads(8)
     torch.set_num_threads(cores)
+    t = 16
+    g = torch.Generator().manual_seed(1)
+    img = torch.randint(0, 256, (1, t, 128, 128, 3), generator=g, dtype=torch.uint8)
+    first = torch.zeros(1, t, dtype=torch.bool)
+    ref_zip = make_ref.reference_path()
+    rates, kind = {}, "port"
+    if ref_zip is not None:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "oracle", "ref_stubs"))
+            sys.path.insert(0, ref_zip)
+            import lib.torch_util as tu          # the reference's own modules (zipimport)
+            tu.set_default_torch_device("cpu")
+            from gym3.types import DictType
+            from lib.action_mapping import CameraHierarchicalMapping
+            from lib.policy import MinecraftAgentPolicy as RefPolicy
+            space = DictType(**CameraHierarchicalMapping(n_camera_bins=11).get_action_space_update())
+            for name in dict.fromkeys([model, "1x"]):
+                cfg = O.config_from_policy_kwargs(O.policy_kwargs_for(name), dict(temperature=2.0))
+                pol = RefPolicy(space, O.policy_kwargs_for(name), dict(temperature=2.0))
+                pol.load_state_dict(O.synthetic_state_dict(cfg, seed=0), strict=False)
+                pol.eval()
+                st = pol.initial_state(1)
+                with torch.no_grad():
+                    med, n = _median_time(lambda: pol({"img": img}, first, st), 12.0)
+                rates[name] = (t / med, n)
+                del pol
+            kind = "reference"
+        except Exception as e:     # a broken archive must not take the bench line down
+            rates, kind = {}, "port"
+            sys.stderr.write(f"cpu_baseline: reference archive unusable ({type(e).__name__}: {e}); timing the oracle port\n")
+    if not rates:
+        for name in dict.fromkeys([model, "1x"]):
+            cfg = O.config_from_policy_kwargs(O.policy_kwargs_for(name), dict(temperature=2.0))
+            sd = O.synthetic_state_dict(cfg, seed=0)
+            st = O.initial_state(cfg, 1)
+            med, n = _median_time(lambda: O.policy_forward(sd, cfg, img, first, st), 12.0)
+            rates[name] = (t / med, n)
+    what = "the unmodified reference MinecraftAgentPolicy.forward (oracle/_ref/vpt_reference.zip)" if kind == "reference" else "oracle/vpt_oracle.py (fp32 port)"
+    out = dict(value=round(rates[model][0], 2), unit="frames/s", cores=cores, kind=kind,
+               sample=f"{what}, fp32, {model} model, B=1 T={t} synthetic frames, median of {rates[model][1]} after 1 warm-up, torch.set_num_threads({cores})")
+    if "1x" in rates and model != "1x":
+        out["config1_1x_frames_per_s"] = round(rates["1x"][0], 2)     # BASELINE.json configs[0]: 1x, B=1, T=16 on CPU
+    return out
+
+
+def parity_block(model: str, dev):
+    """Parity of what was just benchmarked, on a bounded sample (B=1, T=8 of the same model and weights family) against the
+    CPU oracle: the bf16 default and the fp16 parity mode, metrics of tests/parity.py."""
+    from oracle import vpt_oracle as O
+    from tests import parity as P
+    from vpt_amd.lib.policy import MinecraftAgentPolicy
+    from vpt_amd.lib.types import minecraft_action_space
+    torch.set_num_threads(_host_threads(32))
     pk = O.policy_kwargs_for(model)
     cfg = O.config_from_policy_kwargs(pk, dict(temperature=2.0))
     sd = O.synthetic_state_dict(cfg, seed=0)
-    g = torch.Generator().manual_seed(1)
-    t = 16
-    img = torch.randint(0, 256, (1, t, 128, 128, 3), generator=g, dtype=torch.uint8)
-    first = torch.zeros(1, t, dtype=torch.bool)
-    st = O.initial_state(cfg, 1)
-    O.policy_forward(sd, cfg, img, first, st)  # warm-up
-    times = []
-    t_start = time.time()
-    while len(times) < 5 and time.time() - t_start < seconds_budget:
-        t0 = time.time()
-        O.policy_forward(sd, cfg, img, first, st)
-        times.append(time.time() - t0)
-    times.sort()
-    med = times[len(times) // 2]
-    return dict(value=round(t / med, 2), unit="frames/s", cores=cores, kind="port",
-                sample=f"oracle/vpt_oracle.py fp32 forward, {model} model, B=1 T={t} synthetic frames, median of {len(times)} after 1 warm-up")
+    g = torch.Generator().manual_seed(3)
+    img = torch.randint(0, 256, (1, 8, 128, 128, 3), generator=g, dtype=torch.uint8)
+    first = torch.zeros(1, 8, dtype=torch.bool)
+    ref = O.policy_forward(sd, cfg, img, first, O.initial_state(cfg, 1))
+    pol = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0))
+    pol.load_state_dict(sd, strict=False)
+    pol = pol.to(dev)
+    out = {"sample": f"{model} model, B=1 T=8, synthetic weights seed 0, vs oracle/vpt_oracle.py (fp32, pinned to the live reference's golden vectors)"}
+    for mode in ("bf16", "fp16"):
+        pol.set_precision(mode)
+        with torch.no_grad():
+            (pd, vpred, _), _ = pol({"img": img.to(dev)}, first.to(dev), pol.initial_state(1))
+        torch.cuda.synchronize()
+        m = P.policy_metrics(dict(buttons=pd["buttons"], camera=pd["camera"], vpred=vpred), ref)
+        out[mode] = {"logprob_rel_l2": round(max(m["buttons.lp_l2"], m["camera.lp_l2"]), 6), "logprob_max_rel": round(max(m["buttons.lp_max"], m["camera.lp_max"]), 6),
+                     "centred_logits_rel_l2": round(max(m["buttons.c_l2"], m["camera.c_l2"]), 5), "value_rel": round(m["v_rel"], 5),
+                     "argmax_mismatch_outside_noise_band": m["buttons.argmax_safe_mismatch"] + m["camera.argmax_safe_mismatch"],
+                     "within_bounds": all(m[f"{h}.{k}"] < P.BOUNDS[mode][k] for h in ("buttons", "camera") for k in ("lp_l2", "lp_max", "c_l2", "c_max"))}
+    return out
 
 
 def main():
@@ -71,7 +148,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--seq", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--bc-steps", type=int, default=3, help="timed behavioural-cloning steps after the forward measurement (0: skip)")
+    ap.add_argument("--bc-steps", type=int, default=10, help="timed behavioural-cloning steps after the forward measurement (0: skip)")
     ap.add_argument("--bc-warmup", type=int, default=1)
     args = ap.parse_args()
 
@@ -113,7 +190,8 @@ def main():
     state = pol.initial_state(B)
 
     def step(st):
-        (pd, vpred, _), st = pol({"img": img}, first, st)
+        with torch.no_grad():      # inference path (a grad-enabled call would go through the autograd boundary and keep activations)
+            (pd, vpred, _), st = pol({"img": img}, first, st)
         return st
 
     def barrier():
@@ -134,6 +212,26 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    # the same workload in the parity mode (precision="fp16": identical kernels built with IEEE-half operands), 1 GPU only
+    fp16_rate = None
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            pol.set_precision("fp16")
+            st16 = pol.initial_state(B)
+            st16 = step(step(st16))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(max(2, args.steps // 2)):
+                st16 = step(st16)
+            torch.cuda.synchronize()
+            fp16_rate = dict(frames_per_s=round(B * T * max(2, args.steps // 2) / (time.perf_counter() - t1), 1),
+                             note="precision='fp16' (libvpt_hip_f16.so), same workload; not the headline value")
+            del st16
+        except Exception as e:
+            fp16_rate = dict(error=f"{type(e).__name__}: {e}")
+        finally:
+            pol.set_precision("bf16")
 
     # instrumented extra step (outside the timed region): per-kernel HIP-event durations
     roof = None
@@ -220,6 +318,11 @@ def main():
             "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
+            line["fp16_mode"] = fp16_rate
+            try:
+                line["parity"] = parity_block(args.model, dev)
+            except Exception as e:
+                line["parity"] = dict(error=f"{type(e).__name__}: {e}")
             line["cpu_baseline"] = cpu_baseline(args.model)
         print(json.dumps(line))
     if distributed:

@@ -111,6 +111,17 @@ int vpt_kv_memory_update(const float* qkvr, const float* kmem, const float* vmem
 int vpt_log_softmax_forward(const float* logits, float* out, int M, int ld, int col0, int n, float temperature,
                             void* stream);
 
+/* The whole CategoricalActionHead on one head's columns (lib/action_head.py:163-207): log-probs as above, with
+ *   mask   [M][n] uint8, optional: 0 = unavailable action, its scaled logit becomes LOG0 = -100 before the softmax
+ *          (shaped_out[~mask] = LOG0, lib/action_head.py:170-171; obs["mask"] of lib/policy.py:257-266);
+ *   action [M] int64, optional: CategoricalActionHead.sample -- arg-max of the log-probs (deterministic), or of
+ *          log-probs - log(-log u) with u = noise[M][n] uniform in [0,1] (Gumbel-max, u == 1 -> 0.999 as the reference);
+ *          the FIRST maximum, as torch.argmax.  The caller owns the random numbers (the reference draws them from torch's
+ *          generator, lib/action_head.py:200);
+ *   action_logp [M] fp32, optional: log-prob of that action (CategoricalActionHead.logprob, lib/action_head.py:176-184). */
+int vpt_action_head_forward(const float* logits, const uint8_t* mask, const float* noise, float* out, int64_t* action,
+                            float* action_logp, int M, int ld, int col0, int n, float temperature, void* stream);
+
 /* Fused Adam update of one flat fp32 bucket: th.optim.Adam(lr, weight_decay).step() as configured by
  * behavioural_cloning.py:63-67,122 (L2 weight decay folded into the gradient, bias-corrected moments).
  * `step` counts from 1; grad_scale multiplies the gradient first (1/world_size of the data-parallel mean). */
@@ -129,9 +140,11 @@ int vpt_bc_nll_backward(const float* lp_buttons, const float* lp_camera, const i
  * MinecraftAgentPolicy.forward / get_output_for_observation (lib/policy.py:252-305) when the caller writes its own loss, as
  * behavioural_cloning.py:101-119 does: g_buttons / g_camera = d loss / d log-prob ([M][nb] / [M][nc], either may be NULL),
  * g_value = d loss / d (raw value-head output) ([M], may be NULL).  dz = (g - exp(lp) * rowsum(g)) / temperature per head,
- * the value column passes through; bf16 [M][ldz], ldz >= nb + nc + 1, padding zero. */
+ * the value column passes through; bf16 [M][ldz], ldz >= nb + nc + 1, padding zero.  mask_* (uint8 [M][n], optional): the
+ * availability masks of the forward -- a masked logit was overwritten with the constant LOG0, so its dz is 0. */
 int vpt_heads_logprob_backward(const float* lp_buttons, const float* lp_camera, const float* g_buttons, const float* g_camera,
-                               const float* g_value, void* dz, int M, int nb, int nc, int ldz, float temperature, void* stream);
+                               const float* g_value, const uint8_t* mask_buttons, const uint8_t* mask_camera, void* dz,
+                               int M, int nb, int nc, int ldz, float temperature, void* stream);
 
 /* nn.LayerNorm backward (optionally through a ReLU on the LayerNorm's input): dx = dx_add + dLN(x, dy);
  * dgain / dbias are accumulated with atomics (caller zeroes). */

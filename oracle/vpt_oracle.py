@@ -223,12 +223,17 @@ def recurrent_block(sd, pfx, x, first_b, state, heads, maxlen, causal=True):
 # ----------------------------------------------------------------------------------------------
 # heads
 # ----------------------------------------------------------------------------------------------
-def categorical_head(sd, pfx, latent, temperature: float):
-    """CategoricalActionHead.forward (lib/action_head.py:163-174): linear, /temperature, fp32 log_softmax.
-    Returns [B,T,1,n] like the reference (output_shape = shape + (n,), shape=(1,))."""
+LOG0 = -100.0   # lib/action_head.py:13
+
+
+def categorical_head(sd, pfx, latent, temperature: float, mask=None):
+    """CategoricalActionHead.forward (lib/action_head.py:163-174): linear, /temperature, [~mask] = LOG0, fp32 log_softmax.
+    Returns [B,T,1,n] like the reference (output_shape = shape + (n,), shape=(1,)); mask: bool [B,T,1,n] or None."""
     z = latent @ sd[pfx + "linear_layer.weight"].t() + sd[pfx + "linear_layer.bias"]
-    z = z / temperature
-    return torch.log_softmax(z.float(), dim=-1).unsqueeze(-2)
+    z = (z / temperature).unsqueeze(-2)
+    if mask is not None:
+        z = torch.where(mask, z, torch.full_like(z, LOG0))
+    return torch.log_softmax(z.float(), dim=-1)
 
 
 def value_head(sd, pfx, latent):
@@ -255,7 +260,7 @@ def initial_state(cfg: dict, batch: int):
 
 
 def policy_forward(sd: Dict[str, torch.Tensor], cfg: dict, img_u8: torch.Tensor, first: torch.Tensor,
-                   state_in: List[Tuple], taps: Optional[dict] = None, grad: bool = False):
+                   state_in: List[Tuple], taps: Optional[dict] = None, grad: bool = False, mask: Optional[dict] = None):
     """MinecraftAgentPolicy.forward (lib/policy.py:252-269) -> MinecraftPolicy.forward (lib/policy.py:193-218).
     img_u8 [B,T,128,128,3] uint8, first [B,T] bool (only first[:,0] is honoured, lib/masked_attention.py:167).
     Returns dict(buttons, camera log-probs [B,T,1,n]; vpred [B,T,1]; latent [B,T,hid]; state_out).
@@ -281,8 +286,9 @@ def policy_forward(sd: Dict[str, torch.Tensor], cfg: dict, img_u8: torch.Tensor,
             taps["y"] = x
         x = layer_norm(x, sd["net.final_ln.weight"], sd["net.final_ln.bias"])
         out = dict(
-            buttons=categorical_head(sd, "pi_head.buttons.", x, cfg["temperature"]),
-            camera=categorical_head(sd, "pi_head.camera.", x, cfg["temperature"]),
+            # obs["mask"] -> DictActionHead.forward(mask=...) (lib/policy.py:257-266, lib/action_head.py:240-248)
+            buttons=categorical_head(sd, "pi_head.buttons.", x, cfg["temperature"], (mask or {}).get("buttons")),
+            camera=categorical_head(sd, "pi_head.camera.", x, cfg["temperature"], (mask or {}).get("camera")),
             vpred=value_head(sd, "value_head.", x),
             latent=x,
             state_out=state_out,
@@ -533,11 +539,12 @@ def bc_loss_and_grads(sd, cfg, img_u8, first, state_in, act_buttons, act_camera)
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point}
     state_det = [(m, (k.detach(), v.detach())) for m, (k, v) in state_in]
     out = policy_forward(leaves, cfg, img_u8, first, state_det, grad=True)
-    lp = out["buttons"][:, :, 0].gather(-1, act_buttons.unsqueeze(-1)).squeeze(-1) \
-        + out["camera"][:, :, 0].gather(-1, act_camera.unsqueeze(-1)).squeeze(-1)
-    loss = -lp.mean()
-    names = list(leaves)
-    grads = torch.autograd.grad(loss, [leaves[n] for n in names], allow_unused=True)
+    with torch.enable_grad():    # (the caller may sit inside torch.no_grad(): the GPU tests' inference fixture)
+        lp = out["buttons"][:, :, 0].gather(-1, act_buttons.unsqueeze(-1)).squeeze(-1) \
+            + out["camera"][:, :, 0].gather(-1, act_camera.unsqueeze(-1)).squeeze(-1)
+        loss = -lp.mean()
+        names = list(leaves)
+        grads = torch.autograd.grad(loss, [leaves[n] for n in names], allow_unused=True)
     gd = {n: (g if g is not None else torch.zeros_like(leaves[n])) for n, g in zip(names, grads)}
     state_out = [(m, (k.detach(), v.detach())) for m, (k, v) in out["state_out"]]
     return float(loss.detach()), gd, state_out

@@ -148,9 +148,10 @@ def bc_loss_and_grads(sd, cfg, img_u8, first, state_in, act_buttons, act_camera,
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point}
     state_det = [(m, (k.detach(), v.detach())) for m, (k, v) in state_in]
     out = policy_forward(leaves, cfg, img_u8, first, state_det, grad=True, rnd=rnd)
-    lp = out["buttons"][:, :, 0].gather(-1, act_buttons.unsqueeze(-1)).squeeze(-1) \
-        + out["camera"][:, :, 0].gather(-1, act_camera.unsqueeze(-1)).squeeze(-1)
-    loss = -lp.mean()
-    names = list(leaves)
-    grads = torch.autograd.grad(loss, [leaves[n] for n in names], allow_unused=True)
+    with torch.enable_grad():    # (the caller may sit inside torch.no_grad(): the GPU tests' inference fixture)
+        lp = out["buttons"][:, :, 0].gather(-1, act_buttons.unsqueeze(-1)).squeeze(-1) \
+            + out["camera"][:, :, 0].gather(-1, act_camera.unsqueeze(-1)).squeeze(-1)
+        loss = -lp.mean()
+        names = list(leaves)
+        grads = torch.autograd.grad(loss, [leaves[n] for n in names], allow_unused=True)
     return float(loss.detach()), {n: (g if g is not None else torch.zeros_like(leaves[n])) for n, g in zip(names, grads)}

@@ -19,6 +19,14 @@ from tests import parity as P  # noqa: E402
 DEV = "cuda"
 
 
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    """These tests exercise the inference engine (what act() / bench.py run); a grad-enabled call takes the autograd
+    boundary instead (same kernels, activations kept) -- tests/test_gpu_training.py covers that path."""
+    with torch.no_grad():
+        yield
+
+
 def _l2(a, ref):
     return float(np.linalg.norm((a - ref).ravel()) / np.linalg.norm(ref.ravel()))
 

@@ -270,3 +270,32 @@ def test_linear_wgrad_tn(m, n, k, accumulate):
     if accumulate:
         ref = ref + base
     assert _relerr(out.cpu(), ref) < 2e-3, _relerr(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("m,n,ld,col0,stochastic", [(7, 8641, 8763, 0, False), (7, 121, 8763, 8641, True), (40, 2, 2, 0, True), (3, 8641, 8641, 0, True)])
+def test_action_head_mask_sample_logprob(m, n, ld, col0, stochastic):
+    """vpt_action_head_forward: CategoricalActionHead.forward with a mask (LOG0) + sample (arg-max / Gumbel-max on the caller's
+    uniforms, first maximum) + logprob in one kernel (lib/action_head.py:163-207)."""
+    g = torch.Generator().manual_seed(9)
+    temp = 2.0
+    logits = torch.randn(m, ld, generator=g) * 3
+    mask = torch.rand(m, n, generator=g) > 0.4
+    mask[:, 0] = True
+    u = torch.rand(m, n, generator=g)
+    u[0, min(5, n - 1)] = 1.0                    # the reference's guard: u == 1 -> 0.999
+    z = logits[:, col0:col0 + n] / temp
+    ref = torch.log_softmax(torch.where(mask, z, torch.full_like(z, -100.0)), -1)
+    uu = u.clone(); uu[uu == 1.0] = 0.999
+    want = torch.argmax(ref - torch.log(-torch.log(uu)), -1) if stochastic else torch.argmax(ref, -1)
+    lp, ac, alp = ops.log_softmax_cols(logits.to(DEV), col0, n, temp, mask=mask.to(torch.uint8).to(DEV),
+                                       noise=u.to(DEV) if stochastic else None, want_action=True)
+    torch.cuda.synchronize()
+    assert torch.allclose(lp.cpu(), ref, atol=2e-5)
+    assert torch.equal(ac.cpu(), want)
+    assert torch.allclose(alp.cpu(), ref.gather(1, want[:, None])[:, 0], atol=2e-5)
+    # ties: the FIRST maximum, as torch.argmax
+    tie = torch.zeros(2, 300)
+    tie[0, 17] = tie[0, 200] = 5.0
+    tie[1, 299] = tie[1, 3] = 2.0
+    _, ac2, _ = ops.log_softmax_cols(tie.to(DEV), 0, 300, 1.0, want_action=True)
+    assert ac2.cpu().tolist() == [17, 3]

@@ -19,6 +19,14 @@ from tests import parity as P  # noqa: E402
 DEV = "cuda"
 
 
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    """These tests exercise the inference engine (what act() / bench.py run); a grad-enabled call takes the autograd
+    boundary instead (same kernels, activations kept) -- tests/test_gpu_training.py covers that path."""
+    with torch.no_grad():
+        yield
+
+
 def _inputs(seed, b, t):
     g = torch.Generator().manual_seed(seed)
     return torch.randint(0, 256, (b, t, 128, 128, 3), generator=g, dtype=torch.uint8)
@@ -238,3 +246,51 @@ def test_policy_vs_oracle_ragged_shapes(pol_1x, b, ts, firsts):
         for (m1, (k1, v1)), (m2, (k2, v2)) in zip(sg, so):
             assert torch.equal(m1.cpu(), m2)
             assert _l2(k1, k2) < B["kv_l2"] and _l2(v1, v2) < B["kv_l2"]
+
+
+def test_logit_mask_vs_live_reference_golden(pol_1x):
+    """obs["mask"] (lib/policy.py:257-266): masked actions get LOG0 before the softmax; golden from the unmodified reference."""
+    import os
+    pol, cfg, sd = pol_1x
+    mode = pol.precision
+    G = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "mask_1x_seed0.npz")))
+    b, t = 2, 3
+    img = _inputs(321, b, t)
+    gm = torch.Generator().manual_seed(5)
+    mb = torch.rand(b, t, 1, 8641, generator=gm) > 0.3
+    mc = torch.rand(b, t, 1, 121, generator=gm) > 0.5
+    mb[..., 0] = True
+    mc[..., 60] = True
+    obs = {"img": img.to(DEV), "mask": {"buttons": mb.to(DEV), "camera": mc.to(DEV)}}
+    (pd, _, _), _ = pol(obs, torch.zeros(b, t, dtype=torch.bool, device=DEV), pol.initial_state(b))
+    torch.cuda.synchronize()
+    assert "mask" in obs                                             # the caller's dict is not mutated (lib/policy.py:255)
+    for k, mk in (("buttons", mb), ("camera", mc)):
+        got = pd[k].cpu()
+        assert float(got[~mk].max()) < -90.0                         # LOG0 - logsumexp
+        hm = P.head_metrics(got[mk], torch.from_numpy(G[k])[mk])     # on the available actions
+        print(f"PARITY[{mode}] masked {k}: {P.fmt(hm)}")
+        assert hm["lp_max"] < P.BOUNDS[mode]["lp_max"] and hm["lp_l2"] < P.BOUNDS[mode]["lp_l2"]
+        assert bool(mk.gather(-1, got.argmax(-1, keepdim=True)).all())   # the arg-max is always an available action
+
+
+def test_act_uses_fused_sampling(pol_1x):
+    """act(): the action and its log-prob come out of the head kernel (a16); they must agree with the generic
+    CategoricalActionHead algebra on the returned pd, in deterministic mode exactly."""
+    pol, cfg, sd = pol_1x
+    b = 3
+    img = _inputs(808, b, 1)[:, 0].to(DEV)
+    first = torch.zeros(b, dtype=torch.bool, device=DEV)
+    ac, st, res = pol.act({"img": img}, first, pol.initial_state(b), stochastic=False, return_pd=True)
+    for k in ("buttons", "camera"):
+        assert ac[k].shape == (b, 1) and ac[k].dtype == torch.int64
+        assert torch.equal(ac[k], res["pd"][k].argmax(-1))
+    lp = sum(res["pd"][k].gather(-1, ac[k].unsqueeze(-1))[:, 0, 0] for k in ("buttons", "camera"))
+    assert torch.allclose(res["log_prob"], lp, atol=1e-5)
+    torch.manual_seed(0)
+    ac_s, _, res_s = pol.act({"img": img}, first, pol.initial_state(b), stochastic=True, return_pd=True)
+    lp_s = sum(res_s["pd"][k].gather(-1, ac_s[k].unsqueeze(-1))[:, 0, 0] for k in ("buttons", "camera"))
+    assert torch.allclose(res_s["log_prob"], lp_s, atol=1e-5)
+    # taken_action: log-prob of a given action through the generic path
+    ac_t, _, res_t = pol.act({"img": img}, first, pol.initial_state(b), taken_action=ac)
+    assert torch.allclose(res_t["log_prob"], res["log_prob"], atol=1e-5)

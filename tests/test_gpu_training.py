@@ -582,3 +582,36 @@ def test_reference_bc_loop_runs_unchanged():
             assert cos > 0.7, (n, cos)               # bf16 ReLU-gate flips: see test_bc_gradients_vs_oracle for the calibrated bounds
     print(f"PARITY reference BC loop: param.grad vs BCTrainer worst rel-L2 {worst:.2e}; worst cosine vs fp32 oracle autograd {worst_cos:.3f}; "
           f"loss {batch_loss:.4f} (trainer {loss_sum:.4f}, oracle {loss_ref:.4f})")
+
+
+def test_autograd_boundary_with_logit_mask():
+    """obs["mask"] under autograd: a masked logit was overwritten by the constant LOG0 in the forward
+    (lib/action_head.py:170-171), so no gradient reaches it -- the bias gradient of an always-masked action is exactly 0, the
+    others match torch autograd through the oracle."""
+    pk = O.policy_kwargs_for("1x")
+    cfg = O.config_from_policy_kwargs(pk, dict(temperature=2.0))
+    sd = O.synthetic_state_dict(cfg, seed=0)
+    pol = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0))
+    pol.load_state_dict(sd, strict=False)
+    pol = pol.to(DEV)
+    g = torch.Generator().manual_seed(91)
+    b, t = 1, 3
+    img = torch.randint(0, 256, (b, t, 128, 128, 3), generator=g, dtype=torch.uint8)
+    mb = torch.rand(b, t, 1, 8641, generator=g) > 0.3
+    mb[..., :50] = False            # actions 0..49 never available
+    mb[..., 100] = True
+    first = torch.zeros(b, t, dtype=torch.bool)
+    tgt = torch.full((b, t, 1, 1), 100, dtype=torch.int64)
+    (pd, _, _), _ = pol({"img": img.to(DEV), "mask": {"buttons": mb.to(DEV)}}, first.to(DEV), pol.initial_state(b))
+    assert pd["buttons"].requires_grad
+    loss = -(pd["buttons"].gather(-1, tgt.to(DEV)).mean() + pd["camera"][..., 7].mean())
+    loss.backward()
+    torch.cuda.synchronize()
+    gb = pol.pi_head.buttons.linear_layer.bias.grad.cpu()
+    assert float(gb[:50].abs().max()) == 0.0
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point}
+    ref = O.policy_forward(leaves, cfg, img, first, O.initial_state(cfg, b), grad=True, mask={"buttons": mb})
+    loss_ref = -(ref["buttons"].gather(-1, tgt).mean() + ref["camera"][..., 7].mean())
+    gref, = torch.autograd.grad(loss_ref, [leaves["pi_head.buttons.linear_layer.bias"]])
+    assert abs(float(loss) - float(loss_ref)) < 2e-2
+    assert _l2(gb, gref) < 5e-2, _l2(gb, gref)

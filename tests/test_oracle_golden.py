@@ -1,10 +1,14 @@
 """The oracle (oracle/vpt_oracle.py) against the golden vectors produced by the live reference
 (tests/golden/make_golden.py).  CPU only.  Tolerance: fp32 CPU vs fp32 CPU, different op order ->
 1e-4 absolute on log-probs (values O(10)), exact on masks and deterministic action indices."""
+import os
+
 import numpy as np
 import torch
 
 from oracle import vpt_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _inputs(seed, b, t):
@@ -127,3 +131,24 @@ def test_bc_gradients_match_reference():
     assert checked == 134
     # value head receives no gradient from the BC loss
     assert float(G["norm/value_head.linear.weight"]) == 0.0
+
+
+def test_oracle_logit_mask_matches_live_reference_golden():
+    """obs["mask"] (lib/policy.py:257-266 -> lib/action_head.py:170-171): masked logits become LOG0 = -100 before the softmax.
+    Golden: tests/golden/make_golden_mask.py (unmodified reference)."""
+    G = dict(np.load(os.path.join(ROOT, "tests", "golden", "mask_1x_seed0.npz")))
+    g = torch.Generator().manual_seed(321)
+    b, t = 2, 3
+    img = torch.randint(0, 256, (b, t, 128, 128, 3), generator=g, dtype=torch.uint8)
+    gm = torch.Generator().manual_seed(5)
+    mb = torch.rand(b, t, 1, 8641, generator=gm) > 0.3
+    mc = torch.rand(b, t, 1, 121, generator=gm) > 0.5
+    mb[..., 0] = True
+    mc[..., 60] = True
+    cfg = O.config_from_policy_kwargs(O.policy_kwargs_for("1x"), dict(temperature=2.0))
+    sd = O.synthetic_state_dict(cfg, seed=0)
+    out = O.policy_forward(sd, cfg, img, torch.zeros(b, t, dtype=torch.bool), O.initial_state(cfg, b), mask={"buttons": mb, "camera": mc})
+    for k in ("buttons", "camera"):
+        assert np.abs(out[k].numpy() - G[k]).max() < 2e-4
+        assert np.array_equal(out[k].argmax(-1).numpy(), G["argmax_" + k])
+        assert float(out[k][~(mb if k == "buttons" else mc)].max()) < -90.0      # masked entries sit at LOG0 - logsumexp

@@ -3,6 +3,8 @@ python tools/idm_bench.py [--batch 1] [--seq 128] [--steps 3]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+
+torch.set_grad_enabled(False)
 import __graft_entry__ as ge
 ge.build()
 from vpt_amd import ops

@@ -31,6 +31,7 @@ SIGNATURES = {
     "vpt_masked_attention_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "vpt_kv_memory_update": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_log_softmax_forward": [_P, _P, _I, _I, _I, _I, _F, _P],
+    "vpt_action_head_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "vpt_conv_backward_prepare": [_P] * 14 + [_I, _I, _I, _I, _I, _P],
     "vpt_conv3x3_dgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_conv_first_backward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -43,7 +44,7 @@ SIGNATURES = {
     "vpt_maxpool_backward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_frame_affine_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_bc_nll_backward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
-    "vpt_heads_logprob_backward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "vpt_heads_logprob_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "vpt_layernorm_backward": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "vpt_gate_cast_bf16": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_column_sum": [_P, _P, _I, _I, _I, _P],

@@ -188,7 +188,17 @@ int vpt_log_softmax_forward(const float* logits, float* out, int M, int ld, int 
                             void* stream) {
   VptLogSoftmaxArgs a;
   a.logits = logits; a.out = out; a.M = M; a.ld = ld; a.col0 = col0; a.n = n; a.temperature = temperature;
+  a.mask = nullptr; a.noise = nullptr; a.action = nullptr; a.action_logp = nullptr;
   CHECK_LAUNCH(vpt_logsoftmax_launch(&a, (hipStream_t)stream), "vpt_log_softmax_forward");
+}
+
+int vpt_action_head_forward(const float* logits, const uint8_t* mask, const float* noise, float* out, int64_t* action,
+                            float* action_logp, int M, int ld, int col0, int n, float temperature, void* stream) {
+  if (action_logp && !action) return fail(-1, "vpt_action_head_forward: action_logp needs action");
+  VptLogSoftmaxArgs a;
+  a.logits = logits; a.out = out; a.M = M; a.ld = ld; a.col0 = col0; a.n = n; a.temperature = temperature;
+  a.mask = mask; a.noise = noise; a.action = (long*)action; a.action_logp = action_logp;
+  CHECK_LAUNCH(vpt_logsoftmax_launch(&a, (hipStream_t)stream), "vpt_action_head_forward");
 }
 
 int vpt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, int step,
@@ -211,10 +221,12 @@ int vpt_bc_nll_backward(const float* lp_buttons, const float* lp_camera, const i
 }
 
 int vpt_heads_logprob_backward(const float* lp_buttons, const float* lp_camera, const float* g_buttons, const float* g_camera,
-                               const float* g_value, void* dz, int M, int nb, int nc, int ldz, float temperature, void* stream) {
+                               const float* g_value, const uint8_t* mask_buttons, const uint8_t* mask_camera, void* dz,
+                               int M, int nb, int nc, int ldz, float temperature, void* stream) {
   if (!(temperature > 0.f)) return fail(-1, "vpt_heads_logprob_backward: temperature must be positive");
   VptHeadsBwdArgs a;
   a.lp_buttons = lp_buttons; a.lp_camera = lp_camera; a.g_buttons = g_buttons; a.g_camera = g_camera; a.g_value = g_value;
+  a.mask_buttons = mask_buttons; a.mask_camera = mask_camera;
   a.dz = (vpt_op16*)dz; a.M = M; a.nb = nb; a.nc = nc; a.ldz = ldz; a.inv_temp = 1.0f / temperature;
   CHECK_LAUNCH(vpt_heads_bwd_launch(&a, (hipStream_t)stream), "vpt_heads_logprob_backward");
 }

@@ -118,6 +118,10 @@ struct VptLogSoftmaxArgs {
   float* out;              // [M][n]
   int M, ld, col0, n;
   float temperature;
+  const uint8_t* mask;     // optional [M][n]: 0 = action not available -> its scaled logit is LOG0 = -100 (lib/action_head.py:170-171)
+  const float* noise;      // optional [M][n] uniforms in [0, 1]: Gumbel-max sampling (lib/action_head.py:198-207); null = argmax
+  long* action;            // optional [M]: sampled / arg-max index (first maximum)
+  float* action_logp;      // optional [M]: out[row][action[row]]
 };
 
 struct VptAffineBwdArgs {
@@ -196,6 +200,8 @@ struct VptHeadsBwdArgs {   // generic backward of the two log-softmax heads + th
   const float* g_buttons;  // optional [M][nb]: incoming d loss / d log-prob
   const float* g_camera;   // optional [M][nc]
   const float* g_value;    // optional [M]: incoming d loss / d (raw value-head output)
+  const uint8_t* mask_buttons;  // optional [M][nb] / [M][nc]: 0 = the logit was replaced by the constant LOG0 in the forward
+  const uint8_t* mask_camera;   //   (lib/action_head.py:170-171): no gradient reaches it
   vpt_op16* dz;            // [M][ldz]: d loss / d (fused head logits), padding columns zero
   int M, nb, nc, ldz;
   float inv_temp;          // 1 / temperature

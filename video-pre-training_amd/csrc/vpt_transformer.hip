@@ -258,24 +258,57 @@ extern "C" int vpt_kv_update_launch(const VptKvUpdateArgs* a, hipStream_t stream
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vpt_logsoftmax_kernel(VptLogSoftmaxArgs a) {
-  __shared__ float red[8];
+  __shared__ float red[12];
+  __shared__ int redi[4];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const float* z = a.logits + (size_t)row * a.ld + a.col0;
+  const uint8_t* mk = a.mask ? a.mask + (size_t)row * a.n : nullptr;
   const float T = a.temperature;
+#define SCALED(i_) ((mk && !mk[i_]) ? -100.0f : z[i_] / T)   /* shaped_out /= T; shaped_out[~mask] = LOG0 */
   float m = -3.0e38f;
-  for (int i = tid; i < a.n; i += 256) m = fmaxf(m, z[i] / T);
+  for (int i = tid; i < a.n; i += 256) m = fmaxf(m, SCALED(i));
   m = wave_max(m);
   if (lane == 0) red[w] = m;
   __syncthreads();
   m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float s = 0.f;
-  for (int i = tid; i < a.n; i += 256) s += expf(z[i] / T - m);
+  for (int i = tid; i < a.n; i += 256) s += expf(SCALED(i) - m);
   s = wave_sum(s);
   if (lane == 0) red[4 + w] = s;
   __syncthreads();
   const float lse = m + logf((red[4] + red[5]) + (red[6] + red[7]));
   float* o = a.out + (size_t)row * a.n;
-  for (int i = tid; i < a.n; i += 256) o[i] = z[i] / T - lse;
+  // CategoricalActionHead.sample (lib/action_head.py:195-207) on the way out: argmax of the log-probs, or of
+  // log-probs - log(-log u) (Gumbel-max; u == 1 -> 0.999 as the reference guards); FIRST maximum, as torch.argmax.
+  const float* u = a.noise ? a.noise + (size_t)row * a.n : nullptr;
+  float best = -3.0e38f;
+  int besti = 0x7fffffff;
+  for (int i = tid; i < a.n; i += 256) {
+    const float lp = SCALED(i) - lse;
+    o[i] = lp;
+    if (a.action) {
+      float sc = lp;
+      if (u) { float ui = u[i]; if (ui == 1.0f) ui = 0.999f; sc = lp - logf(-logf(ui)); }
+      if (sc > best) { best = sc; besti = i; }     // ascending i per thread: keeps the first maximum
+    }
+  }
+#undef SCALED
+  if (a.action) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ob = __shfl_xor(best, off, 64);
+      const int oi = __shfl_xor(besti, off, 64);
+      if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    if (lane == 0) { red[8 + w] = best; redi[w] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int k = 1; k < 4; ++k)
+        if (red[8 + k] > best || (red[8 + k] == best && redi[k] < besti)) { best = red[8 + k]; besti = redi[k]; }
+      a.action[row] = besti;
+      if (a.action_logp) a.action_logp[row] = ((mk && !mk[besti]) ? -100.0f : z[besti] / T) - lse;
+    }
+  }
 }
 
 extern "C" int vpt_logsoftmax_launch(const VptLogSoftmaxArgs* a, hipStream_t stream) {

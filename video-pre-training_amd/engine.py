@@ -82,6 +82,33 @@ def resolve_precision(precision: Optional[str]) -> str:
     return p
 
 
+def action_heads(logits, heads, bsz, t, temperature, mask=None, sample=None):
+    """DictActionHead.forward (+ sample / logprob) over the fused head logits.  heads: (name, first column, groups, classes);
+    a head's logits are [M, groups * classes] -> log-probs [B, T, groups, classes].  Returns the dict entries to merge."""
+    if sample not in (None, "deterministic", "stochastic"):
+        raise ValueError(f"sample must be None, 'deterministic' or 'stochastic', got {sample!r}")
+    out, actions, logp = {}, {}, None
+    for name, col0, groups, n in heads:
+        z = logits if groups == 1 else logits[:, col0:col0 + groups * n].reshape(-1, n)
+        c0 = col0 if groups == 1 else 0
+        rows = z.shape[0]
+        mk = None
+        if mask is not None and mask.get(name) is not None:
+            mk = mask[name].reshape(rows, n).to(torch.uint8).contiguous()
+        if sample is None:
+            lp = ops.log_softmax_cols(z, c0, n, temperature, mask=mk)
+        else:
+            noise = torch.rand(rows, n, dtype=torch.float32, device=z.device) if sample == "stochastic" else None
+            lp, ac, alp = ops.log_softmax_cols(z, c0, n, temperature, mask=mk, noise=noise, want_action=True)
+            actions[name] = ac.view(bsz, t, groups)
+            alp = alp.view(bsz, t, groups).sum(-1)
+            logp = alp if logp is None else logp + alp
+        out[name] = lp.view(bsz, t, groups, n)
+    if sample is not None:
+        out["action"], out["action_log_prob"] = actions, logp
+    return out
+
+
 class PolicyEngine:
     """precision: format of every 16-bit MFMA operand / stored CNN activation.  "bf16" (default, what bench.py
     measures) or "fp16": the same kernels built with IEEE-half operands (libvpt_hip_f16.so) -- same MFMA rate and
@@ -230,7 +257,11 @@ class PolicyEngine:
         return x
 
     @torch.no_grad()
-    def forward(self, img_u8: torch.Tensor, first: torch.Tensor, state_in: List):
+    def forward(self, img_u8: torch.Tensor, first: torch.Tensor, state_in: List, mask: Optional[dict] = None,
+                sample: Optional[str] = None):
+        """mask: optional {"buttons" / "camera": bool [B,T,1,n]} availability masks (obs["mask"], lib/policy.py:257-266).
+        sample: None, "deterministic" or "stochastic" -- CategoricalActionHead.sample + logprob fused into the head kernel
+        (lib/action_head.py:176-207); adds out["action"] (int64 [B,T,1] per head) and out["action_log_prob"] ([B,T])."""
         if not self.packed:
             raise RuntimeError("PolicyEngine.pack(state_dict) must be called before forward")
         cfg, w = self.cfg, self.w
@@ -265,10 +296,11 @@ class PolicyEngine:
         nb, nc = self.n_buttons, self.n_camera
         logits, _ = ops.linear(lb, w["heads.w"], nb + nc + 1, bias=w["heads.b"])
         temp = cfg["temperature"]
-        buttons = ops.log_softmax_cols(logits, 0, nb, temp).view(bsz, t, 1, nb)
-        camera = ops.log_softmax_cols(logits, nb, nc, temp).view(bsz, t, 1, nc)
-        vpred = logits[:, nb + nc:nb + nc + 1].reshape(bsz, t, 1).clone()
-        return dict(buttons=buttons, camera=camera, vpred=vpred, latent=latent.view(bsz, t, hid), state_out=state_out)
+        out = dict(latent=latent.view(bsz, t, hid), state_out=state_out)
+        heads_out = action_heads(logits, (("buttons", 0, 1, nb), ("camera", nb, 1, nc)), bsz, t, temp, mask, sample)
+        out.update(heads_out)
+        out["vpred"] = logits[:, nb + nc:nb + nc + 1].reshape(bsz, t, 1).clone()
+        return out
 
 
 class IDMEngine(PolicyEngine):
@@ -330,7 +362,7 @@ class IDMEngine(PolicyEngine):
         self.packed = True
 
     @torch.no_grad()
-    def forward(self, img_u8: torch.Tensor):
+    def forward(self, img_u8: torch.Tensor, mask: Optional[dict] = None, sample: Optional[str] = None):
         if not self.packed:
             raise RuntimeError("IDMEngine.pack(state_dict) must be called before forward")
         cfg, w = self.cfg, self.w
@@ -367,10 +399,16 @@ class IDMEngine(PolicyEngine):
         latent, lb = ops.layernorm(x, w["final.g"], w["final.b"], relu_in=True, out_f32=True, dtype=self.dtype)
         out = {}
         temp = cfg["temperature"]
+        logp = None
         for h, shape in (("buttons", self.button_shape), ("camera", self.camera_shape)):
             n_groups, n = shape
             z, _ = ops.linear(lb, w[h + ".w"], n_groups * n, bias=w[h + ".b"])
-            lp = ops.log_softmax_cols(z.view(bsz * t * n_groups, n), 0, n, temp)
-            out[h] = lp.view(bsz, t, n_groups, n)
+            r = action_heads(z, ((h, 0, n_groups, n),), bsz, t, temp, mask, sample)
+            out[h] = r[h]
+            if sample is not None:
+                out.setdefault("action", {})[h] = r["action"][h]
+                logp = r["action_log_prob"] if logp is None else logp + r["action_log_prob"]
+        if sample is not None:
+            out["action_log_prob"] = logp
         out["latent"] = latent.view(bsz, t, hid)
         return out

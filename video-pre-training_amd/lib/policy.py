@@ -159,8 +159,8 @@ class _PolicyForwardFn(torch.autograd.Function):
     detaches it, behavioural_cloning.py:111; gradients never cross chunk boundaries)."""
 
     @staticmethod
-    def forward(ctx, policy, grad_engine, img, first, state_in, names, *params):
-        S = grad_engine.forward_saving(img, first, state_in)
+    def forward(ctx, policy, grad_engine, img, first, state_in, mask, names, *params):
+        S = grad_engine.forward_saving(img, first, state_in, mask=mask)
         bsz, t = S["bsz"], S["t"]
         nb, nc = grad_engine.engine.n_buttons, grad_engine.engine.n_camera
         ctx.S, ctx.grad_engine, ctx.names = S, grad_engine, names
@@ -187,10 +187,11 @@ class _PolicyForwardFn(torch.autograd.Function):
         nb, nc = eng.engine.n_buttons, eng.engine.n_camera
         gv = None if g_v is None else g_v.reshape(m).float().contiguous()
         with torch.no_grad():
-            dz = ops.heads_logprob_backward(S["lp_b"], S["lp_c"], flat2(g_b, nb), flat2(g_c, nc), gv, S["ldz"], eng.engine.cfg["temperature"])
+            dz = ops.heads_logprob_backward(S["lp_b"], S["lp_c"], flat2(g_b, nb), flat2(g_c, nc), gv, S["ldz"], eng.engine.cfg["temperature"],
+                                            mask_buttons=S["mask"]["buttons"], mask_camera=S["mask"]["camera"])
             g = eng.backward_from(S, dz, value_grads=gv is not None)
         grads = tuple(g[n].reshape(shape) if n in g else None for n, shape in zip(ctx.names, ctx.param_shapes))
-        return (None, None, None, None, None, None) + grads
+        return (None, None, None, None, None, None, None) + grads
 
 
 class MinecraftAgentPolicy(nn.Module):
@@ -266,11 +267,11 @@ class MinecraftAgentPolicy(nn.Module):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):           # warm-up outside capture (lazy kernel attributes, allocator pools)
             for _ in range(2):
-                eng.forward(sg["img"], sg["first"], sg["state"])
+                eng.forward(sg["img"], sg["first"], sg["state"], sample="deterministic")
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            out = eng.forward(sg["img"], sg["first"], sg["state"])
+            out = eng.forward(sg["img"], sg["first"], sg["state"], sample="deterministic")   # arg-max + its log-prob ride in the graph
             for (m_in, (k_in, v_in)), (m_out, (k_out, v_out)) in zip(sg["state"], out["state_out"]):
                 m_in.copy_(m_out); k_in.copy_(k_out); v_in.copy_(v_out)
         for m_in, (k_in, v_in) in sg["state"]:    # the warm-up / capture runs advanced nothing: start from a clean state
@@ -293,6 +294,9 @@ class MinecraftAgentPolicy(nn.Module):
         sg["graph"].replay()
         out = dict(sg["out"])
         out["state_out"] = sg["state"]
+        if "action" in out:      # handed to the caller: must survive the next replay (the other outputs are consumed at once)
+            out["action"] = {k: v.clone() for k, v in out["action"].items()}
+            out["action_log_prob"] = out["action_log_prob"].clone()
         return out
 
     def initial_state(self, batch_size: int):
@@ -303,43 +307,49 @@ class MinecraftAgentPolicy(nn.Module):
 
     # ---- the reference API ---------------------------------------------------------------------
     def forward(self, obs, first: torch.Tensor, state_in):
+        (pd, vpred, _), state_out, _ = self._run(obs, first, state_in, sample=None)
+        return (pd, vpred, None), state_out
+
+    def _run(self, obs, first, state_in, sample=None):
+        """forward() plus, on request, the fused CategoricalActionHead.sample / logprob of the head kernel (act())."""
         if isinstance(obs, dict):
             obs = obs.copy()
-            mask = obs.pop("mask", None)
+            mask = obs.pop("mask", None)        # {"buttons"/"camera": bool [B,T,1,n]}: False -> LOG0 (lib/action_head.py:170-171)
         else:
             mask = None
-        if mask is not None:
-            raise NotImplementedError("logit masking (obs['mask']) is not implemented on the HIP path")
         assert len(state_in) == self._cfg["n_layers"], (
             f"Length of state {len(state_in)} did not match length of blocks {self._cfg['n_layers']}")
         self._ensure_packed()
         img = obs["img"]
         if img.dtype != torch.uint8:
             raise TypeError("obs['img'] must be uint8 [B,T,128,128,3] (the /255 is fused into the first conv)")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            return self._forward_differentiable(img, first, state_in)
+        if torch.is_grad_enabled() and self._engine.precision == "bf16" and any(p.requires_grad for p in self.parameters()):
+            # gradient-enabled call, as the reference's forward is: the outputs join the autograd graph.  (precision="fp16" is
+            # inference only: its outputs carry no grad_fn, so a loss.backward() on them fails in autograd itself.)
+            pd_v, state_out = self._forward_differentiable(img, first, state_in, mask)
+            return pd_v, state_out, {}
         sg = self._step_graph
-        if sg is not None and img.shape[0] == sg["batch"] and img.shape[1] == 1:
+        if sg is not None and mask is None and img.shape[0] == sg["batch"] and img.shape[1] == 1:
             out = self._graphed_forward(img, first, state_in)
+            if sample == "stochastic":
+                out = {k: v for k, v in out.items() if k not in ("action", "action_log_prob")}   # the graph holds the arg-max only
         else:
-            out = self._engine.forward(img, first, state_in)
+            out = self._engine.forward(img, first, state_in, mask=mask, sample=sample)
         pi_logits = {"camera": out["camera"], "buttons": out["buttons"]}
-        return (pi_logits, out["vpred"], None), out["state_out"]
+        extra = {k: out[k] for k in ("action", "action_log_prob") if k in out}
+        return (pi_logits, out["vpred"], None), out["state_out"], extra
 
-    def _forward_differentiable(self, img, first, state_in):
+    def _forward_differentiable(self, img, first, state_in, mask=None):
         """Gradient-enabled call (the reference's get_output_for_observation is, lib/policy.py:287-305): same kernels, every
         activation kept for the backward, outputs attached to the autograd graph through _PolicyForwardFn."""
         from ..training import BCTrainer
-        if self._engine.precision != "bf16":
-            raise NotImplementedError("gradients are implemented for precision='bf16' only: wrap inference in torch.no_grad() "
-                                      "(policy.act / policy.v already are) or call set_precision('bf16') before training")
         named = [(n, p) for n, p in self.named_parameters()]
         train_cnn = any(p.requires_grad for n, p in named if n.startswith("net.img_process.cnn."))
         eng = self._grad_engines.get(train_cnn)
         if eng is None:
             eng = self._grad_engines[train_cnn] = BCTrainer(self, train_cnn=train_cnn, optimizer_state=False)
         names = [n for n, _ in named]
-        out = _PolicyForwardFn.apply(self, eng, img, first, state_in, names, *[p for _, p in named])
+        out = _PolicyForwardFn.apply(self, eng, img, first, state_in, mask, names, *[p for _, p in named])
         lp_b, lp_c, vpred = out[:3]
         flat = out[3:]
         state_out = [(flat[3 * l], (flat[3 * l + 1], flat[3 * l + 2])) for l in range(self._cfg["n_layers"])]
@@ -364,12 +374,18 @@ class MinecraftAgentPolicy(nn.Module):
     def act(self, obs, first, state_in, stochastic: bool = True, taken_action=None, return_pd=False):
         obs = tree_map(lambda x: x.unsqueeze(1), obs)
         first = first.unsqueeze(1)
-        (pd, vpred, _), state_out = self(obs=obs, first=first, state_in=state_in)
-        if taken_action is None:
-            ac = self.pi_head.sample(pd, deterministic=not stochastic)
+        want = None if taken_action is not None else ("stochastic" if stochastic else "deterministic")
+        (pd, vpred, _), state_out, extra = self._run(obs, first, state_in, sample=want)
+        if taken_action is None and "action" in extra:
+            # CategoricalActionHead.sample / logprob (lib/action_head.py:176-207) came out of the head kernel
+            ac = {k: extra["action"][k] for k in pd}
+            log_prob = extra["action_log_prob"]
         else:
-            ac = tree_map(lambda x: x.unsqueeze(1), taken_action)
-        log_prob = self.pi_head.logprob(ac, pd)
+            if taken_action is None:
+                ac = self.pi_head.sample(pd, deterministic=not stochastic)
+            else:
+                ac = tree_map(lambda x: x.unsqueeze(1), taken_action)
+            log_prob = self.pi_head.logprob(ac, pd)
         assert not torch.isnan(log_prob).any()
         result = {"log_prob": log_prob[:, 0], "vpred": self.value_head.denormalize(vpred)[:, 0]}
         if return_pd:
@@ -445,26 +461,30 @@ class InverseActionPolicy(nn.Module):
         return [(None, (z(), z())) for _ in range(self._cfg["n_layers"])]
 
     def forward(self, obs, first: torch.Tensor, state_in, **kwargs):
+        (pd, _, _), state_out, _ = self._run(obs, state_in, sample=None)
+        return (pd, None, None), state_out
+
+    def _run(self, obs, state_in, sample=None):
         if isinstance(obs, dict):
             obs = obs.copy()
-            mask = obs.pop("mask", None)
+            mask = obs.pop("mask", None)        # {"buttons": bool [B,T,20,2], "camera": bool [B,T,2,11]}: False -> LOG0
         else:
             mask = None
-        if mask is not None:
-            raise NotImplementedError("logit masking (obs['mask']) is not implemented on the HIP path")
         self._ensure_packed()
         img = obs["img"]
         if img.dtype != torch.uint8:
             raise TypeError("obs['img'] must be uint8 [B,T,128,128,3]")
-        out = self._engine.forward(img)
+        out = self._engine.forward(img, mask=mask, sample=sample)
         pi_logits = {"buttons": out["buttons"], "camera": out["camera"]}
+        extra = {k: out[k] for k in ("action", "action_log_prob") if k in out}
         # mask "none" / maxlen 0: the state passes through empty (lib/xf.py:366-391 with cache_keep_len = 0)
-        return (pi_logits, None, None), state_in
+        return (pi_logits, None, None), state_in, extra
 
     @torch.no_grad()
     def predict(self, obs, deterministic: bool = True, **kwargs):
-        (pd, _, _), state_out = self(obs=obs, **kwargs)
-        ac = self.pi_head.sample(pd, deterministic=deterministic)
-        log_prob = self.pi_head.logprob(ac, pd)
+        state_in = kwargs.get("state_in")
+        (pd, _, _), state_out, extra = self._run(obs, state_in, sample="deterministic" if deterministic else "stochastic")
+        ac = {k: extra["action"][k] for k in pd}          # CategoricalActionHead.sample, fused into the head kernel
+        log_prob = extra["action_log_prob"]
         assert not torch.isnan(log_prob).any()
         return ac, state_out, {"log_prob": log_prob, "pd": pd}

@@ -237,13 +237,22 @@ def kv_memory_update(qkvr, kmem, vmem, batch, t, hid):
     return kout, vout
 
 
-def log_softmax_cols(logits, col0, n, temperature):
-    _chk(logits, torch.float32, "logits")
+def log_softmax_cols(logits, col0, n, temperature, mask=None, noise=None, want_action=False):
+    """log_softmax(logits[:, col0:col0+n] / T) -> fp32 [M, n]; mask uint8 [M, n] (0 -> LOG0).  want_action: also
+    CategoricalActionHead.sample + logprob in the same kernel -> (lp, action int64 [M], action_logp fp32 [M]); noise fp32
+    [M, n] uniforms = stochastic (Gumbel-max), None = deterministic arg-max."""
+    _chk(logits, torch.float32, "logits"); _chk(mask, torch.uint8, "mask"); _chk(noise, torch.float32, "noise")
     m = logits.shape[0]
     out = torch.empty(m, n, dtype=torch.float32, device=logits.device)
-    _call("vpt_log_softmax_forward", dict(bytes=8.0 * m * n), ptr(logits), ptr(out), m, logits.shape[1], col0, n,
-                 ctypes.c_float(temperature), _stream())
-    return out
+    if mask is None and not want_action:
+        _call("vpt_log_softmax_forward", dict(bytes=8.0 * m * n), ptr(logits), ptr(out), m, logits.shape[1], col0, n,
+              ctypes.c_float(temperature), _stream())
+        return out
+    action = torch.empty(m, dtype=torch.int64, device=logits.device) if want_action else None
+    alp = torch.empty(m, dtype=torch.float32, device=logits.device) if want_action else None
+    _call("vpt_action_head_forward", dict(bytes=8.0 * m * n), ptr(logits), ptr(mask), ptr(noise), ptr(out), ptr(action), ptr(alp),
+          m, logits.shape[1], col0, n, ctypes.c_float(temperature), _stream())
+    return (out, action, alp) if want_action else out
 
 
 def adam_step_(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
@@ -270,16 +279,17 @@ def nll_backward(lp_buttons, lp_camera, act_buttons, act_camera, ldz, scale):
     return dz
 
 
-def heads_logprob_backward(lp_buttons, lp_camera, g_buttons, g_camera, g_value, ldz, temperature):
+def heads_logprob_backward(lp_buttons, lp_camera, g_buttons, g_camera, g_value, ldz, temperature, mask_buttons=None, mask_camera=None):
     """bf16 [M, ldz] gradient w.r.t. the fused head logits for arbitrary incoming gradients of the two log-prob tensors and of the
     raw value output (any of them None = zero).  The autograd boundary of lib/policy.py uses this; the BC fast path uses nll_backward."""
     _chk(lp_buttons, torch.float32, "lp_buttons"); _chk(lp_camera, torch.float32, "lp_camera")
     _chk(g_buttons, torch.float32, "g_buttons"); _chk(g_camera, torch.float32, "g_camera"); _chk(g_value, torch.float32, "g_value")
+    _chk(mask_buttons, torch.uint8, "mask_buttons"); _chk(mask_camera, torch.uint8, "mask_camera")
     m, nb = lp_buttons.shape
     nc = lp_camera.shape[1]
     dz = torch.empty(m, ldz, dtype=torch.bfloat16, device=lp_buttons.device)
     _call("vpt_heads_logprob_backward", dict(bytes=10.0 * m * ldz), ptr(lp_buttons), ptr(lp_camera), ptr(g_buttons), ptr(g_camera), ptr(g_value),
-          ptr(dz), m, nb, nc, ldz, ctypes.c_float(temperature), _stream())
+          ptr(mask_buttons), ptr(mask_camera), ptr(dz), m, nb, nc, ldz, ctypes.c_float(temperature), _stream())
     return dz
 
 

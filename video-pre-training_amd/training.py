@@ -114,7 +114,7 @@ class BCTrainer:
         return loss, g, S["state_out"]
 
     @torch.no_grad()
-    def forward_saving(self, img_u8, first, state_in) -> dict:
+    def forward_saving(self, img_u8, first, state_in, mask: Optional[dict] = None) -> dict:
         """The policy forward with every activation the backward needs kept alive.  Returns the saved-state dict S:
         S["lp_b"] / S["lp_c"] fp32 [M, n] log-probs, S["logits"] fp32 [M, nb+nc+1] (last column: raw value), S["state_out"]."""
         pol, eng = self.policy, self.engine
@@ -173,10 +173,12 @@ class BCTrainer:
         _, lb = ops.layernorm(y, w["final.g"], w["final.b"])
         logits, _ = ops.linear(lb, w["heads.w"], nb + nc + 1, bias=w["heads.b"])
         temp = cfg["temperature"]
-        lp_b = ops.log_softmax_cols(logits, 0, nb, temp)
-        lp_c = ops.log_softmax_cols(logits, nb, nc, temp)
+        mk = {h: (mask[h].reshape(m, n_).to(torch.uint8).contiguous() if mask is not None and mask.get(h) is not None else None)
+              for h, n_ in (("buttons", nb), ("camera", nc))}
+        lp_b = ops.log_softmax_cols(logits, 0, nb, temp, mask=mk["buttons"])
+        lp_c = ops.log_softmax_cols(logits, nb, nc, temp, mask=mk["camera"])
         return dict(m=m, bsz=bsz, t=t, dev=dev, d=d, dn=dn, x_lin16=x_lin16, saved=saved, x_trunk=x_trunk, xb=xb, y=y, y16=y16, lb=lb,
-                    logits=logits, lp_b=lp_b, lp_c=lp_c, cnn_saved=cnn_saved, state_out=state_out, ldz=_round_up(nb + nc + 1, 64))
+                    logits=logits, lp_b=lp_b, lp_c=lp_c, cnn_saved=cnn_saved, state_out=state_out, ldz=_round_up(nb + nc + 1, 64), mask=mk)
 
     @torch.no_grad()
     def backward_from(self, S: dict, dz: torch.Tensor, on_trunk_grads=None, debug: Optional[dict] = None, value_grads: bool = False):
