@@ -180,7 +180,8 @@ int vpt_conv_backward_prepare(const void* dy, const void* dpooled, const uint8_t
 
 /* Input gradient of the layer: dx = conv^T(W', dacc) + skip + coef[f][0] + coef[f][1] * xin, i.e. the implicit-GEMM
  * kernel of vpt_conv3x3_forward on the transposed, spatially flipped weights (wpk_t: [ceil(Cin/128)][Cout/32][9][128][32])
- * with the GroupNorm-statistics terms c0_f + c1_f x added in its epilogue.  dacc has Cout channels, dx / xin / skip Cin. */
+ * with the GroupNorm-statistics terms c0_f + c1_f x added in its epilogue.  dacc has Cout channels, dx / xin / skip Cin.
+ * xin and coef are required (rejected with -1 otherwise); skip may be NULL. */
 int vpt_conv3x3_dgrad(const void* dacc, const void* wpk_t, const void* skip, const void* xin, const float* coef, void* dx,
                       int frames, int H, int W, int Cout, int Cin, void* stream);
 

@@ -32,6 +32,11 @@ def _stats_of(x_nchw):
     (1, 32, 32, 64, 160, False),
     (3, 64, 64, 128, 256, False),
     (2, 32, 32, 256, 256, True),
+    (3, 64, 64, 64, 64, True),      # 1x stack-0 block: two channel blocks only, residual
+    (2, 64, 64, 128, 128, True),    # 2x stack-0 block
+    (2, 32, 32, 128, 128, True),
+    (5, 16, 16, 256, 256, True),
+    (2, 64, 64, 64, 128, False),    # 1x stack-1 firstconv
 ])
 def test_conv3x3(frames, h, w, cin, cout, use_res):
     g = torch.Generator().manual_seed(1)

@@ -27,7 +27,7 @@ st_in = torch.stack([xf.sum(1), (xf * xf).sum(1)], 1).contiguous()
 st_out = torch.zeros(f, 2, dtype=torch.float64, device=dev)
 out = torch.empty(f, cout // 32, hw, hw, 32, dtype=torch.bfloat16, device=dev)
 grid = f * (hw // 16) ** 2 * ((cout + 127) // 128)
-trace = torch.zeros(grid, 6, dtype=torch.int64, device=dev)
+trace = torch.zeros(grid, 12, dtype=torch.int64, device=dev)
 lib = _native.load()
 lib.vpt_conv3x3_set_trace.argtypes = [ctypes.c_void_p]
 lib.vpt_conv3x3_set_trace.restype = None
@@ -46,6 +46,12 @@ print(f"shape {hw}x{hw} {cin}->{cout} res={use_res} frames={f}: grid {grid}, ker
 pro, main, epi = T[:, 1] - T[:, 0], T[:, 2] - T[:, 1], T[:, 3] - T[:, 2]
 for name, v in (("prologue", pro), ("main loop", main), ("epilogue", epi), ("tile total", T[:, 3] - T[:, 0])):
     print(f"  {name:10s} us: mean {v.mean():6.2f}  p10 {np.percentile(v, 10):6.2f}  median {np.median(v):6.2f}  p90 {np.percentile(v, 90):6.2f}")
+E = (t[:, 6:11] - t0) / 100.0
+names = ["epi start -> subtile 0 begins", "subtile 0", "subtile 1", "subtile 2", "subtile 3", "stats + barrier + atomics"]
+segs = [E[:, 0] - T[:, 2], E[:, 1] - E[:, 0], E[:, 2] - E[:, 1], E[:, 3] - E[:, 2], E[:, 4] - E[:, 3], T[:, 3] - E[:, 4]]
+print("  epilogue anatomy of wave 0 (us, mean / median / p90):")
+for nme, v in zip(names, segs):
+    print(f"    {nme:32s} {v.mean():6.2f} {np.median(v):6.2f} {np.percentile(v, 90):6.2f}")
 # per CU: fraction of time with 0 / 1 / 2 workgroups in their main loop
 span = T[:, 3].max()
 n_main = {0: 0.0, 1: 0.0, 2: 0.0}

@@ -52,13 +52,17 @@ __device__ __forceinline__ int sub_row(int i) { return ((i >> 4) ^ (i >> 2) ^ (i
 // COUNTED: the wait in front of each step's barrier is a counted s_waitcnt that retires the weight DMA only and leaves the
 // younger halo / residual prefetch loads in flight across the barrier (a plain __syncthreads() drains vmcnt to 0 because an
 // LDS-DMA is pending).
-template <bool COUNTED>
+// MODE (compile time, so the epilogue carries no runtime branches): 0 forward, 1 forward + residual,
+// 2 dgrad (+ c0 + c1 * xin), 3 dgrad + skip connection.
+template <bool COUNTED, int MODE>
 __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
+  constexpr bool BWD = MODE >= 2, HAS_RES = (MODE == 1 || MODE == 3), USE_X = MODE >= 2;
+  constexpr bool DEFER_STORES = MODE != 3;   // mode 3 holds skip + xin pieces as well: no registers left for the packed results
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   // profiling (vpt_conv3x3_set_trace): CU id + 100 MHz timestamps of the tile's phases
   int cu_key = -1;
-  long long t_trace[3];
+  long long t_trace[3], t_epi[5] = {0, 0, 0, 0, 0};
   if (a.trace && tid == 0) {
     t_trace[0] = wall_clock64();
     const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID: cu_id[11:8] sh_id[12] se_id[15:13]
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
 #pragma unroll
   for (int m = 0; m < 6; ++m) areg[m] = *(const u32x4*)((const char*)xplane + a_gbyte[m]);
   float mean = 0.f, rstd = 1.f, c0f = 0.f, c1f = 0.f;
-  if (!a.bwd) {
+  if (!BWD) {
     frame_mean_rstd(a.stats_in, f, a.inv_count_in, mean, rstd);
   } else if (a.coef) {
     c0f = a.coef[2 * f];
@@ -134,8 +138,8 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     for (int k = 0; k < 5; ++k) {  // 9*128 = 4.5 * 256 entries: all ten loads in flight together
       const int idx = tid + 256 * k;
       const int o = (idx >> 7) * a.CoutPad + nt * 128 + (idx & 127);
-      ksa[k] = (idx < 9 * 128 && !a.bwd) ? a.edge_sa[o] : 0.f;
-      ksg[k] = (idx < 9 * 128 && !a.bwd) ? a.edge_sg[o] : 0.f;
+      ksa[k] = (idx < 9 * 128 && !BWD) ? a.edge_sa[o] : 0.f;
+      ksg[k] = (idx < 9 * 128 && !BWD) ? a.edge_sg[o] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -164,33 +168,29 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   const unsigned char* bL1 = smem + A_BYTES + (wn * 64 + l31) * 64 + (((2 + hi) ^ bsw) << 4);  // ks = 1
 
   // epilogue addressing (needed early: the residual is requested during the last channel block)
+  // Operands are SWAPPED in the MFMA (weights = A rows, pixels = B columns): a lane holds ONE pixel (column l31 of the
+  // 2x16-pixel subtile) and, per accumulator, four groups g of 4 consecutive output channels 8g + 4hi .. +3 -- 8 bytes of
+  // the pixel's 64-byte channel row per group, the partner lane (l31, 1 - hi) holding the 8 bytes next to them.  One
+  // v_permlane32_swap per dword turns the pair (g = 2p, 2p + 1) into 16 CONTIGUOUS bytes per lane (lower half-wave: bytes
+  // 32p.., upper: 32p + 16..), so the residual / xin / output move as 16-byte accesses covering 32 contiguous bytes per
+  // pixel and instruction, with no LDS staging at all.  (Round 1 staged them through a wave-private LDS tile: four LDS round
+  // trips per subtile that queued behind the co-resident workgroup's main-loop LDS traffic -- the phase trace showed the
+  // epilogue taking 8 us alone and 14 us beside a main loop.)
   const int CB_out = a.Cout >> 5;
   const int cb0 = nt * 4 + wn * 2;                 // 32-channel block of n2 = 0
   const bool nvalid[2] = {(cb0 + 0) < CB_out, (cb0 + 1) < CB_out};
-  const size_t nstep = (size_t)HW * 32;            // next 32-channel block
-  // Coalesced side of the epilogue: global accesses are 16 bytes per lane over 16 consecutive pixels x 64 B (one full
-  // 1 KB run per instruction) and pass through a wave-private LDS staging tile; the lane-local side (one pixel, four
-  // consecutive channels per access) only touches LDS.  Going to memory straight from the accumulator layout made
-  // every instruction visit 32 cache lines for 16 useful bytes each -- the L1 line rate, not HBM, was what the
-  // residual / output traffic of the K = 1152 layers was waiting for.
-  const int cq = lane >> 2, cchunk = lane & 3;         // staging role: pixel column of the 2x16 patch, 16-byte chunk
-  int st_lds[2];                                      // LDS offset of (patch row j2, column cq) in l31 order
-  size_t goff0[2];                                    // global element offset of (m = 0, j2) for channel block cb0
-  const size_t gm = (size_t)(2 * a.W) * 32;           // + m * gm: two image rows further down
+  // Addresses = wave-uniform base (frame, channel block n2) + a 32-bit per-lane byte offset: global accesses with an SGPR
+  // base, no 64-bit vector address arithmetic, no address registers kept across the main loop.
+  const unsigned gm_b = (unsigned)(2 * a.W) * 64u;   // + m * gm_b: two image rows further down (bytes)
+  const unsigned voff = (unsigned)(((ty0 + wm * 8 + sub_row(l31)) * a.W + tx0 + (l31 & 15)) * 32 + 8 * hi) * 2u;  // pair 0 of subtile 0
+  size_t cbase[2];                                  // element offset of channel block n2 of this frame
 #pragma unroll
-  for (int j2 = 0; j2 < 2; ++j2) {
-    const int l31q = cq + 16 * ((j2 ^ (cq >> 2) ^ (cq >> 3)) & 1);   // inverse of sub_row(): lane that owns this pixel
-    st_lds[j2] = l31q * ST_RS + cchunk * 16;
-    const int y = ty0 + wm * 8 + j2, x = tx0 + cq;
-    goff0[j2] = ((size_t)(f * CB_out + (nvalid[0] ? cb0 : 0)) * HW + (size_t)(y * a.W + x)) * 32 + cchunk * 8;
-  }
-  const int ll_lds = l31 * ST_RS + 8 * hi;             // lane-local: + n2 * ST_N2 + 16 * g
-  unsigned char* stg = smem + w * ST_WAVE;             // [residual / output tile][xin tile], reused for every m
-  u32x4 rq[4][2][2];
+  for (int n2 = 0; n2 < 2; ++n2) cbase[n2] = (size_t)(f * CB_out + (nvalid[n2] ? cb0 + n2 : 0)) * HW * 32;
+  u32x4 rq[4][2][2];                                // residual pieces [subtile m][n2][pair p]
+#define EPI_LD(ptr_, m_, n2_, p_) (*(const u32x4*)((const char*)((ptr_) + cbase[n2_]) + (voff + (unsigned)(m_) * gm_b + 32u * (p_))))
 #define LOAD_RES(m_)                                                                                      \
   _Pragma("unroll") for (int n2_ = 0; n2_ < 2; ++n2_)                                                     \
-    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                      \
-      rq[m_][n2_][j_] = *(const u32x4*)(a.res + goff0[j_] + (m_) * gm + (nvalid[n2_] ? n2_ : 0) * nstep)
+    _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) rq[m_][n2_][p_] = EPI_LD(a.res, m_, n2_, p_)
 
   // ---- main loop ----------------------------------------------------------------------------------------------------
   // One K step = one kernel row (3 taps) of one 32-channel block = 6 groups (tap dx, 16-channel half ks) of 8 MFMAs per
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   //     step in registers, the next step's weights (requested >= 24 MFMAs earlier) have landed, so the next step's
   //     first fragments are requested behind the barrier and arrive under group 5's MFMAs.
   op16x8 fa[2][4], fb[2][2];
-  const op16_t* resp = a.res ? a.res : a.y;   // no residual: the prefetch still runs (exact counted waits), result unused
+  const op16_t* resp = a.res;
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define MM(set_, m_, n_) acc[m_][n_] = VPT_MFMA_32X32X16(fb[set_][n_], fa[set_][m_], acc[m_][n_], 0, 0, 0)
 #define FA_LD(set_, dy_, g_, m_) \
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp_ + (m_) * 2048),    \
                                    (__attribute__((address_space(3))) void*)(bd_ + (m_) * 4096), 16, 0, 0)
 #define XA(m_) areg[m_] = *(const u32x4*)((const char*)xplane + (cbo_ + a_gbyte[m_]))
-#define XR(m_, n2_, j_) rq[m_][n2_][j_] = *(const u32x4*)(resp + goff0[j_] + (m_) * gm + (nvalid[n2_] ? n2_ : 0) * nstep)
+#define XR(m_, n2_, p_) rq[m_][n2_][p_] = EPI_LD(resp, m_, n2_, p_)
 #define NOP_() ((void)0)
 #define WAIT_BARRIER(n_late_)                                                                             \
   do {                                                                                                    \
@@ -249,8 +249,10 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     SB();                                                                                                 \
   } while (0)
   // Memory ops are issued in a FIXED order and count per wave -- weight DMA (6), then either the halo of the next block
-  // (6, PRE_A) or the residual of subtiles 0 / 1 (8, PRE_R) -- so the counted wait in front of the barrier is exact: it
-  // retires the DMA and leaves the younger loads in flight across the barrier.
+  // (6, PRE_A) or, in the modes with a residual, subtiles 0 / 1 of it (8, PRE_R) -- so the counted wait in front of the barrier
+  // is exact: it retires the DMA and leaves the younger loads in flight across the barrier.  Every counted load must be LIVE
+  // (a load whose result is unused is deleted by the compiler and the count would then release the barrier early -- this
+  // bit once: the residual prefetch of a residual-free instantiation), hence the compile-time HAS_RES in the step.
 #define CONV_STEP(cb_, dy_, NEXT_DY, PRE_A, WR_A, PRE_R, LAST)                                            \
   do {                                                                                                    \
     const int s_ = (cb_) * 3 + (dy_);                                                                     \
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
       GROUP(1, dy_, 4, boff_, do { XA(0); XA(1); } while (0), do { XA(2); } while (0));                   \
       GROUP(0, dy_, 5, boff_, do { XA(3); XA(4); } while (0), do { XA(5); } while (0));                   \
       WAIT_BARRIER(6);                                                                                    \
-    } else if (PRE_R) {                                                                                   \
+    } else if ((PRE_R) && HAS_RES) { /* compile-time: without a residual the loads would be dead code and the count wrong */ \
       GROUP(1, dy_, 4, boff_, do { XR(0, 0, 0); XR(0, 0, 1); } while (0), do { XR(0, 1, 0); XR(0, 1, 1); } while (0)); \
       GROUP(0, dy_, 5, boff_, do { XR(1, 0, 0); XR(1, 0, 1); } while (0), do { XR(1, 1, 0); XR(1, 1, 1); } while (0)); \
       WAIT_BARRIER(8);                                                                                    \
@@ -338,19 +340,9 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     if (t == 12345.678f) a.y[0] = (vpt_op16)t;
     return;
   }
-  // the fragment registers are dead: the residual of subtiles 2 / 3 travels while subtiles 0 / 1 are processed
-  if (a.res) {
-    if (a.ablate == 2) { LOAD_RES(0); LOAD_RES(1); }
-    LOAD_RES(2); LOAD_RES(3);
-  }
+  if (HAS_RES && a.ablate == 2) { LOAD_RES(0); LOAD_RES(1); }
   SB();
 
-  // Operands are SWAPPED in the MFMA (weights = A rows, pixels = B columns), so a lane holds ONE pixel
-  // (column l31 of the subtile) and, per accumulator, four groups of 4 consecutive output channels
-  // (rows (r&3) + 8*(r>>2) + 4*hi): the arithmetic is lane-local -- 16-byte reads of the constant table, 8-byte
-  // reads of the staged residual / xin, 8-byte writes of the bf16 result back into the staging tile -- and the
-  // staging tile moves to / from memory in full 1 KB runs (see above).  The last step's barrier has retired every
-  // read of the weight / halo buffers, so the staging tiles may overlay them.
   int eoff[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
@@ -362,69 +354,80 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   }
   const float* kk = (const float*)(smem + KK_OFF);
   float s_sum = 0.f, s_sq = 0.f;
-  const bool use_x = a.bwd && a.xin;
-  u32x4 xq[2][2];
-  if (use_x) {
-#pragma unroll
-    for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) xq[n2][j] = *(const u32x4*)(a.xin + goff0[j] + (nvalid[n2] ? n2 : 0) * nstep);
-  }
+  constexpr bool use_x = USE_X;
+  u32x4 xq[2][2][2];          // dgrad: the forward layer's input, [parity of m][n2][pair], one subtile ahead
+  u32x4 outv[4][2][2];        // packed results: ALL stores are issued after the last load has been consumed.  gfx950 has one
+                              // counter (vmcnt) for loads and stores, which may retire out of order relative to each other, so a
+                              // wait for a load issued among stores degenerates to vmcnt(0) = "every store has reached L2" --
+                              // the round-2 trace showed the first subtile waiting 4-14 us that way.
+#define LOAD_XIN(m_)                                                                                      \
+  _Pragma("unroll") for (int n2_ = 0; n2_ < 2; ++n2_)                                                     \
+    _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) xq[(m_) & 1][n2_][p_] = EPI_LD(a.xin, m_, n2_, p_)
+  if (use_x) LOAD_XIN(0);
+
+  // 16-byte piece {first half x, y | second half z, w} of a lane pair -> this lane's own 8 bytes of group 2p (e) and 2p + 1 (o)
+#define UNSWAP(v_, e_, o_)                                                                                \
+  do {                                                                                                    \
+    const auto s0_ = __builtin_amdgcn_permlane32_swap((v_).x, (v_).z, false, false);                      \
+    const auto s1_ = __builtin_amdgcn_permlane32_swap((v_).y, (v_).w, false, false);                      \
+    (e_).x = s0_[0]; (o_).x = s0_[1]; (e_).y = s1_[0]; (o_).y = s1_[1];                                   \
+  } while (0)
 
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
-    // stage the coalesced inputs of this 2x16-pixel subtile
-#pragma unroll
-    for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (a.res) *(u32x4*)(stg + n2 * ST_N2 + st_lds[j]) = rq[m][n2][j];
-        if (use_x) *(u32x4*)(stg + ST_X + n2 * ST_N2 + st_lds[j]) = xq[n2][j];
-      }
-    if (use_x && m < 3) {   // next subtile's xin: in flight while this one is processed
-#pragma unroll
-      for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) xq[n2][j] = *(const u32x4*)(a.xin + goff0[j] + (m + 1) * gm + (nvalid[n2] ? n2 : 0) * nstep);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private tile: in-order LDS queue, no barrier needed
+    if (a.trace && tid == 0) t_epi[m] = wall_clock64();
+    if (HAS_RES && m < 2) LOAD_RES(m + 2);   // rolling prefetch, two subtiles ahead (0 / 1 were requested during the last channel block)
+    if (use_x && m < 3) LOAD_XIN(m + 1);   // next subtile's xin: in flight while this one is processed
 #pragma unroll
     for (int n2 = 0; n2 < 2; ++n2) {
       if (!nvalid[n2]) continue;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 k4 = *(const f32x4*)(kk + eoff[m] + n2 * 32 + 8 * g);
-        float v0 = fmaf(rstd, acc[m][n2][4 * g + 0], k4.x), v1 = fmaf(rstd, acc[m][n2][4 * g + 1], k4.y);
-        float v2 = fmaf(rstd, acc[m][n2][4 * g + 2], k4.z), v3 = fmaf(rstd, acc[m][n2][4 * g + 3], k4.w);
-        unsigned char* cell = stg + n2 * ST_N2 + ll_lds + 16 * g;
-        if (!a.bwd) {
-          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-        } else if (use_x) {  // dgrad: + d(mu, rstd)/dx terms of the GroupNorm statistics
-          const u32x2 xi = *(const u32x2*)(cell + ST_X);
-          v0 += fmaf(c1f, op16_lo_to_f32(xi.x), c0f); v1 += fmaf(c1f, op16_hi_to_f32(xi.x), c0f);
-          v2 += fmaf(c1f, op16_lo_to_f32(xi.y), c0f); v3 += fmaf(c1f, op16_hi_to_f32(xi.y), c0f);
+      for (int p = 0; p < 2; ++p) {
+        u32x2 r2[2] = {{0u, 0u}, {0u, 0u}}, x2[2] = {{0u, 0u}, {0u, 0u}}, pk[2];
+        if (HAS_RES) UNSWAP(rq[m][n2][p], r2[0], r2[1]);
+        if (use_x) UNSWAP(xq[m & 1][n2][p], x2[0], x2[1]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int g = 2 * p + q;
+          const f32x4 k4 = *(const f32x4*)(kk + eoff[m] + n2 * 32 + 8 * g);
+          float v0 = fmaf(rstd, acc[m][n2][4 * g + 0], k4.x), v1 = fmaf(rstd, acc[m][n2][4 * g + 1], k4.y);
+          float v2 = fmaf(rstd, acc[m][n2][4 * g + 2], k4.z), v3 = fmaf(rstd, acc[m][n2][4 * g + 3], k4.w);
+          if (!BWD) {
+            v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+          } else if (use_x) {  // dgrad: + d(mu, rstd)/dx terms of the GroupNorm statistics
+            v0 += fmaf(c1f, op16_lo_to_f32(x2[q].x), c0f); v1 += fmaf(c1f, op16_hi_to_f32(x2[q].x), c0f);
+            v2 += fmaf(c1f, op16_lo_to_f32(x2[q].y), c0f); v3 += fmaf(c1f, op16_hi_to_f32(x2[q].y), c0f);
+          }
+          if (HAS_RES) {
+            v0 += op16_lo_to_f32(r2[q].x); v1 += op16_hi_to_f32(r2[q].x);
+            v2 += op16_lo_to_f32(r2[q].y); v3 += op16_hi_to_f32(r2[q].y);
+          }
+          s_sum += (v0 + v1) + (v2 + v3);
+          s_sq = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, fmaf(v3, v3, s_sq))));
+          pk[q].x = pack_op16x2(v0, v1);
+          pk[q].y = pack_op16x2(v2, v3);
         }
-        if (a.res) {
-          const u32x2 r2 = *(const u32x2*)cell;
-          v0 += op16_lo_to_f32(r2.x); v1 += op16_hi_to_f32(r2.x);
-          v2 += op16_lo_to_f32(r2.y); v3 += op16_hi_to_f32(r2.y);
-        }
-        s_sum += (v0 + v1) + (v2 + v3);
-        s_sq = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, fmaf(v3, v3, s_sq))));
-        const u32x2 pk = {pack_op16x2(v0, v1), pack_op16x2(v2, v3)};
-        *(u32x2*)cell = pk;
+        // back to 16 contiguous bytes per lane (the swap is an involution) and out
+        const auto o0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+        const auto o1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+        const u32x4 ov = {o0[0], o1[0], o0[1], o1[1]};
+        if (DEFER_STORES) outv[m][n2][p] = ov;
+        else *(u32x4*)((char*)(a.y + cbase[n2]) + (voff + (unsigned)m * gm_b + 32u * p)) = ov;
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int n2 = 0; n2 < 2; ++n2) {
-      if (!nvalid[n2]) continue;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        *(u32x4*)(a.y + goff0[j] + m * gm + n2 * nstep) = *(const u32x4*)(stg + n2 * ST_N2 + st_lds[j]);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile is rewritten by the next subtile
   }
+#undef UNSWAP
+#undef LOAD_XIN
+  if (DEFER_STORES)
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n2 = 0; n2 < 2; ++n2) {
+      if (!nvalid[n2]) continue;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) *(u32x4*)((char*)(a.y + cbase[n2]) + (voff + (unsigned)m * gm_b + 32u * p)) = outv[m][n2][p];
+    }
+  if (a.trace && tid == 0) t_epi[4] = wall_clock64();
   if (a.stats_out) {
     float* red = (float*)(smem + KK_OFF + KK_BYTES);
     s_sum = wave_sum(s_sum);
@@ -437,13 +440,14 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     }
   }
   if (a.trace && tid == 0) {
-    long long* t = a.trace + (size_t)blockIdx.x * 6;
+    long long* t = a.trace + (size_t)blockIdx.x * 12;
     t[0] = t_trace[0]; t[1] = t_trace[1]; t[2] = t_trace[2]; t[3] = wall_clock64(); t[4] = cu_key; t[5] = 0;
+    for (int k = 0; k < 5; ++k) t[6 + k] = t_epi[k];
   }
 }
 
 static long long* g_conv_trace = nullptr;
-extern "C" void vpt_conv3x3_set_trace(void* buf) { g_conv_trace = (long long*)buf; }  // profiling: [grid][6] int64, or null
+extern "C" void vpt_conv3x3_set_trace(void* buf) { g_conv_trace = (long long*)buf; }  // profiling: [grid][12] int64, or null
 
 extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream) {
   static int ablate = -1, extra_lds = 0;
@@ -453,8 +457,8 @@ extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream
     const char* xl = getenv("VPT_CONV_EXTRA_LDS");  // profiling: dynamic LDS bytes (> 2 KB forces one workgroup per CU)
     extra_lds = xl ? atoi(xl) : 0;
     if (extra_lds > 0) {
-      hipFuncSetAttribute((const void*)vpt_conv3x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds);
-      hipFuncSetAttribute((const void*)vpt_conv3x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds);
+      hipFuncSetAttribute((const void*)vpt_conv3x3_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds);
+      hipFuncSetAttribute((const void*)vpt_conv3x3_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds);
     }
   }
   VptConv3x3Args a_copy = *a_in;
@@ -464,9 +468,13 @@ extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream
   if ((a->H & 15) || (a->W & 15) || (a->Cin & 31) || (a->Cout & 31) || a->frames <= 0) return -1;
   const long grid = (long)a->frames * (a->H >> 4) * (a->W >> 4) * a->NT;
   if (grid > 0x7fffffffL) return -2;
+  const int mode = a->bwd ? (a->res ? 3 : 2) : (a->res ? 1 : 0);
+  if (a->bwd && (!a->xin || !a->coef)) return -1;   // dgrad always carries the GroupNorm-statistics terms (c0 + c1 * xin)
   static int counted = -1;
   if (counted < 0) { const char* e = getenv("VPT_CONV_COUNTED"); counted = e ? atoi(e) : 1; }
-  if (counted) hipLaunchKernelGGL(vpt_conv3x3_kernel<true>, dim3((unsigned)grid), dim3(256), extra_lds, stream, *a);
-  else hipLaunchKernelGGL(vpt_conv3x3_kernel<false>, dim3((unsigned)grid), dim3(256), extra_lds, stream, *a);
+#define LAUNCH_(C_, M_) hipLaunchKernelGGL((vpt_conv3x3_kernel<C_, M_>), dim3((unsigned)grid), dim3(256), extra_lds, stream, *a)
+  if (counted) { if (mode == 0) LAUNCH_(true, 0); else if (mode == 1) LAUNCH_(true, 1); else if (mode == 2) LAUNCH_(true, 2); else LAUNCH_(true, 3); }
+  else { if (mode == 0) LAUNCH_(false, 0); else if (mode == 1) LAUNCH_(false, 1); else if (mode == 2) LAUNCH_(false, 2); else LAUNCH_(false, 3); }
+#undef LAUNCH_
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
