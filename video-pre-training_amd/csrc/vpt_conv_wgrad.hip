@@ -121,21 +121,36 @@ __global__ __launch_bounds__(512, 1) void vpt_conv_wgrad_kernel(VptConvWgradArgs
     const unsigned char* base = smem + (s & 1) * BUF;
     const unsigned char* dA = base + wo * DCB + lane_off;
     const unsigned char* xB = base + 4 * DCB + wi * XCB + lane_off;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int q0 = ks * 16;
-      const int r = q0 / W, x0 = q0 % W;
-      op16x8 af[3], bfr[3];
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) af[dx] = tr_frag(dA + (r * DP + x0 - dx + 2) * 64);
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) bfr[dy] = tr_frag(xB + ((r + dy) * W + x0) * 64);
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
-          acc[dy * 3 + dx] = VPT_MFMA_32X32X16(af[dx], bfr[dy], acc[dy * 3 + dx], 0, 0, 0);
-    }
+    // Two fragment register sets: while the nine MFMAs of 16-pixel slice ks issue, the six fragments of slice ks + 1 are
+    // requested, one behind each of the first six MFMAs (pinned with sched_barrier: left alone the scheduler sinks every
+    // read next to its use and the matrix pipe drains for an LDS round trip per slice -- the same finding as in
+    // vpt_conv3x3_kernel, round 2).  Only slice 0 of a step, whose buffer was filled behind the barrier, is exposed.
+    op16x8 af[2][3], bfr[2][3];
+#define WG_SB() __builtin_amdgcn_sched_barrier(0)
+#define WG_LDA(set_, ks_, dx_) af[set_][dx_] = tr_frag(dA + ((((ks_) * 16) / W) * DP + (((ks_) * 16) % W) - (dx_) + 2) * 64)
+#define WG_LDB(set_, ks_, dy_) bfr[set_][dy_] = tr_frag(xB + (((((ks_) * 16) / W) + (dy_)) * W + (((ks_) * 16) % W)) * 64)
+#define WG_MM(set_, t_) acc[t_] = VPT_MFMA_32X32X16(af[set_][(t_) % 3], bfr[set_][(t_) / 3], acc[t_], 0, 0, 0)
+#define WG_SLICE(set_, ks_, NEXT)                                                                         \
+  do {                                                                                                    \
+    WG_MM(set_, 0); if (NEXT) WG_LDA(1 - (set_), (ks_) + 1, 0); WG_SB();                                  \
+    WG_MM(set_, 1); if (NEXT) WG_LDB(1 - (set_), (ks_) + 1, 0); WG_SB();                                  \
+    WG_MM(set_, 2); if (NEXT) WG_LDA(1 - (set_), (ks_) + 1, 1); WG_SB();                                  \
+    WG_MM(set_, 3); if (NEXT) WG_LDA(1 - (set_), (ks_) + 1, 2); WG_SB();                                  \
+    WG_MM(set_, 4); if (NEXT) WG_LDB(1 - (set_), (ks_) + 1, 1); WG_SB();                                  \
+    WG_MM(set_, 5); if (NEXT) WG_LDB(1 - (set_), (ks_) + 1, 2); WG_SB();                                  \
+    WG_MM(set_, 6); WG_MM(set_, 7); WG_MM(set_, 8); WG_SB();                                              \
+  } while (0)
+    WG_LDA(0, 0, 0); WG_LDB(0, 0, 0); WG_LDA(0, 0, 1); WG_LDA(0, 0, 2); WG_LDB(0, 0, 1); WG_LDB(0, 0, 2);
+    WG_SB();
+    WG_SLICE(0, 0, true);
+    WG_SLICE(1, 1, true);
+    WG_SLICE(0, 2, true);
+    WG_SLICE(1, 3, false);
+#undef WG_SLICE
+#undef WG_MM
+#undef WG_LDA
+#undef WG_LDB
+#undef WG_SB
     store_step((s + 1) & 1);
     __syncthreads();
   }
