@@ -32,6 +32,24 @@ const char* vpt_operand_format(void);
 /* Human-readable reason for the most recent non-zero return on this thread. */
 const char* vpt_last_error(void);
 
+/* ---- weight re-packing (the `.weights` state_dict, fp32, reference shapes -> what the kernels stream) ------------------
+ * A host needs nothing else to prepare a model: sizes from the three queries, then one launch per layer.
+ *   vpt_pack_conv3x3: Conv2d weight [Cout][Cin][3][3] of a FanInInitReLULayer with GroupNorm(1, Cin) (lib/util.py:58-82,
+ *     lib/impala_cnn.py:30-52,86-97) -> wpk (16-bit, vpt_conv3x3_packed_elems elements: round(W * gain) in the swizzled LDS
+ *     image of vpt_conv3x3_forward) and, when edge_sa / edge_sg are given (forward use; both or neither), the tables of the
+ *     GroupNorm fold (vpt_conv3x3_table_floats floats each).  For vpt_conv3x3_dgrad pass the transposed, spatially flipped
+ *     weight, gain = ones, no tables.
+ *   vpt_pack_linear: nn.Linear weight [N][K] (row stride ldw) -> [ceil(N/128)][K/32][128][32] 16-bit, rows >= N zero,
+ *     K % 64 == 0.  With transposed = 1 the packed matrix is the TRANSPOSE of a [src_rows][ldw] source (element (n, k) =
+ *     source[k][n], zero for k >= src_rows): the operand of the input-gradient GEMM dx = dy W, with the reduction dimension
+ *     (the layer's output width) padded to K. */
+long vpt_conv3x3_packed_elems(int Cout, int Cin);
+long vpt_conv3x3_table_floats(int Cout);
+long vpt_linear_packed_elems(int N, int K);
+int vpt_pack_conv3x3(const float* weight, const float* gain, const float* bias, void* wpk, float* edge_sa, float* edge_sg,
+                     int Cout, int Cin, void* stream);
+int vpt_pack_linear(const float* weight, void* wpk, int N, int K, int transposed, int ldw, int src_rows, void* stream);
+
 /* Stack-0 firstconv + ingest + ReLU + max-pool.
  * Replaces ImgPreprocessing.forward (lib/policy.py:39-45), the permute at lib/impala_cnn.py:190,
  * CnnDownStack.firstconv of stack 0 (lib/impala_cnn.py:86-97,115) and F.max_pool2d (lib/impala_cnn.py:117).

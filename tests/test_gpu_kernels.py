@@ -304,3 +304,39 @@ def test_action_head_mask_sample_logprob(m, n, ld, col0, stochastic):
     tie[1, 299] = tie[1, 3] = 2.0
     _, ac2, _ = ops.log_softmax_cols(tie.to(DEV), 0, 300, 1.0, want_action=True)
     assert ac2.cpu().tolist() == [17, 3]
+
+
+@pytest.mark.parametrize("cout,cin,dtype", [(128, 128, torch.bfloat16), (160, 64, torch.bfloat16), (256, 256, torch.float16)])
+def test_device_pack_conv3x3_bit_exact(cout, cin, dtype):
+    """vpt_pack_conv3x3 (the C-ABI re-pack a torch-free host would use) == packing.pack_conv3x3, bit for bit."""
+    g = torch.Generator().manual_seed(12)
+    W = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(DEV)
+    gain = (1 + 0.2 * torch.randn(cin, generator=g)).to(DEV)
+    bias = (0.1 * torch.randn(cin, generator=g)).to(DEV)
+    wref, sa_ref, sg_ref = packing.pack_conv3x3(W, gain, bias, dtype=dtype)
+    wpk, sa, sg = ops.pack_conv3x3(W, gain, bias, dtype=dtype)
+    torch.cuda.synchronize()
+    assert torch.equal(wpk.view(torch.int16), wref.view(torch.int16))
+    assert torch.allclose(sa, sa_ref, rtol=0, atol=1e-6 * float(sa_ref.abs().max()))
+    assert torch.allclose(sg, sg_ref, rtol=0, atol=1e-6 * float(sg_ref.abs().max()))
+    # dgrad operand: transposed + flipped weight, unit gain, no tables
+    wd = (W * gain.view(1, -1, 1, 1)).to(dtype).float().permute(1, 0, 2, 3).flip(2, 3).contiguous()
+    ones = torch.ones(cout, device=DEV)
+    wpk_d, none_a, none_g = ops.pack_conv3x3(wd, ones, None, tables=False, dtype=dtype)
+    assert none_a is None and none_g is None
+    ref_d = packing.pack_conv3x3(wd, ones, None, tables=False, dtype=dtype)[0]
+    bad = (wpk_d.view(torch.int16) != ref_d.view(torch.int16))
+    assert int(bad.sum()) == 0, (int(bad.sum()), wpk_d[bad][:4], ref_d[bad][:4])
+
+
+@pytest.mark.parametrize("n,k", [(8763, 2048), (256, 65536), (2048, 256)])
+def test_device_pack_linear_bit_exact(n, k):
+    g = torch.Generator().manual_seed(13)
+    W = (torch.randn(n, k, generator=g) / k ** 0.5).to(DEV)
+    assert torch.equal(ops.pack_linear(W).view(torch.int16), packing.pack_linear(W).view(torch.int16))
+    # transposed: the input-gradient operand W^T with the reduction dimension (n) padded to a multiple of 64
+    if k <= 8192:
+        np_ = (n + 63) // 64 * 64
+        wt = torch.zeros(k, np_, device=DEV)
+        wt[:, :n] = W.t()
+        assert torch.equal(ops.pack_linear(W, transposed=True, k_pad=np_).view(torch.int16), packing.pack_linear(wt).view(torch.int16))

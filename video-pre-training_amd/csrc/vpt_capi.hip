@@ -19,6 +19,24 @@ const char* vpt_version(void) { return "vpt_hip 0.2 gfx950"; }
 const char* vpt_operand_format(void) { return VPT_OPERAND_NAME; }
 const char* vpt_last_error(void) { return g_err; }
 
+long vpt_conv3x3_packed_elems(int Cout, int Cin) { return (long)((Cout + 127) / 128) * (Cin / 32) * 9 * 128 * 32; }
+long vpt_conv3x3_table_floats(int Cout) { return 9L * ((Cout + 127) / 128) * 128; }
+long vpt_linear_packed_elems(int N, int K) { return (long)((N + 127) / 128) * 128 * K; }
+
+int vpt_pack_conv3x3(const float* weight, const float* gain, const float* bias, void* wpk, float* edge_sa, float* edge_sg,
+                     int Cout, int Cin, void* stream) {
+  if ((edge_sa == nullptr) != (edge_sg == nullptr)) return fail(-1, "vpt_pack_conv3x3: give both edge tables or neither");
+  if (edge_sa && !bias) return fail(-1, "vpt_pack_conv3x3: the edge tables need the GroupNorm bias");
+  VptPackConvArgs a;
+  a.weight = weight; a.gain = gain; a.bias = bias; a.wpk = (vpt_op16*)wpk; a.edge_sa = edge_sa; a.edge_sg = edge_sg;
+  a.Cout = Cout; a.Cin = Cin; a.NT = (Cout + 127) / 128;
+  CHECK_LAUNCH(vpt_pack_conv3x3_launch(&a, (hipStream_t)stream), "vpt_pack_conv3x3");
+}
+
+int vpt_pack_linear(const float* weight, void* wpk, int N, int K, int transposed, int ldw, int src_rows, void* stream) {
+  CHECK_LAUNCH(vpt_pack_linear_launch(weight, wpk, N, K, transposed, ldw, src_rows, (hipStream_t)stream), "vpt_pack_linear");
+}
+
 int vpt_conv_first_forward(const uint8_t* img, const void* wfrag, void* y, double* stats_out,
                            int frames, int H, int W, int Cout, void* stream) {
   VptConvFirstArgs a;

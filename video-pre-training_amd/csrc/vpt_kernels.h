@@ -29,6 +29,16 @@ struct VptConv3x3Args {
   const float* coef;       // [F][2]
 };
 
+struct VptPackConvArgs {
+  const float* weight;     // [Cout][Cin][3][3]
+  const float* gain;       // [Cin]  GroupNorm weight
+  const float* bias;       // [Cin]  GroupNorm bias (unused when edge_sa is null)
+  vpt_op16* wpk;           // [NT][Cin/32][9][128][32]
+  float* edge_sa;          // optional [9][NT*128]
+  float* edge_sg;          // optional [9][NT*128]
+  int Cout, Cin, NT;
+};
+
 struct VptConvFirstArgs {
   const uint8_t* img;      // [F][H][W][3]
   const vpt_op16* wfrag;   // [NT][4][2][64][8]  MFMA A-operand fragments (bias folded in k=27,28)
@@ -266,6 +276,8 @@ int vpt_camera_codec_launch(int decode, const void* in, void* out, long n, doubl
 int vpt_action_mapping_launch(int to_factored, const long* a, const long* b, long* oa, long* ob, long n, int n_camera_bins, hipStream_t s);
 int vpt_conv_wgrad_groups(int frames, int Cin, int Cout);
 int vpt_conv_wgrad_launch(const VptConvWgradArgs* a, hipStream_t s);
+int vpt_pack_conv3x3_launch(const VptPackConvArgs* a, hipStream_t s);
+int vpt_pack_linear_launch(const float* w, void* out, int N, int K, int transposed, int ldw, int src_rows, hipStream_t s);
 int vpt_nll_bwd_launch(const VptNllBwdArgs* a, hipStream_t s);
 int vpt_heads_bwd_launch(const VptHeadsBwdArgs* a, hipStream_t s);
 int vpt_ln_bwd_launch(const VptLnBwdArgs* a, hipStream_t s);

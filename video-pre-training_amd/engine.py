@@ -141,21 +141,21 @@ class PolicyEngine:
             if s == 0:
                 w[p + "firstconv"] = packing.pack_conv_first(f32(sd[p + "firstconv.layer.weight"]), f32(sd[p + "firstconv.layer.bias"]), dtype=self.dtype)
             else:
-                w[p + "firstconv"] = packing.pack_conv3x3(f32(sd[p + "firstconv.layer.weight"]), f32(sd[p + "firstconv.norm.weight"]), f32(sd[p + "firstconv.norm.bias"]), dtype=self.dtype)
+                w[p + "firstconv"] = ops.pack_conv3x3(f32(sd[p + "firstconv.layer.weight"]), f32(sd[p + "firstconv.norm.weight"]), f32(sd[p + "firstconv.norm.bias"]), dtype=self.dtype)
             w[p + "n.g"], w[p + "n.b"] = f32(sd[p + "n.weight"]), f32(sd[p + "n.bias"])
             for b in range(2):
                 for cv in range(2):
                     q = f"{p}blocks.{b}.conv{cv}"
-                    w[q] = packing.pack_conv3x3(f32(sd[q + ".layer.weight"]), f32(sd[q + ".norm.weight"]), f32(sd[q + ".norm.bias"]), dtype=self.dtype)
+                    w[q] = ops.pack_conv3x3(f32(sd[q + ".layer.weight"]), f32(sd[q + ".norm.weight"]), f32(sd[q + ".norm.bias"]), dtype=self.dtype)
             cin = c
         c2 = cfg["chans"][-1]
         p = "net.img_process.cnn.dense."
         w[p + "g"] = packing.chw_to_blocked_vector(f32(sd[p + "norm.weight"]), c2, 16, 16)
         w[p + "b"] = packing.chw_to_blocked_vector(f32(sd[p + "norm.bias"]), c2, 16, 16)
-        w[p + "w"] = packing.pack_linear(packing.chw_to_blocked_columns(f32(sd[p + "layer.weight"]), c2, 16, 16), dtype=self.dtype)
+        w[p + "w"] = ops.pack_linear(packing.chw_to_blocked_columns(f32(sd[p + "layer.weight"]), c2, 16, 16), dtype=self.dtype)
         p = "net.img_process.linear."
         w[p + "g"], w[p + "b"] = f32(sd[p + "norm.weight"]), f32(sd[p + "norm.bias"])
-        w[p + "w"] = packing.pack_linear(f32(sd[p + "layer.weight"]), dtype=self.dtype)
+        w[p + "w"] = ops.pack_linear(f32(sd[p + "layer.weight"]), dtype=self.dtype)
         hid = cfg["hidsize"]
         for l in range(cfg["n_layers"]):
             p = f"net.recurrent_layer.blocks.{l}."
@@ -165,21 +165,21 @@ class PolicyEngine:
                             f32(sd[o + "v_layer.weight"]), f32(sd[o + "r_layer.weight"])], dim=0)
             nr = sd[o + "r_layer.weight"].shape[0]
             bq = torch.cat([f32(sd[o + "q_layer.bias"]), torch.zeros(2 * hid, device=wq.device), f32(sd[o + "r_layer.bias"])])
-            w[p + "qkvr.w"], w[p + "qkvr.b"] = packing.pack_linear(wq, dtype=self.dtype), bq.contiguous()
+            w[p + "qkvr.w"], w[p + "qkvr.b"] = ops.pack_linear(wq, dtype=self.dtype), bq.contiguous()
             w[p + "b_nd"] = f32(sd[o + "b_nd"])
-            w[p + "proj.w"], w[p + "proj.b"] = packing.pack_linear(f32(sd[o + "proj_layer.weight"]), dtype=self.dtype), f32(sd[o + "proj_layer.bias"])
+            w[p + "proj.w"], w[p + "proj.b"] = ops.pack_linear(f32(sd[o + "proj_layer.weight"]), dtype=self.dtype), f32(sd[o + "proj_layer.bias"])
             w[p + "ln2.g"], w[p + "ln2.b"] = f32(sd[p + "mlp0.norm.weight"]), f32(sd[p + "mlp0.norm.bias"])
-            w[p + "mlp0.w"] = packing.pack_linear(f32(sd[p + "mlp0.layer.weight"]), dtype=self.dtype)
-            w[p + "mlp1.w"], w[p + "mlp1.b"] = packing.pack_linear(f32(sd[p + "mlp1.layer.weight"]), dtype=self.dtype), f32(sd[p + "mlp1.layer.bias"])
+            w[p + "mlp0.w"] = ops.pack_linear(f32(sd[p + "mlp0.layer.weight"]), dtype=self.dtype)
+            w[p + "mlp1.w"], w[p + "mlp1.b"] = ops.pack_linear(f32(sd[p + "mlp1.layer.weight"]), dtype=self.dtype), f32(sd[p + "mlp1.layer.bias"])
             self.n_qkvr = 3 * hid + nr
         w["last.g"], w["last.b"] = f32(sd["net.lastlayer.norm.weight"]), f32(sd["net.lastlayer.norm.bias"])
-        w["last.w"] = packing.pack_linear(f32(sd["net.lastlayer.layer.weight"]), dtype=self.dtype)
+        w["last.w"] = ops.pack_linear(f32(sd["net.lastlayer.layer.weight"]), dtype=self.dtype)
         w["final.g"], w["final.b"] = f32(sd["net.final_ln.weight"]), f32(sd["net.final_ln.bias"])
         wh = torch.cat([f32(sd["pi_head.buttons.linear_layer.weight"]), f32(sd["pi_head.camera.linear_layer.weight"]),
                         f32(sd["value_head.linear.weight"])], dim=0)
         bh = torch.cat([f32(sd["pi_head.buttons.linear_layer.bias"]), f32(sd["pi_head.camera.linear_layer.bias"]),
                         f32(sd["value_head.linear.bias"])])
-        w["heads.w"], w["heads.b"] = packing.pack_linear(wh, dtype=self.dtype), bh.contiguous()
+        w["heads.w"], w["heads.b"] = ops.pack_linear(wh, dtype=self.dtype), bh.contiguous()
         self.w = w
         self.packed = True
 
@@ -328,20 +328,20 @@ class IDMEngine(PolicyEngine):
         self.c3d_out = sd["net.conv3d_layer.layer.weight"].shape[0]
         for s, c in enumerate(cfg["chans"]):
             p = f"net.img_process.cnn.stacks.{s}."
-            w[p + "firstconv"] = packing.pack_conv3x3(f32(sd[p + "firstconv.layer.weight"]), f32(sd[p + "firstconv.norm.weight"]), f32(sd[p + "firstconv.norm.bias"]), dtype=self.dtype)
+            w[p + "firstconv"] = ops.pack_conv3x3(f32(sd[p + "firstconv.layer.weight"]), f32(sd[p + "firstconv.norm.weight"]), f32(sd[p + "firstconv.norm.bias"]), dtype=self.dtype)
             w[p + "n.g"], w[p + "n.b"] = f32(sd[p + "n.weight"]), f32(sd[p + "n.bias"])
             for b in range(2):
                 for cv in range(2):
                     q = f"{p}blocks.{b}.conv{cv}"
-                    w[q] = packing.pack_conv3x3(f32(sd[q + ".layer.weight"]), f32(sd[q + ".norm.weight"]), f32(sd[q + ".norm.bias"]), dtype=self.dtype)
+                    w[q] = ops.pack_conv3x3(f32(sd[q + ".layer.weight"]), f32(sd[q + ".norm.weight"]), f32(sd[q + ".norm.bias"]), dtype=self.dtype)
         c2 = cfg["chans"][-1]
         p = "net.img_process.cnn.dense."
         w[p + "g"] = packing.chw_to_blocked_vector(f32(sd[p + "norm.weight"]), c2, 16, 16)
         w[p + "b"] = packing.chw_to_blocked_vector(f32(sd[p + "norm.bias"]), c2, 16, 16)
-        w[p + "w"] = packing.pack_linear(packing.chw_to_blocked_columns(f32(sd[p + "layer.weight"]), c2, 16, 16), dtype=self.dtype)
+        w[p + "w"] = ops.pack_linear(packing.chw_to_blocked_columns(f32(sd[p + "layer.weight"]), c2, 16, 16), dtype=self.dtype)
         p = "net.img_process.linear."
         w[p + "g"], w[p + "b"] = f32(sd[p + "norm.weight"]), f32(sd[p + "norm.bias"])
-        w[p + "w"] = packing.pack_linear(f32(sd[p + "layer.weight"]), dtype=self.dtype)
+        w[p + "w"] = ops.pack_linear(f32(sd[p + "layer.weight"]), dtype=self.dtype)
         hid = cfg["hidsize"]
         for l in range(cfg["n_layers"]):
             p = f"net.recurrent_layer.blocks.{l}."
@@ -349,14 +349,14 @@ class IDMEngine(PolicyEngine):
             w[p + "ln1.g"], w[p + "ln1.b"] = f32(sd[p + "pre_r_ln.weight"]), f32(sd[p + "pre_r_ln.bias"])
             wq = torch.cat([f32(sd[o + "q_layer.weight"]), f32(sd[o + "k_layer.weight"]), f32(sd[o + "v_layer.weight"])], dim=0)
             bq = torch.cat([f32(sd[o + "q_layer.bias"]), torch.zeros(2 * hid, device=wq.device)])
-            w[p + "qkv.w"], w[p + "qkv.b"] = packing.pack_linear(wq, dtype=self.dtype), bq.contiguous()
-            w[p + "proj.w"], w[p + "proj.b"] = packing.pack_linear(f32(sd[o + "proj_layer.weight"]), dtype=self.dtype), f32(sd[o + "proj_layer.bias"])
+            w[p + "qkv.w"], w[p + "qkv.b"] = ops.pack_linear(wq, dtype=self.dtype), bq.contiguous()
+            w[p + "proj.w"], w[p + "proj.b"] = ops.pack_linear(f32(sd[o + "proj_layer.weight"]), dtype=self.dtype), f32(sd[o + "proj_layer.bias"])
             w[p + "ln2.g"], w[p + "ln2.b"] = f32(sd[p + "mlp0.norm.weight"]), f32(sd[p + "mlp0.norm.bias"])
-            w[p + "mlp0.w"] = packing.pack_linear(f32(sd[p + "mlp0.layer.weight"]), dtype=self.dtype)
-            w[p + "mlp1.w"], w[p + "mlp1.b"] = packing.pack_linear(f32(sd[p + "mlp1.layer.weight"]), dtype=self.dtype), f32(sd[p + "mlp1.layer.bias"])
+            w[p + "mlp0.w"] = ops.pack_linear(f32(sd[p + "mlp0.layer.weight"]), dtype=self.dtype)
+            w[p + "mlp1.w"], w[p + "mlp1.b"] = ops.pack_linear(f32(sd[p + "mlp1.layer.weight"]), dtype=self.dtype), f32(sd[p + "mlp1.layer.bias"])
         w["final.g"], w["final.b"] = f32(sd["net.final_ln.weight"]), f32(sd["net.final_ln.bias"])
         for h in ("buttons", "camera"):
-            w[h + ".w"] = packing.pack_linear(f32(sd[f"pi_head.{h}.linear_layer.weight"]), dtype=self.dtype)
+            w[h + ".w"] = ops.pack_linear(f32(sd[f"pi_head.{h}.linear_layer.weight"]), dtype=self.dtype)
             w[h + ".b"] = f32(sd[f"pi_head.{h}.linear_layer.bias"])
         self.w = w
         self.packed = True

@@ -87,6 +87,39 @@ def _chk(t, dtype, name):
         raise ValueError(f"{name}: tensor must be contiguous")
 
 
+def pack_conv3x3(weight, gain, bias=None, tables=True, dtype=torch.bfloat16):
+    """Device re-pack of a GN -> conv3x3 layer (vpt_pack_conv3x3): -> (wpk, edge_sa, edge_sg) exactly as packing.pack_conv3x3."""
+    _chk(weight, torch.float32, "weight"); _chk(gain, torch.float32, "gain"); _chk(bias, torch.float32, "bias")
+    cout, cin = weight.shape[:2]
+    dt, fmt = _fmt(dtype=dtype)
+    lib = _native.load(fmt)
+    nt = (cout + 127) // 128
+    wpk = torch.empty(nt, cin // 32, 9, 128, 32, dtype=dt, device=weight.device)
+    assert wpk.numel() == lib.vpt_conv3x3_packed_elems(cout, cin)
+    sa = sg = None
+    if tables:
+        sa = torch.empty(9, nt * 128, dtype=torch.float32, device=weight.device)
+        sg = torch.empty(9, nt * 128, dtype=torch.float32, device=weight.device)
+    _call("vpt_pack_conv3x3", None, ptr(weight), ptr(gain), ptr(bias), ptr(wpk), ptr(sa), ptr(sg), cout, cin, _stream(), fmt=fmt)
+    return wpk, sa, sg
+
+
+def pack_linear(weight, dtype=torch.bfloat16, transposed=False, k_pad=None):
+    """Device re-pack of an nn.Linear weight [N, K] (vpt_pack_linear) -> [ceil(N/128)][K/32][128][32].
+    transposed=True: the packed matrix is weight^T, i.e. [K rows][N reduction] with the reduction dimension zero-padded to
+    k_pad (a multiple of 64) -- the operand of the input-gradient GEMM dx = dy W (training.linear_backward)."""
+    _chk(weight, torch.float32, "weight")
+    dt, fmt = _fmt(dtype=dtype)
+    rows, cols = weight.shape
+    if transposed:
+        n_out, k_red, src_rows = cols, (k_pad or rows), rows
+    else:
+        n_out, k_red, src_rows = rows, cols, rows
+    out = torch.empty((n_out + 127) // 128, k_red // 32, 128, 32, dtype=dt, device=weight.device)
+    _call("vpt_pack_linear", None, ptr(weight), ptr(out), n_out, k_red, 1 if transposed else 0, cols, src_rows, _stream(), fmt=fmt)
+    return out
+
+
 def conv_first(img_u8, wfrag, cout, stats_out=None):
     """img_u8 [F,H,W,3] uint8 -> pooled blocked bf16 [F, cout/32, H/2, W/2, 32]."""
     _chk(img_u8, torch.uint8, "img"); _chk(wfrag, OP16, "wfrag"); _chk(stats_out, torch.float64, "stats_out")

@@ -42,10 +42,9 @@ def linear_backward(dy16: torch.Tensor, n: int, x16: Optional[torch.Tensor], wei
     k = weight.shape[1]
     dev = dy16.device
     dx32 = dx16 = dw = None
-    if need_dx:
-        wt = torch.zeros(k, np_, dtype=torch.bfloat16, device=dev)
-        wt[:, :n] = weight.t()
-        dx32, dx16 = ops.linear(dy16, packing.pack_linear(wt), k, res=res, mask=mask, out_f32=dx_f32,
+    if need_dx:   # W^T packed straight from the fp32 master by one kernel (was: zero, transpose, cast, permute -- four tensor ops)
+        wt = ops.pack_linear(weight.contiguous(), transposed=True, k_pad=np_)
+        dx32, dx16 = ops.linear(dy16, wt, k, res=res, mask=mask, out_f32=dx_f32,
                                 out_bf16=dx_bf16_ld is not None, out_bf16_ld=dx_bf16_ld)
         del wt
     if need_dw:       # dW = dy^T x straight from the row-major activations (vpt_gemm_tn_kernel: LDS transpose reads, no copies)
