@@ -253,16 +253,16 @@ def main():
         if c and c["ms"] > 0:
             ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
             # HBM traffic cannot be counted live (PMC needs rocprofv3): report the committed PMC measurement of this same
-            # workload (profiles/r01_bench_conv3x3_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate passes), per launch
+            # workload (profiles/r02_bench_conv3x3_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate passes), per launch
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_bench_conv3x3_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r02_bench_conv3x3_traffic.json")
             if args.model == "2x" and B * T == 8192 and os.path.exists(tpath):
                 try:
                     traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
                 except Exception:
                     traffic = None
             roof = dict(bound="mfma", kernel="vpt_conv3x3_kernel", achieved=round(ach, 1), peak=2500.0, unit="TFLOP/s",
-                        frac=round(ach / 2500.0, 4), traffic=traffic, traffic_unit="HBM bytes per launch (committed PMC pass; algorithmic 1.55e9)", launches=c["calls"],
+                        frac=round(ach / 2500.0, 4), traffic=traffic, traffic_unit="HBM bytes per launch (committed rocprofv3 PMC pass of this workload, tools/profile_round.sh; algorithmic 1.55e9)", launches=c["calls"],
                         avg_launch_ms=round(c["ms"] / c["calls"], 4),
                         share_of_step_time=round(c["ms"] / total_ms, 3))
 
