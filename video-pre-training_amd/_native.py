@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libvpt_hip.so")
+_LIB_PATH = os.environ.get("VPT_HIP_LIB") or os.path.join(_HERE, "libvpt_hip.so")   # VPT_HIP_LIB: profiling builds (tools/)
 # one library per 16-bit operand format (vpt_operand_format()): same sources, same ABI
 _LIB_PATHS = {"bf16": _LIB_PATH, "fp16": os.path.join(_HERE, "libvpt_hip_f16.so")}
 _libs = {}

@@ -30,6 +30,10 @@
 #include "vpt_common.h"
 #include "vpt_kernels.h"
 #include <stdlib.h>
+#include <type_traits>
+#ifndef VPT_EPI_ABLATE
+#define VPT_EPI_ABLATE 0   // profiling builds: 1 = no output stores, 2 = no residual loads inside the epilogue
+#endif
 
 #define A_RS 80
 #define A_BYTES (324 * A_RS)            // 25920
@@ -49,13 +53,16 @@
 __device__ __forceinline__ int sub_row(int i) { return ((i >> 4) ^ (i >> 2) ^ (i >> 3)) & 1; }
 
 
-// COUNTED: the wait in front of each step's barrier is a counted s_waitcnt that retires the weight DMA only and leaves the
-// younger halo / residual prefetch loads in flight across the barrier (a plain __syncthreads() drains vmcnt to 0 because an
-// LDS-DMA is pending).
+// The wait in front of each step's barrier is a counted s_waitcnt that retires the weight DMA only and leaves the younger
+// halo / residual prefetch loads in flight across the barrier (a plain __syncthreads() drains vmcnt to 0 because an LDS-DMA
+// is pending).
+// TRACE (tools/conv_trace.py): phase timestamps.  Compile time because s_memrealtime is a scalar-memory operation: one of them
+// in flight makes lgkmcnt out of order and every LDS wait of the epilogue degenerates to lgkmcnt(0).
 // MODE (compile time, so the epilogue carries no runtime branches): 0 forward, 1 forward + residual,
 // 2 dgrad (+ c0 + c1 * xin), 3 dgrad + skip connection.
-template <bool COUNTED, int MODE>
+template <bool TRACE, int MODE>
 __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
+  constexpr bool COUNTED = true;
   constexpr bool BWD = MODE >= 2, HAS_RES = (MODE == 1 || MODE == 3), USE_X = MODE >= 2;
   constexpr bool DEFER_STORES = MODE != 3;   // mode 3 holds skip + xin pieces as well: no registers left for the packed results
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   // profiling (vpt_conv3x3_set_trace): CU id + 100 MHz timestamps of the tile's phases
   int cu_key = -1;
   long long t_trace[3], t_epi[5] = {0, 0, 0, 0, 0};
-  if (a.trace && tid == 0) {
+  if (TRACE && tid == 0) {
     t_trace[0] = wall_clock64();
     const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID: cu_id[11:8] sh_id[12] se_id[15:13]
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_REG_XCC_ID[3:0]
@@ -72,6 +79,15 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;
   const int hi = lane >> 5, l31 = lane & 31;
+  // Anti-phase start: the dispatcher places blocks b and b + 256 of the first generation on the same CU.  Both then run
+  // prologue -> main loop -> epilogue in lock step for the whole launch (a finished workgroup is replaced in place, so the
+  // phase is inherited), and the matrix pipe idles whenever both are outside their main loops (round-2 trace: 28 % / 15 % of
+  // the time).  Holding the second one back by half a tile period once makes one workgroup's epilogue coincide with the
+  // other's main loop from then on.
+  if (a.antiphase > 0 && (blockIdx.x - 256u) < 256u) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < a.antiphase) __builtin_amdgcn_s_sleep(32);
+  }
 
   const int tilesX = a.W >> 4, tilesY = a.H >> 4;
   int L = xcd_remap(blockIdx.x, gridDim.x);
@@ -172,22 +188,29 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   // 2x16-pixel subtile) and, per accumulator, four groups g of 4 consecutive output channels 8g + 4hi .. +3 -- 8 bytes of
   // the pixel's 64-byte channel row per group, the partner lane (l31, 1 - hi) holding the 8 bytes next to them.  One
   // v_permlane32_swap per dword turns the pair (g = 2p, 2p + 1) into 16 CONTIGUOUS bytes per lane (lower half-wave: bytes
-  // 32p.., upper: 32p + 16..), so the residual / xin / output move as 16-byte accesses covering 32 contiguous bytes per
-  // pixel and instruction, with no LDS staging at all.  (Round 1 staged them through a wave-private LDS tile: four LDS round
-  // trips per subtile that queued behind the co-resident workgroup's main-loop LDS traffic -- the phase trace showed the
-  // epilogue taking 8 us alone and 14 us beside a main loop.)
+  // 32p.., upper: 32p + 16..), and one v_permlane16_swap per dword (lanes l <-> l ^ 16, p = 0 <-> 1) regroups those so that one
+  // 16-byte access per lane covers the WHOLE 64-byte channel row of 16 pixels: the residual / xin / output move as complete
+  // 128-byte lines, with no LDS staging at all.  (Round 1 staged them through a wave-private LDS tile: four LDS round trips
+  // per subtile that queued behind the co-resident workgroup's main-loop LDS traffic.  The first LDS-free version moved 32
+  // bytes per pixel and instruction, so every line was touched by two instructions; an ablation without the output stores ran
+  // 6-14 % faster, whole-line stores recovered 2-4.4 % of that.)
   const int CB_out = a.Cout >> 5;
   const int cb0 = nt * 4 + wn * 2;                 // 32-channel block of n2 = 0
   const bool nvalid[2] = {(cb0 + 0) < CB_out, (cb0 + 1) < CB_out};
   // Addresses = wave-uniform base (frame, channel block n2) + a 32-bit per-lane byte offset: global accesses with an SGPR
   // base, no 64-bit vector address arithmetic, no address registers kept across the main loop.
   const unsigned gm_b = (unsigned)(2 * a.W) * 64u;   // + m * gm_b: two image rows further down (bytes)
-  const unsigned voff = (unsigned)(((ty0 + wm * 8 + sub_row(l31)) * a.W + tx0 + (l31 & 15)) * 32 + 8 * hi) * 2u;  // pair 0 of subtile 0
+  // instruction j = 0 / 1 of a pair carries the 64-byte rows of the pixels held by lanes (l31 & 15) + 16 j; this lane supplies
+  // (receives) bytes 32 (l31 >> 4) + 16 hi .. + 15 of them
+  unsigned svoff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    svoff[j] = (unsigned)(((ty0 + wm * 8 + sub_row((l31 & 15) + 16 * j)) * a.W + tx0 + (l31 & 15)) * 32 + 16 * (l31 >> 4) + 8 * hi) * 2u;
   size_t cbase[2];                                  // element offset of channel block n2 of this frame
 #pragma unroll
   for (int n2 = 0; n2 < 2; ++n2) cbase[n2] = (size_t)(f * CB_out + (nvalid[n2] ? cb0 + n2 : 0)) * HW * 32;
-  u32x4 rq[4][2][2];                                // residual pieces [subtile m][n2][pair p]
-#define EPI_LD(ptr_, m_, n2_, p_) (*(const u32x4*)((const char*)((ptr_) + cbase[n2_]) + (voff + (unsigned)(m_) * gm_b + 32u * (p_))))
+  u32x4 rq[4][2][2];                                // residual [subtile m][n2][instruction j of the pair]
+#define EPI_LD(ptr_, m_, n2_, p_) (*(const u32x4*)((const char*)((ptr_) + cbase[n2_]) + (svoff[p_] + (unsigned)(m_) * gm_b)))
 #define LOAD_RES(m_)                                                                                      \
   _Pragma("unroll") for (int n2_ = 0; n2_ < 2; ++n2_)                                                     \
     _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) rq[m_][n2_][p_] = EPI_LD(a.res, m_, n2_, p_)
@@ -300,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     }                                                                                                     \
   } while (0)
 
-  if (a.trace && tid == 0) t_trace[1] = wall_clock64();
+  if (TRACE && tid == 0) t_trace[1] = wall_clock64();
   if (a.ablate != 2) {
     FB_LD(0, 0, 0, 0); FA_LD(0, 0, 0, 0); FB_LD(0, 0, 1, 0); FA_LD(0, 0, 0, 1); FA_LD(0, 0, 0, 2); FA_LD(0, 0, 0, 3);
     SB();
@@ -328,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
 #undef FB_LD
 
   // ---------------- epilogue ----------------
-  if (a.trace && tid == 0) t_trace[2] = wall_clock64();
+  if (TRACE && tid == 0) t_trace[2] = wall_clock64();
   if (a.ablate == 1) {  // profiling: keep the accumulators live, skip the epilogue
     float t = 0.f;
 #pragma unroll
@@ -343,6 +366,11 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   if (HAS_RES && a.ablate == 2) { LOAD_RES(0); LOAD_RES(1); }
   SB();
 
+  f32x2 s_sum2 = {0.f, 0.f}, s_sq2 = {0.f, 0.f};   // packed fp32 (v_pk_add_f32 / v_pk_fma_f32): two values per VALU issue
+  // The body is instantiated for NV = 2 and NV = 1 valid 32-channel blocks of this wave (Cout / 32 odd) and selected by one
+  // uniform branch: with no control flow inside, the waits on the prefetched table / residual pieces stay counted.
+  auto epilogue = [&](auto nv_) __attribute__((always_inline)) {
+  constexpr int NV = decltype(nv_)::value;
   int eoff[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
@@ -353,17 +381,25 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     eoff[m] = (ey * 3 + ex) * 128 + wn * 64 + 4 * hi;
   }
   const float* kk = (const float*)(smem + KK_OFF);
-  float s_sum = 0.f, s_sq = 0.f;
   constexpr bool use_x = USE_X;
   u32x4 xq[2][2][2];          // dgrad: the forward layer's input, [parity of m][n2][pair], one subtile ahead
   u32x4 outv[4][2][2];        // packed results: ALL stores are issued after the last load has been consumed.  gfx950 has one
                               // counter (vmcnt) for loads and stores, which may retire out of order relative to each other, so a
                               // wait for a load issued among stores degenerates to vmcnt(0) = "every store has reached L2" --
                               // the round-2 trace showed the first subtile waiting 4-14 us that way.
+  // Forward: the constant table of the GroupNorm fold, one subtile AHEAD.  Read at the point of use (two ds_read_b128, wait,
+  // eight FMAs) every pair paid a full LDS round trip behind the co-resident workgroup's fragment reads -- 32 exposed round
+  // trips per tile, which is why an epilogue beside a main loop took twice as long as one beside another epilogue and the two
+  // workgroups of a CU re-locked their phases within one tile even when started half a period apart.
+  f32x4 kq[2][4];             // [parity of chunk c = 2 m + n2][channel group g], one chunk (half a subtile, ~150 VALU) ahead
+#define LOAD_KK(c_)                                                                                       \
+  _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) kq[(c_) & 1][g_] = *(const f32x4*)(kk + eoff[(c_) >> 1] + ((c_) & 1) * 32 + 8 * g_)
 #define LOAD_XIN(m_)                                                                                      \
   _Pragma("unroll") for (int n2_ = 0; n2_ < 2; ++n2_)                                                     \
     _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) xq[(m_) & 1][n2_][p_] = EPI_LD(a.xin, m_, n2_, p_)
   if (use_x) LOAD_XIN(0);
+  if (!BWD) LOAD_KK(0);
+  SB();
 
   // 16-byte piece {first half x, y | second half z, w} of a lane pair -> this lane's own 8 bytes of group 2p (e) and 2p + 1 (o)
 #define UNSWAP(v_, e_, o_)                                                                                \
@@ -372,63 +408,100 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     const auto s1_ = __builtin_amdgcn_permlane32_swap((v_).y, (v_).w, false, false);                      \
     (e_).x = s0_[0]; (o_).x = s0_[1]; (e_).y = s1_[0]; (o_).y = s1_[1];                                   \
   } while (0)
+  const f32x2 zero2 = {0.f, 0.f};
+  const f32x2 rstd2 = {rstd, rstd}, c0f2 = {c0f, c0f}, c1f2 = {c1f, c1f};
 
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
-    if (a.trace && tid == 0) t_epi[m] = wall_clock64();
-    if (HAS_RES && m < 2) LOAD_RES(m + 2);   // rolling prefetch, two subtiles ahead (0 / 1 were requested during the last channel block)
+    if (HAS_RES && m < 2 && !(VPT_EPI_ABLATE & 2)) LOAD_RES(m + 2);   // rolling prefetch, two subtiles ahead (0 / 1 were requested during the last channel block)
     if (use_x && m < 3) LOAD_XIN(m + 1);   // next subtile's xin: in flight while this one is processed
+    SB();
 #pragma unroll
     for (int n2 = 0; n2 < 2; ++n2) {
-      if (!nvalid[n2]) continue;
+      if (!BWD && 2 * m + n2 < 7) { LOAD_KK(2 * m + n2 + 1); SB(); }
+      if (n2 >= NV) continue;
+      u32x4 ovp[2], rp[2], xp[2];
+      // residual / xin arrive as whole pixel rows (instruction j: the pixels of lanes (l31 & 15) + 16 j); the same exchange as for
+      // the stores, run backwards, gives every lane the two 16-byte pieces (p = 0, 1) of its own pixel
+#define ROWS_TO_PIECES(src_, dst_)                                                                        \
+  _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                      \
+    const auto sw_ = __builtin_amdgcn_permlane16_swap((src_)[0][j_], (src_)[1][j_], false, false);        \
+    (dst_)[0][j_] = sw_[0]; (dst_)[1][j_] = sw_[1];                                                       \
+  }
+      if (HAS_RES) ROWS_TO_PIECES(rq[(VPT_EPI_ABLATE & 2) ? (m & 1) : m][n2], rp);
+      if (use_x) ROWS_TO_PIECES(xq[m & 1][n2], xp);
+#undef ROWS_TO_PIECES
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         u32x2 r2[2] = {{0u, 0u}, {0u, 0u}}, x2[2] = {{0u, 0u}, {0u, 0u}}, pk[2];
-        if (HAS_RES) UNSWAP(rq[m][n2][p], r2[0], r2[1]);
-        if (use_x) UNSWAP(xq[m & 1][n2][p], x2[0], x2[1]);
+        if (HAS_RES) UNSWAP(rp[p], r2[0], r2[1]);
+        if (use_x) UNSWAP(xp[p], x2[0], x2[1]);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const int g = 2 * p + q;
-          const f32x4 k4 = *(const f32x4*)(kk + eoff[m] + n2 * 32 + 8 * g);
-          float v0 = fmaf(rstd, acc[m][n2][4 * g + 0], k4.x), v1 = fmaf(rstd, acc[m][n2][4 * g + 1], k4.y);
-          float v2 = fmaf(rstd, acc[m][n2][4 * g + 2], k4.z), v3 = fmaf(rstd, acc[m][n2][4 * g + 3], k4.w);
+          f32x2 v01 = {acc[m][n2][4 * g + 0], acc[m][n2][4 * g + 1]}, v23 = {acc[m][n2][4 * g + 2], acc[m][n2][4 * g + 3]};
           if (!BWD) {
-            v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+            const f32x4 k4 = kq[n2][g];
+            const f32x2 k01 = {k4.x, k4.y}, k23 = {k4.z, k4.w};
+            v01 = __builtin_elementwise_max(rstd2 * v01 + k01, zero2);
+            v23 = __builtin_elementwise_max(rstd2 * v23 + k23, zero2);
           } else if (use_x) {  // dgrad: + d(mu, rstd)/dx terms of the GroupNorm statistics
-            v0 += fmaf(c1f, op16_lo_to_f32(x2[q].x), c0f); v1 += fmaf(c1f, op16_hi_to_f32(x2[q].x), c0f);
-            v2 += fmaf(c1f, op16_lo_to_f32(x2[q].y), c0f); v3 += fmaf(c1f, op16_hi_to_f32(x2[q].y), c0f);
+            const f32x2 x01 = {op16_lo_to_f32(x2[q].x), op16_hi_to_f32(x2[q].x)}, x23 = {op16_lo_to_f32(x2[q].y), op16_hi_to_f32(x2[q].y)};
+            v01 += c1f2 * x01 + c0f2;
+            v23 += c1f2 * x23 + c0f2;
           }
           if (HAS_RES) {
-            v0 += op16_lo_to_f32(r2[q].x); v1 += op16_hi_to_f32(r2[q].x);
-            v2 += op16_lo_to_f32(r2[q].y); v3 += op16_hi_to_f32(r2[q].y);
+            const f32x2 r01 = {op16_lo_to_f32(r2[q].x), op16_hi_to_f32(r2[q].x)}, r23 = {op16_lo_to_f32(r2[q].y), op16_hi_to_f32(r2[q].y)};
+            v01 += r01;
+            v23 += r23;
           }
-          s_sum += (v0 + v1) + (v2 + v3);
-          s_sq = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, fmaf(v3, v3, s_sq))));
-          pk[q].x = pack_op16x2(v0, v1);
-          pk[q].y = pack_op16x2(v2, v3);
+          if (!BWD) {   // frame statistics of the output (the next layer's GroupNorm); dgrad has no consumer for them
+            s_sum2 += v01 + v23;
+            s_sq2 = v01 * v01 + (v23 * v23 + s_sq2);
+          }
+          pk[q].x = pack_op16x2(v01.x, v01.y);
+          pk[q].y = pack_op16x2(v23.x, v23.y);
         }
         // back to 16 contiguous bytes per lane (the swap is an involution) and out
         const auto o0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
         const auto o1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
-        const u32x4 ov = {o0[0], o1[0], o0[1], o1[1]};
-        if (DEFER_STORES) outv[m][n2][p] = ov;
-        else *(u32x4*)((char*)(a.y + cbase[n2]) + (voff + (unsigned)m * gm_b + 32u * p)) = ov;
+        ovp[p] = u32x4{o0[0], o1[0], o0[1], o1[1]};
+      }
+      // One more exchange, between lanes l and l ^ 16 (v_permlane16_swap), so that each store instruction writes all 64 bytes of
+      // 16 pixels -- whole 128-byte lines -- instead of one 32-byte half of 32 pixels' rows (every line was then written by two
+      // instructions: twice the write requests on the CU's path to L2).
+      {
+        u32x4 oa, ob;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const auto sw = __builtin_amdgcn_permlane16_swap(ovp[0][j], ovp[1][j], false, false);
+          oa[j] = sw[0]; ob[j] = sw[1];
+        }
+        if (DEFER_STORES) { outv[m][n2][0] = oa; outv[m][n2][1] = ob; }
+        else {
+          *(u32x4*)((char*)(a.y + cbase[n2]) + (svoff[0] + (unsigned)m * gm_b)) = oa;
+          *(u32x4*)((char*)(a.y + cbase[n2]) + (svoff[1] + (unsigned)m * gm_b)) = ob;
+        }
       }
     }
   }
+#undef LOAD_KK
 #undef UNSWAP
 #undef LOAD_XIN
   if (DEFER_STORES)
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
-    for (int n2 = 0; n2 < 2; ++n2) {
-      if (!nvalid[n2]) continue;
+    for (int n2 = 0; n2 < NV; ++n2) {
 #pragma unroll
-      for (int p = 0; p < 2; ++p) *(u32x4*)((char*)(a.y + cbase[n2]) + (voff + (unsigned)m * gm_b + 32u * p)) = outv[m][n2][p];
+      for (int p = 0; p < 2; ++p)
+        if (!(VPT_EPI_ABLATE & 1) || s_sum2.x == 12345.678f) *(u32x4*)((char*)(a.y + cbase[n2]) + (svoff[p] + (unsigned)m * gm_b)) = outv[m][n2][p];
     }
-  if (a.trace && tid == 0) t_epi[4] = wall_clock64();
-  if (a.stats_out) {
+  };
+  if (nvalid[1]) epilogue(std::integral_constant<int, 2>{});
+  else if (nvalid[0]) epilogue(std::integral_constant<int, 1>{});
+  float s_sum = s_sum2.x + s_sum2.y, s_sq = s_sq2.x + s_sq2.y;
+  if (!BWD && a.stats_out) {
     float* red = (float*)(smem + KK_OFF + KK_BYTES);
     s_sum = wave_sum(s_sum);
     s_sq = wave_sum(s_sq);
@@ -439,7 +512,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
       atomicAdd(a.stats_out + 2 * f + 1, (double)((red[4] + red[5]) + (red[6] + red[7])));
     }
   }
-  if (a.trace && tid == 0) {
+  if (TRACE && tid == 0) {
     long long* t = a.trace + (size_t)blockIdx.x * 12;
     t[0] = t_trace[0]; t[1] = t_trace[1]; t[2] = t_trace[2]; t[3] = wall_clock64(); t[4] = cu_key; t[5] = 0;
     for (int k = 0; k < 5; ++k) t[6 + k] = t_epi[k];
@@ -457,12 +530,19 @@ extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream
     const char* xl = getenv("VPT_CONV_EXTRA_LDS");  // profiling: dynamic LDS bytes (> 2 KB forces one workgroup per CU)
     extra_lds = xl ? atoi(xl) : 0;
     if (extra_lds > 0) {
-      hipFuncSetAttribute((const void*)vpt_conv3x3_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds);
-      hipFuncSetAttribute((const void*)vpt_conv3x3_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds);
+      (void)hipFuncSetAttribute((const void*)vpt_conv3x3_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds);
+      (void)hipFuncSetAttribute((const void*)vpt_conv3x3_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds);
     }
   }
   VptConv3x3Args a_copy = *a_in;
   a_copy.ablate = ablate;
+  {
+    static int ap_us = -2;
+    if (ap_us == -2) { const char* e = getenv("VPT_CONV_ANTIPHASE_US"); ap_us = e ? atoi(e) : -1; }
+    // default: half of (prologue + epilogue ~ 14 us, main loop ~ 5.3 us per channel block at two workgroups per CU)
+    const int us = ap_us >= 0 ? ap_us : 0;
+    a_copy.antiphase = us * 100;
+  }
   a_copy.trace = g_conv_trace;
   const VptConv3x3Args* a = &a_copy;
   if ((a->H & 15) || (a->W & 15) || (a->Cin & 31) || (a->Cout & 31) || a->frames <= 0) return -1;
@@ -470,10 +550,8 @@ extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream
   if (grid > 0x7fffffffL) return -2;
   const int mode = a->bwd ? (a->res ? 3 : 2) : (a->res ? 1 : 0);
   if (a->bwd && (!a->xin || !a->coef)) return -1;   // dgrad always carries the GroupNorm-statistics terms (c0 + c1 * xin)
-  static int counted = -1;
-  if (counted < 0) { const char* e = getenv("VPT_CONV_COUNTED"); counted = e ? atoi(e) : 1; }
-#define LAUNCH_(C_, M_) hipLaunchKernelGGL((vpt_conv3x3_kernel<C_, M_>), dim3((unsigned)grid), dim3(256), extra_lds, stream, *a)
-  if (counted) { if (mode == 0) LAUNCH_(true, 0); else if (mode == 1) LAUNCH_(true, 1); else if (mode == 2) LAUNCH_(true, 2); else LAUNCH_(true, 3); }
+#define LAUNCH_(T_, M_) hipLaunchKernelGGL((vpt_conv3x3_kernel<T_, M_>), dim3((unsigned)grid), dim3(256), extra_lds, stream, *a)
+  if (a->trace) { if (mode == 0) LAUNCH_(true, 0); else if (mode == 1) LAUNCH_(true, 1); else if (mode == 2) LAUNCH_(true, 2); else LAUNCH_(true, 3); }
   else { if (mode == 0) LAUNCH_(false, 0); else if (mode == 1) LAUNCH_(false, 1); else if (mode == 2) LAUNCH_(false, 2); else LAUNCH_(false, 3); }
 #undef LAUNCH_
   return hipGetLastError() == hipSuccess ? 0 : -3;
