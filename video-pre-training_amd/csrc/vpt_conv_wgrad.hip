@@ -26,10 +26,15 @@ __device__ __forceinline__ op16x8 tr_frag(const unsigned char* p) {  // 8 pixels
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+#ifndef VPT_WGRAD_PXS
+#define VPT_WGRAD_PXS 128               // pixels of one frame per step (one barrier per step)
+#endif
+
 template <int W>
 __global__ __launch_bounds__(512, 1) void vpt_conv_wgrad_kernel(VptConvWgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int RB = 64 / W;            // image rows per step
+  constexpr int PXS = VPT_WGRAD_PXS;
+  constexpr int RB = PXS / W;           // image rows per step
   constexpr int XR = RB + 2;            // x rows per step (halo rows above / below)
   constexpr int DP = W + 2;             // dacc pixels per row in LDS (halo columns, kept zero)
   constexpr int DCB = RB * DP * 64;     // bytes of one cout block's dacc slab
@@ -69,17 +74,18 @@ __global__ __launch_bounds__(512, 1) void vpt_conv_wgrad_kernel(VptConvWgradArgs
   const int steps_per_frame = H / RB;
   const int nsteps = (f1 - f0) * steps_per_frame;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  u32x4 dreg[2], xreg[NX];
+  constexpr int ND = 4 * PXS * 4 / 512;
+  u32x4 dreg[ND], xreg[NX];
 
   // branch-free staging: every load executes from a clamped (valid) address and is zeroed afterwards when it lies
   // outside the image / beyond the channel count
   auto load_step = [&](int s) {
     const int f = f0 + s / steps_per_frame, y0 = (s % steps_per_frame) * RB;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {          // 4 cout blocks x 64 pixels x 4 parts = 1024 chunks; a block's 64 pixels are contiguous in HBM
+    for (int m = 0; m < ND; ++m) {         // 4 cout blocks x PXS pixels x 4 parts chunks; a block's PXS pixels are contiguous in HBM
       const int q = tid + 512 * m;
-      const int cbo = ot * 4 + (q >> 8);
-      const u32x4 v = *(const u32x4*)(a.dacc + ((size_t)(f * CBo + min(cbo, CBo - 1)) * HW + (size_t)y0 * W) * 32 + (q & 255) * 8);
+      const int cbo = ot * 4 + q / (PXS * 4);
+      const u32x4 v = *(const u32x4*)(a.dacc + ((size_t)(f * CBo + min(cbo, CBo - 1)) * HW + (size_t)y0 * W) * 32 + (q % (PXS * 4)) * 8);
       dreg[m] = (cbo < CBo) ? v : zero4;
     }
 #pragma unroll
@@ -95,10 +101,10 @@ __global__ __launch_bounds__(512, 1) void vpt_conv_wgrad_kernel(VptConvWgradArgs
   auto store_step = [&](int buf) {
     unsigned char* base = smem + buf * BUF;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < ND; ++m) {
       const int q = tid + 512 * m;
-      const int pix = (q & 255) >> 2, part = q & 3;
-      *(u32x4*)(base + (q >> 8) * DCB + ((pix / W) * DP + (pix % W) + 1) * 64 + part * 16) = dreg[m];
+      const int pix = (q % (PXS * 4)) >> 2, part = q & 3;
+      *(u32x4*)(base + (q / (PXS * 4)) * DCB + ((pix / W) * DP + (pix % W) + 1) * 64 + part * 16) = dreg[m];
     }
 #pragma unroll
     for (int m = 0; m < NX; ++m) {
@@ -145,7 +151,15 @@ __global__ __launch_bounds__(512, 1) void vpt_conv_wgrad_kernel(VptConvWgradArgs
     WG_SLICE(0, 0, true);
     WG_SLICE(1, 1, true);
     WG_SLICE(0, 2, true);
-    WG_SLICE(1, 3, false);
+    if constexpr (PXS == 64) {
+      WG_SLICE(1, 3, false);
+    } else {
+      WG_SLICE(1, 3, true);
+      WG_SLICE(0, 4, true);
+      WG_SLICE(1, 5, true);
+      WG_SLICE(0, 6, true);
+      WG_SLICE(1, 7, false);
+    }
 #undef WG_SLICE
 #undef WG_MM
 #undef WG_LDA
@@ -191,18 +205,18 @@ extern "C" int vpt_conv_wgrad_groups(int frames, int Cin, int Cout) {
 
 extern "C" int vpt_conv_wgrad_launch(const VptConvWgradArgs* a_in, hipStream_t stream) {
   VptConvWgradArgs a = *a_in;
-  if ((a.Cin & 31) || (a.Cout & 31) || a.frames <= 0 || (a.W != 16 && a.W != 32 && a.W != 64) || (a.H % (64 / a.W)) || !a.partial) return -1;
+  if ((a.Cin & 31) || (a.Cout & 31) || a.frames <= 0 || (a.W != 16 && a.W != 32 && a.W != 64) || (a.H % (VPT_WGRAD_PXS / a.W)) || !a.partial) return -1;
   a.OT = (a.Cout + 127) / 128;
   const int tiles = a.OT * (((a.Cin >> 5) + 1) >> 1);
   const int groups = vpt_conv_wgrad_groups(a.frames, a.Cin, a.Cout);
   a.frames_per_wg = (a.frames + groups - 1) / groups;
-  const int RB = 64 / a.W;
+  const int RB = VPT_WGRAD_PXS / a.W;
   const size_t lds = 2 * (size_t)(4 * RB * (a.W + 2) * 64 + 2 * (RB + 2) * a.W * 64);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)vpt_conv_wgrad_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)vpt_conv_wgrad_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)vpt_conv_wgrad_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)vpt_conv_wgrad_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)vpt_conv_wgrad_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)vpt_conv_wgrad_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return -4;
     attr_set = true;
   }
