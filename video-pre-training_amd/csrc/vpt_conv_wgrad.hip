@@ -77,10 +77,57 @@ __global__ __launch_bounds__(512, 1) void vpt_conv_wgrad_kernel(VptConvWgradArgs
   constexpr int ND = 4 * PXS * 4 / 512;
   u32x4 dreg[ND], xreg[NX];
 
-  // branch-free staging: every load executes from a clamped (valid) address and is zeroed afterwards when it lies
-  // outside the image / beyond the channel count
+  // Staging addresses = wave-uniform base of the step (frame, first image row: scalar arithmetic) + a per-lane byte offset computed
+  // once.  Interior steps of fully valid tiles -- no image row above / below missing, no channel block beyond Cin / Cout --
+  // load straight through; the first version recomputed every 64-bit address per lane and step (18 quarter-rate integer
+  // multiplies + 30 selects per step, ~25 % of the step's MFMA time in vector issue slots).
+  unsigned doff[ND], xoff[NX];
+  unsigned xfirst = 0, xlast = 0;   // bit m: chunk m belongs to the halo row above / below the step's rows
+#pragma unroll
+  for (int m = 0; m < ND; ++m) {
+    const int q = tid + 512 * m;
+    const int cbo = min(ot * 4 + q / (PXS * 4), CBo - 1);
+    doff[m] = (unsigned)(cbo * HW * 32 + (q % (PXS * 4)) * 8) * 2u;
+  }
+#pragma unroll
+  for (int m = 0; m < NX; ++m) {
+    const int q = min(tid + 512 * m, NXC - 1);
+    const int cb = q / (XR * W * 4), rem = q % (XR * W * 4);
+    const int cbi = min(cp * 2 + cb, CBi - 1);
+    xoff[m] = (unsigned)((cbi * HW) * 32 + rem * 8) * 2u;   // rem = (row r, pixel, part): rows are W * 64 bytes apart in HBM too
+    const int r = rem / (W * 4);
+    xfirst |= (r == 0) ? (1u << m) : 0u;
+    xlast |= (r == XR - 1) ? (1u << m) : 0u;
+  }
+  const bool all_valid = (ot * 4 + 4 <= CBo) && (cp * 2 + 2 <= CBi);
   auto load_step = [&](int s) {
     const int f = f0 + s / steps_per_frame, y0 = (s % steps_per_frame) * RB;
+    if (all_valid && y0 > 0 && y0 + RB < H) {
+      const char* dbase = (const char*)(a.dacc + ((size_t)f * CBo * HW + (size_t)y0 * W) * 32);
+      const char* xbase = (const char*)(a.x + ((size_t)f * CBi * HW + (size_t)(y0 - 1) * W) * 32);
+#pragma unroll
+      for (int m = 0; m < ND; ++m) dreg[m] = *(const u32x4*)(dbase + doff[m]);
+#pragma unroll
+      for (int m = 0; m < NX; ++m) xreg[m] = *(const u32x4*)(xbase + xoff[m]);
+      return;
+    }
+    if (all_valid) {   // first / last rows of a frame: the halo row outside the image is fetched from its neighbour row and zeroed
+      const bool top = y0 == 0, bot = y0 + RB >= H;
+      const char* dbase = (const char*)(a.dacc + ((size_t)f * CBo * HW + (size_t)y0 * W) * 32);
+      const char* xbase = (const char*)(a.x + ((size_t)f * CBi * HW) * 32) + ((long)(y0 - 1) * W) * 64;
+#pragma unroll
+      for (int m = 0; m < ND; ++m) dreg[m] = *(const u32x4*)(dbase + doff[m]);
+#pragma unroll
+      for (int m = 0; m < NX; ++m) {
+        const bool zt = top && ((xfirst >> m) & 1u), zb = bot && ((xlast >> m) & 1u);
+        const int adj = zt ? W * 64 : (zb ? -W * 64 : 0);
+        const u32x4 v = *(const u32x4*)(xbase + (long)xoff[m] + adj);
+        xreg[m] = (zt || zb) ? zero4 : v;
+      }
+      return;
+    }
+    // partial tiles (Cout not a multiple of 128 / Cin of 64): every load executes from a clamped (valid) address and is zeroed
+    // afterwards when it lies outside the image / beyond the channel count
 #pragma unroll
     for (int m = 0; m < ND; ++m) {         // 4 cout blocks x PXS pixels x 4 parts chunks; a block's PXS pixels are contiguous in HBM
       const int q = tid + 512 * m;
@@ -173,14 +220,12 @@ __global__ __launch_bounds__(512, 1) void vpt_conv_wgrad_kernel(VptConvWgradArgs
   const int cbi = cp * 2 + wi, cbo = ot * 4 + wo;
   if (cbi < CBi && cbo < CBo) {
     float* part = a.partial + (size_t)grp * a.Cout * 9 * a.Cin;
-    const int c = cbi * 32 + l31;
+    // element (o, t, c) with o = cbo * 32 + 4 hi + (r & 3) + 8 (r >> 2): one per-lane base, the rest are uniform multiples of Cin
+    float* pl = part + ((size_t)(cbo * 32 + 4 * hi) * 9) * a.Cin + cbi * 32 + l31;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = cbo * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        part[((size_t)o * 9 + t) * a.Cin + c] = acc[t][r];
-      }
+      for (int r = 0; r < 16; ++r) pl[(size_t)((((r & 3) + 8 * (r >> 2)) * 9 + t)) * a.Cin] = acc[t][r];
   }
 }
 
