@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3d_t5_kernel(VptConv3dArgs a) 
   __shared__ __attribute__((aligned(16))) unsigned char in[5 * 768];
   __shared__ __attribute__((aligned(16))) float bias_s[128];
   __shared__ float red[8];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
   const int HW = a.H * a.W;
   const int chunks = HW >> 8;  // 256-pixel chunks per frame

@@ -26,7 +26,7 @@ typedef short i16x8 __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[CT_BYTES + IN_BYTES];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
   const int PH = a.H >> 1, PW = a.W >> 1;
   const int tilesX = PW >> 3, tilesY = PH >> 3;

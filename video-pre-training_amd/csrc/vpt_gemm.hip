@@ -22,7 +22,7 @@
 
 __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[GA_BYTES + GB_BYTES];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;
   const int hi = lane >> 5, l31 = lane & 31;
 
@@ -185,7 +185,7 @@ __device__ __forceinline__ op16x8 tn_frag(const unsigned char* p, int row_stride
 
 __global__ __launch_bounds__(256, 2) void vpt_gemm_tn_kernel(VptGemmTnArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[TA_BYTES + TB_BYTES];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;
   const int hi = lane >> 5, l31 = lane & 31;
   const int t1 = (a.N1 + 255) >> 8, t2 = (a.N2 + 127) >> 7;

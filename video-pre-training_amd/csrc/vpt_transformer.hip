@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void vpt_attn_kernel(VptAttnArgs a) {
   float* Bs = sm + ATT_B_OFF;
   float* Sc = sm + ATT_SC_OFF;
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.y / a.heads, h = blockIdx.y - b * a.heads;
   const int q0 = blockIdx.x * ATT_QT;
   const int maxlen = a.maxlen, t = a.t, hid = a.hid;
