@@ -79,16 +79,6 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;
   const int hi = lane >> 5, l31 = lane & 31;
-  // Anti-phase start: the dispatcher places blocks b and b + 256 of the first generation on the same CU.  Both then run
-  // prologue -> main loop -> epilogue in lock step for the whole launch (a finished workgroup is replaced in place, so the
-  // phase is inherited), and the matrix pipe idles whenever both are outside their main loops (round-2 trace: 28 % / 15 % of
-  // the time).  Holding the second one back by half a tile period once makes one workgroup's epilogue coincide with the
-  // other's main loop from then on.
-  if (a.antiphase > 0 && (blockIdx.x - 256u) < 256u) {
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < a.antiphase) __builtin_amdgcn_s_sleep(32);
-  }
-
   const int tilesX = a.W >> 4, tilesY = a.H >> 4;
   int L = xcd_remap(blockIdx.x, gridDim.x);
   const int nt = L % a.NT; L /= a.NT;
@@ -561,13 +551,6 @@ extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream
   }
   VptConv3x3Args a_copy = *a_in;
   a_copy.ablate = ablate;
-  {
-    static int ap_us = -2;
-    if (ap_us == -2) { const char* e = getenv("VPT_CONV_ANTIPHASE_US"); ap_us = e ? atoi(e) : -1; }
-    // default: half of (prologue + epilogue ~ 14 us, main loop ~ 5.3 us per channel block at two workgroups per CU)
-    const int us = ap_us >= 0 ? ap_us : 0;
-    a_copy.antiphase = us * 100;
-  }
   a_copy.trace = g_conv_trace;
   const VptConv3x3Args* a = &a_copy;
   if ((a->H & 15) || (a->W & 15) || (a->Cin & 31) || (a->Cout & 31) || a->frames <= 0) return -1;

@@ -38,16 +38,17 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
   const int s_end = min(s_begin + per, nsteps_total);
   if (s_begin >= s_end) return;
 
-  // staging maps
+  // staging maps: A row (m0 + arow + 32 m), 16-byte part apart; one 32-bit offset + a validity mask instead of eight pointers
   const int arow = tid >> 3, apart = tid & 7;
-  const vpt_op16* aptr[8];
-  bool avalid[8];
+  const char* abase = (const char*)(a.A + (size_t)m0 * a.lda);           // wave-uniform
+  const unsigned astride = 32u * (unsigned)a.lda * 2u;                   // bytes between staged rows
+  const unsigned aoff0 = (unsigned)arow * (unsigned)a.lda * 2u + apart * 16u;
+  unsigned avmask = 0;
 #pragma unroll
-  for (int m = 0; m < 8; ++m) {
-    const int grow = m0 + arow + 32 * m;
-    avalid[m] = grow < a.M;
-    aptr[m] = a.A + (size_t)(avalid[m] ? grow : 0) * a.lda + apart * 8;
-  }
+  for (int m = 0; m < 8; ++m) avmask |= (m0 + arow + 32 * m < a.M) ? (1u << m) : 0u;
+  // rows beyond M read row m0 (always valid) and are zeroed
+#define A_LOAD(m_, s_) ((((avmask >> (m_)) & 1u) != 0u) ? *(const u32x4*)(abase + (size_t)(s_) * 128 + (aoff0 + (m_) * astride)) \
+                                                         : zero4)
   unsigned char* ast = smem + arow * GA_RS + apart * 16;
   const vpt_op16* wbase = a.wpk + (size_t)nt * (a.K >> 5) * 4096 + tid * 8;
   unsigned char* bst = smem + GA_BYTES + (tid >> 2) * GB_RS + (tid & 3) * 16;
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
   u32x4 areg[8], breg[4];
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 #pragma unroll
-  for (int m = 0; m < 8; ++m) areg[m] = avalid[m] ? *(const u32x4*)(aptr[m] + (size_t)s_begin * 64) : zero4;
+  for (int m = 0; m < 8; ++m) areg[m] = A_LOAD(m, s_begin);
 #pragma unroll
   for (int m = 0; m < 4; ++m) breg[m] = *(const u32x4*)(wbase + (size_t)s_begin * 8192 + m * 2048);
 #pragma unroll
@@ -75,37 +76,72 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
   const unsigned char* aL = smem + (wm * 128 + l31) * GA_RS + hi * 16;
   const unsigned char* bL = smem + GA_BYTES + (wn * 64 + l31) * GB_RS + hi * 16;
 
-  for (int s = s_begin; s < s_end; ++s) {
-    const bool more = (s + 1 < s_end);
-    if (more) {
-#pragma unroll
-      for (int m = 0; m < 8; ++m) areg[m] = avalid[m] ? *(const u32x4*)(aptr[m] + (size_t)(s + 1) * 64) : zero4;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) breg[m] = *(const u32x4*)(wbase + (size_t)(s + 1) * 8192 + m * 2048);
-    }
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      op16x8 af[4], bf[2];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) af[m] = *(const op16x8*)(aL + m * (32 * GA_RS) + kk * 32);
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
-        bf[n] = *(const op16x8*)(bL + (kk >> 1) * (128 * GB_RS) + n * (32 * GB_RS) + (kk & 1) * 32);
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-          acc[m][n] = VPT_MFMA_32X32X16(af[m], bf[n], acc[m][n], 0, 0, 0);
-    }
+  // Main loop, one k-step (64) = 4 slices of 16 = 4 groups of 8 MFMAs per wave.  The schedule is explicit and pinned with
+  // sched_barrier, the pattern of vpt_conv3x3_kernel (round 2), within this kernel's register budget (128 accumulators + 48
+  // staging registers): the four A fragments ROLL -- fragment m of slice kk + 1 is requested into its own registers right after
+  // the two MFMAs that consumed fragment m of slice kk, six or more MFMAs ahead of its use -- and only the two B fragments, which
+  // all eight MFMAs of a slice read, are double-buffered; the next step's twelve global loads ride in the remaining slots; the
+  // barrier that frees the LDS tile stands in front of the LAST slice's MFMAs (its fragments are in registers), so the ds_writes
+  // of the next tile issue between those MFMAs.  The first version read six fragments, waited, issued eight MFMAs, four times
+  // per step, plus two bare barriers: 670 TF/s on the trunk GEMMs.
+  op16x8 fa[4], fb[2][2];
+#define GSB() __builtin_amdgcn_sched_barrier(0)
+#define GMM(setb_, m_, n_) acc[m_][n_] = VPT_MFMA_32X32X16(fa[m_], fb[setb_][n_], acc[m_][n_], 0, 0, 0)
+#define GFA(kk_, m_) fa[m_] = *(const op16x8*)(aL + (m_) * (32 * GA_RS) + (kk_) * 32)
+#define GFB(setb_, kk_, n_) fb[setb_][n_] = *(const op16x8*)(bL + ((kk_) >> 1) * (128 * GB_RS) + (n_) * (32 * GB_RS) + ((kk_) & 1) * 32)
+#define GLA(m_) areg[m_] = A_LOAD(m_, s + 1)
+#define GLB(m_) breg[m_] = *(const u32x4*)(wbase + (size_t)(s + 1) * 8192 + (m_) * 2048)
+#define GNOP() ((void)0)
+#define GGROUP(setb_, nkk_, X0, X1, X2, X3)                                                               \
+  do {                                                                                                    \
+    GMM(setb_, 0, 0); GFB(1 - (setb_), nkk_, 0); GFB(1 - (setb_), nkk_, 1); GSB();                        \
+    GMM(setb_, 0, 1); GFA(nkk_, 0); GSB();                                                                \
+    GMM(setb_, 1, 0); X0; GSB();                                                                          \
+    GMM(setb_, 1, 1); GFA(nkk_, 1); X1; GSB();                                                            \
+    GMM(setb_, 2, 0); X2; GSB();                                                                          \
+    GMM(setb_, 2, 1); GFA(nkk_, 2); X3; GSB();                                                            \
+    GMM(setb_, 3, 0); GSB();                                                                              \
+    GMM(setb_, 3, 1); GFA(nkk_, 3); GSB();                                                                \
+  } while (0)
+#define GFIRST() do { GFB(0, 0, 0); GFA(0, 0); GFB(0, 0, 1); GFA(0, 1); GFA(0, 2); GFA(0, 3); GSB(); } while (0)
+  GFIRST();
+#pragma unroll 1
+  for (int s = s_begin; s + 1 < s_end; ++s) {   // every step but the last: prefetches its successor
+    GGROUP(0, 1, GLB(0), GLB(1), GLB(2), GLB(3));
+    GGROUP(1, 2, GLA(0), GLA(1), GLA(2), GLA(3));
+    GGROUP(0, 3, GLA(4), GLA(5), GLA(6), GLA(7));
+    __syncthreads();   // every wave holds its last fragments of this step: the tile may be overwritten
+    GSB();
+    // last slice's MFMAs with the next tile's ds_writes between them (each waits for its own global load)
+    GMM(1, 0, 0); *(u32x4*)(bst + 0 * 64 * GB_RS) = breg[0]; *(u32x4*)(bst + 1 * 64 * GB_RS) = breg[1]; GSB();
+    GMM(1, 0, 1); *(u32x4*)(bst + 2 * 64 * GB_RS) = breg[2]; *(u32x4*)(bst + 3 * 64 * GB_RS) = breg[3]; GSB();
+    GMM(1, 1, 0); *(u32x4*)(ast + 0 * 32 * GA_RS) = areg[0]; *(u32x4*)(ast + 1 * 32 * GA_RS) = areg[1]; GSB();
+    GMM(1, 1, 1); *(u32x4*)(ast + 2 * 32 * GA_RS) = areg[2]; *(u32x4*)(ast + 3 * 32 * GA_RS) = areg[3]; GSB();
+    GMM(1, 2, 0); *(u32x4*)(ast + 4 * 32 * GA_RS) = areg[4]; *(u32x4*)(ast + 5 * 32 * GA_RS) = areg[5]; GSB();
+    GMM(1, 2, 1); *(u32x4*)(ast + 6 * 32 * GA_RS) = areg[6]; *(u32x4*)(ast + 7 * 32 * GA_RS) = areg[7]; GSB();
+    GMM(1, 3, 0); GSB();
+    GMM(1, 3, 1); GSB();
     __syncthreads();
-    if (more) {
-#pragma unroll
-      for (int m = 0; m < 8; ++m) *(u32x4*)(ast + m * 32 * GA_RS) = areg[m];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) *(u32x4*)(bst + m * 64 * GB_RS) = breg[m];
-    }
-    __syncthreads();
+    GSB();
+    GFIRST();
   }
+  {   // last step
+    GGROUP(0, 1, GNOP(), GNOP(), GNOP(), GNOP());
+    GGROUP(1, 2, GNOP(), GNOP(), GNOP(), GNOP());
+    GGROUP(0, 3, GNOP(), GNOP(), GNOP(), GNOP());
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { GMM(1, m, 0); GMM(1, m, 1); }
+  }
+#undef GFIRST
+#undef GGROUP
+#undef GNOP
+#undef GLA
+#undef A_LOAD
+#undef GLB
+#undef GFA
+#undef GFB
+#undef GMM
+#undef GSB
 
   // ---- epilogue (direct from the accumulator layout: lane = column, 16 rows per accumulator) ----
   // One accumulator (16 values) at a time, the optional stages as separate uniform-branch loops over 32-bit offsets

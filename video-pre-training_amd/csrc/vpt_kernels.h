@@ -22,7 +22,6 @@ struct VptConv3x3Args {
   int frames, H, W, Cin, Cout, CoutPad, NT;
   double inv_count_in;     // 1 / (Cin*H*W)
   int ablate;              // profiling only (env VPT_CONV_ABLATE)
-  int antiphase;           // 100 MHz ticks the second workgroup of each CU waits at kernel start (0: off)
   long long* trace;        // profiling only: per-workgroup phase timestamps (vpt_conv3x3_set_trace)
   // dgrad mode (bwd != 0): no GroupNorm fold, no ReLU; out = conv + res + coef[f][0] + coef[f][1] * xin
   int bwd;
