@@ -67,14 +67,15 @@ extern "C" int vpt_layernorm_launch(const VptLayerNormArgs* a, hipStream_t strea
 #define ATT_QT 32
 #define ATT_NK 160                      // keys staged per query tile (31 + maxlen, maxlen <= 129)
 #define ATT_RS (ATT_DH + 4)             // padded fp32 row
-#define ATT_SS 161                      // padded score row
+#define ATT_SS 164                      // padded score row (16-byte aligned: the P operand is read as float4)
 #define ATT_Q_OFF 0
 #define ATT_KV_OFF (ATT_QT * ATT_RS)                      // floats
 #define ATT_S_OFF (ATT_KV_OFF + ATT_NK * ATT_RS)
 #define ATT_R_OFF (ATT_S_OFF + ATT_QT * ATT_SS)
 #define ATT_B_OFF (ATT_R_OFF + ATT_QT * 10)
 #define ATT_SC_OFF (ATT_B_OFF + 10 * 129)
-#define ATT_FLOATS (ATT_SC_OFF + ATT_QT)
+#define ATT_PT_OFF ((ATT_SC_OFF + ATT_QT + 3) & ~3)       // partial logits of key tile 4: [wave][16][64]
+#define ATT_FLOATS (ATT_PT_OFF + 4 * 16 * 64)
 
 __global__ __launch_bounds__(256) void vpt_attn_kernel(VptAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -116,52 +117,69 @@ __global__ __launch_bounds__(256) void vpt_attn_kernel(VptAttnArgs a) {
   for (int idx = tid; idx < 10 * maxlen; idx += 256) Bs[idx] = a.b_nd[idx];
   __syncthreads();
 
-  // ---- logits: thread = (query qi, key group kg); keys kg + 8*n ----
+  // ---- logits on the fp32 matrix cores (v_mfma_f32_32x32x2_f32): D[query][key] = sum_d Q[query][d] K[key][d] ----
+  // Round 2: this phase and P V below ran on the vector ALU with every query thread re-reading the K / V rows from LDS (5
+  // ds_read_b128 per 16 FMAs): 20 TF/s.  A lane supplies Q[l31][d] and K[key tile * 32 + l31][d] for d = 8 g + 4 hi + e,
+  // e = 0..3 -- one float4 each per four MFMAs (the k order of an MFMA step is free as long as both operands agree).
+  // Key tiles 0..3 belong to waves 0..3; tile 4 (keys 128..159) is split over the waves by d (four groups each) and summed
+  // through LDS, so every wave issues 80 MFMAs.
+  const int l31 = lane & 31, hi = lane >> 5;
   {
-    const int qi = tid & 31, kg = tid >> 5;
-    const float* qrow = Qs + qi * ATT_RS;
-    float rq[10];
+    f32x16 acc, acc4;
 #pragma unroll
-    for (int n = 0; n < 10; ++n) rq[n] = Rs[qi * 10 + n];
-    const bool qvalid = (q0 + qi) < t;
-    for (int nb = 0; nb < 5; ++nb) {
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
-      const float* k0 = KVs + (kg + 8 * (4 * nb + 0)) * ATT_RS;
-      const float* k1 = KVs + (kg + 8 * (4 * nb + 1)) * ATT_RS;
-      const float* k2 = KVs + (kg + 8 * (4 * nb + 2)) * ATT_RS;
-      const float* k3 = KVs + (kg + 8 * (4 * nb + 3)) * ATT_RS;
-#pragma unroll 8
-      for (int d = 0; d < ATT_DH; d += 4) {
-        const f32x4 q = *(const f32x4*)(qrow + d);
-        const f32x4 x0 = *(const f32x4*)(k0 + d), x1 = *(const f32x4*)(k1 + d);
-        const f32x4 x2 = *(const f32x4*)(k2 + d), x3 = *(const f32x4*)(k3 + d);
-        acc[0] = fmaf(q.x, x0.x, fmaf(q.y, x0.y, fmaf(q.z, x0.z, fmaf(q.w, x0.w, acc[0]))));
-        acc[1] = fmaf(q.x, x1.x, fmaf(q.y, x1.y, fmaf(q.z, x1.z, fmaf(q.w, x1.w, acc[1]))));
-        acc[2] = fmaf(q.x, x2.x, fmaf(q.y, x2.y, fmaf(q.z, x2.z, fmaf(q.w, x2.w, acc[2]))));
-        acc[3] = fmaf(q.x, x3.x, fmaf(q.y, x3.y, fmaf(q.z, x3.z, fmaf(q.w, x3.w, acc[3]))));
-      }
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc4[r] = 0.f; }
+    const float* qa = Qs + l31 * ATT_RS + 4 * hi;
+    const float* kb = KVs + (w * 32 + l31) * ATT_RS + 4 * hi;
+    const float* kb4 = KVs + (128 + l31) * ATT_RS + 4 * hi;
+#pragma unroll 4
+    for (int g = 0; g < 16; ++g) {
+      const f32x4 q4 = *(const f32x4*)(qa + 8 * g), k4 = *(const f32x4*)(kb + 8 * g);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.x, k4.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.y, k4.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.z, k4.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.w, k4.w, acc, 0, 0, 0);
+    }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int kk = kg + 8 * (4 * nb + u);
-        const int off = maxlen - 1 + qi - kk;  // 0 = the query itself, maxlen-1 = oldest key in the band
-        const int j = jbase + kk;
-        bool vis = a.causal ? (qvalid && off >= 0 && off < maxlen) : (qvalid && kk < t);
-        if (vis && a.causal && j < maxlen) vis = a.memvalid[(size_t)b * maxlen + j] != 0;
-        float s = -3.0e38f;
-        if (vis) {
-          float rb = 0.f;
-          if (a.causal) {
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int g = 4 * w + g4;
+      const f32x4 q4 = *(const f32x4*)(qa + 8 * g), k4 = *(const f32x4*)(kb4 + 8 * g);
+      acc4 = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.x, k4.x, acc4, 0, 0, 0);
+      acc4 = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.y, k4.y, acc4, 0, 0, 0);
+      acc4 = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.z, k4.z, acc4, 0, 0, 0);
+      acc4 = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.w, k4.w, acc4, 0, 0, 0);
+    }
+    float* Pt = sm + ATT_PT_OFF;
 #pragma unroll
-            for (int n = 0; n < 10; ++n) rb = fmaf(rq[n], Bs[n * maxlen + off], rb);
-          }
-          s = acc[u] * (1.0f / ATT_DH) + rb;
+    for (int r = 0; r < 16; ++r) Pt[(w * 16 + r) * 64 + lane] = acc4[r];
+    __syncthreads();
+    // scale, relative-position bias, visibility -> Ss.  Lane = key column; accumulator register r = query (r & 3) + 8 (r >> 2) + 4 hi.
+    auto finish = [&](int kk, int r, float dot) {
+      const int qi = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const bool qvalid = (q0 + qi) < t;
+      const int off = maxlen - 1 + qi - kk;  // 0 = the query itself, maxlen-1 = oldest key in the band
+      const int j = jbase + kk;
+      bool vis = a.causal ? (qvalid && off >= 0 && off < maxlen) : (qvalid && kk < t);
+      if (vis && a.causal && j < maxlen) vis = a.memvalid[(size_t)b * maxlen + j] != 0;
+      float sc = -3.0e38f;
+      if (vis) {
+        float rb = 0.f;
+        if (a.causal) {
+#pragma unroll
+          for (int n = 0; n < 10; ++n) rb = fmaf(Rs[qi * 10 + n], Bs[n * maxlen + off], rb);
         }
-        Ss[qi * ATT_SS + kk] = s;
+        sc = dot * (1.0f / ATT_DH) + rb;
       }
+      Ss[qi * ATT_SS + kk] = sc;
+    };
+#pragma unroll
+    for (int r = 0; r < 16; ++r) finish(w * 32 + l31, r, acc[r]);
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {   // key tile 4: this wave finishes accumulator registers 4 w .. 4 w + 3
+      const int r = 4 * w + r4;
+      const float dot = (Pt[(0 * 16 + r) * 64 + lane] + Pt[(1 * 16 + r) * 64 + lane]) + (Pt[(2 * 16 + r) * 64 + lane] + Pt[(3 * 16 + r) * 64 + lane]);
+      finish(128 + l31, r, dot);
     }
   }
-  __syncthreads();
-
   // ---- softmax rows (8 per wave); stage V into the slab meanwhile ----
   for (int r = w * 8; r < w * 8 + 8; ++r) {
     float* srow = Ss + r * ATT_SS;
@@ -186,30 +204,27 @@ __global__ __launch_bounds__(256) void vpt_attn_kernel(VptAttnArgs a) {
   }
   __syncthreads();
 
-  // ---- out = P V : thread = (query qi, 16-wide slice of d_head) ----
+  // ---- out = P V on the fp32 matrix cores: wave w owns d_head slice 32 w .. 32 w + 31; D[query][d] = sum_key P[query][key] V[key][d] ----
   {
-    const int qi = tid & 31, dg = tid >> 5;
-    float o[16];
+    f32x16 o;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) o[i] = 0.f;
-    const float* prow = Ss + qi * ATT_SS;
-    const float* vcol = KVs + dg * 16;
-    for (int kk = 0; kk < ATT_NK; ++kk) {
-      const float p = prow[kk];
-      const f32x4 v0 = *(const f32x4*)(vcol + kk * ATT_RS), v1 = *(const f32x4*)(vcol + kk * ATT_RS + 4);
-      const f32x4 v2 = *(const f32x4*)(vcol + kk * ATT_RS + 8), v3 = *(const f32x4*)(vcol + kk * ATT_RS + 12);
-      o[0] = fmaf(p, v0.x, o[0]); o[1] = fmaf(p, v0.y, o[1]); o[2] = fmaf(p, v0.z, o[2]); o[3] = fmaf(p, v0.w, o[3]);
-      o[4] = fmaf(p, v1.x, o[4]); o[5] = fmaf(p, v1.y, o[5]); o[6] = fmaf(p, v1.z, o[6]); o[7] = fmaf(p, v1.w, o[7]);
-      o[8] = fmaf(p, v2.x, o[8]); o[9] = fmaf(p, v2.y, o[9]); o[10] = fmaf(p, v2.z, o[10]); o[11] = fmaf(p, v2.w, o[11]);
-      o[12] = fmaf(p, v3.x, o[12]); o[13] = fmaf(p, v3.y, o[13]); o[14] = fmaf(p, v3.z, o[14]); o[15] = fmaf(p, v3.w, o[15]);
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    const float* pa = Ss + l31 * ATT_SS + 4 * hi;             // A: row = query, k = keys 8 g + 4 hi + e (contiguous in the score row)
+    const float* vb = KVs + (4 * hi) * ATT_RS + w * 32 + l31;  // B: column = d, k = the same keys (rows of the V slab)
+#pragma unroll 4
+    for (int g = 0; g < ATT_NK / 8; ++g) {
+      const f32x4 p4 = *(const f32x4*)(pa + 8 * g);
+      const float* vg = vb + (8 * g) * ATT_RS;
+      const float v0 = vg[0], v1 = vg[ATT_RS], v2 = vg[2 * ATT_RS], v3 = vg[3 * ATT_RS];
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(p4.x, v0, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(p4.y, v1, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(p4.z, v2, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(p4.w, v3, o, 0, 0, 0);
     }
-    if (q0 + qi < t) {
-      const float sc = Sc[qi];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) o[i] *= sc;
-      vpt_op16* dst = a.out + (tok0 + q0 + qi) * hid + h * ATT_DH + dg * 16;
-      *(u32x4*)dst = pack8(o);
-      *(u32x4*)(dst + 8) = pack8(o + 8);
+    for (int r = 0; r < 16; ++r) {
+      const int qi = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (q0 + qi < t) a.out[(tok0 + q0 + qi) * hid + h * ATT_DH + w * 32 + l31] = (vpt_op16)(o[r] * Sc[qi]);
     }
   }
 }
