@@ -69,3 +69,15 @@ def test_camera_quantizer_bit_exact():
     assert set(env) == set(A.BUTTONS_ALL) | {"camera"} and env["camera"].shape == (16, 2)
     pol = t.env2policy(dict(camera=ang[:16], attack=np.ones(16)))
     assert pol["buttons"].shape == (16, 20) and pol["buttons"][:, 0].all() and not pol["buttons"][:, 1:].any()
+
+
+def test_out_of_range_indices_fail_loudly():
+    """The reference raises (IndexError / KeyError) on indices outside its tables; the kernels decode blindly, so the op checks."""
+    m = CameraHierarchicalMapping(n_camera_bins=11)
+    bad_joint = dict(buttons=np.array([[8641]], dtype=np.int64), camera=np.array([[60]], dtype=np.int64))
+    with pytest.raises(IndexError):
+        m.to_factored(bad_joint)
+    bad_cam = dict(buttons=np.zeros((1, 20), dtype=np.int64), camera=np.array([[11, 5]], dtype=np.int64))
+    with pytest.raises(IndexError):
+        m.from_factored(bad_cam)
+

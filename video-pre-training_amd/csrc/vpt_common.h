@@ -118,3 +118,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return start + k;
 }
+
+// ---- host helper: large dynamic LDS opt-in, once per (kernel, device) ------------------------------------------
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device attribute; a process driving several GPUs needs it on each.
+static inline bool vpt_lds_optin(const void* func, int bytes, unsigned long long* done_mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (dev < 0 || dev >= 64) return hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+  const unsigned long long bit = 1ull << dev;
+  if (__atomic_load_n(done_mask, __ATOMIC_ACQUIRE) & bit) return true;
+  if (hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  __atomic_fetch_or(done_mask, bit, __ATOMIC_RELEASE);
+  return true;
+}
+

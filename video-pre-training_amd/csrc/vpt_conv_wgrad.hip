@@ -257,14 +257,11 @@ extern "C" int vpt_conv_wgrad_launch(const VptConvWgradArgs* a_in, hipStream_t s
   a.frames_per_wg = (a.frames + groups - 1) / groups;
   const int RB = VPT_WGRAD_PXS / a.W;
   const size_t lds = 2 * (size_t)(4 * RB * (a.W + 2) * 64 + 2 * (RB + 2) * a.W * 64);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)vpt_conv_wgrad_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)vpt_conv_wgrad_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)vpt_conv_wgrad_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return -4;
-    attr_set = true;
-  }
+  static unsigned long long optin_done[3] = {0, 0, 0};
+  if (!vpt_lds_optin((const void*)vpt_conv_wgrad_kernel<64>, 160 * 1024, &optin_done[0]) ||
+      !vpt_lds_optin((const void*)vpt_conv_wgrad_kernel<32>, 160 * 1024, &optin_done[1]) ||
+      !vpt_lds_optin((const void*)vpt_conv_wgrad_kernel<16>, 160 * 1024, &optin_done[2]))
+    return -4;
   const dim3 grid((unsigned)(tiles * groups));
   if (a.W == 64) hipLaunchKernelGGL(vpt_conv_wgrad_kernel<64>, grid, dim3(512), lds, stream, a);
   else if (a.W == 32) hipLaunchKernelGGL(vpt_conv_wgrad_kernel<32>, grid, dim3(512), lds, stream, a);

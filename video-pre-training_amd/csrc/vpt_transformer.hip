@@ -232,12 +232,9 @@ __global__ __launch_bounds__(256) void vpt_attn_kernel(VptAttnArgs a) {
 extern "C" int vpt_attn_launch(const VptAttnArgs* a, hipStream_t stream) {
   if (a->hid != a->heads * ATT_DH) return -1;
   if (a->causal ? (a->maxlen < 1 || a->maxlen > 129) : (a->maxlen != 0 || a->t > ATT_NK)) return -1;
-  static bool attr_set = false;
+  static unsigned long long optin_done = 0;
   const size_t lds = ATT_FLOATS * sizeof(float);
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)vpt_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -4;
-    attr_set = true;
-  }
+  if (!vpt_lds_optin((const void*)vpt_attn_kernel, (int)lds, &optin_done)) return -4;
   dim3 grid((a->t + ATT_QT - 1) / ATT_QT, a->B * a->heads);
   hipLaunchKernelGGL(vpt_attn_kernel, grid, dim3(256), lds, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -3;

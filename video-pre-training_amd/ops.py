@@ -476,6 +476,9 @@ def action_from_factored(buttons, camera, n_camera_bins=11):
     jb = torch.empty(n, dtype=torch.int64, device=buttons.device)
     jc = torch.empty(n, dtype=torch.int64, device=buttons.device)
     if n:
+        # camera bins outside 0..n_bins-1 are a KeyError in the reference's table lookup (buttons are truthy flags there: any value)
+        if int(camera.min()) < 0 or int(camera.max()) >= n_camera_bins:
+            raise IndexError(f"factored action out of range: camera bins must lie in 0..{n_camera_bins - 1}")
         _call("vpt_action_from_factored", dict(bytes=192.0 * n), ptr(buttons), ptr(camera), ptr(jb), ptr(jc), n, int(n_camera_bins), _stream())
     return jb, jc
 
@@ -487,5 +490,10 @@ def action_to_factored(joint_buttons, joint_camera, n_camera_bins=11):
     b = torch.empty(n, 20, dtype=torch.int64, device=joint_buttons.device)
     c = torch.empty(n, 2, dtype=torch.int64, device=joint_buttons.device)
     if n:
+        # the kernel decodes blindly; the reference raises IndexError / KeyError on indices outside its tables
+        lo_b, hi_b = int(joint_buttons.min()), int(joint_buttons.max())
+        lo_c, hi_c = int(joint_camera.min()), int(joint_camera.max())
+        if lo_b < 0 or hi_b > 8640 or lo_c < 0 or hi_c >= n_camera_bins * n_camera_bins:
+            raise IndexError(f"joint action index out of range: buttons [{lo_b}, {hi_b}] (0..8640), camera [{lo_c}, {hi_c}] (0..{n_camera_bins * n_camera_bins - 1})")
         _call("vpt_action_to_factored", dict(bytes=192.0 * n), ptr(joint_buttons), ptr(joint_camera), ptr(b), ptr(c), n, int(n_camera_bins), _stream())
     return b, c
