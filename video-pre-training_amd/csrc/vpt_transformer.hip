@@ -68,9 +68,7 @@ extern "C" int vpt_layernorm_launch(const VptLayerNormArgs* a, hipStream_t strea
 #define ATT_NK 160                      // keys staged per query tile (31 + maxlen, maxlen <= 129)
 #define ATT_RS (ATT_DH + 4)             // padded fp32 row
 #define ATT_SS 164                      // padded score row (16-byte aligned: the P operand is read as float4)
-#define ATT_Q_OFF 0
-#define ATT_KV_OFF (ATT_QT * ATT_RS)                      // floats
-#define ATT_S_OFF (ATT_KV_OFF + ATT_NK * ATT_RS)
+#define ATT_S_OFF 0                                       // scores / probabilities [32][ATT_SS]
 #define ATT_R_OFF (ATT_S_OFF + ATT_QT * ATT_SS)
 #define ATT_B_OFF (ATT_R_OFF + ATT_QT * 10)
 #define ATT_SC_OFF (ATT_B_OFF + 10 * 129)
@@ -79,8 +77,6 @@ extern "C" int vpt_layernorm_launch(const VptLayerNormArgs* a, hipStream_t strea
 
 __global__ __launch_bounds__(256) void vpt_attn_kernel(VptAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* Qs = sm + ATT_Q_OFF;
-  float* KVs = sm + ATT_KV_OFF;
   float* Ss = sm + ATT_S_OFF;
   float* Rs = sm + ATT_R_OFF;
   float* Bs = sm + ATT_B_OFF;
@@ -95,21 +91,7 @@ __global__ __launch_bounds__(256) void vpt_attn_kernel(VptAttnArgs a) {
   // lib/masked_attention.py:139-141 with maxlen = 0): every query sees all t <= ATT_NK rows of the chunk.
   const int jbase = a.causal ? q0 + 1 : 0;
 
-  // ---- stage Q tile, K slab, R rows, b_nd ----
-  for (int idx = tid; idx < ATT_QT * (ATT_DH / 4); idx += 256) {
-    const int r = idx >> 5, c4 = idx & 31;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (q0 + r < t) v = *(const f32x4*)(a.qkvr + (tok0 + q0 + r) * a.ld + h * ATT_DH + c4 * 4);
-    *(f32x4*)(Qs + r * ATT_RS + c4 * 4) = v;
-  }
-  for (int idx = tid; idx < ATT_NK * (ATT_DH / 4); idx += 256) {
-    const int kk = idx >> 5, c4 = idx & 31;
-    const int j = jbase + kk;  // index into [memory ; chunk]
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (j < maxlen) v = *(const f32x4*)(a.kmem + ((size_t)b * maxlen + j) * hid + h * ATT_DH + c4 * 4);
-    else if (j - maxlen < t) v = *(const f32x4*)(a.qkvr + (tok0 + j - maxlen) * a.ld + hid + h * ATT_DH + c4 * 4);
-    *(f32x4*)(KVs + kk * ATT_RS + c4 * 4) = v;
-  }
+  // ---- stage the R rows and b_nd (Q, K and V never pass through LDS: every element is used by exactly one lane) ----
   for (int idx = tid; idx < ATT_QT * 10; idx += 256) {
     const int r = idx / 10, n = idx - r * 10;
     Rs[idx] = (a.causal && q0 + r < t) ? a.qkvr[(tok0 + q0 + r) * a.ld + 3 * hid + h * 10 + n] : 0.f;
@@ -124,16 +106,25 @@ __global__ __launch_bounds__(256) void vpt_attn_kernel(VptAttnArgs a) {
   // Key tiles 0..3 belong to waves 0..3; tile 4 (keys 128..159) is split over the waves by d (four groups each) and summed
   // through LDS, so every wave issues 80 MFMAs.
   const int l31 = lane & 31, hi = lane >> 5;
+  // row j of [memory ; chunk] -> pointer to its K (which = 1) / V (which = 2) row of this head, or null beyond the chunk
+  auto kv_row = [&](int j, int which) -> const float* {
+    if (j < maxlen) return (which == 1 ? a.kmem : a.vmem) + ((size_t)b * maxlen + j) * hid + h * ATT_DH;
+    if (j - maxlen < t) return a.qkvr + (tok0 + j - maxlen) * a.ld + which * hid + h * ATT_DH;
+    return nullptr;
+  };
   {
     f32x16 acc, acc4;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc4[r] = 0.f; }
-    const float* qa = Qs + l31 * ATT_RS + 4 * hi;
-    const float* kb = KVs + (w * 32 + l31) * ATT_RS + 4 * hi;
-    const float* kb4 = KVs + (128 + l31) * ATT_RS + 4 * hi;
-#pragma unroll 4
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const float* qa = (q0 + l31 < t) ? a.qkvr + (tok0 + q0 + l31) * a.ld + h * ATT_DH + 4 * hi : nullptr;
+    const float* kr = kv_row(jbase + w * 32 + l31, 1);
+    const float* kr4 = kv_row(jbase + 128 + l31, 1);
+    const float* kb = kr ? kr + 4 * hi : nullptr;
+    const float* kb4 = kr4 ? kr4 + 4 * hi : nullptr;
+#pragma unroll 8
     for (int g = 0; g < 16; ++g) {
-      const f32x4 q4 = *(const f32x4*)(qa + 8 * g), k4 = *(const f32x4*)(kb + 8 * g);
+      const f32x4 q4 = qa ? *(const f32x4*)(qa + 8 * g) : z4, k4 = kb ? *(const f32x4*)(kb + 8 * g) : z4;
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.x, k4.x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.y, k4.y, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.z, k4.z, acc, 0, 0, 0);
@@ -142,7 +133,7 @@ __global__ __launch_bounds__(256) void vpt_attn_kernel(VptAttnArgs a) {
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const int g = 4 * w + g4;
-      const f32x4 q4 = *(const f32x4*)(qa + 8 * g), k4 = *(const f32x4*)(kb4 + 8 * g);
+      const f32x4 q4 = qa ? *(const f32x4*)(qa + 8 * g) : z4, k4 = kb4 ? *(const f32x4*)(kb4 + 8 * g) : z4;
       acc4 = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.x, k4.x, acc4, 0, 0, 0);
       acc4 = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.y, k4.y, acc4, 0, 0, 0);
       acc4 = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.z, k4.z, acc4, 0, 0, 0);
@@ -180,7 +171,7 @@ __global__ __launch_bounds__(256) void vpt_attn_kernel(VptAttnArgs a) {
       finish(128 + l31, r, dot);
     }
   }
-  // ---- softmax rows (8 per wave); stage V into the slab meanwhile ----
+  // ---- softmax rows (8 per wave) ----
   for (int r = w * 8; r < w * 8 + 8; ++r) {
     float* srow = Ss + r * ATT_SS;
     const float s0 = srow[lane], s1 = srow[lane + 64], s2 = (lane + 128 < ATT_NK) ? srow[lane + 128] : -3.0e38f;
@@ -194,14 +185,6 @@ __global__ __launch_bounds__(256) void vpt_attn_kernel(VptAttnArgs a) {
     if (lane + 128 < ATT_NK) srow[lane + 128] = e2;
     if (lane == 0) Sc[r] = (tot > 0.f) ? 1.0f / tot : 0.f;
   }
-  for (int idx = tid; idx < ATT_NK * (ATT_DH / 4); idx += 256) {
-    const int kk = idx >> 5, c4 = idx & 31;
-    const int j = jbase + kk;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (j < maxlen) v = *(const f32x4*)(a.vmem + ((size_t)b * maxlen + j) * hid + h * ATT_DH + c4 * 4);
-    else if (j - maxlen < t) v = *(const f32x4*)(a.qkvr + (tok0 + j - maxlen) * a.ld + 2 * hid + h * ATT_DH + c4 * 4);
-    *(f32x4*)(KVs + kk * ATT_RS + c4 * 4) = v;
-  }
   __syncthreads();
 
   // ---- out = P V on the fp32 matrix cores: wave w owns d_head slice 32 w .. 32 w + 31; D[query][d] = sum_key P[query][key] V[key][d] ----
@@ -210,16 +193,22 @@ __global__ __launch_bounds__(256) void vpt_attn_kernel(VptAttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
     const float* pa = Ss + l31 * ATT_SS + 4 * hi;             // A: row = query, k = keys 8 g + 4 hi + e (contiguous in the score row)
-    const float* vb = KVs + (4 * hi) * ATT_RS + w * 32 + l31;  // B: column = d, k = the same keys (rows of the V slab)
+    const int dcol = w * 32 + l31;                             // B: column = d; its four keys' rows are wave-uniform per half-wave
 #pragma unroll 4
     for (int g = 0; g < ATT_NK / 8; ++g) {
       const f32x4 p4 = *(const f32x4*)(pa + 8 * g);
-      const float* vg = vb + (8 * g) * ATT_RS;
-      const float v0 = vg[0], v1 = vg[ATT_RS], v2 = vg[2 * ATT_RS], v3 = vg[3 * ATT_RS];
-      o = __builtin_amdgcn_mfma_f32_32x32x2f32(p4.x, v0, o, 0, 0, 0);
-      o = __builtin_amdgcn_mfma_f32_32x32x2f32(p4.y, v1, o, 0, 0, 0);
-      o = __builtin_amdgcn_mfma_f32_32x32x2f32(p4.z, v2, o, 0, 0, 0);
-      o = __builtin_amdgcn_mfma_f32_32x32x2f32(p4.w, v3, o, 0, 0, 0);
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* r0 = kv_row(jbase + 8 * g + e, 2);        // scalar arithmetic: the key index is uniform
+        const float* r1 = kv_row(jbase + 8 * g + 4 + e, 2);
+        const float* rr = hi ? r1 : r0;
+        v[e] = rr ? rr[dcol] : 0.f;
+      }
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(p4.x, v[0], o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(p4.y, v[1], o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(p4.z, v[2], o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(p4.w, v[3], o, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
