@@ -160,7 +160,8 @@ def test_layernorm(m, d, relu_in):
     assert _relerr(o16.cpu().float(), ref) < 5e-3
 
 
-@pytest.mark.parametrize("bsz,t,heads,first_flags", [(2, 128, 2, [False, True]), (3, 5, 2, [False, False, True]), (2, 1, 2, [False, False]), (1, 70, 2, [False])])
+@pytest.mark.parametrize("bsz,t,heads,first_flags", [(2, 128, 2, [False, True]), (3, 5, 2, [False, False, True]), (2, 1, 2, [False, False]), (1, 70, 2, [False]),
+                                                    (32, 128, 16, [False] * 31 + [True])])   # the bench's grid shape: 2048 workgroups, several per CU (caught a missing barrier)
 def test_masked_attention_and_kv_update(bsz, t, heads, first_flags):
     g = torch.Generator().manual_seed(6)
     hid, maxlen = heads * 128, 128

@@ -212,108 +212,119 @@ extern "C" int vpt_colsum_launch(const VptColsumArgs* a, hipStream_t stream) {
 #define ATT_DH 128
 #define ATT_QT 32
 #define ATT_NK 160
-#define ATT_RS (ATT_DH + 4)
-#define ATT_SS 161
-#define AB_Q_OFF 0
-#define AB_KV_OFF (ATT_QT * ATT_RS)
-#define AB_S_OFF (AB_KV_OFF + ATT_NK * ATT_RS)
-#define AB_DO_OFF (AB_S_OFF + ATT_QT * ATT_SS)
-#define AB_R_OFF (AB_DO_OFF + ATT_QT * ATT_RS)
+#define ATT_SS 164                      // padded score row, 16-byte aligned
+#define AB_P_OFF 0                                        // P  [32][ATT_SS]
+#define AB_D_OFF (AB_P_OFF + ATT_QT * ATT_SS)             // dP, then dS  [32][ATT_SS]
+#define AB_R_OFF (AB_D_OFF + ATT_QT * ATT_SS)
 #define AB_B_OFF (AB_R_OFF + ATT_QT * 10)
-#define AB_DB_OFF (AB_B_OFF + 10 * 129)
-#define AB_RED_OFF (AB_DB_OFF + 10 * 129)
-#define AB_FLOATS (AB_RED_OFF + 8 * ATT_QT)
+#define AB_PT_OFF ((AB_B_OFF + 10 * 129 + 3) & ~3)        // partial tiles of key tile 4: [wave][16][64]
+#define AB_FLOATS (AB_PT_OFF + 4 * 16 * 64)
 
-__global__ __launch_bounds__(256) void vpt_attn_bwd_kernel(VptAttnBwdArgs a) {
+// Round 2: every contraction runs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) with its operands taken straight from global
+// memory (each element is used by exactly one lane) or from the 32 x 160 score tiles in LDS; 65 KB of LDS -> two workgroups per
+// CU.  The first version staged Q, dO and the K / V slab in 151 KB of LDS and did the five contractions on the vector ALU.
+//   "QK-like"  (logits, dP):  M = queries, N = keys, K = d_head; A = a query row, B = a key row, both contiguous in d.
+//   "PV-like"  (dQ):          M = queries, N = d_head, K = keys;  A = a score row (LDS, contiguous in keys), B = key rows.
+//   "dV-like"  (dV, dK):      M = keys,    N = d_head, K = queries; A = a score column (LDS), B = query rows.
+// A lane supplies the k values 8 g + 4 hi + e, e = 0..3, of group g in every case (the k order of an MFMA step is free as long
+// as both operands agree).
+__global__ __launch_bounds__(256, 2) void vpt_attn_bwd_kernel(VptAttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* Qs = sm + AB_Q_OFF;
-  float* KVs = sm + AB_KV_OFF;
-  float* Ss = sm + AB_S_OFF;
-  float* dOs = sm + AB_DO_OFF;
+  float* Ps = sm + AB_P_OFF;
+  float* Ds = sm + AB_D_OFF;
   float* Rs = sm + AB_R_OFF;
   float* Bs = sm + AB_B_OFF;
-  float* dBs = sm + AB_DB_OFF;
-  float* Red = sm + AB_RED_OFF;
+  float* Pt = sm + AB_PT_OFF;
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
   const int b = blockIdx.y / a.heads, h = blockIdx.y - b * a.heads;
   const int q0 = blockIdx.x * ATT_QT;
   const int maxlen = a.maxlen, t = a.t, hid = a.hid;
   const size_t tok0 = (size_t)b * t;
   const float inv_dh = 1.0f / ATT_DH;
+  const int jbase = q0 + 1;             // key kk of the band = row jbase + kk of [memory ; chunk]
 
-  // ---- stage Q, dO, K slab, R, b_nd; zero the db_nd accumulator ----
-  for (int idx = tid; idx < ATT_QT * (ATT_DH / 4); idx += 256) {
-    const int r = idx >> 5, c4 = idx & 31;
-    f32x4 q = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
-    if (q0 + r < t) {
-      q = *(const f32x4*)(a.qkvr + (tok0 + q0 + r) * a.ld + h * ATT_DH + c4 * 4);
-      d = *(const f32x4*)(a.dout + (tok0 + q0 + r) * hid + h * ATT_DH + c4 * 4);
-    }
-    *(f32x4*)(Qs + r * ATT_RS + c4 * 4) = q;
-    *(f32x4*)(dOs + r * ATT_RS + c4 * 4) = d;
-  }
-  for (int idx = tid; idx < ATT_NK * (ATT_DH / 4); idx += 256) {
-    const int kk = idx >> 5, c4 = idx & 31;
-    const int j = q0 + 1 + kk;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (j < maxlen) v = *(const f32x4*)(a.kmem + ((size_t)b * maxlen + j) * hid + h * ATT_DH + c4 * 4);
-    else if (j - maxlen < t) v = *(const f32x4*)(a.qkvr + (tok0 + j - maxlen) * a.ld + hid + h * ATT_DH + c4 * 4);
-    *(f32x4*)(KVs + kk * ATT_RS + c4 * 4) = v;
-  }
   for (int idx = tid; idx < ATT_QT * 10; idx += 256) {
     const int r = idx / 10, n = idx - r * 10;
     Rs[idx] = (q0 + r < t) ? a.qkvr[(tok0 + q0 + r) * a.ld + 3 * hid + h * 10 + n] : 0.f;
   }
-  for (int idx = tid; idx < 10 * maxlen; idx += 256) { Bs[idx] = a.b_nd[idx]; dBs[idx] = 0.f; }
+  for (int idx = tid; idx < 10 * maxlen; idx += 256) Bs[idx] = a.b_nd[idx];
   __syncthreads();
 
-  const int qi = tid & 31, kg = tid >> 5;
-  const bool qvalid = (q0 + qi) < t;
-  // ---- logits (as the forward kernel) ----
-  {
-    const float* qrow = Qs + qi * ATT_RS;
-    float rq[10];
+  // row j of [memory ; chunk] -> its K (which = 1) / V (which = 2) row of this head, or null beyond the chunk
+  auto kv_row = [&](int j, int which) -> const float* {
+    if (j < maxlen) return (which == 1 ? a.kmem : a.vmem) + ((size_t)b * maxlen + j) * hid + h * ATT_DH;
+    if (j - maxlen < t) return a.qkvr + (tok0 + j - maxlen) * a.ld + which * hid + h * ATT_DH;
+    return nullptr;
+  };
+  auto q_row = [&](int qi) -> const float* { return (q0 + qi < t) ? a.qkvr + (tok0 + q0 + qi) * a.ld + h * ATT_DH : nullptr; };
+  auto do_row = [&](int qi) -> const float* { return (q0 + qi < t) ? a.dout + (tok0 + q0 + qi) * hid + h * ATT_DH : nullptr; };
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const uint8_t* memv = a.memvalid + (size_t)b * maxlen;
+
+  // QK-like contraction: key tiles 0..3 belong to waves 0..3 (acc), tile 4 (keys 128..159) is split over the waves by d
+  // (four groups each, acc4) and summed through Pt, so every wave issues 80 MFMAs.  emit(key, r, value) receives the tile.
+  auto qk_like = [&](const float* arow, int which, auto emit) __attribute__((always_inline)) {
+    f32x16 acc, acc4;
 #pragma unroll
-    for (int n = 0; n < 10; ++n) rq[n] = Rs[qi * 10 + n];
-    for (int nb = 0; nb < 5; ++nb) {
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
-      const float* k0 = KVs + (kg + 8 * (4 * nb + 0)) * ATT_RS;
-      const float* k1 = KVs + (kg + 8 * (4 * nb + 1)) * ATT_RS;
-      const float* k2 = KVs + (kg + 8 * (4 * nb + 2)) * ATT_RS;
-      const float* k3 = KVs + (kg + 8 * (4 * nb + 3)) * ATT_RS;
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc4[r] = 0.f; }
+    const float* qa = arow ? arow + 4 * hi : nullptr;
+    const float* kr = kv_row(jbase + w * 32 + l31, which);
+    const float* kr4 = kv_row(jbase + 128 + l31, which);
+    const float* kb = kr ? kr + 4 * hi : nullptr;
+    const float* kb4 = kr4 ? kr4 + 4 * hi : nullptr;
 #pragma unroll 8
-      for (int d = 0; d < ATT_DH; d += 4) {
-        const f32x4 q = *(const f32x4*)(qrow + d);
-        const f32x4 x0 = *(const f32x4*)(k0 + d), x1 = *(const f32x4*)(k1 + d);
-        const f32x4 x2 = *(const f32x4*)(k2 + d), x3 = *(const f32x4*)(k3 + d);
-        acc[0] = fmaf(q.x, x0.x, fmaf(q.y, x0.y, fmaf(q.z, x0.z, fmaf(q.w, x0.w, acc[0]))));
-        acc[1] = fmaf(q.x, x1.x, fmaf(q.y, x1.y, fmaf(q.z, x1.z, fmaf(q.w, x1.w, acc[1]))));
-        acc[2] = fmaf(q.x, x2.x, fmaf(q.y, x2.y, fmaf(q.z, x2.z, fmaf(q.w, x2.w, acc[2]))));
-        acc[3] = fmaf(q.x, x3.x, fmaf(q.y, x3.y, fmaf(q.z, x3.z, fmaf(q.w, x3.w, acc[3]))));
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int kk = kg + 8 * (4 * nb + u);
-        const int off = maxlen - 1 + qi - kk;
-        const int j = q0 + 1 + kk;
-        bool vis = qvalid && off >= 0 && off < maxlen;
-        if (vis && j < maxlen) vis = a.memvalid[(size_t)b * maxlen + j] != 0;
-        float s = -3.0e38f;
-        if (vis) {
-          float rb = 0.f;
-#pragma unroll
-          for (int n = 0; n < 10; ++n) rb = fmaf(rq[n], Bs[n * maxlen + off], rb);
-          s = acc[u] * inv_dh + rb;
-        }
-        Ss[qi * ATT_SS + kk] = s;
-      }
+    for (int g = 0; g < 16; ++g) {
+      const f32x4 q4 = qa ? *(const f32x4*)(qa + 8 * g) : z4, k4 = kb ? *(const f32x4*)(kb + 8 * g) : z4;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.x, k4.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.y, k4.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.z, k4.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.w, k4.w, acc, 0, 0, 0);
     }
-  }
-  __syncthreads();
-  // ---- softmax -> normalised P in Ss ----
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int g = 4 * w + g4;
+      const f32x4 q4 = qa ? *(const f32x4*)(qa + 8 * g) : z4, k4 = kb4 ? *(const f32x4*)(kb4 + 8 * g) : z4;
+      acc4 = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.x, k4.x, acc4, 0, 0, 0);
+      acc4 = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.y, k4.y, acc4, 0, 0, 0);
+      acc4 = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.z, k4.z, acc4, 0, 0, 0);
+      acc4 = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.w, k4.w, acc4, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Pt[(w * 16 + r) * 64 + lane] = acc4[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) emit(w * 32 + l31, r, acc[r]);
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {   // key tile 4: this wave finishes accumulator registers 4 w .. 4 w + 3
+      const int r = 4 * w + r4;
+      emit(128 + l31, r, (Pt[(0 * 16 + r) * 64 + lane] + Pt[(1 * 16 + r) * 64 + lane]) + (Pt[(2 * 16 + r) * 64 + lane] + Pt[(3 * 16 + r) * 64 + lane]));
+    }
+    __syncthreads();
+  };
+  // accumulator register r of a lane = row (r & 3) + 8 (r >> 2) + 4 hi of the 32 x 32 tile, column l31
+#define ROW_OF(r_) (((r_) & 3) + 8 * ((r_) >> 2) + 4 * hi)
+
+  // ---- 1. logits (as the forward kernel) -> Ps ----
+  qk_like(q_row(l31), 1, [&](int kk, int r, float dot) {
+    const int qi = ROW_OF(r);
+    const int off = maxlen - 1 + qi - kk;  // 0 = the query itself, maxlen-1 = oldest key in the band
+    const int j = jbase + kk;
+    bool vis = (q0 + qi) < t && off >= 0 && off < maxlen;
+    if (vis && j < maxlen) vis = memv[j] != 0;
+    float sc = -3.0e38f;
+    if (vis) {
+      float rb = 0.f;
+#pragma unroll
+      for (int n = 0; n < 10; ++n) rb = fmaf(Rs[qi * 10 + n], Bs[n * maxlen + off], rb);
+      sc = dot * inv_dh + rb;
+    }
+    Ps[qi * ATT_SS + kk] = sc;
+  });
+  // ---- softmax -> normalised P in Ps (8 rows per wave) ----
   for (int r = w * 8; r < w * 8 + 8; ++r) {
-    float* srow = Ss + r * ATT_SS;
+    float* srow = Ps + r * ATT_SS;
     const float s0 = srow[lane], s1 = srow[lane + 64], s2 = (lane + 128 < ATT_NK) ? srow[lane + 128] : -3.0e38f;
     const float m = wave_max(fmaxf(s0, fmaxf(s1, s2)));
     const float e0 = (s0 > -1.0e38f) ? expf(s0 - m) : 0.f;
@@ -325,150 +336,99 @@ __global__ __launch_bounds__(256) void vpt_attn_bwd_kernel(VptAttnBwdArgs a) {
     srow[lane + 64] = e1 * inv;
     if (lane + 128 < ATT_NK) srow[lane + 128] = e2 * inv;
   }
-  // ---- stage V ----
-  for (int idx = tid; idx < ATT_NK * (ATT_DH / 4); idx += 256) {
-    const int kk = idx >> 5, c4 = idx & 31;
-    const int j = q0 + 1 + kk;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (j < maxlen) v = *(const f32x4*)(a.vmem + ((size_t)b * maxlen + j) * hid + h * ATT_DH + c4 * 4);
-    else if (j - maxlen < t) v = *(const f32x4*)(a.qkvr + (tok0 + j - maxlen) * a.ld + 2 * hid + h * ATT_DH + c4 * 4);
-    *(f32x4*)(KVs + kk * ATT_RS + c4 * 4) = v;
+  // ---- 2. dP = dO V^T -> Ds (its trailing barrier also publishes P) ----
+  qk_like(do_row(l31), 2, [&](int kk, int r, float dot) { Ds[ROW_OF(r) * ATT_SS + kk] = dot; });
+  // ---- 3. D_i = sum_k P dP;  dS = P (dP - D_i) -> Ds (0 where masked since P = 0) ----
+  for (int r = w * 8; r < w * 8 + 8; ++r) {
+    const float* prow = Ps + r * ATT_SS;
+    float* drow = Ds + r * ATT_SS;
+    const float p0 = prow[lane], p1 = prow[lane + 64], p2 = (lane + 128 < ATT_NK) ? prow[lane + 128] : 0.f;
+    const float d0 = drow[lane], d1 = drow[lane + 64], d2 = (lane + 128 < ATT_NK) ? drow[lane + 128] : 0.f;
+    const float Di = wave_sum(fmaf(p0, d0, fmaf(p1, d1, p2 * d2)));
+    drow[lane] = p0 * (d0 - Di);
+    drow[lane + 64] = p1 * (d1 - Di);
+    if (lane + 128 < ATT_NK) drow[lane + 128] = p2 * (d2 - Di);
   }
   __syncthreads();
 
-  // ---- dV[kk][d] += sum_qi P[qi][kk] dO[qi][d]   (thread = key group kg, 4-wide d slice dl) ----
-  {
-    const int dl = tid & 31;
-    float acc[20][4];
+  const int dcol = w * 32 + l31;        // wave w owns d_head slice 32 w .. 32 w + 31 from here on
+  // dV-like contraction: out[key][d] = scale * sum_query X[query][key] Y[query][d]; accumulated into the K / V columns of the
+  // chunk's keys (memory keys are detached state: no gradient)
+  auto dv_like = [&](const float* X, auto yrow, int which, float scale) __attribute__((always_inline)) {
+    f32x16 acc[5];
 #pragma unroll
-    for (int n = 0; n < 20; ++n) { acc[n][0] = acc[n][1] = acc[n][2] = acc[n][3] = 0.f; }
-    for (int q = 0; q < ATT_QT; ++q) {
-      const f32x4 d = *(const f32x4*)(dOs + q * ATT_RS + dl * 4);
-      const float* prow = Ss + q * ATT_SS + kg;
+    for (int kt = 0; kt < 5; ++kt)
 #pragma unroll
-      for (int n = 0; n < 20; ++n) {
-        const float p = prow[8 * n];
-        acc[n][0] = fmaf(p, d.x, acc[n][0]); acc[n][1] = fmaf(p, d.y, acc[n][1]);
-        acc[n][2] = fmaf(p, d.z, acc[n][2]); acc[n][3] = fmaf(p, d.w, acc[n][3]);
-      }
-    }
+      for (int r = 0; r < 16; ++r) acc[kt][r] = 0.f;
+#pragma unroll 1
+    for (int g = 0; g < 4; ++g) {   // not unrolled: eight wave-uniform row pointers per iteration live in scalar registers
+      float y[4];
 #pragma unroll
-    for (int n = 0; n < 20; ++n) {
-      const int j = q0 + 1 + kg + 8 * n;
-      if (j >= maxlen && j - maxlen < t) {
-        float* dst = a.dqkvr + (tok0 + j - maxlen) * a.ld + 2 * hid + h * ATT_DH + dl * 4;
-        atomicAdd(dst + 0, acc[n][0]); atomicAdd(dst + 1, acc[n][1]);
-        atomicAdd(dst + 2, acc[n][2]); atomicAdd(dst + 3, acc[n][3]);
-      }
-    }
-  }
-  // ---- dP = dO V^T, D_i = sum_k P dP, dS = P (dP - D_i) ----
-  float dp[20];
-  {
-    const float* drow = dOs + qi * ATT_RS;
-    for (int nb = 0; nb < 5; ++nb) {
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
-      const float* v0 = KVs + (kg + 8 * (4 * nb + 0)) * ATT_RS;
-      const float* v1 = KVs + (kg + 8 * (4 * nb + 1)) * ATT_RS;
-      const float* v2 = KVs + (kg + 8 * (4 * nb + 2)) * ATT_RS;
-      const float* v3 = KVs + (kg + 8 * (4 * nb + 3)) * ATT_RS;
-#pragma unroll 8
-      for (int d = 0; d < ATT_DH; d += 4) {
-        const f32x4 q = *(const f32x4*)(drow + d);
-        const f32x4 x0 = *(const f32x4*)(v0 + d), x1 = *(const f32x4*)(v1 + d);
-        const f32x4 x2 = *(const f32x4*)(v2 + d), x3 = *(const f32x4*)(v3 + d);
-        acc[0] = fmaf(q.x, x0.x, fmaf(q.y, x0.y, fmaf(q.z, x0.z, fmaf(q.w, x0.w, acc[0]))));
-        acc[1] = fmaf(q.x, x1.x, fmaf(q.y, x1.y, fmaf(q.z, x1.z, fmaf(q.w, x1.w, acc[1]))));
-        acc[2] = fmaf(q.x, x2.x, fmaf(q.y, x2.y, fmaf(q.z, x2.z, fmaf(q.w, x2.w, acc[2]))));
-        acc[3] = fmaf(q.x, x3.x, fmaf(q.y, x3.y, fmaf(q.z, x3.z, fmaf(q.w, x3.w, acc[3]))));
+      for (int e = 0; e < 4; ++e) {
+        const float* r0 = yrow(8 * g + e);          // wave-uniform rows: scalar address arithmetic
+        const float* r1 = yrow(8 * g + 4 + e);
+        const float* rr = hi ? r1 : r0;
+        y[e] = rr ? rr[dcol] : 0.f;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) dp[4 * nb + u] = acc[u];
-    }
-    float part = 0.f;
-#pragma unroll
-    for (int n = 0; n < 20; ++n) part = fmaf(Ss[qi * ATT_SS + kg + 8 * n], dp[n], part);
-    Red[kg * ATT_QT + qi] = part;
-  }
-  __syncthreads();  // all dV reads of P and all D partials are done
-  {
-    float Di = 0.f;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) Di += Red[g * ATT_QT + qi];
-#pragma unroll
-    for (int n = 0; n < 20; ++n) {
-      const int kk = kg + 8 * n;
-      const float p = Ss[qi * ATT_SS + kk];
-      Ss[qi * ATT_SS + kk] = p * (dp[n] - Di);  // dS (0 where masked since P = 0)
-    }
-  }
-  // ---- reload K ----
-  for (int idx = tid; idx < ATT_NK * (ATT_DH / 4); idx += 256) {
-    const int kk = idx >> 5, c4 = idx & 31;
-    const int j = q0 + 1 + kk;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (j < maxlen) v = *(const f32x4*)(a.kmem + ((size_t)b * maxlen + j) * hid + h * ATT_DH + c4 * 4);
-    else if (j - maxlen < t) v = *(const f32x4*)(a.qkvr + (tok0 + j - maxlen) * a.ld + hid + h * ATT_DH + c4 * 4);
-    *(f32x4*)(KVs + kk * ATT_RS + c4 * 4) = v;
-  }
-  __syncthreads();
-
-  // ---- dQ[qi][d] = 1/d_h * sum_kk dS[qi][kk] K[kk][d]   (thread = query qi, 16-wide d slice dg) ----
-  {
-    const int dg = tid >> 5;
-    float o[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) o[i] = 0.f;
-    const float* prow = Ss + qi * ATT_SS;
-    const float* kcol = KVs + dg * 16;
-    for (int kk = 0; kk < ATT_NK; ++kk) {
-      const float p = prow[kk];
-      const f32x4 v0 = *(const f32x4*)(kcol + kk * ATT_RS), v1 = *(const f32x4*)(kcol + kk * ATT_RS + 4);
-      const f32x4 v2 = *(const f32x4*)(kcol + kk * ATT_RS + 8), v3 = *(const f32x4*)(kcol + kk * ATT_RS + 12);
-      o[0] = fmaf(p, v0.x, o[0]); o[1] = fmaf(p, v0.y, o[1]); o[2] = fmaf(p, v0.z, o[2]); o[3] = fmaf(p, v0.w, o[3]);
-      o[4] = fmaf(p, v1.x, o[4]); o[5] = fmaf(p, v1.y, o[5]); o[6] = fmaf(p, v1.z, o[6]); o[7] = fmaf(p, v1.w, o[7]);
-      o[8] = fmaf(p, v2.x, o[8]); o[9] = fmaf(p, v2.y, o[9]); o[10] = fmaf(p, v2.z, o[10]); o[11] = fmaf(p, v2.w, o[11]);
-      o[12] = fmaf(p, v3.x, o[12]); o[13] = fmaf(p, v3.y, o[13]); o[14] = fmaf(p, v3.z, o[14]); o[15] = fmaf(p, v3.w, o[15]);
-    }
-    if (qvalid) {
-      float* dst = a.dqkvr + (tok0 + q0 + qi) * a.ld + h * ATT_DH + dg * 16;
-#pragma unroll
-      for (int i = 0; i < 16; i += 4) *(f32x4*)(dst + i) = (f32x4){o[i] * inv_dh, o[i + 1] * inv_dh, o[i + 2] * inv_dh, o[i + 3] * inv_dh};
-    }
-  }
-  // ---- dK[kk][d] += 1/d_h * sum_qi dS[qi][kk] Q[qi][d] ----
-  {
-    const int dl = tid & 31;
-    float acc[20][4];
-#pragma unroll
-    for (int n = 0; n < 20; ++n) { acc[n][0] = acc[n][1] = acc[n][2] = acc[n][3] = 0.f; }
-    for (int q = 0; q < ATT_QT; ++q) {
-      const f32x4 d = *(const f32x4*)(Qs + q * ATT_RS + dl * 4);
-      const float* prow = Ss + q * ATT_SS + kg;
-#pragma unroll
-      for (int n = 0; n < 20; ++n) {
-        const float p = prow[8 * n];
-        acc[n][0] = fmaf(p, d.x, acc[n][0]); acc[n][1] = fmaf(p, d.y, acc[n][1]);
-        acc[n][2] = fmaf(p, d.z, acc[n][2]); acc[n][3] = fmaf(p, d.w, acc[n][3]);
+      for (int kt = 0; kt < 5; ++kt) {
+        const float* xc = X + (8 * g + 4 * hi) * ATT_SS + kt * 32 + l31;     // A: row = key, k = queries 8 g + 4 hi + e
+        acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(xc[0], y[0], acc[kt], 0, 0, 0);
+        acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(xc[ATT_SS], y[1], acc[kt], 0, 0, 0);
+        acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(xc[2 * ATT_SS], y[2], acc[kt], 0, 0, 0);
+        acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(xc[3 * ATT_SS], y[3], acc[kt], 0, 0, 0);
       }
     }
+    // wave-uniform base + one 32-bit per-lane index per element (80 64-bit vector addresses would not fit the register file)
+    float* colbase = a.dqkvr + tok0 * a.ld + which * hid + h * ATT_DH;
+    const int jr0 = jbase - maxlen + 4 * hi;          // chunk row of accumulator register 0 of key tile 0
 #pragma unroll
-    for (int n = 0; n < 20; ++n) {
-      const int j = q0 + 1 + kg + 8 * n;
-      if (j >= maxlen && j - maxlen < t) {
-        float* dst = a.dqkvr + (tok0 + j - maxlen) * a.ld + hid + h * ATT_DH + dl * 4;
-        atomicAdd(dst + 0, acc[n][0] * inv_dh); atomicAdd(dst + 1, acc[n][1] * inv_dh);
-        atomicAdd(dst + 2, acc[n][2] * inv_dh); atomicAdd(dst + 3, acc[n][3] * inv_dh);
+    for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jr = jr0 + kt * 32 + (r & 3) + 8 * (r >> 2);
+        if (jr >= 0 && jr < t) atomicAdd(colbase + (jr * a.ld + dcol), acc[kt][r] * scale);
       }
+  };
+  // ---- 4. dV += P^T dO ;  5. dK += dS^T Q / d_h ----
+  dv_like(Ps, do_row, 2, 1.0f);
+  dv_like(Ds, q_row, 1, inv_dh);
+  // ---- 6. dQ = dS K / d_h (PV-like) ----
+  {
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    const float* pa = Ds + l31 * ATT_SS + 4 * hi;
+#pragma unroll 2
+    for (int g = 0; g < ATT_NK / 8; ++g) {
+      const f32x4 p4 = *(const f32x4*)(pa + 8 * g);
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* r0 = kv_row(jbase + 8 * g + e, 1);
+        const float* r1 = kv_row(jbase + 8 * g + 4 + e, 1);
+        const float* rr = hi ? r1 : r0;
+        v[e] = rr ? rr[dcol] : 0.f;
+      }
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(p4.x, v[0], o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(p4.y, v[1], o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(p4.z, v[2], o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(p4.w, v[3], o, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = ROW_OF(r);
+      if (q0 + qi < t) a.dqkvr[(tok0 + q0 + qi) * a.ld + h * ATT_DH + dcol] = o[r] * inv_dh;
     }
   }
-  // ---- dR[qi][n] = sum_kk dS B[n][off];  db_nd[n][off] += sum_qi dS R[qi][n] ----
+#undef ROW_OF
+  // ---- 7. dR[qi][n] = sum_kk dS B[n][off];  db_nd[n][off] += sum_qi dS R[qi][n] ----
   for (int idx = tid; idx < ATT_QT * 10; idx += 256) {
     const int r = idx / 10, n = idx - r * 10;
     float s = 0.f;
     for (int kk = 0; kk < ATT_NK; ++kk) {
       const int off = maxlen - 1 + r - kk;
-      if (off >= 0 && off < maxlen) s = fmaf(Ss[r * ATT_SS + kk], Bs[n * maxlen + off], s);
+      if (off >= 0 && off < maxlen) s = fmaf(Ds[r * ATT_SS + kk], Bs[n * maxlen + off], s);
     }
     if (q0 + r < t) a.dqkvr[(tok0 + q0 + r) * a.ld + 3 * hid + h * 10 + n] = s;
   }
@@ -477,11 +437,10 @@ __global__ __launch_bounds__(256) void vpt_attn_bwd_kernel(VptAttnBwdArgs a) {
     float s = 0.f;
     for (int r = 0; r < ATT_QT; ++r) {
       const int kk = maxlen - 1 + r - off;
-      if (kk >= 0 && kk < ATT_NK) s = fmaf(Ss[r * ATT_SS + kk], Rs[r * 10 + n], s);
+      if (kk >= 0 && kk < ATT_NK) s = fmaf(Ds[r * ATT_SS + kk], Rs[r * 10 + n], s);
     }
     if (s != 0.f) atomicAdd(a.db_nd + idx, s);
   }
-  (void)dBs; (void)lane;
 }
 
 extern "C" int vpt_attn_bwd_launch(const VptAttnBwdArgs* a, hipStream_t stream) {

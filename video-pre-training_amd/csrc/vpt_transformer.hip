@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256) void vpt_attn_kernel(VptAttnArgs a) {
       finish(128 + l31, r, dot);
     }
   }
+  __syncthreads();   // a softmax row collects the key tiles of all four waves
   // ---- softmax rows (8 per wave) ----
   for (int r = w * 8; r < w * 8 + 8; ++r) {
     float* srow = Ss + r * ATT_SS;
