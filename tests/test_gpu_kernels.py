@@ -37,6 +37,7 @@ def _stats_of(x_nchw):
     (2, 32, 32, 128, 128, True),
     (5, 16, 16, 256, 256, True),
     (2, 64, 64, 64, 128, False),    # 1x stack-1 firstconv
+    (2, 16, 16, 32, 64, True),      # a single 32-channel block: no peeled first block, the last one starts from zeroed accumulators
 ])
 def test_conv3x3(frames, h, w, cin, cout, use_res):
     g = torch.Generator().manual_seed(1)
