@@ -41,12 +41,6 @@
 #define KK_OFF (A_BYTES + 2 * B_BYTES)  // 75072
 #define KK_BYTES (9 * 128 * 4)          // 4608
 #define SMEM_BYTES (KK_OFF + KK_BYTES + 32)  // 79712 (+32: block stats reduction)
-// epilogue staging (overlays the halo / weight buffers after the last step): per wave [res|out tile][xin tile], each
-// 2 channel blocks x 32 pixels x 64 B at an 80-byte pixel pitch (16-byte aligned rows, <= 2-way conflicts on the 8-byte side)
-#define ST_RS 80
-#define ST_N2 (32 * ST_RS)              // 2560
-#define ST_X (2 * ST_N2)                // 5120
-#define ST_WAVE (2 * ST_X)              // 10240 per wave, 40960 per workgroup
 
 // MFMA M-subtile row i (0..31) -> pixel (row 0/1, col 0..15) of a 2x16 patch.  Rows are swapped for columns
 // 4..11 so that each 16-lane ds_read_b128 group {0-3,12-15,20-27} / {4-11,16-19,28-31} stays in one image row.
@@ -62,14 +56,13 @@ __device__ __forceinline__ int sub_row(int i) { return ((i >> 4) ^ (i >> 2) ^ (i
 // 2 dgrad (+ c0 + c1 * xin), 3 dgrad + skip connection.
 template <bool TRACE, int MODE>
 __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
-  constexpr bool COUNTED = true;
   constexpr bool BWD = MODE >= 2, HAS_RES = (MODE == 1 || MODE == 3), USE_X = MODE >= 2;
   constexpr bool DEFER_STORES = MODE != 3;   // mode 3 holds skip + xin pieces as well: no registers left for the packed results
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   // profiling (vpt_conv3x3_set_trace): CU id + 100 MHz timestamps of the tile's phases
   int cu_key = -1;
-  long long t_trace[3], t_epi[5] = {0, 0, 0, 0, 0};
+  long long t_trace[3];
   if (TRACE && tid == 0) {
     t_trace[0] = wall_clock64();
     const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID: cu_id[11:8] sh_id[12] se_id[15:13]
@@ -252,13 +245,9 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
 #define NOP_() ((void)0)
 #define WAIT_BARRIER(n_late_)                                                                             \
   do {                                                                                                    \
-    if constexpr (COUNTED) {                                                                              \
-      asm volatile("s_waitcnt vmcnt(" #n_late_ ") lgkmcnt(0)" ::: "memory");                              \
-      __builtin_amdgcn_s_barrier();                                                                       \
-      asm volatile("" ::: "memory");                                                                      \
-    } else {                                                                                              \
-      __syncthreads();                                                                                    \
-    }                                                                                                     \
+    asm volatile("s_waitcnt vmcnt(" #n_late_ ") lgkmcnt(0)" ::: "memory");                                \
+    __builtin_amdgcn_s_barrier();                                                                         \
+    asm volatile("" ::: "memory");                                                                        \
     SB();                                                                                                 \
   } while (0)
   // Memory ops are issued in a FIXED order and count per wave -- weight DMA (6), then either the halo of the next block
@@ -530,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   if (TRACE && tid == 0) {
     long long* t = a.trace + (size_t)blockIdx.x * 12;
     t[0] = t_trace[0]; t[1] = t_trace[1]; t[2] = t_trace[2]; t[3] = wall_clock64(); t[4] = cu_key; t[5] = 0;
-    for (int k = 0; k < 5; ++k) t[6 + k] = t_epi[k];
+    for (int k = 0; k < 5; ++k) t[6 + k] = 0;   // (slots of the former per-subtile stamps: they perturbed the epilogue's waits)
   }
 }
 
