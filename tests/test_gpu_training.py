@@ -353,7 +353,7 @@ def test_conv_layer_param_grads():
     assert eW < 6e-2 and eg < 1e-1 and eb < 1e-1
 
 
-@pytest.mark.parametrize("frames,cout", [(2, 128), (1, 64)])
+@pytest.mark.parametrize("frames,cout", [(2, 128), (1, 64), (12, 128)])   # 12 frames = 768 tiles: every persistent workgroup sweeps several
 def test_conv_first_backward(frames, cout):
     g = torch.Generator().manual_seed(16)
     W = (torch.randn(cout, 3, 3, 3, generator=g) * 0.3).requires_grad_(True)
