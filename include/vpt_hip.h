@@ -146,6 +146,13 @@ int vpt_action_head_forward(const float* logits, const uint8_t* mask, const floa
 int vpt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, int step,
                   float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
 
+/* The same update for EVERY parameter tensor in one launch (th.optim.Adam(policy.parameters()).step(), behavioural_cloning.py:63-67,
+ * 122).  `table` is a DEVICE array of `ntensors` descriptors { float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+ * uint64_t n; int64_t first_block; } (48 bytes each), sorted by first_block, where first_block counts 1024-element blocks:
+ * first_block[0] = 0, first_block[i+1] = first_block[i] + ceil(n[i] / 1024); total_blocks = the sum. */
+int vpt_adam_step_multi(const void* table, int ntensors, int64_t total_blocks, int step, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, float grad_scale, void* stream);
+
 /* ---- behavioural-cloning step: backward of the heads / trunk / transformer (the reference uses torch autograd,
  * behavioural_cloning.py:117-119).  Linear layers reuse vpt_linear_forward (dgrad: W^T packed; wgrad: A = dY^T). */
 

@@ -264,6 +264,26 @@ def test_adam_step_matches_torch():
     assert torch.allclose(p2, p3, atol=1e-7)
 
 
+def test_adam_step_multi_equals_per_tensor():
+    """One launch over a table of tensors (vpt_adam_step_multi) = the per-tensor kernel, bit for bit, odd sizes and offsets included."""
+    g = torch.Generator().manual_seed(11)
+    sizes = [1, 3, 1024, 1025, 100003, 7, 4096, 2049]
+    flat = torch.randn(sum(sizes) + 3, generator=g).to(DEV)          # views at odd element offsets into one buffer
+    views, off = [], 3
+    for n in sizes:
+        views.append(flat[off:off + n]); off += n
+    grads = [torch.randn(n, generator=g).to(DEV) * 0.1 for n in sizes]
+    pa = [v.clone() for v in views]; ma = [torch.zeros_like(v) for v in views]; va = [torch.zeros_like(v) for v in views]
+    pb = [v.clone() for v in views]; mb = [torch.zeros_like(v) for v in views]; vb = [torch.zeros_like(v) for v in views]
+    for step in (1, 2):
+        for p_, g_, m_, v_ in zip(pa, grads, ma, va):
+            ops.adam_step_(p_, g_, m_, v_, step, lr=0.000181, weight_decay=0.039428, grad_scale=0.5)
+        ops.adam_step_multi_(pb, grads, mb, vb, step, lr=0.000181, weight_decay=0.039428, grad_scale=0.5)
+    torch.cuda.synchronize()
+    for x, y in zip(pa + ma + va, pb + mb + vb):
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("m,n,k,accumulate", [(300, 256, 192, False), (1000, 8768, 2048, False), (64, 65536, 256, True), (8192, 2048, 2048, False)])
 def test_linear_wgrad_tn(m, n, k, accumulate):
     """dW = dY^T X from the row-major activations (vpt_gemm_tn_kernel, LDS transpose reads) against torch."""

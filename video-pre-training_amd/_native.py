@@ -52,6 +52,7 @@ SIGNATURES = {
     "vpt_column_sum": [_P, _P, _I, _I, _I, _P],
     "vpt_masked_attention_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vpt_adam_step": [_P, _P, _P, _P, ctypes.c_uint64, _I, _F, _F, _F, _F, _F, _F, _P],
+    "vpt_adam_step_multi": [_P, _I, _L, _I, _F, _F, _F, _F, _F, _F, _P],
 }
 
 

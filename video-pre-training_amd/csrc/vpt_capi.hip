@@ -230,6 +230,18 @@ int vpt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
   CHECK_LAUNCH(vpt_adam_launch(&a, (hipStream_t)stream), "vpt_adam_step");
 }
 
+int vpt_adam_step_multi(const void* table, int ntensors, int64_t total_blocks, int step, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, float grad_scale, void* stream) {
+  if (step < 1) return fail(-1, "vpt_adam_step_multi: step counts from 1");
+  if (!table && ntensors > 0) return fail(-1, "vpt_adam_step_multi: null table");
+  VptAdamArgs a;
+  a.p = nullptr; a.g = nullptr; a.m = nullptr; a.v = nullptr; a.n = 0;
+  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.grad_scale = grad_scale;
+  a.step_size = (float)((double)lr / (1.0 - pow((double)beta1, (double)step)));
+  a.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+  CHECK_LAUNCH(vpt_adam_multi_launch((const VptAdamTensor*)table, ntensors, (long)total_blocks, &a, (hipStream_t)stream), "vpt_adam_step_multi");
+}
+
 int vpt_bc_nll_backward(const float* lp_buttons, const float* lp_camera, const int64_t* act_buttons,
                         const int64_t* act_camera, void* dz, int M, int nb, int nc, int ldz, float scale, void* stream) {
   VptNllBwdArgs a;

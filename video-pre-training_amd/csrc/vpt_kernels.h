@@ -253,6 +253,15 @@ struct VptAttnBwdArgs {
   int B, t, heads, hid, ld, maxlen;
 };
 
+struct VptAdamTensor {      // one parameter tensor of a multi-tensor Adam step (device array, sorted by first_block)
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  unsigned long long n;     // elements
+  long long first_block;    // first 1024-element block of the launch that belongs to this tensor
+};
+
 struct VptAdamArgs {
   float* p;                // parameters (updated in place)
   const float* g;          // gradients
@@ -266,6 +275,7 @@ struct VptAdamArgs {
 
 extern "C" {
 int vpt_adam_launch(const VptAdamArgs* a, hipStream_t s);
+int vpt_adam_multi_launch(const VptAdamTensor* table_dev, int ntensors, long total_blocks, const VptAdamArgs* h, hipStream_t s);
 int vpt_affine_bwd_launch(const VptAffineBwdArgs* a, int pass, hipStream_t s);
 int vpt_pool_bwd_launch(const VptPoolBwdArgs* a, hipStream_t s);
 int vpt_conv_bwd_prep_launch(const VptConvBwdPrepArgs* a, hipStream_t s);

@@ -47,3 +47,36 @@ extern "C" int vpt_adam_launch(const VptAdamArgs* a, hipStream_t stream) {
   hipLaunchKernelGGL(vpt_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
+
+// ---- multi-tensor form: ONE launch updates every parameter tensor of the model (129 on the 2x policy; the per-tensor form cost
+// 129 launches of ~15 us for 2 ms of HBM traffic).  `table` is a device array of descriptors sorted by first_block; block b
+// finds its tensor by binary search and handles 1024 elements of it (256 threads x float4).
+__global__ __launch_bounds__(256) void vpt_adam_multi_kernel(const VptAdamTensor* __restrict__ table, int ntensors, VptAdamArgs h) {
+  int lo = 0, hi = ntensors - 1;
+  const long b = blockIdx.x;
+  while (lo < hi) {   // last descriptor with first_block <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].first_block <= b) lo = mid; else hi = mid - 1;
+  }
+  const VptAdamTensor t = table[lo];
+  const size_t i0 = ((size_t)(b - t.first_block) * 256 + threadIdx.x) * 4;
+  const float c1 = 1.0f - h.beta1, c2 = 1.0f - h.beta2;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {   // scalar accesses: the tensors are views with arbitrary element alignment
+    const size_t i = i0 + k;
+    if (i >= t.n) break;
+    const float pk = t.p[i];
+    const float gk = fmaf(h.weight_decay, pk, t.g[i] * h.grad_scale);
+    const float m = fmaf(h.beta1, t.m[i], c1 * gk), v = fmaf(h.beta2, t.v[i], c2 * gk * gk);
+    t.m[i] = m; t.v[i] = v;
+    t.p[i] = pk - h.step_size * (m / (sqrtf(v) * h.inv_sqrt_bc2 + h.eps));
+  }
+}
+
+extern "C" int vpt_adam_multi_launch(const VptAdamTensor* table_dev, int ntensors, long total_blocks, const VptAdamArgs* h, hipStream_t stream) {
+  if (ntensors <= 0 || total_blocks <= 0) return 0;
+  if (total_blocks > 0x7fffffffL) return -2;
+  hipLaunchKernelGGL(vpt_adam_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream, table_dev, ntensors, *h);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+

@@ -299,6 +299,29 @@ def adam_step_(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.99
           ctypes.c_float(grad_scale), _stream())
 
 
+def adam_step_multi_(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    """The Adam update of adam_step_ for a list of tensors in ONE launch (flat fp32 views; same arithmetic per element)."""
+    import numpy as np
+    n_t = len(params)
+    if n_t == 0:
+        return
+    rec = np.zeros(n_t, dtype=[("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<u8"), ("fb", "<i8")])
+    blk = 0
+    for i, (p, g, m, v) in enumerate(zip(params, grads, exp_avgs, exp_avg_sqs)):
+        for t, nme in ((p, "param"), (g, "grad"), (m, "exp_avg"), (v, "exp_avg_sq")):
+            _chk(t, torch.float32, nme)
+            assert t.is_contiguous()
+        n = p.numel()
+        assert g.numel() == n and m.numel() == n and v.numel() == n
+        rec[i] = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, blk)
+        blk += (n + 1023) // 1024
+    table = torch.from_numpy(rec.view(np.uint8)).to(params[0].device, non_blocking=False)
+    _call("vpt_adam_step_multi", dict(bytes=28.0 * sum(p.numel() for p in params)), ptr(table), n_t, blk, int(step),
+          ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps), ctypes.c_float(weight_decay),
+          ctypes.c_float(grad_scale), _stream())
+    return table   # keep alive until the launch has been enqueued (the caller may drop it afterwards: stream-ordered free)
+
+
 # ---- backward (behavioural-cloning step) ---------------------------------------------------------------
 def nll_backward(lp_buttons, lp_camera, act_buttons, act_camera, ldz, scale):
     """bf16 [M, ldz] gradient of the BC loss w.r.t. the fused head logits (value column and padding zero)."""

@@ -474,11 +474,10 @@ class BCTrainer:
         loss, grads, state_out = self.reduced_loss_and_grads(img_u8, first, state_in, act_buttons, act_camera)
         names = [n for n in self.trainable if n in grads]
         self.step_count += 1
-        for n in names:
-            gr = grads[n].contiguous().view(-1)
-            p = self.params[n].data.view(-1)
-            ops.adam_step_(p, gr, self.m[n].view(-1), self.v[n].view(-1), self.step_count, lr=self.lr, beta1=self.betas[0],
-                           beta2=self.betas[1], eps=self.eps, weight_decay=self.wd)
+        # one launch for all tensors (th.optim.Adam(policy.parameters()).step(), behavioural_cloning.py:122)
+        ops.adam_step_multi_([self.params[n].data.view(-1) for n in names], [grads[n].contiguous().view(-1) for n in names],
+                             [self.m[n].view(-1) for n in names], [self.v[n].view(-1) for n in names], self.step_count,
+                             lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.wd)
         self.policy._packed_key = None  # weights changed: re-pack before the next forward
         return float(loss), state_out
 
