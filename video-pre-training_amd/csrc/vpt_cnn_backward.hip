@@ -349,76 +349,76 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_kernel(VptConvBwdPrepAr
   for (int i = threadIdx.x; i < 9 * 32; i += 256) srow[(i >> 5) * Cout + cb * 32 + (i & 31)] = tab_[i];
 }
 
-#define FIN_COLS 16  // 256 * 16 >= 9 * Cout  (Cout <= 448)
-// finish: grid = ceil(frames / 16) workgroups, each walks 16 frames; thread = columns (e, c) of the [9][Cout] table
+#define FIN_FB 32  // frames per column-sum workgroup
+// finish, one launch with two kinds of workgroups (all independent, so the launch is one round of loads deep):
+//   blocks [0, ceil(F/4)):  one WAVE per frame: T1, T2 and the (c0, c1) coefficients from that frame's row of sbuf;
+//   the rest:               one thread per column (e, c) of the [9][Cout] table x 32 frames: dSA, dSG partial sums -> atomics.
 __global__ __launch_bounds__(256) void vpt_conv_bwd_finish_kernel(VptConvBwdPrepArgs a) {
-  __shared__ float red_[8];
-  const int Cout = a.CB * 32, ncol = 9 * Cout;
-  const int f0 = blockIdx.x * 16, f1 = min(f0 + 16, a.frames);
-  float acc_sa[FIN_COLS], acc_sg[FIN_COLS], sa[FIN_COLS], sg[FIN_COLS];
-#pragma unroll
-  for (int j = 0; j < FIN_COLS; ++j) {
-    acc_sa[j] = acc_sg[j] = 0.f;
-    const int i = threadIdx.x + 256 * j;
-    const int e = i / Cout, c = i - e * Cout;
-    sa[j] = (i < ncol) ? a.edge_sa[e * a.CoutPad + c] : 0.f;
-    sg[j] = (i < ncol) ? a.edge_sg[e * a.CoutPad + c] : 0.f;
-  }
-  for (int f = f0; f < f1; ++f) {
+  __shared__ float nrm_[FIN_FB];
+  const int Cout = a.CB * 32, ncol = 9 * Cout, ld = ncol + a.CB;
+  const int nA = (a.frames + 3) >> 2;
+  const int lane = threadIdx.x & 63;
+  if ((int)blockIdx.x < nA) {
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= a.frames) return;
     float mean, rstd;
     frame_mean_rstd(a.stats_in, f, a.inv_count_in, mean, rstd);
-    const float nrm = -rstd * mean;
-    const float* srow = a.sbuf + (size_t)f * (ncol + a.CB);
+    const float* srow = a.sbuf + (size_t)f * ld;
     float t1c = 0.f, t2c = 0.f;
-#pragma unroll
-    for (int j = 0; j < FIN_COLS; ++j) {
-      const int i = threadIdx.x + 256 * j;
-      if (i < ncol) {
-        const float S = srow[i];
-        acc_sa[j] += S;
-        acc_sg[j] = fmaf(nrm, S, acc_sg[j]);
-        t1c = fmaf(sa[j], S, t1c);
-        t2c = fmaf(sg[j], S, t2c);
-      }
+#pragma unroll 4
+    for (int i = lane; i < ncol; i += 64) {
+      const int e = i / Cout, c = i - e * Cout;
+      const float S = srow[i];
+      t1c = fmaf(a.edge_sa[e * a.CoutPad + c], S, t1c);
+      t2c = fmaf(a.edge_sg[e * a.CoutPad + c], S, t2c);
     }
     t1c = wave_sum(t1c);
     t2c = wave_sum(t2c);
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red_[w] = t1c; red_[4 + w] = t2c; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    if (lane == 0) {
       double tv = 0.0;
       for (int cb = 0; cb < a.CB; ++cb) tv += (double)srow[ncol + cb];
-      const double T1 = tv - (double)((red_[0] + red_[1]) + (red_[2] + red_[3]));
-      const double T2 = (double)((red_[4] + red_[5]) + (red_[6] + red_[7]));
+      const double T1 = tv - (double)t1c, T2 = (double)t2c;
       if (a.t12) { a.t12[2 * f] = T1; a.t12[2 * f + 1] = T2; }
       // statistics terms of the input gradient: dx += c0 + c1 x,  c1 = -rstd^2 T1 / n,  c0 = -rstd T2 / n - c1 mu
       const double c1 = -(double)rstd * rstd * T1 * a.inv_count_in;
       a.coef[2 * f] = (float)(-(double)rstd * T2 * a.inv_count_in - c1 * mean);
       a.coef[2 * f + 1] = (float)c1;
     }
-    __syncthreads();
+    return;
   }
-#pragma unroll
-  for (int j = 0; j < FIN_COLS; ++j) {
-    const int i = threadIdx.x + 256 * j;
-    if (i < ncol) {
-      const int e = i / Cout, c = i - e * Cout;
-      atomicAdd(a.d_sa + e * a.CoutPad + c, acc_sa[j]);
-      atomicAdd(a.d_sg + e * a.CoutPad + c, acc_sg[j]);
-    }
+  const int b = blockIdx.x - nA, ncb = (ncol + 255) >> 8;
+  const int colb = b % ncb, f0 = (b / ncb) * FIN_FB, nf = min(FIN_FB, a.frames - f0);
+  if ((int)threadIdx.x < nf) {
+    float mean, rstd;
+    frame_mean_rstd(a.stats_in, f0 + threadIdx.x, a.inv_count_in, mean, rstd);
+    nrm_[threadIdx.x] = -rstd * mean;
   }
+  __syncthreads();
+  const int i = colb * 256 + threadIdx.x;
+  if (i >= ncol) return;
+  const float* s = a.sbuf + (size_t)f0 * ld + i;
+  float asa = 0.f, asg = 0.f;
+#pragma unroll 8
+  for (int k = 0; k < nf; ++k) {
+    const float S = s[(size_t)k * ld];
+    asa += S;
+    asg = fmaf(nrm_[k], S, asg);
+  }
+  const int e = i / Cout, c = i - e * Cout;
+  atomicAdd(a.d_sa + e * a.CoutPad + c, asa);
+  atomicAdd(a.d_sg + e * a.CoutPad + c, asg);
 }
 
 extern "C" int vpt_conv_bwd_prep_launch(const VptConvBwdPrepArgs* a0, hipStream_t stream) {
   VptConvBwdPrepArgs a = *a0;
   if (a.frames <= 0 || !a.sbuf || !a.coef) return -1;
-  if (a.W < 8 || a.W > 64 || (a.W & (a.W - 1)) || a.CB * 32 * 9 > 256 * FIN_COLS) return -1;  // column-per-thread mapping: W in {8,16,32,64}
+  if (a.W < 8 || a.W > 64 || (a.W & (a.W - 1))) return -1;  // column-per-thread mapping: W in {8,16,32,64}
   if (!a.dy && (!a.dpooled || !a.argmax || (a.H & 1) || (a.W & 1))) return -1;
   a.wshift = 31 - __builtin_clz((unsigned)a.W);
   const long grid = (long)a.frames * a.CB;
   if (grid > 0x7fffffffL) return -2;
   hipLaunchKernelGGL(vpt_conv_bwd_prep_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
-  hipLaunchKernelGGL(vpt_conv_bwd_finish_kernel, dim3((unsigned)((a.frames + 15) / 16)), dim3(256), 0, stream, a);
+  const int fin_blocks = (a.frames + 3) / 4 + ((9 * a.CB * 32 + 255) / 256) * ((a.frames + FIN_FB - 1) / FIN_FB);
+  hipLaunchKernelGGL(vpt_conv_bwd_finish_kernel, dim3((unsigned)fin_blocks), dim3(256), 0, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

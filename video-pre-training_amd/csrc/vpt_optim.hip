@@ -61,10 +61,23 @@ __global__ __launch_bounds__(256) void vpt_adam_multi_kernel(const VptAdamTensor
   const VptAdamTensor t = table[lo];
   const size_t i0 = ((size_t)(b - t.first_block) * 256 + threadIdx.x) * 4;
   const float c1 = 1.0f - h.beta1, c2 = 1.0f - h.beta2;
+  if (i0 + 4 <= t.n) {   // 16-byte accesses like vpt_adam_kernel (views may start at any element: unaligned dwordx4 is legal on gfx950)
+    f32x4 p = *(const f32x4*)(t.p + i0), g = *(const f32x4*)(t.g + i0);
+    f32x4 m = *(const f32x4*)(t.m + i0), v = *(const f32x4*)(t.v + i0);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {   // scalar accesses: the tensors are views with arbitrary element alignment
-    const size_t i = i0 + k;
-    if (i >= t.n) break;
+    for (int k = 0; k < 4; ++k) {
+      const float gk = fmaf(h.weight_decay, p[k], g[k] * h.grad_scale);
+      m[k] = fmaf(h.beta1, m[k], c1 * gk);
+      v[k] = fmaf(h.beta2, v[k], c2 * gk * gk);
+      const float denom = sqrtf(v[k]) * h.inv_sqrt_bc2 + h.eps;
+      p[k] -= h.step_size * (m[k] / denom);
+    }
+    *(f32x4*)(t.p + i0) = p;
+    *(f32x4*)(t.m + i0) = m;
+    *(f32x4*)(t.v + i0) = v;
+    return;
+  }
+  for (size_t i = i0; i < t.n; ++i) {   // the tensor's last (partial) group of four
     const float pk = t.p[i];
     const float gk = fmaf(h.weight_decay, pk, t.g[i] * h.grad_scale);
     const float m = fmaf(h.beta1, t.m[i], c1 * gk), v = fmaf(h.beta2, t.v[i], c2 * gk * gk);
