@@ -43,6 +43,7 @@ __device__ __forceinline__ float sum_oct16(float v) {  // over the 16 lanes shar
   return v;
 }
 
+template <bool PER_ELEMENT>
 __global__ __launch_bounds__(256) void vpt_affine_bwd_reduce_kernel(VptAffineBwdArgs a) {
   __shared__ float part_[4 * 64];
   const int chunks = (a.HW + RED_PIX - 1) / RED_PIX;
@@ -56,32 +57,46 @@ __global__ __launch_bounds__(256) void vpt_affine_bwd_reduce_kernel(VptAffineBwd
   float g[8], dgc[8], dbc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    g[k] = a.per_element ? 0.f : a.gain[cb * 32 + oct * 8 + k];
+    g[k] = PER_ELEMENT ? 0.f : a.gain[cb * 32 + oct * 8 + k];
     dgc[k] = dbc[k] = 0.f;
   }
   float s1 = 0.f, s2 = 0.f;
   const int p_end = min(a.HW, (chunk + 1) * RED_PIX);
-#pragma unroll 4
-  for (int pix = chunk * RED_PIX + (threadIdx.x >> 2); pix < p_end; pix += 64) {
-    const size_t eoff = ((size_t)cb * a.HW + pix) * 32 + oct * 8;
-    float x[8], dy[8];
-    unpack8(*(const u32x4*)(a.x + fbase + eoff), x);
-    unpack8(*(const u32x4*)(a.dy + fbase + eoff), dy);
-    if (a.per_element) {
-      const f32x4 g0 = *(const f32x4*)(a.gain + eoff), g1 = *(const f32x4*)(a.gain + eoff + 4);
-      g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+  // four pixels per trip: their loads (clamped, so unconditional) all go out before the first is used
+  for (int p0 = chunk * RED_PIX + (threadIdx.x >> 2); p0 < p_end; p0 += 256) {
+    u32x4 xv[4], dv[4];
+    f32x4 gv[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int pix = min(p0 + 64 * j, p_end - 1);
+      const size_t eoff = ((size_t)cb * a.HW + pix) * 32 + oct * 8;
+      xv[j] = *(const u32x4*)(a.x + fbase + eoff);
+      dv[j] = *(const u32x4*)(a.dy + fbase + eoff);
+      if (PER_ELEMENT) { gv[j][0] = *(const f32x4*)(a.gain + eoff); gv[j][1] = *(const f32x4*)(a.gain + eoff + 4); }
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float xh = (x[k] - mean) * rstd, dg = dy[k] * g[k];
-      s1 += dg;
-      s2 = fmaf(dg, xh, s2);
-      dgc[k] = fmaf(dy[k], xh, dgc[k]);
-      dbc[k] += dy[k];
+    for (int j = 0; j < 4; ++j) {
+      const bool live = p0 + 64 * j < p_end;
+      float x[8], dy[8];
+      unpack8(xv[j], x);
+      unpack8(dv[j], dy);
+      if (PER_ELEMENT) {
+        g[0] = gv[j][0].x; g[1] = gv[j][0].y; g[2] = gv[j][0].z; g[3] = gv[j][0].w;
+        g[4] = gv[j][1].x; g[5] = gv[j][1].y; g[6] = gv[j][1].z; g[7] = gv[j][1].w;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float d = live ? dy[k] : 0.f;   // a clamped duplicate contributes nothing
+        const float xh = (x[k] - mean) * rstd, dg = d * g[k];
+        s1 += dg;
+        s2 = fmaf(dg, xh, s2);
+        dgc[k] = fmaf(d, xh, dgc[k]);
+        dbc[k] += d;
+      }
     }
   }
   block_sum2_atomic_f64(s1, s2, a.ab + 2 * f);
-  if (!a.per_element) {
+  if (!PER_ELEMENT) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -105,6 +120,7 @@ __global__ __launch_bounds__(256) void vpt_affine_bwd_reduce_kernel(VptAffineBwd
 }
 
 // pass 2: dx = rstd (dy g - A/n - xhat B/n) [+ dx_add]
+template <bool PER_ELEMENT, bool HAS_ADD>
 __global__ __launch_bounds__(256) void vpt_affine_bwd_apply_kernel(VptAffineBwdArgs a) {
   const int per_frame = a.CB * a.HW * 4;
   const int blocks_per_frame = (per_frame + EW_PER_BLOCK - 1) / EW_PER_BLOCK;
@@ -113,23 +129,36 @@ __global__ __launch_bounds__(256) void vpt_affine_bwd_apply_kernel(VptAffineBwdA
   float mean, rstd;
   frame_mean_rstd(a.stats_in, f, a.inv_count, mean, rstd);
   const float A = (float)(a.ab[2 * f] * a.inv_count), B = (float)(a.ab[2 * f + 1] * a.inv_count);
+  // all loads of the thread's EW_ITEMS items first (clamped index, so unconditional), then the arithmetic
+  u32x4 xv[EW_ITEMS], dv[EW_ITEMS], ev[EW_ITEMS];
+  f32x4 g0[EW_ITEMS], g1[EW_ITEMS];
+#pragma unroll
+  for (int it = 0; it < EW_ITEMS; ++it) {
+    const int item = min(base + it * 256, per_frame - 1);
+    const size_t off = (size_t)f * per_frame * 8 + (size_t)item * 8;
+    xv[it] = *(const u32x4*)(a.x + off);
+    dv[it] = *(const u32x4*)(a.dy + off);
+    if (HAS_ADD) ev[it] = *(const u32x4*)(a.dx_add + off);
+    const int gidx = PER_ELEMENT ? item * 8 : (item / (a.HW * 4)) * 32 + (item & 3) * 8;
+    g0[it] = *(const f32x4*)(a.gain + gidx); g1[it] = *(const f32x4*)(a.gain + gidx + 4);
+  }
 #pragma unroll
   for (int it = 0; it < EW_ITEMS; ++it) {
     const int item = base + it * 256;
     if (item >= per_frame) break;
     const size_t off = (size_t)f * per_frame * 8 + (size_t)item * 8;
     float x[8], dy[8], o[8];
-    unpack8(*(const u32x4*)(a.x + off), x);
-    unpack8(*(const u32x4*)(a.dy + off), dy);
-    const int gidx = a.per_element ? item * 8 : (item / (a.HW * 4)) * 32 + (item & 3) * 8;
+    unpack8(xv[it], x);
+    unpack8(dv[it], dy);
+    const float g[8] = {g0[it].x, g0[it].y, g0[it].z, g0[it].w, g1[it].x, g1[it].y, g1[it].z, g1[it].w};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float xh = (x[k] - mean) * rstd;
-      o[k] = rstd * (dy[k] * a.gain[gidx + k] - A - xh * B);
+      o[k] = rstd * (dy[k] * g[k] - A - xh * B);
     }
-    if (a.dx_add) {
+    if (HAS_ADD) {
       float e[8];
-      unpack8(*(const u32x4*)(a.dx_add + off), e);
+      unpack8(ev[it], e);
 #pragma unroll
       for (int k = 0; k < 8; ++k) o[k] += e[k];
     }
@@ -173,9 +202,19 @@ extern "C" int vpt_affine_bwd_launch(const VptAffineBwdArgs* a, int pass, hipStr
   if (pass == 1) {
     const long g1 = (long)a->frames * a->CB * ((a->HW + RED_PIX - 1) / RED_PIX);
     if (g1 > 0x7fffffffL) return -2;
-    hipLaunchKernelGGL(vpt_affine_bwd_reduce_kernel, dim3((unsigned)g1), dim3(256), 0, stream, *a);
+    if (a->per_element) hipLaunchKernelGGL(vpt_affine_bwd_reduce_kernel<true>, dim3((unsigned)g1), dim3(256), 0, stream, *a);
+    else hipLaunchKernelGGL(vpt_affine_bwd_reduce_kernel<false>, dim3((unsigned)g1), dim3(256), 0, stream, *a);
   }
-  else if (pass == 2) hipLaunchKernelGGL(vpt_affine_bwd_apply_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *a);
+  else if (pass == 2) {
+    const dim3 g((unsigned)grid), b(256);
+    if (a->per_element) {
+      if (a->dx_add) hipLaunchKernelGGL((vpt_affine_bwd_apply_kernel<true, true>), g, b, 0, stream, *a);
+      else hipLaunchKernelGGL((vpt_affine_bwd_apply_kernel<true, false>), g, b, 0, stream, *a);
+    } else {
+      if (a->dx_add) hipLaunchKernelGGL((vpt_affine_bwd_apply_kernel<false, true>), g, b, 0, stream, *a);
+      else hipLaunchKernelGGL((vpt_affine_bwd_apply_kernel<false, false>), g, b, 0, stream, *a);
+    }
+  }
   else {
     const int gy = a->frames >= 512 ? 32 : (a->frames >= 16 ? 8 : 1);
     hipLaunchKernelGGL(vpt_affine_bwd_elem_kernel, dim3((per_frame + 255) / 256, gy), dim3(256), 0, stream, *a);
@@ -249,6 +288,15 @@ extern "C" int vpt_pool_bwd_launch(const VptPoolBwdArgs* a, hipStream_t stream) 
 // With (dpooled, argmax) instead of dy the max-pool backward is fused in: dy(y,x) = sum over the <= 4 windows that
 // contain (y,x) of dpooled[window] * [argmax[window] == position code of (y,x)].
 
+// Loads are issued one row ahead of their use (the variants are compile-time, so no branch sits between a load and
+// the next): per thread 32..112 bytes in flight, which is what keeps a workgroup-per-plane walk at HBM speed.
+struct PrepRow {
+  u32x4 y, dy, res;
+  u32x4 dp[4];
+  uint64_t am[4];
+};
+
+template <bool HAS_DY, bool HAS_RES>
 __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_kernel(VptConvBwdPrepArgs a) {
   __shared__ float tab_[9 * 32];
   const int HW = a.H * a.W;
@@ -262,36 +310,54 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_kernel(VptConvBwdPrepAr
   const size_t plane = ((size_t)(f * a.CB + cb) * HW) * 32 + oct * 8;
   const int PH = a.H >> 1, PW = a.W >> 1;
   const size_t pplane = ((size_t)(f * a.CB + cb) * PH * PW) * 32 + oct * 8;
-  const int px_lo = x >> 1, px_hi = min((x + 1) >> 1, PW - 1);
+  // the <= 2 x 2 pooling windows that contain (y, x): A = coord >> 1 (always), B = (coord + 1) >> 1 (odd coord, inside)
+  const int pxA = x >> 1, pxB = min((x + 1) >> 1, PW - 1);
+  const bool vxB = (x & 1) && ((x + 1) >> 1) < PW;
+  const unsigned cxA = (unsigned)(x & 1) + 1u;   // window column code of x: x - 2 px + 1 (B: always 0)
+  auto load_row = [&](int y, PrepRow& r) {
+    const size_t off = plane + (size_t)(y * a.W + x) * 32;
+    r.y = *(const u32x4*)(a.y + off);
+    if (HAS_RES) r.res = *(const u32x4*)(a.res + off);
+    if (HAS_DY) {
+      r.dy = *(const u32x4*)(a.dy + off);
+    } else {
+      const int pyA = y >> 1, pyB = min((y + 1) >> 1, PH - 1);
+      const size_t p0 = pplane + (size_t)(pyA * PW + pxA) * 32, p1 = pplane + (size_t)(pyA * PW + pxB) * 32;
+      const size_t p2 = pplane + (size_t)(pyB * PW + pxA) * 32, p3 = pplane + (size_t)(pyB * PW + pxB) * 32;
+      r.am[0] = *(const uint64_t*)(a.argmax + p0); r.dp[0] = *(const u32x4*)(a.dpooled + p0);
+      r.am[1] = *(const uint64_t*)(a.argmax + p1); r.dp[1] = *(const u32x4*)(a.dpooled + p1);
+      r.am[2] = *(const uint64_t*)(a.argmax + p2); r.dp[2] = *(const u32x4*)(a.dpooled + p2);
+      r.am[3] = *(const uint64_t*)(a.argmax + p3); r.dp[3] = *(const u32x4*)(a.dpooled + p3);
+    }
+  };
   float all[8], top[8], bot[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) all[k] = top[k] = bot[k] = 0.f;
   float tv = 0.f;
-#pragma unroll 2
-  for (int y = ry; y < a.H; y += R) {
-    const size_t off = plane + (size_t)(y * a.W + x) * 32;
+  auto process = [&](int y, const PrepRow& cur) {
     float dy[8], v[8], o[8];
-    unpack8(*(const u32x4*)(a.y + off), v);
-    if (a.dy) {
-      unpack8(*(const u32x4*)(a.dy + off), dy);
+    unpack8(cur.y, v);
+    if (HAS_DY) {
+      unpack8(cur.dy, dy);
     } else {
 #pragma unroll
       for (int k = 0; k < 8; ++k) dy[k] = 0.f;
-      const int py_lo = y >> 1, py_hi = min((y + 1) >> 1, PH - 1);
-      for (int py = py_lo; py <= py_hi; ++py)
-        for (int px = px_lo; px <= px_hi; ++px) {
-          const unsigned code = (unsigned)((y - 2 * py + 1) * 3 + (x - 2 * px + 1));
-          const size_t po = pplane + (size_t)(py * PW + px) * 32;
-          const uint64_t am = *(const uint64_t*)(a.argmax + po);
-          float d[8];
-          unpack8(*(const u32x4*)(a.dpooled + po), d);
+      const bool vyB = (y & 1) && ((y + 1) >> 1) < PH;
+      const unsigned cyA = ((unsigned)(y & 1) + 1u) * 3u;
+      const unsigned code[4] = {cyA + cxA, cyA, cxA, 0u};
+      const bool valid[4] = {true, vxB, vyB, vxB && vyB};
 #pragma unroll
-          for (int k = 0; k < 8; ++k) dy[k] += (((unsigned)(am >> (8 * k)) & 0xffu) == code) ? d[k] : 0.f;
-        }
+      for (int q = 0; q < 4; ++q) {   // same order as the window scan (py, px ascending)
+        float d[8];
+        unpack8(cur.dp[q], d);
+        const unsigned want = valid[q] ? code[q] : 0xffu;   // 0xff matches no stored code (0..8, 15)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dy[k] += (((unsigned)(cur.am[q] >> (8 * k)) & 0xffu) == want) ? d[k] : 0.f;
+      }
     }
-    if (a.res) {
+    if (HAS_RES) {
       float rr[8];
-      unpack8(*(const u32x4*)(a.res + off), rr);
+      unpack8(cur.res, rr);
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] -= rr[k];
     }
@@ -305,7 +371,20 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_kernel(VptConvBwdPrepAr
       top[k] = is_top ? dz : top[k];
       bot[k] = is_bot ? dz : bot[k];
     }
-    *(u32x4*)(a.dacc + off) = pack8(o);
+    *(u32x4*)(a.dacc + plane + (size_t)(y * a.W + x) * 32) = pack8(o);
+  };
+  // two row buffers in ping-pong, so a row's loads are issued a full iteration before their first use and no
+  // register copy forces an early wait
+  PrepRow ra, rb;
+  if (ry < a.H) load_row(ry, ra);
+  for (int y = ry; y < a.H; y += 2 * R) {
+    load_row(min(y + R, a.H - 1), rb);       // (clamped: past the end the row is re-read, not used)
+    __builtin_amdgcn_sched_barrier(0);       // keep the loads ABOVE the arithmetic of the other buffer
+    process(y, ra);
+    __builtin_amdgcn_sched_barrier(0);
+    load_row(min(y + 2 * R, a.H - 1), ra);
+    __builtin_amdgcn_sched_barrier(0);
+    if (y + R < a.H) process(y + R, rb);
   }
   // S[ey][ex][channel]: reduce over the threads of this column class
   const int ex = (x == 0) ? 0 : ((x == a.W - 1) ? 2 : 1);
@@ -417,7 +496,13 @@ extern "C" int vpt_conv_bwd_prep_launch(const VptConvBwdPrepArgs* a0, hipStream_
   a.wshift = 31 - __builtin_clz((unsigned)a.W);
   const long grid = (long)a.frames * a.CB;
   if (grid > 0x7fffffffL) return -2;
-  hipLaunchKernelGGL(vpt_conv_bwd_prep_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
+  if (a.dy) {
+    if (a.res) hipLaunchKernelGGL((vpt_conv_bwd_prep_kernel<true, true>), dim3((unsigned)grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((vpt_conv_bwd_prep_kernel<true, false>), dim3((unsigned)grid), dim3(256), 0, stream, a);
+  } else {
+    if (a.res) hipLaunchKernelGGL((vpt_conv_bwd_prep_kernel<false, true>), dim3((unsigned)grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((vpt_conv_bwd_prep_kernel<false, false>), dim3((unsigned)grid), dim3(256), 0, stream, a);
+  }
   const int fin_blocks = (a.frames + 3) / 4 + ((9 * a.CB * 32 + 255) / 256) * ((a.frames + FIN_FB - 1) / FIN_FB);
   hipLaunchKernelGGL(vpt_conv_bwd_finish_kernel, dim3((unsigned)fin_blocks), dim3(256), 0, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -3;

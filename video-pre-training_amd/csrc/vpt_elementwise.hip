@@ -19,6 +19,10 @@ typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 #define EW_ITEMS 4
 #define EW_PER_BLOCK (256 * EW_ITEMS)
 
+// All nine loads of a window are issued unconditionally from clamped coordinates (only row 2py-1 at py = 0 and column
+// 2px-1 at px = 0 can fall outside: H, W even) and a padded position is zeroed after the load, so no branch sits
+// between the loads and a thread keeps 9..36 of them in flight.
+template <bool ARGMAX>
 __global__ __launch_bounds__(256) void vpt_pool_kernel(VptPoolArgs a) {
   const int PH = a.H >> 1, PW = a.W >> 1;
   const int per_frame = a.CB * PH * PW * 4;  // 16-byte items
@@ -26,54 +30,70 @@ __global__ __launch_bounds__(256) void vpt_pool_kernel(VptPoolArgs a) {
   const int f = blockIdx.x / blocks_per_frame;
   const int base = (blockIdx.x - f * blocks_per_frame) * EW_PER_BLOCK + threadIdx.x;
   float s_sum = 0.f, s_sq = 0.f;
+  u16x8 v[2][9];
+  auto decode = [&](int it, int& oct, int& px, int& py, int& cb) {
+    const int item = min(base + it * 256, per_frame - 1);
+    oct = item & 3;
+    int r = item >> 2;
+    px = r % PW; r /= PW;
+    py = r % PH;
+    cb = r / PH;
+  };
+  auto load = [&](int it, u16x8* dst) {
+    int oct, px, py, cb;
+    decode(it, oct, px, py, cb);
+    const vpt_op16* plane = a.x + ((size_t)(f * a.CB + cb) * a.H * a.W) * 32 + oct * 8;
+    const int yy[3] = {max(2 * py - 1, 0), 2 * py, 2 * py + 1}, xx[3] = {max(2 * px - 1, 0), 2 * px, 2 * px + 1};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) dst[dy * 3 + dx] = *(const u16x8*)(plane + (size_t)(yy[dy] * a.W + xx[dx]) * 32);
+  };
+  load(0, v[0]);
 #pragma unroll
   for (int it = 0; it < EW_ITEMS; ++it) {
-    const int item = base + it * 256;
-    if (item >= per_frame) break;
-    const int oct = item & 3;
-    int r = item >> 2;
-    const int px = r % PW; r /= PW;
-    const int py = r % PH;
-    const int cb = r / PH;
-    const vpt_op16* plane = a.x + ((size_t)(f * a.CB + cb) * a.H * a.W) * 32 + oct * 8;
+    if (it + 1 < EW_ITEMS) load(it + 1, v[(it + 1) & 1]);   // the next window's loads go out before this one is reduced
+    __builtin_amdgcn_sched_barrier(0);
+    int oct, px, py, cb;
+    decode(it, oct, px, py, cb);
+    const unsigned short row_keep = py ? 0xffff : 0, col_keep = px ? 0xffff : 0;
     u16x8 m = {0, 0, 0, 0, 0, 0, 0, 0};
     u16x8 am = {15, 15, 15, 15, 15, 15, 15, 15};
 #pragma unroll
-    for (int dy = -1; dy <= 1; ++dy) {
-      const int y = 2 * py + dy;
-      if (y < 0 || y >= a.H) continue;
+    for (int q = 0; q < 9; ++q) {
+      u16x8 w = v[it & 1][q];
+      if (q < 3) w &= row_keep;
+      if (q % 3 == 0) w &= col_keep;
+      if (ARGMAX) {  // strict > keeps the FIRST maximum in scan order (torch's rule); an all-zero window keeps 15
 #pragma unroll
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int x = 2 * px + dx;
-        if (x < 0 || x >= a.W) continue;
-        const u16x8 v = *(const u16x8*)(plane + (size_t)(y * a.W + x) * 32);
-        if (a.argmax) {  // strict > keeps the FIRST maximum in scan order (torch's rule); an all-zero window keeps 15
-          const unsigned short code = (unsigned short)((dy + 1) * 3 + (dx + 1));
-#pragma unroll
-          for (int k = 0; k < 8; ++k) am[k] = (v[k] > m[k]) ? code : am[k];
-        }
-        m = __builtin_elementwise_max(m, v);
+        for (int k = 0; k < 8; ++k) am[k] = (w[k] > m[k]) ? (unsigned short)q : am[k];
       }
+      m = __builtin_elementwise_max(m, w);
     }
-    if (a.argmax) {
-      uint64_t pk = 0;
+    if (base + it * 256 < per_frame) {
+      const size_t po = ((size_t)(f * a.CB + cb) * PH * PW + (size_t)(py * PW + px)) * 32 + oct * 8;
+      if (ARGMAX) {
+        uint64_t pk = 0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) pk |= (uint64_t)(am[k] & 0xff) << (8 * k);
-      *(uint64_t*)(a.argmax + ((size_t)(f * a.CB + cb) * PH * PW + (size_t)(py * PW + px)) * 32 + oct * 8) = pk;
-    }
-    const u32x4 mv = __builtin_bit_cast(u32x4, m);
-    float vals[8];
-    unpack8(mv, vals);
+        for (int k = 0; k < 8; ++k) pk |= (uint64_t)(am[k] & 0xff) << (8 * k);
+        *(uint64_t*)(a.argmax + po) = pk;
+      }
+      const u32x4 mv = __builtin_bit_cast(u32x4, m);
+      float vals[8];
+      unpack8(mv, vals);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      s_sum += vals[k];
-      s_sq = fmaf(vals[k], vals[k], s_sq);
+      for (int k = 0; k < 8; ++k) {
+        s_sum += vals[k];
+        s_sq = fmaf(vals[k], vals[k], s_sq);
+      }
+      *(u32x4*)(a.y + po) = mv;
     }
-    *(u32x4*)(a.y + ((size_t)(f * a.CB + cb) * PH * PW + (size_t)(py * PW + px)) * 32 + oct * 8) = mv;
+    __builtin_amdgcn_sched_barrier(0);
   }
   if (a.stats_out) block_stats_atomic(s_sum, s_sq, a.stats_out, f);
 }
 
+template <bool PER_ELEMENT>
 __global__ __launch_bounds__(256) void vpt_affine_kernel(VptAffineArgs a) {
   const int per_frame = a.CB * a.HW * 4;  // 16-byte items
   const int blocks_per_frame = (per_frame + EW_PER_BLOCK - 1) / EW_PER_BLOCK;
@@ -82,37 +102,34 @@ __global__ __launch_bounds__(256) void vpt_affine_kernel(VptAffineArgs a) {
   float mean, rstd;
   frame_mean_rstd(a.stats_in, f, a.inv_count, mean, rstd);
   const float shift = -mean * rstd;
+  // every load of the thread (x, gain, bias of its EW_ITEMS items; clamped, so unconditional) is issued before the first use
   u32x4 xv[EW_ITEMS];
+  f32x4 g0[EW_ITEMS], g1[EW_ITEMS], b0[EW_ITEMS], b1[EW_ITEMS];
 #pragma unroll
   for (int it = 0; it < EW_ITEMS; ++it) {
-    const int item = base + it * 256;
-    if (item < per_frame) xv[it] = *(const u32x4*)(a.x + (size_t)f * per_frame * 8 + (size_t)item * 8);
+    const int item = min(base + it * 256, per_frame - 1);
+    xv[it] = *(const u32x4*)(a.x + (size_t)f * per_frame * 8 + (size_t)item * 8);
+    const int gidx = PER_ELEMENT ? item * 8 : (item / (a.HW * 4)) * 32 + (item & 3) * 8;
+    g0[it] = *(const f32x4*)(a.gain + gidx); g1[it] = *(const f32x4*)(a.gain + gidx + 4);
+    b0[it] = *(const f32x4*)(a.bias + gidx); b1[it] = *(const f32x4*)(a.bias + gidx + 4);
   }
   float s_sum = 0.f, s_sq = 0.f;
 #pragma unroll
   for (int it = 0; it < EW_ITEMS; ++it) {
     const int item = base + it * 256;
-    if (item >= per_frame) break;
     float v[8];
     unpack8(xv[it], v);
-    int gidx;
-    if (a.per_element) {
-      gidx = item * 8;
-    } else {
-      const int cb = item / (a.HW * 4);
-      gidx = cb * 32 + (item & 3) * 8;
-    }
-    const f32x4 g0 = *(const f32x4*)(a.gain + gidx), g1 = *(const f32x4*)(a.gain + gidx + 4);
-    const f32x4 b0 = *(const f32x4*)(a.bias + gidx), b1 = *(const f32x4*)(a.bias + gidx + 4);
-    const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-    const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    const float g[8] = {g0[it].x, g0[it].y, g0[it].z, g0[it].w, g1[it].x, g1[it].y, g1[it].z, g1[it].w};
+    const float b[8] = {b0[it].x, b0[it].y, b0[it].z, b0[it].w, b1[it].x, b1[it].y, b1[it].z, b1[it].w};
+    if (item < per_frame) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      v[k] = fmaf(fmaf(v[k], rstd, shift), g[k], b[k]);
-      s_sum += v[k];
-      s_sq = fmaf(v[k], v[k], s_sq);
+      for (int k = 0; k < 8; ++k) {
+        v[k] = fmaf(fmaf(v[k], rstd, shift), g[k], b[k]);
+        s_sum += v[k];
+        s_sq = fmaf(v[k], v[k], s_sq);
+      }
+      *(u32x4*)(a.y + (size_t)f * per_frame * 8 + (size_t)item * 8) = pack8(v);
     }
-    *(u32x4*)(a.y + (size_t)f * per_frame * 8 + (size_t)item * 8) = pack8(v);
   }
   if (a.stats_out) block_stats_atomic(s_sum, s_sq, a.stats_out, f);
 }
@@ -122,7 +139,8 @@ extern "C" int vpt_pool_launch(const VptPoolArgs* a, hipStream_t stream) {
   const int per_frame = a->CB * (a->H >> 1) * (a->W >> 1) * 4;
   const long grid = (long)a->frames * ((per_frame + EW_PER_BLOCK - 1) / EW_PER_BLOCK);
   if (grid > 0x7fffffffL) return -2;
-  hipLaunchKernelGGL(vpt_pool_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *a);
+  if (a->argmax) hipLaunchKernelGGL(vpt_pool_kernel<true>, dim3((unsigned)grid), dim3(256), 0, stream, *a);
+  else hipLaunchKernelGGL(vpt_pool_kernel<false>, dim3((unsigned)grid), dim3(256), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -131,6 +149,7 @@ extern "C" int vpt_affine_launch(const VptAffineArgs* a, hipStream_t stream) {
   const int per_frame = a->CB * a->HW * 4;
   const long grid = (long)a->frames * ((per_frame + EW_PER_BLOCK - 1) / EW_PER_BLOCK);
   if (grid > 0x7fffffffL) return -2;
-  hipLaunchKernelGGL(vpt_affine_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *a);
+  if (a->per_element) hipLaunchKernelGGL(vpt_affine_kernel<true>, dim3((unsigned)grid), dim3(256), 0, stream, *a);
+  else hipLaunchKernelGGL(vpt_affine_kernel<false>, dim3((unsigned)grid), dim3(256), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
