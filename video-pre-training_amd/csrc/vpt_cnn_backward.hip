@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256) void vpt_affine_bwd_reduce_kernel(VptAffineBwd
     for (int j = 0; j < 4; ++j) {
       const int pix = min(p0 + 64 * j, p_end - 1);
       const size_t eoff = ((size_t)cb * a.HW + pix) * 32 + oct * 8;
-      xv[j] = *(const u32x4*)(a.x + fbase + eoff);
-      dv[j] = *(const u32x4*)(a.dy + fbase + eoff);
+      xv[j] = VPT_LD_STREAM((const u32x4*)(a.x + fbase + eoff));
+      dv[j] = VPT_LD_STREAM((const u32x4*)(a.dy + fbase + eoff));
       if (PER_ELEMENT) { gv[j][0] = *(const f32x4*)(a.gain + eoff); gv[j][1] = *(const f32x4*)(a.gain + eoff + 4); }
     }
 #pragma unroll
@@ -136,9 +136,9 @@ __global__ __launch_bounds__(256) void vpt_affine_bwd_apply_kernel(VptAffineBwdA
   for (int it = 0; it < EW_ITEMS; ++it) {
     const int item = min(base + it * 256, per_frame - 1);
     const size_t off = (size_t)f * per_frame * 8 + (size_t)item * 8;
-    xv[it] = *(const u32x4*)(a.x + off);
-    dv[it] = *(const u32x4*)(a.dy + off);
-    if (HAS_ADD) ev[it] = *(const u32x4*)(a.dx_add + off);
+    xv[it] = VPT_LD_STREAM((const u32x4*)(a.x + off));
+    dv[it] = VPT_LD_STREAM((const u32x4*)(a.dy + off));
+    if (HAS_ADD) ev[it] = VPT_LD_STREAM((const u32x4*)(a.dx_add + off));
     const int gidx = PER_ELEMENT ? item * 8 : (item / (a.HW * 4)) * 32 + (item & 3) * 8;
     g0[it] = *(const f32x4*)(a.gain + gidx); g1[it] = *(const f32x4*)(a.gain + gidx + 4);
   }
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void vpt_affine_bwd_apply_kernel(VptAffineBwdA
 #pragma unroll
       for (int k = 0; k < 8; ++k) o[k] += e[k];
     }
-    *(u32x4*)(a.dx + off) = pack8(o);
+    VPT_ST_STREAM(pack8(o), (u32x4*)(a.dx + off));
   }
 }
 
@@ -316,10 +316,10 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_kernel(VptConvBwdPrepAr
   const unsigned cxA = (unsigned)(x & 1) + 1u;   // window column code of x: x - 2 px + 1 (B: always 0)
   auto load_row = [&](int y, PrepRow& r) {
     const size_t off = plane + (size_t)(y * a.W + x) * 32;
-    r.y = *(const u32x4*)(a.y + off);
-    if (HAS_RES) r.res = *(const u32x4*)(a.res + off);
+    r.y = VPT_LD_STREAM((const u32x4*)(a.y + off));
+    if (HAS_RES) r.res = VPT_LD_STREAM((const u32x4*)(a.res + off));
     if (HAS_DY) {
-      r.dy = *(const u32x4*)(a.dy + off);
+      r.dy = VPT_LD_STREAM((const u32x4*)(a.dy + off));
     } else {
       const int pyA = y >> 1, pyB = min((y + 1) >> 1, PH - 1);
       const size_t p0 = pplane + (size_t)(pyA * PW + pxA) * 32, p1 = pplane + (size_t)(pyA * PW + pxB) * 32;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_kernel(VptConvBwdPrepAr
       top[k] = is_top ? dz : top[k];
       bot[k] = is_bot ? dz : bot[k];
     }
-    *(u32x4*)(a.dacc + plane + (size_t)(y * a.W + x) * 32) = pack8(o);
+    VPT_ST_STREAM(pack8(o), (u32x4*)(a.dacc + plane + (size_t)(y * a.W + x) * 32));
   };
   // two row buffers in ping-pong, so a row's loads are issued a full iteration before their first use and no
   // register copy forces an early wait

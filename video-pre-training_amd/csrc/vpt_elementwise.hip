@@ -12,6 +12,9 @@
 // Every lane moves 16 bytes (8 bf16) per access, EW_ITEMS accesses per thread (all loads issued before the
 // first use); one block-level reduction and one pair of fp64 atomics per block keeps the per-frame
 // statistics off the critical path.
+// Plain (cached) accesses here: with nontemporal ones the forward step measured 2 ms SLOWER (118.1 vs 115.9 ms, same box) -- the
+// consumer of these outputs is the next convolution of the same chunk, which still finds part of them in the 256 MB MALL.
+#define VPT_STREAM_PLAIN 1
 #include "vpt_common.h"
 #include "vpt_kernels.h"
 
@@ -47,7 +50,7 @@ __global__ __launch_bounds__(256) void vpt_pool_kernel(VptPoolArgs a) {
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) dst[dy * 3 + dx] = *(const u16x8*)(plane + (size_t)(yy[dy] * a.W + xx[dx]) * 32);
+      for (int dx = 0; dx < 3; ++dx) dst[dy * 3 + dx] = VPT_LD_STREAM((const u16x8*)(plane + (size_t)(yy[dy] * a.W + xx[dx]) * 32));
   };
   load(0, v[0]);
 #pragma unroll
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256) void vpt_pool_kernel(VptPoolArgs a) {
         uint64_t pk = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) pk |= (uint64_t)(am[k] & 0xff) << (8 * k);
-        *(uint64_t*)(a.argmax + po) = pk;
+        VPT_ST_STREAM(pk, (uint64_t*)(a.argmax + po));
       }
       const u32x4 mv = __builtin_bit_cast(u32x4, m);
       float vals[8];
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256) void vpt_pool_kernel(VptPoolArgs a) {
         s_sum += vals[k];
         s_sq = fmaf(vals[k], vals[k], s_sq);
       }
-      *(u32x4*)(a.y + po) = mv;
+      VPT_ST_STREAM(mv, (u32x4*)(a.y + po));
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256) void vpt_affine_kernel(VptAffineArgs a) {
 #pragma unroll
   for (int it = 0; it < EW_ITEMS; ++it) {
     const int item = min(base + it * 256, per_frame - 1);
-    xv[it] = *(const u32x4*)(a.x + (size_t)f * per_frame * 8 + (size_t)item * 8);
+    xv[it] = VPT_LD_STREAM((const u32x4*)(a.x + (size_t)f * per_frame * 8 + (size_t)item * 8));
     const int gidx = PER_ELEMENT ? item * 8 : (item / (a.HW * 4)) * 32 + (item & 3) * 8;
     g0[it] = *(const f32x4*)(a.gain + gidx); g1[it] = *(const f32x4*)(a.gain + gidx + 4);
     b0[it] = *(const f32x4*)(a.bias + gidx); b1[it] = *(const f32x4*)(a.bias + gidx + 4);
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256) void vpt_affine_kernel(VptAffineArgs a) {
         s_sum += v[k];
         s_sq = fmaf(v[k], v[k], s_sq);
       }
-      *(u32x4*)(a.y + (size_t)f * per_frame * 8 + (size_t)item * 8) = pack8(v);
+      VPT_ST_STREAM(pack8(v), (u32x4*)(a.y + (size_t)f * per_frame * 8 + (size_t)item * 8));
     }
   }
   if (a.stats_out) block_stats_atomic(s_sum, s_sq, a.stats_out, f);
