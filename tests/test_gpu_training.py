@@ -38,7 +38,7 @@ def test_nll_backward():
     assert float(dz[:, nb + nc:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("m,d,relu_in", [(70, 2048, False), (33, 256, True), (5, 1024, True)])
+@pytest.mark.parametrize("m,d,relu_in", [(70, 2048, False), (33, 256, True), (5, 1024, True), (9, 3072, False), (40, 4096, True), (7, 1000, False)])
 def test_layernorm_backward(m, d, relu_in):
     g = torch.Generator().manual_seed(2)
     x = (torch.randn(m, d, generator=g) * 1.5 + 0.3).requires_grad_(True)

@@ -103,90 +103,116 @@ extern "C" int vpt_gate_cast_launch(const VptGateCastArgs* a, hipStream_t stream
 #define LNB_ROWS 32  // rows per workgroup (8 per wave)
 #define LNB_MAXD4 16 // D <= 4096
 
+// ND4 = float4 slots per lane (D <= 256 ND4), a compile-time bound: the row lives in registers (x always, dy too when
+// ND4 <= 8) for its four passes, and the per-lane column partials pg / pb are indexed statically.
+template <int ND4>
 __global__ __launch_bounds__(256) void vpt_ln_bwd_kernel(VptLnBwdArgs a) {
+  constexpr bool KEEP_DY = ND4 <= 8;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int n4 = a.D >> 2;            // float4 per row
-  const int per_lane = (n4 + 63) >> 6;  // <= LNB_MAXD4
-  f32x4 pg[LNB_MAXD4], pb[LNB_MAXD4];
+  f32x4 pg[ND4], pb[ND4];
 #pragma unroll
-  for (int i = 0; i < LNB_MAXD4; ++i) { pg[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; pb[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  for (int q = 0; q < ND4; ++q) { pg[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; pb[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   const float invD = 1.0f / (float)a.D;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  __shared__ float comb_[2 * 256 * ND4];
+  for (int c = threadIdx.x; c < 2 * 256 * ND4; c += 256) comb_[c] = 0.f;
+  __syncthreads();
   for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
     const int row = blockIdx.x * LNB_ROWS + w * (LNB_ROWS / 4) + rr;
     if (row >= a.M) break;
     const float* x = a.x + (size_t)row * a.D;
     const float* dy = a.dy + (size_t)row * a.D;
+    f32x4 xv[ND4], dv[KEEP_DY ? ND4 : 1];
+#pragma unroll
+    for (int q = 0; q < ND4; ++q) {
+      const int i = lane + 64 * q;
+      xv[q] = (i < n4) ? *(const f32x4*)(x + 4 * i) : zero;
+      if (KEEP_DY) dv[q] = (i < n4) ? *(const f32x4*)(dy + 4 * i) : zero;
+    }
     float s = 0.f;
-    for (int i = lane; i < n4; i += 64) {
-      f32x4 v = *(const f32x4*)(x + 4 * i);
-      if (a.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      s += (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int q = 0; q < ND4; ++q) {
+      if (a.relu_in) { xv[q].x = fmaxf(xv[q].x, 0.f); xv[q].y = fmaxf(xv[q].y, 0.f); xv[q].z = fmaxf(xv[q].z, 0.f); xv[q].w = fmaxf(xv[q].w, 0.f); }
+      s += (xv[q].x + xv[q].y) + (xv[q].z + xv[q].w);     // (slots past the row hold zeros)
     }
     const float mean = wave_sum(s) * invD;
     float ss = 0.f;
-    for (int i = lane; i < n4; i += 64) {
-      f32x4 v = *(const f32x4*)(x + 4 * i);
-      if (a.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-      ss += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+    for (int q = 0; q < ND4; ++q) {
+      if (lane + 64 * q < n4) {
+        const float d0 = xv[q].x - mean, d1 = xv[q].y - mean, d2 = xv[q].z - mean, d3 = xv[q].w - mean;
+        ss += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
     }
     const float rstd = rsqrtf(wave_sum(ss) * invD + VPT_NORM_EPS);
     // sums of dy*g and dy*g*xhat over the row
     float s1 = 0.f, s2 = 0.f;
-    for (int i = lane; i < n4; i += 64) {
-      f32x4 v = *(const f32x4*)(x + 4 * i);
-      if (a.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      const f32x4 g = *(const f32x4*)(a.gain + 4 * i), d = *(const f32x4*)(dy + 4 * i);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float xh = (v[k] - mean) * rstd, dg = d[k] * g[k];
-        s1 += dg;
-        s2 = fmaf(dg, xh, s2);
+    for (int q = 0; q < ND4; ++q) {
+      const int i = lane + 64 * q;
+      if (i < n4) {
+        const f32x4 g = *(const f32x4*)(a.gain + 4 * i), d = KEEP_DY ? dv[q] : *(const f32x4*)(dy + 4 * i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float xh = (xv[q][k] - mean) * rstd, dg = d[k] * g[k];
+          s1 += dg;
+          s2 = fmaf(dg, xh, s2);
+        }
       }
     }
     s1 = wave_sum(s1) * invD;
     s2 = wave_sum(s2) * invD;
-    int slot = 0;
-    for (int i = lane; i < n4; i += 64, ++slot) {
-      const f32x4 raw = *(const f32x4*)(x + 4 * i);
-      f32x4 v = raw;
-      if (a.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      const f32x4 g = *(const f32x4*)(a.gain + 4 * i), d = *(const f32x4*)(dy + 4 * i);
-      f32x4 o;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float xh = (v[k] - mean) * rstd;
-        float dxk = rstd * (d[k] * g[k] - s1 - xh * s2);
-        if (a.relu_in && !(raw[k] > 0.f)) dxk = 0.f;
-        o[k] = dxk;
+    for (int q = 0; q < ND4; ++q) {
+      const int i = lane + 64 * q;
+      if (i < n4) {
+        const f32x4 g = *(const f32x4*)(a.gain + 4 * i), d = KEEP_DY ? dv[q] : *(const f32x4*)(dy + 4 * i);
+        f32x4 o;
 #pragma unroll
-        for (int q = 0; q < LNB_MAXD4; ++q)
-          if (q == slot) { pg[q][k] = fmaf(d[k], xh, pg[q][k]); pb[q][k] += d[k]; }
+        for (int k = 0; k < 4; ++k) {
+          const float xh = (xv[q][k] - mean) * rstd;
+          float dxk = rstd * (d[k] * g[k] - s1 - xh * s2);
+          if (a.relu_in && !(xv[q][k] > 0.f)) dxk = 0.f;     // max(x, 0) > 0  <=>  x > 0
+          o[k] = dxk;
+          pg[q][k] = fmaf(d[k], xh, pg[q][k]);
+          pb[q][k] += d[k];
+        }
+        if (a.dx_add) {
+          const f32x4 e = *(const f32x4*)(a.dx_add + (size_t)row * a.D + 4 * i);
+          o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+        }
+        *(f32x4*)(a.dx + (size_t)row * a.D + 4 * i) = o;
       }
-      if (a.dx_add) {
-        const f32x4 e = *(const f32x4*)(a.dx_add + (size_t)row * a.D + 4 * i);
-        o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
-      }
-      *(f32x4*)(a.dx + (size_t)row * a.D + 4 * i) = o;
     }
   }
-  // flush the per-lane column partials: one atomic per column per wave
+  // column partials: the four waves combine in LDS, then ONE global atomic per column per workgroup
 #pragma unroll
-  for (int q = 0; q < LNB_MAXD4; ++q) {
+  for (int q = 0; q < ND4; ++q) {
     const int i = lane + 64 * q;
-    if (q < per_lane && i < n4) {
+    if (i < n4) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        atomicAdd(a.dgain + 4 * i + k, pg[q][k]);
-        atomicAdd(a.dbias + 4 * i + k, pb[q][k]);
+        atomicAdd(&comb_[4 * i + k], pg[q][k]);
+        atomicAdd(&comb_[256 * ND4 + 4 * i + k], pb[q][k]);
       }
     }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < a.D; c += 256) {
+    atomicAdd(a.dgain + c, comb_[c]);
+    atomicAdd(a.dbias + c, comb_[256 * ND4 + c]);
   }
 }
 
 extern "C" int vpt_ln_bwd_launch(const VptLnBwdArgs* a, hipStream_t stream) {
   if (a->M <= 0 || (a->D & 3) || a->D > 4 * 64 * LNB_MAXD4) return -1;
-  hipLaunchKernelGGL(vpt_ln_bwd_kernel, dim3((a->M + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 0, stream, *a);
+  const dim3 g((a->M + LNB_ROWS - 1) / LNB_ROWS), b(256);
+  const int nd4 = ((a->D >> 2) + 63) >> 6;
+  if (nd4 <= 4) hipLaunchKernelGGL(vpt_ln_bwd_kernel<4>, g, b, 0, stream, *a);
+  else if (nd4 <= 8) hipLaunchKernelGGL(vpt_ln_bwd_kernel<8>, g, b, 0, stream, *a);
+  else if (nd4 <= 12) hipLaunchKernelGGL(vpt_ln_bwd_kernel<12>, g, b, 0, stream, *a);
+  else hipLaunchKernelGGL(vpt_ln_bwd_kernel<16>, g, b, 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
