@@ -247,6 +247,18 @@ int vpt_camera_undiscretize(const long* bins, double* xy, long n, double maxval,
 int vpt_action_from_factored(const long* buttons, const long* camera, long* joint_buttons, long* joint_camera, long n, int n_camera_bins, void* stream);
 int vpt_action_to_factored(const long* joint_buttons, const long* joint_camera, long* buttons, long* camera, long n, int n_camera_bins, void* stream);
 
+/* ---- clip data path on the device ---- */
+
+/* One launch turns `frames` decoded video frames (uint8 BGR [frames][height][width][3], as cv2.VideoCapture.read() returns
+ * them) into the policy's input frames (uint8 RGB [frames][out_height][out_width][3]): the per-frame body of
+ * data_loader.py:113-122 = composite_images_with_alpha (data_loader.py:34-46) where cursor_state[f] = (gui open, x, y) says a
+ * GUI is open (x, y >= 0: the cursor's top-left corner, already scaled by height / 720), cv2.cvtColor(BGR2RGB) and
+ * resize_image = cv2.resize(.., (out_width, out_height), INTER_LINEAR) (agent.py:100-103).  Bit-identical to that CPU path:
+ * fp64 blend truncated like astype(uint8); OpenCV's 11-bit fixed-point bilinear (exact 2 x 2 decimation -> INTER_AREA).
+ * cursor_state may be null (no compositing); cursor_bgr [cursor_h][cursor_w][3], cursor_alpha fp64 [cursor_h][cursor_w] in 0..1. */
+int vpt_clip_frames(const uint8_t* src_bgr, int frames, int height, int width, const int32_t* cursor_state, const uint8_t* cursor_bgr,
+                    const double* cursor_alpha, int cursor_h, int cursor_w, uint8_t* dst_rgb, int out_height, int out_width, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

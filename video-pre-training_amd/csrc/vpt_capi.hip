@@ -308,3 +308,13 @@ int vpt_action_from_factored(const long* buttons, const long* camera, long* join
 int vpt_action_to_factored(const long* joint_buttons, const long* joint_camera, long* buttons, long* camera, long n, int n_camera_bins, void* stream) {
   CHECK_LAUNCH(vpt_action_mapping_launch(1, joint_buttons, joint_camera, buttons, camera, n, n_camera_bins, (hipStream_t)stream), "vpt_action_to_factored");
 }
+
+/* ---- clip data path (data_loader.py:34-46,113-122; agent.py:100-103) ---- */
+int vpt_clip_frames(const uint8_t* src_bgr, int frames, int height, int width, const int32_t* cursor_state, const uint8_t* cursor_bgr,
+                    const double* cursor_alpha, int cursor_h, int cursor_w, uint8_t* dst_rgb, int out_height, int out_width, void* stream) {
+  if (!src_bgr || !dst_rgb) return fail(-1, "vpt_clip_frames");
+  VptClipArgs a{};
+  a.src = src_bgr; a.cursor = cursor_state; a.cursor_img = cursor_bgr; a.cursor_alpha = cursor_alpha; a.dst = dst_rgb;
+  a.frames = frames; a.H = height; a.W = width; a.OH = out_height; a.OW = out_width; a.CH = cursor_h; a.CW = cursor_w;
+  CHECK_LAUNCH(vpt_clip_launch(&a, (hipStream_t)stream), "vpt_clip_frames");
+}

@@ -235,6 +235,17 @@ struct VptLnBwdArgs {
   int M, D, relu_in;
 };
 
+struct VptClipArgs {
+  const uint8_t* src;          // [F][H][W][3] decoded frames, BGR
+  const int* cursor;           // [F][3] (gui open, cursor x, cursor y) or null: no compositing
+  const uint8_t* cursor_img;   // [CH][CW][3] BGR
+  const double* cursor_alpha;  // [CH][CW] opacity in 0..1
+  uint8_t* dst;                // [F][OH][OW][3] RGB
+  int frames, H, W, OH, OW, CH, CW;
+  double scale_x, scale_y;     // filled by the launcher
+  int area2x2;                 // filled by the launcher
+};
+
 struct VptColsumArgs {
   const vpt_op16* x;       // [M][ld]
   float* out;              // [N] accumulated (caller zeroes)
@@ -293,6 +304,7 @@ int vpt_heads_bwd_launch(const VptHeadsBwdArgs* a, hipStream_t s);
 int vpt_ln_bwd_launch(const VptLnBwdArgs* a, hipStream_t s);
 int vpt_gate_cast_launch(const VptGateCastArgs* a, hipStream_t s);
 int vpt_colsum_launch(const VptColsumArgs* a, hipStream_t s);
+int vpt_clip_launch(const VptClipArgs* a, hipStream_t s);
 int vpt_attn_bwd_launch(const VptAttnBwdArgs* a, hipStream_t s);
 int vpt_conv3x3_launch(const VptConv3x3Args* a, hipStream_t s);
 int vpt_conv_first_launch(const VptConvFirstArgs* a, hipStream_t s);

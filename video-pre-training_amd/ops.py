@@ -520,3 +520,26 @@ def action_to_factored(joint_buttons, joint_camera, n_camera_bins=11):
             raise IndexError(f"joint action index out of range: buttons [{lo_b}, {hi_b}] (0..8640), camera [{lo_c}, {hi_c}] (0..{n_camera_bins * n_camera_bins - 1})")
         _call("vpt_action_to_factored", dict(bytes=192.0 * n), ptr(joint_buttons), ptr(joint_camera), ptr(b), ptr(c), n, int(n_camera_bins), _stream())
     return b, c
+
+
+# ---- clip data path (data_loader.py:113-122 on the device) --------------------------------------------------------
+def clip_frames(frames_bgr, cursor_state=None, cursor_bgr=None, cursor_alpha=None, out_hw=(128, 128), out=None):
+    """uint8 BGR [F,H,W,3] (+ int32 [F,3] (gui open, x, y), uint8 cursor [h,w,3] BGR, fp64 alpha [h,w]) -> uint8 RGB [F,oh,ow,3]:
+    cursor compositing, BGR->RGB and cv2.INTER_LINEAR resize in one launch, bit-identical to the reference's CPU path."""
+    _chk(frames_bgr, torch.uint8, "frames_bgr")
+    if frames_bgr.dim() != 4 or frames_bgr.shape[3] != 3:
+        raise ValueError("frames_bgr must be [F, H, W, 3]")
+    f, h, w, _ = frames_bgr.shape
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    if out is None:
+        out = torch.empty(f, oh, ow, 3, dtype=torch.uint8, device=frames_bgr.device)
+    ch = cw = 0
+    if cursor_state is not None:
+        _chk(cursor_state, torch.int32, "cursor_state"); _chk(cursor_bgr, torch.uint8, "cursor_bgr"); _chk(cursor_alpha, torch.float64, "cursor_alpha")
+        if tuple(cursor_state.shape) != (f, 3) or cursor_bgr.dim() != 3 or cursor_bgr.shape[2] != 3 or tuple(cursor_alpha.shape) != tuple(cursor_bgr.shape[:2]):
+            raise ValueError("cursor_state must be [F, 3], cursor_bgr [h, w, 3], cursor_alpha [h, w]")
+        ch, cw = int(cursor_bgr.shape[0]), int(cursor_bgr.shape[1])
+    if f:
+        _call("vpt_clip_frames", dict(bytes=float(f) * (h * w * 3 + oh * ow * 3)), ptr(frames_bgr), f, h, w, ptr(cursor_state), ptr(cursor_bgr), ptr(cursor_alpha),
+              ch, cw, ptr(out), oh, ow, _stream())
+    return out
