@@ -107,6 +107,15 @@ int vpt_linear_wgrad(const void* dy, const void* x, float* dw, int M, int N, int
 int vpt_linear_splitk_epilogue(const float* part, int splitk, const float* bias, const float* res, float* out_f32, void* out_bf16,
                                int M, int N, int ldr, int ldc, int ldcb, int relu, const void* mask, int ldm, void* stream);
 
+/* Acting path (M = B*T <= 8 rows, K <= 3072; agent.py:190-206): nn.LayerNorm (optional ReLU on its input) FUSED into the linear
+ * layer it feeds -- every LayerNorm of the policy does feed one (lib/xf.py:334-356 pre_r_ln -> q/k/v/r, ln -> mlp0; lib/util.py:58-82
+ * FanInInitReLULayer(norm, linear); lib/policy.py:188,211-214 lastlayer, final_ln -> heads).  Same results, bit for bit, as
+ * vpt_layernorm_forward followed by vpt_linear_forward; ln_out_f32 (optional, [M][K]) receives the normalised rows in fp32
+ * (the residual branch / the latent).  Larger M or K: returns -1, call the two functions. */
+int vpt_layernorm_linear_forward(const float* x, const float* ln_gain, const float* ln_bias, int relu_in, float* ln_out_f32,
+                                 const void* wpk, const float* bias, const float* res, float* out_f32, void* out_bf16,
+                                 int M, int N, int K, int ldr, int ldc, int ldcb, int relu, void* stream);
+
 /* nn.LayerNorm over the last dim with optional ReLU on the input (lib/util.py:61-62,169; lib/policy.py:188,211-214). */
 int vpt_layernorm_forward(const float* x, const float* gain, const float* bias, float* out_f32, void* out_bf16,
                           int M, int D, int relu_in, void* stream);
@@ -124,6 +133,17 @@ int vpt_masked_attention_forward(const float* qkvr, const float* kmem, const flo
 /* SelfAttentionLayer.update_state (lib/xf.py:366-391): kout/vout = last maxlen rows of [memory ; new]. */
 int vpt_kv_memory_update(const float* qkvr, const float* kmem, const float* vmem, float* kout, float* vout,
                          int B, int t, int hid, int ld, int maxlen, void* stream);
+
+/* Acting step (t = 1; agent.py:190-206): the whole recurrent-state step of one transformer block in ONE launch --
+ * vpt_masked_attention_forward(causal = 1, t = 1), vpt_kv_memory_update and the mask bookkeeping of lib/xf.py:366-391
+ * (memory visible where state_mask & ~first; next mask = cat(state_mask[1:] & ~first, [True])).  One query per (sequence, head)
+ * against the newest maxlen - 1 memory rows and the token itself; the rows it reads are written one row up into kout / vout.
+ * state_mask / mask_out: bool bytes [B][maxlen]; first: bool bytes [B].  kout / vout / mask_out MAY alias kmem / vmem /
+ * state_mask (in-place state, as the captured acting graph uses it).  maxlen <= 128.  Same formulas as the general kernel
+ * (lib/xf.py:18-71, lib/masked_attention.py:161-178); sums in a different order: equal to fp32 rounding. */
+int vpt_masked_attention_step(const float* qkvr, const float* kmem, const float* vmem, const uint8_t* state_mask, const uint8_t* first,
+                              const float* b_nd, void* out, float* kout, float* vout, uint8_t* mask_out,
+                              int B, int heads, int hid, int ld, int maxlen, void* stream);
 
 /* CategoricalActionHead.forward tail (lib/action_head.py:170-174): out[M][n] = log_softmax(logits[:, col0:col0+n] / T). */
 int vpt_log_softmax_forward(const float* logits, float* out, int M, int ld, int col0, int n, float temperature,

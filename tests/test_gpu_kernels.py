@@ -264,24 +264,71 @@ def test_adam_step_matches_torch():
     assert torch.allclose(p2, p3, atol=1e-7)
 
 
-def test_adam_step_multi_equals_per_tensor():
-    """One launch over a table of tensors (vpt_adam_step_multi) = the per-tensor kernel, bit for bit, odd sizes and offsets included."""
-    g = torch.Generator().manual_seed(11)
-    sizes = [1, 3, 1024, 1025, 100003, 7, 4096, 2049]
-    flat = torch.randn(sum(sizes) + 3, generator=g).to(DEV)          # views at odd element offsets into one buffer
-    views, off = [], 3
-    for n in sizes:
-        views.append(flat[off:off + n]); off += n
-    grads = [torch.randn(n, generator=g).to(DEV) * 0.1 for n in sizes]
-    pa = [v.clone() for v in views]; ma = [torch.zeros_like(v) for v in views]; va = [torch.zeros_like(v) for v in views]
-    pb = [v.clone() for v in views]; mb = [torch.zeros_like(v) for v in views]; vb = [torch.zeros_like(v) for v in views]
-    for step in (1, 2):
-        for p_, g_, m_, v_ in zip(pa, grads, ma, va):
-            ops.adam_step_(p_, g_, m_, v_, step, lr=0.000181, weight_decay=0.039428, grad_scale=0.5)
-        ops.adam_step_multi_(pb, grads, mb, vb, step, lr=0.000181, weight_decay=0.039428, grad_scale=0.5)
+@pytest.mark.parametrize("m,k,n,relu_in,relu,with_res", [(1, 2048, 2048, False, False, True), (1, 2048, 6304, False, False, False), (1, 256, 2048, True, True, False),
+                                                        (3, 2048, 8192, False, True, False), (8, 3072, 520, True, False, True), (1, 2048, 8763, False, False, False)])
+def test_layernorm_linear_fused_equals_two_kernels(m, k, n, relu_in, relu, with_res):
+    """The acting path's fused LayerNorm -> linear launch = vpt_layernorm_forward + vpt_linear_forward, bit for bit."""
+    g = torch.Generator().manual_seed(m * 7 + k + n)
+    x = (torch.randn(m, k, generator=g) * 1.3 + 0.2).to(DEV)
+    gain = (1 + 0.2 * torch.randn(k, generator=g)).to(DEV)
+    lb = (0.1 * torch.randn(k, generator=g)).to(DEV)
+    w = torch.randn(n, k, generator=g) / k ** 0.5
+    wpk = ops.pack_linear(w.to(DEV))
+    bias = (0.1 * torch.randn(n, generator=g)).to(DEV)
+    res = torch.randn(m, n, generator=g).to(DEV) if with_res else None
+    ln32, ln16 = ops.layernorm(x, gain, lb, relu_in=relu_in, out_f32=True)
+    o32, o16 = ops.linear(ln16, wpk, n, bias=bias, res=res, relu=relu, out_f32=True, out_bf16=True)
+    f_ln32, f32_, f16_ = ops.layernorm_linear(x, gain, lb, wpk, n, bias=bias, res=res, relu=relu, relu_in=relu_in, ln_out_f32=True, out_f32=True, out_bf16=True)
     torch.cuda.synchronize()
-    for x, y in zip(pa + ma + va, pb + mb + vb):
-        assert torch.equal(x, y)
+    assert torch.equal(f_ln32, ln32) and torch.equal(f32_, o32) and torch.equal(f16_, o16)
+    ref = torch.nn.functional.layer_norm(torch.relu(x) if relu_in else x, (k,), gain, lb).cpu() @ w.t() + bias.cpu()
+    if relu:
+        ref = torch.relu(ref)
+    if with_res:
+        ref = ref + res.cpu()
+    assert float((f32_.cpu() - ref).norm() / ref.norm()) < 1e-2
+    with pytest.raises(ValueError):
+        ops.layernorm_linear(x.repeat(9, 1), gain, lb, wpk, n)
+
+
+@pytest.mark.parametrize("batch,heads,maxlen,valid", [(1, 16, 128, "all"), (1, 16, 128, "none"), (3, 8, 128, "random"), (2, 4, 37, "random"), (1, 24, 128, "tail")])
+def test_attention_step_equals_attention_plus_memory_update(batch, heads, maxlen, valid):
+    """Acting step kernel (t = 1) vs vpt_masked_attention_forward + vpt_kv_memory_update: memory bit-identical, output to fp32 rounding."""
+    g = torch.Generator().manual_seed(batch * 100 + heads + maxlen)
+    hid = heads * 128
+    ld = 3 * hid + 10 * heads
+    qkvr = (torch.randn(batch, ld, generator=g) * 1.5).to(DEV)
+    kmem = torch.randn(batch, maxlen, hid, generator=g).to(DEV)
+    vmem = torch.randn(batch, maxlen, hid, generator=g).to(DEV)
+    b_nd = (0.5 * torch.randn(10, maxlen, generator=g)).to(DEV)
+    if valid == "all":
+        mv = torch.ones(batch, maxlen, dtype=torch.uint8)
+    elif valid == "none":
+        mv = torch.zeros(batch, maxlen, dtype=torch.uint8)
+    elif valid == "tail":
+        mv = torch.zeros(batch, maxlen, dtype=torch.uint8); mv[:, -5:] = 1
+    else:
+        mv = (torch.rand(batch, maxlen, generator=g) < 0.6).to(torch.uint8)
+    mv = mv.to(DEV)
+    first = torch.zeros(batch, dtype=torch.bool); first[0] = valid == "random"       # an episode start ignores (and invalidates) the memory
+    first = first.to(DEV)
+    memvalid = (mv.bool() & ~first[:, None]).to(torch.uint8).contiguous()
+    ref = ops.masked_attention(qkvr, kmem, vmem, memvalid, b_nd, batch, 1, heads, hid)
+    kref, vref = ops.kv_memory_update(qkvr, kmem, vmem, batch, 1, hid)
+    mref = torch.cat([memvalid[:, 1:], torch.ones(batch, 1, dtype=torch.uint8, device=DEV)], dim=1)
+    out, kout, vout, mout = ops.masked_attention_step(qkvr, kmem, vmem, mv.bool(), first, b_nd, batch, heads, hid)
+    torch.cuda.synchronize()
+    assert torch.equal(kout, kref) and torch.equal(vout, vref) and torch.equal(mout, mref)
+    o, r = out.float().cpu(), ref.float().cpu()
+    assert float((o - r).abs().max()) <= 2.0 ** -7 * float(r.abs().max()) + 1e-6      # one bf16 ulp of the largest value
+    assert float((o - r).norm() / r.norm()) < 2e-3
+    # in place: the same results land in the input buffers
+    k2, v2, m2 = kmem.clone(), vmem.clone(), mv.clone()
+    out2, ka, va, ma = ops.masked_attention_step(qkvr, k2, v2, m2, first, b_nd, batch, heads, hid, inplace=True)
+    torch.cuda.synchronize()
+    assert ka.data_ptr() == k2.data_ptr() and torch.equal(k2, kref) and torch.equal(v2, vref) and torch.equal(m2, mref) and torch.equal(out2, out)
+    with pytest.raises(ValueError):
+        ops.masked_attention_step(qkvr.repeat(2, 1), kmem, vmem, mv, first, b_nd, batch, heads, hid)
 
 
 @pytest.mark.parametrize("m,n,k,accumulate", [(300, 256, 192, False), (1000, 8768, 2048, False), (64, 65536, 256, True), (8192, 2048, 2048, False)])

@@ -53,6 +53,8 @@ SIGNATURES = {
     "vpt_masked_attention_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vpt_adam_step": [_P, _P, _P, _P, ctypes.c_uint64, _I, _F, _F, _F, _F, _F, _F, _P],
     "vpt_adam_step_multi": [_P, _I, _L, _I, _F, _F, _F, _F, _F, _F, _P],
+    "vpt_layernorm_linear_forward": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vpt_masked_attention_step": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_clip_frames": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _P],
 }
 

@@ -152,13 +152,25 @@ int vpt_linear_forward(const void* A, const void* wpk, const float* bias, const 
                        float* out_f32, void* out_bf16, int M, int N, int K,
                        int lda, int ldr, int ldc, int ldcb, int relu, int splitk, const void* mask, int ldm,
                        void* stream) {
-  VptGemmArgs a;
+  VptGemmArgs a{};
   a.mask = (const vpt_op16*)mask; a.ldm = ldm;
   a.A = (const vpt_op16*)A; a.wpk = (const vpt_op16*)wpk; a.bias = bias; a.res = res;
   a.out_f32 = out_f32; a.out_bf16 = (vpt_op16*)out_bf16;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldr = ldr; a.ldc = ldc; a.ldcb = ldcb;
   a.relu = relu; a.splitk = splitk < 1 ? 1 : splitk; a.atomic_out = a.splitk > 1;
   CHECK_LAUNCH(vpt_gemm_launch(&a, (hipStream_t)stream), "vpt_linear_forward");
+}
+
+int vpt_layernorm_linear_forward(const float* x, const float* ln_gain, const float* ln_bias, int relu_in, float* ln_out_f32,
+                                 const void* wpk, const float* bias, const float* res, float* out_f32, void* out_bf16,
+                                 int M, int N, int K, int ldr, int ldc, int ldcb, int relu, void* stream) {
+  if (M <= 0 || M > 8 || K > 3072 || !x || !ln_gain || !ln_bias)
+    return fail(-1, "vpt_layernorm_linear_forward: M <= 8 rows and K <= 3072 only (use vpt_layernorm_forward + vpt_linear_forward)");
+  VptGemmArgs a{};
+  a.ln_x = x; a.ln_gain = ln_gain; a.ln_bias = ln_bias; a.ln_relu_in = relu_in; a.ln_out_f32 = ln_out_f32;
+  a.wpk = (const vpt_op16*)wpk; a.bias = bias; a.res = res; a.out_f32 = out_f32; a.out_bf16 = (vpt_op16*)out_bf16;
+  a.M = M; a.N = N; a.K = K; a.lda = K; a.ldr = ldr; a.ldc = ldc; a.ldcb = ldcb; a.relu = relu; a.splitk = 1; a.atomic_out = 0;
+  CHECK_LAUNCH(vpt_gemm_launch(&a, (hipStream_t)stream), "vpt_layernorm_linear_forward");   // M <= 8: dispatches to vpt_gemv_launch
 }
 
 int vpt_linear_wgrad(const void* dy, const void* x, float* dw, int M, int N, int K, int ldy, int ldx, int ldw, int accumulate, void* stream) {
@@ -170,7 +182,7 @@ int vpt_linear_wgrad(const void* dy, const void* x, float* dw, int M, int N, int
 
 int vpt_linear_splitk_epilogue(const float* part, int splitk, const float* bias, const float* res, float* out_f32, void* out_bf16,
                                int M, int N, int ldr, int ldc, int ldcb, int relu, const void* mask, int ldm, void* stream) {
-  VptGemmArgs a;
+  VptGemmArgs a{};
   a.A = nullptr; a.wpk = nullptr; a.bias = bias; a.res = res; a.out_f32 = out_f32; a.out_bf16 = (vpt_op16*)out_bf16;
   a.M = M; a.N = N; a.K = 0; a.lda = 0; a.ldr = ldr; a.ldc = ldc; a.ldcb = ldcb; a.relu = relu; a.splitk = splitk; a.atomic_out = 0;
   a.mask = (const vpt_op16*)mask; a.ldm = ldm;
@@ -192,6 +204,15 @@ int vpt_masked_attention_forward(const float* qkvr, const float* kmem, const flo
   a.qkvr = qkvr; a.kmem = kmem; a.vmem = vmem; a.memvalid = memvalid; a.b_nd = b_nd; a.out = (vpt_op16*)out;
   a.B = B; a.t = t; a.heads = heads; a.hid = hid; a.ld = ld; a.maxlen = maxlen; a.causal = causal;
   CHECK_LAUNCH(vpt_attn_launch(&a, (hipStream_t)stream), "vpt_masked_attention_forward");
+}
+
+int vpt_masked_attention_step(const float* qkvr, const float* kmem, const float* vmem, const uint8_t* state_mask, const uint8_t* first,
+                              const float* b_nd, void* out, float* kout, float* vout, uint8_t* mask_out,
+                              int B, int heads, int hid, int ld, int maxlen, void* stream) {
+  VptAttnArgs a;
+  a.qkvr = qkvr; a.kmem = kmem; a.vmem = vmem; a.memvalid = nullptr; a.b_nd = b_nd; a.out = (vpt_op16*)out;
+  a.B = B; a.t = 1; a.heads = heads; a.hid = hid; a.ld = ld; a.maxlen = maxlen; a.causal = 1;
+  CHECK_LAUNCH(vpt_attn_step_launch(&a, state_mask, first, mask_out, kout, vout, (hipStream_t)stream), "vpt_masked_attention_step");
 }
 
 int vpt_kv_memory_update(const float* qkvr, const float* kmem, const float* vmem, float* kout, float* vout,

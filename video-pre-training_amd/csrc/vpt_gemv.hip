@@ -14,10 +14,18 @@
 #include "vpt_common.h"
 #include "vpt_kernels.h"
 
-template <int MR, int ROWS>
+#define GEMV_LN_MAXK 3072   // hidsize of the largest policy (3x); 8 rows x 3072 x 2 B = 48 KB of LDS
+
+// Fused LayerNorm prologue (LN = true): the acting step's LayerNorms all feed a linear layer, and at M = 1 a LayerNorm launch
+// is a 10 us link in a serial chain of 60 kernels for 8 KB of data.  Every workgroup normalises the M rows itself -- wave w takes
+// rows w, w + 4 with EXACTLY the arithmetic of vpt_layernorm_kernel (one wave per row, same lane -> element map, same butterfly
+// sums, same rounding to the 16-bit operand), so the result is bit-identical to the two-kernel path -- into LDS, from where the
+// main loop takes its A operand.  The weight stream does not depend on it: the first weight loads are already in flight.
+template <int MR, int ROWS, bool LN>
 __global__ __launch_bounds__(256) void vpt_gemv_kernel(VptGemmArgs a) {
   constexpr int KPI = 64 / (4 * ROWS);          // k blocks covered by one wave-wide load instruction
   __shared__ float part_[4][ROWS][MR];
+  __shared__ __attribute__((aligned(16))) vpt_op16 arow_[LN ? MR * GEMV_LN_MAXK : 8];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int NB = (a.N + ROWS - 1) / ROWS;
   const int nb = blockIdx.x % NB, split = blockIdx.x / NB;
@@ -31,18 +39,68 @@ __global__ __launch_bounds__(256) void vpt_gemv_kernel(VptGemmArgs a) {
   float acc[MR];
 #pragma unroll
   for (int m = 0; m < MR; ++m) acc[m] = 0.f;
-#pragma unroll 4
-  for (int kb = kb0 + w * KPI + ksub; kb < kb1; kb += 4 * KPI) {
+  const int kbf = kb0 + w * KPI + ksub;        // this lane's first k block
+  u32x4 wpre[4];
+  if (LN) {
+    // the first four weight loads of the lane go out BEFORE the normalisation (they do not depend on it)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kb = min(kbf + j * 4 * KPI, kbs - 1);
+      wpre[j] = *(const u32x4*)(wp + (size_t)kb * 4096);
+    }
+    const int n4 = a.K >> 2;
+    for (int m = w; m < a.M; m += 4) {
+      const float* x = a.ln_x + (size_t)m * a.K;
+      float s = 0.f;
+      for (int i = lane; i < n4; i += 64) {
+        f32x4 v = *(const f32x4*)(x + 4 * i);
+        if (a.ln_relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        s += (v.x + v.y) + (v.z + v.w);
+      }
+      const float mean = wave_sum(s) / (float)a.K;
+      float ss = 0.f;
+      for (int i = lane; i < n4; i += 64) {
+        f32x4 v = *(const f32x4*)(x + 4 * i);
+        if (a.ln_relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+        ss += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
+      const float rstd = rsqrtf(wave_sum(ss) / (float)a.K + VPT_NORM_EPS);
+      for (int i = lane; i < n4; i += 64) {
+        f32x4 v = *(const f32x4*)(x + 4 * i);
+        if (a.ln_relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        const f32x4 g = *(const f32x4*)(a.ln_gain + 4 * i), b = *(const f32x4*)(a.ln_bias + 4 * i);
+        f32x4 y;
+        y.x = fmaf((v.x - mean) * rstd, g.x, b.x);
+        y.y = fmaf((v.y - mean) * rstd, g.y, b.y);
+        y.z = fmaf((v.z - mean) * rstd, g.z, b.z);
+        y.w = fmaf((v.w - mean) * rstd, g.w, b.w);
+        if (a.ln_out_f32 && blockIdx.x == 0) *(f32x4*)(a.ln_out_f32 + (size_t)m * a.K + 4 * i) = y;
+        u32x2 p = {pack_op16x2(y.x, y.y), pack_op16x2(y.z, y.w)};
+        *(u32x2*)(arow_ + (size_t)m * a.K + 4 * i) = p;
+      }
+    }
+    __syncthreads();
+  }
+  auto mac = [&](const u32x4& wraw, int kb) {
     float wv[8];
-    unpack8(*(const u32x4*)(wp + (size_t)kb * 4096), wv);
+    unpack8(wraw, wv);
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
       float av[8];
-      unpack8(*(const u32x4*)(ap + (size_t)min(m, a.M - 1) * a.lda + kb * 32), av);
+      if (LN) unpack8(*(const u32x4*)(arow_ + (size_t)min(m, a.M - 1) * a.K + kb * 32 + chunk * 8), av);
+      else unpack8(*(const u32x4*)(ap + (size_t)min(m, a.M - 1) * a.lda + kb * 32), av);
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc[m] = fmaf(wv[k], av[k], acc[m]);
     }
+  };
+  if (LN) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (kbf + j * 4 * KPI < kb1) mac(wpre[j], kbf + j * 4 * KPI);
   }
+#pragma unroll 4
+  for (int kb = kbf + (LN ? 16 * KPI : 0); kb < kb1; kb += 4 * KPI) mac(*(const u32x4*)(wp + (size_t)kb * 4096), kb);
 #pragma unroll
   for (int m = 0; m < MR; ++m) {
     acc[m] += __shfl_xor(acc[m], 1, 64);
@@ -75,18 +133,22 @@ __global__ __launch_bounds__(256) void vpt_gemv_kernel(VptGemmArgs a) {
 }
 
 extern "C" int vpt_gemv_launch(const VptGemmArgs* a, hipStream_t stream) {
-  if (a->M <= 0 || a->M > 8 || a->N <= 0 || (a->K & 31) || a->splitk < 1 || (a->lda & 7)) return -1;
+  if (a->M <= 0 || a->M > 8 || a->N <= 0 || (a->K & 31) || a->splitk < 1) return -1;
+  if (!a->ln_x && (a->lda & 7)) return -1;
+  if (a->ln_x && (a->K > GEMV_LN_MAXK || a->splitk != 1 || !a->ln_gain || !a->ln_bias)) return -1;
   if (a->splitk > 1 && (!a->atomic_out || a->relu || a->res || a->out_bf16 || a->mask)) return -1;
   const int rows = ((a->N + 15) >> 4) * a->splitk >= 512 ? 16 : 4;
   const long grid = (long)((a->N + rows - 1) / rows) * a->splitk;
   if (grid > 0x7fffffffL) return -2;
   const dim3 g((unsigned)grid), b(256);
-#define GEMV_(MR_) do { if (rows == 16) hipLaunchKernelGGL((vpt_gemv_kernel<MR_, 16>), g, b, 0, stream, *a); \
-                        else hipLaunchKernelGGL((vpt_gemv_kernel<MR_, 4>), g, b, 0, stream, *a); } while (0)
+#define GEMV__(MR_, LN_) do { if (rows == 16) hipLaunchKernelGGL((vpt_gemv_kernel<MR_, 16, LN_>), g, b, 0, stream, *a); \
+                              else hipLaunchKernelGGL((vpt_gemv_kernel<MR_, 4, LN_>), g, b, 0, stream, *a); } while (0)
+#define GEMV_(MR_) do { if (a->ln_x) GEMV__(MR_, true); else GEMV__(MR_, false); } while (0)
   if (a->M == 1) GEMV_(1);
   else if (a->M == 2) GEMV_(2);
   else if (a->M <= 4) GEMV_(4);
   else GEMV_(8);
 #undef GEMV_
+#undef GEMV__
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -86,6 +86,12 @@ struct VptGemmArgs {
   int relu, splitk, atomic_out;
   const vpt_op16* mask;    // optional [M][ldm]: output is zeroed where mask <= 0 (ReLU backward)
   int ldm;
+  // fused LayerNorm prologue (skinny path only, M <= 8, K <= 3072): A = op16(LayerNorm(ln_x)) computed by every workgroup
+  const float* ln_x;       // [M][K] fp32 or null (then A is used)
+  const float* ln_gain;    // [K]
+  const float* ln_bias;    // [K]
+  float* ln_out_f32;       // optional [M][K]: the normalised row in fp32 (residual / latent), written by workgroup 0
+  int ln_relu_in;
 };
 
 struct VptGemmTnArgs {     // C[n1][n2] (+)= sum_m A[m][n1] * B[m][n2]
@@ -305,6 +311,7 @@ int vpt_ln_bwd_launch(const VptLnBwdArgs* a, hipStream_t s);
 int vpt_gate_cast_launch(const VptGateCastArgs* a, hipStream_t s);
 int vpt_colsum_launch(const VptColsumArgs* a, hipStream_t s);
 int vpt_clip_launch(const VptClipArgs* a, hipStream_t s);
+int vpt_attn_step_launch(const VptAttnArgs* a, const uint8_t* state_mask, const uint8_t* first, uint8_t* mask_out, float* kout, float* vout, hipStream_t s);
 int vpt_attn_bwd_launch(const VptAttnBwdArgs* a, hipStream_t s);
 int vpt_conv3x3_launch(const VptConv3x3Args* a, hipStream_t s);
 int vpt_conv_first_launch(const VptConvFirstArgs* a, hipStream_t s);

@@ -231,6 +231,121 @@ extern "C" int vpt_attn_launch(const VptAttnArgs* a, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Acting step (t = 1, agent.py:190-206): one query per (sequence, head) against the maxlen - 1 newest memory rows and itself,
+// FUSED with the recurrent-state update -- the K / V rows this step reads are exactly the rows the shifted memory keeps, so they
+// are stored (one row up) as they pass through, and the visibility it derives (state_mask & ~first, lib/xf.py:366-391) is the
+// next state mask.  The general kernel above spends ~40 us per layer on a 32-query MFMA tile with one live row, plus
+// vpt_kv_update_kernel and five torch kernels for the masks; here a workgroup = (sequence, head) issues all its loads at once:
+//   thread (key, half of d_head): 16 float4 of its K row -> dot with q, pair-sum by shuffle -> logit (+ rel-pos bias, visibility);
+//   block softmax; thread (d, half of the keys): 64 V values (coalesced over d) x probabilities -> output.
+// Every row is loaded into registers before a barrier and stored after it, and a workgroup owns its head's 128 columns of the
+// memory: kout / vout / mask_out MAY ALIAS kmem / vmem / state_mask (the captured acting graph updates its state in place).
+// Same formulas as vpt_attn_kernel (scale 1 / d_head, bias sum_n R[n] b_nd[n][off], invisible rows excluded, all-invisible -> 0);
+// the sums run on the vector ALU in a different order than the matrix cores', so results agree to fp32 rounding, not bit for bit.
+struct VptAttnStepExtra {
+  const uint8_t* state_mask;   // [B][maxlen] bool bytes: the memory rows that hold data
+  const uint8_t* first;        // [B] bool bytes: episode start -> the memory is ignored (and invalidated)
+  uint8_t* mask_out;           // [B][maxlen]: next step's state_mask
+  float* kout;                 // [B][maxlen][hid]
+  float* vout;
+};
+
+__global__ __launch_bounds__(256) void vpt_attn_step_kernel(VptAttnArgs a, VptAttnStepExtra x) {
+  __shared__ float sc_[128], red_[8], part_[128];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int b = blockIdx.x / a.heads, h = blockIdx.x - b * a.heads;
+  const int maxlen = a.maxlen, hid = a.hid;
+  const float* qrow = a.qkvr + (size_t)b * a.ld;            // t = 1: token b
+  // row j of [memory ; new token], this head's slice: K (which = 1) or V (which = 2)
+  auto kv_row = [&](int j, int which) -> const float* {
+    if (j < maxlen) return (which == 1 ? a.kmem : a.vmem) + ((size_t)b * maxlen + j) * hid + h * ATT_DH;
+    return qrow + which * hid + h * ATT_DH;
+  };
+  // ---- logits: thread = (key kk, half) ----
+  const int kk = tid >> 1, half = tid & 1;
+  const bool live = kk < maxlen;
+  const int j = 1 + kk;
+  f32x4 kv[16];
+  float s = -3.0e38f;
+  bool vis = false;
+  if (live) {
+    // every load of the phase first (K row, q, visibility, the rel-pos operands), then the arithmetic
+    const float* kr = kv_row(j, 1) + half * 64;
+    const float* q = qrow + h * ATT_DH + half * 64;
+    f32x4 qv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kv[i] = *(const f32x4*)(kr + 4 * i);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) qv[i] = *(const f32x4*)(q + 4 * i);
+    const unsigned char mv = x.state_mask[(size_t)b * maxlen + min(j, maxlen - 1)];
+    const unsigned char fst = x.first[b];
+    const int off = maxlen - 1 - kk;
+    float rr[10], bb[10];
+#pragma unroll
+    for (int n = 0; n < 10; ++n) { rr[n] = qrow[3 * hid + h * 10 + n]; bb[n] = a.b_nd[n * maxlen + off]; }
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      dot = fmaf(qv[i].x, kv[i].x, dot); dot = fmaf(qv[i].y, kv[i].y, dot); dot = fmaf(qv[i].z, kv[i].z, dot); dot = fmaf(qv[i].w, kv[i].w, dot);
+    }
+    dot += __shfl_xor(dot, 1, 64);
+    vis = (j < maxlen) ? (mv != 0 && fst == 0) : true;     // memory row: state_mask & ~first; the token itself: always
+    if (vis) {
+      float rb = 0.f;
+#pragma unroll
+      for (int n = 0; n < 10; ++n) rb = fmaf(rr[n], bb[n], rb);
+      s = dot * (1.0f / ATT_DH) + rb;
+    }
+  }
+  // ---- block softmax over the keys (every key sits in two lanes: count half 0 only) ----
+  float m = wave_max(s);
+  if (lane == 0) red_[w] = m;
+  __syncthreads();           // (all K rows and mask bytes of the workgroup are in registers now: the shifted stores may alias them)
+  if (live) {
+    float* ko = x.kout + ((size_t)b * maxlen + kk) * hid + h * ATT_DH + half * 64;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) *(f32x4*)(ko + 4 * i) = kv[i];   // memory row kk of the next step = row kk + 1 of [memory ; new]
+    if (h == 0 && half == 0) x.mask_out[(size_t)b * maxlen + kk] = vis ? 1 : 0;   // = cat(state_mask[1:] & ~first, [True])
+  }
+  m = fmaxf(fmaxf(red_[0], red_[1]), fmaxf(red_[2], red_[3]));
+  const float e = (s > -1.0e38f) ? expf(s - m) : 0.f;
+  const float tot_w = wave_sum(half == 0 ? e : 0.f);
+  if (half == 0) sc_[kk] = e;                              // (kk = tid >> 1 < 128)
+  if (lane == 0) red_[4 + w] = tot_w;
+  __syncthreads();
+  const float tot = (red_[4] + red_[5]) + (red_[6] + red_[7]);
+  const float inv = (tot > 0.f) ? 1.0f / tot : 0.f;
+  // ---- out = P V: thread = (d, half of the keys); all 64 values in registers before the barrier, shifted stores after it ----
+  {
+    const int d = tid & 127, kh = tid >> 7;
+    const int k0 = kh * 64;
+    float v[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) v[i] = kv_row(1 + min(k0 + i, maxlen - 1), 2)[d];
+    float o = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i)
+      if (k0 + i < maxlen) o = fmaf(sc_[k0 + i], v[i], o);
+    if (kh == 1) part_[d] = o;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 64; ++i)
+      if (k0 + i < maxlen) x.vout[((size_t)b * maxlen + k0 + i) * hid + h * ATT_DH + d] = v[i];
+    if (kh == 0) a.out[(size_t)b * hid + h * ATT_DH + d] = (vpt_op16)((o + part_[d]) * inv);
+  }
+}
+
+extern "C" int vpt_attn_step_launch(const VptAttnArgs* a, const uint8_t* state_mask, const uint8_t* first, uint8_t* mask_out, float* kout, float* vout,
+                                    hipStream_t stream) {
+  if (a->hid != a->heads * ATT_DH || a->t != 1 || !a->causal || a->maxlen < 1 || a->maxlen > 128) return -1;
+  if (!kout || !vout || !state_mask || !first || !mask_out) return -1;
+  VptAttnStepExtra x;
+  x.state_mask = state_mask; x.first = first; x.mask_out = mask_out; x.kout = kout; x.vout = vout;
+  hipLaunchKernelGGL(vpt_attn_step_kernel, dim3((unsigned)(a->B * a->heads)), dim3(256), 0, stream, *a, x);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vpt_kv_update_kernel(VptKvUpdateArgs a) {
   const int which = blockIdx.y;  // 0 = K, 1 = V
   const size_t n4 = (size_t)a.B * a.maxlen * (a.hid >> 2);

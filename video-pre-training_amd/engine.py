@@ -101,7 +101,7 @@ def action_heads(logits, heads, bsz, t, temperature, mask=None, sample=None):
             noise = torch.rand(rows, n, dtype=torch.float32, device=z.device) if sample == "stochastic" else None
             lp, ac, alp = ops.log_softmax_cols(z, c0, n, temperature, mask=mk, noise=noise, want_action=True)
             actions[name] = ac.view(bsz, t, groups)
-            alp = alp.view(bsz, t, groups).sum(-1)
+            alp = alp.view(bsz, t) if groups == 1 else alp.view(bsz, t, groups).sum(-1)     # (no reduction kernel for the usual single group)
             logp = alp if logp is None else logp + alp
         out[name] = lp.view(bsz, t, groups, n)
     if sample is not None:
@@ -224,6 +224,16 @@ class PolicyEngine:
         p = "net.img_process.cnn.dense."
         return ops.frame_affine(x, w[p + "g"], w[p + "b"], s_x, per_element=True)
 
+    def _ln_linear(self, x, g, b, wpk, n, bias=None, res=None, relu=False, relu_in=False, ln_out_f32=False, out_f32=True, out_bf16=False):
+        """LayerNorm -> linear.  Acting path (<= 8 rows): ONE launch (the normalisation is a prologue of the weight-streaming kernel,
+        bit-identical); otherwise vpt_layernorm_kernel + the GEMM.  -> (normalised rows fp32 | None, fp32 out | None, 16-bit out | None)."""
+        if x.shape[0] <= ops.LN_LINEAR_MAX_ROWS and x.shape[1] <= ops.LN_LINEAR_MAX_K:
+            return ops.layernorm_linear(x, g, b, wpk, n, bias=bias, res=res, relu=relu, relu_in=relu_in, ln_out_f32=ln_out_f32,
+                                        out_f32=out_f32, out_bf16=out_bf16, dtype=self.dtype)
+        ln32, ln16 = ops.layernorm(x, g, b, relu_in=relu_in, out_f32=ln_out_f32, dtype=self.dtype)
+        o32, o16 = ops.linear(ln16, wpk, n, bias=bias, res=res, relu=relu, out_f32=out_f32, out_bf16=out_bf16)
+        return ln32, o32, o16
+
     def _img_process(self, frames: torch.Tensor) -> torch.Tensor:
         """uint8 [N,128,128,3] -> fp32 [N,hid]  (ImgObsProcess.forward, lib/policy.py:79-80)."""
         cfg, w = self.cfg, self.w
@@ -252,16 +262,16 @@ class PolicyEngine:
                 main.wait_stream(st)
         d = outs[0] if len(outs) == 1 else torch.cat(outs, 0)
         p = "net.img_process.linear."
-        _, dn = ops.layernorm(d, w[p + "g"], w[p + "b"], relu_in=True, dtype=self.dtype)
-        x, _ = ops.linear(dn, w[p + "w"], cfg["hidsize"], relu=True)
+        _, x, _ = self._ln_linear(d, w[p + "g"], w[p + "b"], w[p + "w"], cfg["hidsize"], relu=True, relu_in=True)
         return x
 
     @torch.no_grad()
     def forward(self, img_u8: torch.Tensor, first: torch.Tensor, state_in: List, mask: Optional[dict] = None,
-                sample: Optional[str] = None):
+                sample: Optional[str] = None, inplace_state: bool = False):
         """mask: optional {"buttons" / "camera": bool [B,T,1,n]} availability masks (obs["mask"], lib/policy.py:257-266).
         sample: None, "deterministic" or "stochastic" -- CategoricalActionHead.sample + logprob fused into the head kernel
-        (lib/action_head.py:176-207); adds out["action"] (int64 [B,T,1] per head) and out["action_log_prob"] ([B,T])."""
+        (lib/action_head.py:176-207); adds out["action"] (int64 [B,T,1] per head) and out["action_log_prob"] ([B,T]).
+        inplace_state (T = 1 only): state_out IS state_in, updated in place (the captured acting graph's static state)."""
         if not self.packed:
             raise RuntimeError("PolicyEngine.pack(state_dict) must be called before forward")
         cfg, w = self.cfg, self.w
@@ -270,31 +280,37 @@ class PolicyEngine:
         frames = img_u8.reshape(bsz * t, *img_u8.shape[2:]).contiguous()
         x = self._img_process(frames)
 
-        not_first = ~first[:, 0].reshape(bsz, 1, 1)
+        step = t == 1 and maxlen <= ops.ATTENTION_STEP_MAXLEN     # acting step: attention, memory shift and mask update in one launch
+        if step:
+            first8 = first[:, 0].contiguous().view(torch.uint8)
+        else:
+            not_first = ~first[:, 0].reshape(bsz, 1, 1)
         state_out = []
         for l in range(cfg["n_layers"]):
             p = f"net.recurrent_layer.blocks.{l}."
             state_mask, (kmem, vmem) = state_in[l]
             if state_mask is None:
                 state_mask = torch.zeros(bsz, 1, maxlen, dtype=torch.bool, device=x.device)
-            memvalid = (state_mask & not_first).reshape(bsz, maxlen).to(torch.uint8).contiguous()
-            x1, x1b = ops.layernorm(x, w[p + "ln1.g"], w[p + "ln1.b"], out_f32=True, dtype=self.dtype)
-            qkvr, _ = ops.linear(x1b, w[p + "qkvr.w"], self.n_qkvr, bias=w[p + "qkvr.b"])
-            att = ops.masked_attention(qkvr, kmem.contiguous(), vmem.contiguous(), memvalid, w[p + "b_nd"], bsz, t, heads, hid, dtype=self.dtype)
-            kout, vout = ops.kv_memory_update(qkvr, kmem.contiguous(), vmem.contiguous(), bsz, t, hid)
+            x1, qkvr, _ = self._ln_linear(x, w[p + "ln1.g"], w[p + "ln1.b"], w[p + "qkvr.w"], self.n_qkvr, bias=w[p + "qkvr.b"], ln_out_f32=True)
+            if step:
+                att, kout, vout, m8 = ops.masked_attention_step(qkvr, kmem.contiguous(), vmem.contiguous(), state_mask.reshape(bsz, maxlen).contiguous(), first8,
+                                                               w[p + "b_nd"], bsz, heads, hid, dtype=self.dtype, inplace=inplace_state)
+                new_mask = m8.view(torch.bool).view(bsz, 1, maxlen)
+            else:
+                memvalid = (state_mask & not_first).reshape(bsz, maxlen).to(torch.uint8).contiguous()
+                att = ops.masked_attention(qkvr, kmem.contiguous(), vmem.contiguous(), memvalid, w[p + "b_nd"], bsz, t, heads, hid, dtype=self.dtype)
+                kout, vout = ops.kv_memory_update(qkvr, kmem.contiguous(), vmem.contiguous(), bsz, t, hid)
+                new_mask = torch.cat([state_mask[:, :, t:] & not_first,
+                                      torch.ones(bsz, 1, min(t, maxlen), dtype=torch.bool, device=x.device)], dim=-1)
             x2, _ = ops.linear(att, w[p + "proj.w"], hid, bias=w[p + "proj.b"], res=x1)
-            _, hb = ops.layernorm(x2, w[p + "ln2.g"], w[p + "ln2.b"], dtype=self.dtype)
-            _, h2 = ops.linear(hb, w[p + "mlp0.w"], hid * cfg["pointwise_ratio"], relu=True, out_f32=False, out_bf16=True)
+            _, _, h2 = self._ln_linear(x2, w[p + "ln2.g"], w[p + "ln2.b"], w[p + "mlp0.w"], hid * cfg["pointwise_ratio"], relu=True,
+                                       out_f32=False, out_bf16=True)
             x, _ = ops.linear(h2, w[p + "mlp1.w"], hid, bias=w[p + "mlp1.b"], res=x2)
-            new_mask = torch.cat([state_mask[:, :, t:] & not_first,
-                                  torch.ones(bsz, 1, min(t, maxlen), dtype=torch.bool, device=x.device)], dim=-1)
             state_out.append((new_mask, (kout, vout)))
 
-        _, xb = ops.layernorm(x, w["last.g"], w["last.b"], relu_in=True, dtype=self.dtype)
-        y, _ = ops.linear(xb, w["last.w"], hid, relu=True)
-        latent, lb = ops.layernorm(y, w["final.g"], w["final.b"], out_f32=True, dtype=self.dtype)
+        _, y, _ = self._ln_linear(x, w["last.g"], w["last.b"], w["last.w"], hid, relu=True, relu_in=True)
         nb, nc = self.n_buttons, self.n_camera
-        logits, _ = ops.linear(lb, w["heads.w"], nb + nc + 1, bias=w["heads.b"])
+        latent, logits, _ = self._ln_linear(y, w["final.g"], w["final.b"], w["heads.w"], nb + nc + 1, bias=w["heads.b"], ln_out_f32=True)
         temp = cfg["temperature"]
         out = dict(latent=latent.view(bsz, t, hid), state_out=state_out)
         heads_out = action_heads(logits, (("buttons", 0, 1, nb), ("camera", nb, 1, nc)), bsz, t, temp, mask, sample)

@@ -271,9 +271,13 @@ class MinecraftAgentPolicy(nn.Module):
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            out = eng.forward(sg["img"], sg["first"], sg["state"], sample="deterministic")   # arg-max + its log-prob ride in the graph
+            # arg-max + its log-prob ride in the graph; the recurrent state is updated in place (no copies back into the static buffers)
+            out = eng.forward(sg["img"], sg["first"], sg["state"], sample="deterministic", inplace_state=True)
             for (m_in, (k_in, v_in)), (m_out, (k_out, v_out)) in zip(sg["state"], out["state_out"]):
-                m_in.copy_(m_out); k_in.copy_(k_out); v_in.copy_(v_out)
+                if m_out.data_ptr() != m_in.data_ptr():
+                    m_in.copy_(m_out)
+                if k_out.data_ptr() != k_in.data_ptr():
+                    k_in.copy_(k_out); v_in.copy_(v_out)
         for m_in, (k_in, v_in) in sg["state"]:    # the warm-up / capture runs advanced nothing: start from a clean state
             m_in.zero_(); k_in.zero_(); v_in.zero_()
         sg["graph"], sg["out"] = graph, out

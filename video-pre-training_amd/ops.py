@@ -229,6 +229,27 @@ def layernorm(x, gain, bias, relu_in=False, out_f32=False, out_bf16=True, dtype=
     return o32, o16
 
 
+LN_LINEAR_MAX_ROWS, LN_LINEAR_MAX_K = 8, 3072
+
+
+def layernorm_linear(x, gain, ln_bias, wpk, n, bias=None, res=None, relu=False, relu_in=False, ln_out_f32=False, out_f32=True, out_bf16=False,
+                     dtype=torch.bfloat16):
+    """LayerNorm (optionally of relu(x)) fused into the linear layer it feeds, for the acting path (M <= 8 rows, K <= 3072):
+    (normalised rows fp32 or None, [M,n] fp32 or None, [M,n] 16-bit or None) -- bit-identical to layernorm() + linear()."""
+    _chk(x, torch.float32, "x"); _chk(gain, torch.float32, "gain"); _chk(ln_bias, torch.float32, "ln_bias"); _chk(wpk, OP16, "wpk")
+    _chk(bias, torch.float32, "bias"); _chk(res, torch.float32, "res")
+    m, k = x.shape
+    if m > LN_LINEAR_MAX_ROWS or k > LN_LINEAR_MAX_K:
+        raise ValueError(f"layernorm_linear: M <= {LN_LINEAR_MAX_ROWS}, K <= {LN_LINEAR_MAX_K} (got {m} x {k}); call layernorm() and linear()")
+    dt, fmt = _fmt(wpk, dtype=dtype)
+    ln32 = torch.empty_like(x) if ln_out_f32 else None
+    o32 = torch.empty(m, n, dtype=torch.float32, device=x.device) if out_f32 else None
+    o16 = torch.empty(m, n, dtype=dt, device=x.device) if out_bf16 else None
+    _call("vpt_layernorm_linear_forward", dict(flops=2.0 * m * n * k, bytes=2.0 * n * k + 4.0 * m * (n + 2 * k)), ptr(x), ptr(gain), ptr(ln_bias), 1 if relu_in else 0, ptr(ln32),
+          ptr(wpk), ptr(bias), ptr(res), ptr(o32), ptr(o16), m, n, k, n, n, n, 1 if relu else 0, _stream(), fmt=fmt)
+    return ln32, o32, o16
+
+
 def conv3d_t5(img_u8, wfrag, bias, cout, t, stats_out=None):
     """img_u8 [F = B*t, H, W, 3] uint8 -> blocked bf16 [F, cout/32, H, W, 32] (IDM temporal conv + ReLU)."""
     _chk(img_u8, torch.uint8, "img"); _chk(wfrag, OP16, "wfrag"); _chk(bias, torch.float32, "bias")
@@ -268,6 +289,34 @@ def kv_memory_update(qkvr, kmem, vmem, batch, t, hid):
     _call("vpt_kv_memory_update", dict(bytes=16.0 * batch * kmem.shape[1] * hid), ptr(qkvr), ptr(kmem), ptr(vmem), ptr(kout), ptr(vout),
                  batch, t, hid, qkvr.shape[1], kmem.shape[1], _stream())
     return kout, vout
+
+
+ATTENTION_STEP_MAXLEN = 128
+
+
+def masked_attention_step(qkvr, kmem, vmem, state_mask, first, b_nd, batch, heads, hid, dtype=torch.bfloat16, inplace=False):
+    """Acting step (t = 1): masked_attention(), kv_memory_update() and the state-mask bookkeeping in one launch.
+    state_mask bool/uint8 [batch, maxlen], first bool/uint8 [batch] -> (out 16-bit [batch, hid], kout, vout, new mask uint8 [batch, maxlen]).
+    inplace: the outputs ARE kmem / vmem / state_mask (updated in place: the captured acting graph's static state)."""
+    _chk(qkvr, torch.float32, "qkvr"); _chk(kmem, torch.float32, "kmem"); _chk(vmem, torch.float32, "vmem"); _chk(b_nd, torch.float32, "b_nd")
+    if state_mask.dtype == torch.bool:
+        state_mask = state_mask.view(torch.uint8)
+    if first.dtype == torch.bool:
+        first = first.view(torch.uint8)
+    _chk(state_mask, torch.uint8, "state_mask"); _chk(first, torch.uint8, "first")
+    maxlen = kmem.shape[1]
+    if qkvr.shape[0] != batch or maxlen > ATTENTION_STEP_MAXLEN or tuple(state_mask.shape) != (batch, maxlen) or first.numel() != batch:
+        raise ValueError(f"masked_attention_step: one token per sequence, maxlen <= {ATTENTION_STEP_MAXLEN}, state_mask [batch, maxlen], first [batch] "
+                         f"(got {qkvr.shape[0]} rows for batch {batch}, maxlen {maxlen}, mask {tuple(state_mask.shape)})")
+    dt, fmt = _fmt(dtype=dtype)
+    out = torch.empty(batch, hid, dtype=dt, device=qkvr.device)
+    if inplace:
+        kout, vout, mout = kmem, vmem, state_mask
+    else:
+        kout, vout, mout = torch.empty_like(kmem), torch.empty_like(vmem), torch.empty_like(state_mask)
+    _call("vpt_masked_attention_step", dict(flops=4.0 * batch * maxlen * hid, bytes=16.0 * batch * maxlen * hid), ptr(qkvr), ptr(kmem), ptr(vmem), ptr(state_mask), ptr(first),
+          ptr(b_nd), ptr(out), ptr(kout), ptr(vout), ptr(mout), batch, heads, hid, qkvr.shape[1], maxlen, _stream(), fmt=fmt)
+    return out, kout, vout, mout
 
 
 def log_softmax_cols(logits, col0, n, temperature, mask=None, noise=None, want_action=False):
