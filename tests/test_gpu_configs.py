@@ -199,3 +199,51 @@ def test_bc_step_3x():
         worst = min(worst, cos)
         assert cos > 0.7, (name, cos)     # bf16 gate flips: see test_bc_gradients_vs_oracle for the calibrated bound
     print(f"PARITY 3x BC gradients: worst cosine vs fp32 oracle {worst:.3f}")
+
+
+def test_pre_lstm_ln_option_forward_and_bc():
+    """use_pre_lstm_ln=True -- the reference's constructor DEFAULT (lib/policy.py:186-188,202-203), switched off by every released
+    model file: forward (a chunk, then a T = 1 acting step on the carried state) and BC gradients against the oracle."""
+    _threads()
+    pk = dict(O.policy_kwargs_for("1x"))
+    pk["use_pre_lstm_ln"] = True
+    cfg = O.config_from_policy_kwargs(pk, dict(temperature=2.0))
+    assert cfg["use_pre_lstm_ln"]
+    sd = O.synthetic_state_dict(cfg, seed=0)
+    assert "net.pre_lstm_ln.weight" in sd
+    pol = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0))
+    pol.load_state_dict(sd, strict=False)
+    pol = pol.to(DEV)
+    b = 2
+    g = torch.Generator().manual_seed(11)
+    so, sg = O.initial_state(cfg, b), pol.initial_state(b)
+    for t in (5, 1):
+        img = torch.randint(0, 256, (b, t, 128, 128, 3), generator=g, dtype=torch.uint8)
+        first = torch.zeros(b, t, dtype=torch.bool)
+        ref = O.policy_forward(sd, cfg, img, first, so)
+        so = ref["state_out"]
+        (pd, vpred, _), sg = pol({"img": img.to(DEV)}, first.to(DEV), sg)
+        torch.cuda.synchronize()
+        P.check(P.policy_metrics(dict(buttons=pd["buttons"], camera=pd["camera"], vpred=vpred), ref), "bf16", f"pre_lstm_ln t={t}")
+    # the option must matter: without the extra LayerNorm the same weights give different log-probs
+    cfg_off = dict(cfg); cfg_off["use_pre_lstm_ln"] = False
+    off = O.policy_forward(sd, cfg_off, img, first, O.initial_state(cfg, b))
+    assert float((off["buttons"] - ref["buttons"]).abs().max()) > 1e-3
+    # BC gradients (trunk + heads), incl. the new LayerNorm's gain / bias
+    t = 4
+    img = torch.randint(0, 256, (b, t, 128, 128, 3), generator=g, dtype=torch.uint8)
+    first = torch.zeros(b, t, dtype=torch.bool)
+    ab = torch.randint(0, 8641, (b, t), generator=g)
+    ac = torch.randint(0, 121, (b, t), generator=g)
+    with torch.enable_grad():
+        loss_ref, grads_ref = O.bc_loss_and_grads(sd, cfg, img, first, O.initial_state(cfg, b), ab, ac)[:2]
+    tr = BCTrainer(pol, train_cnn=False)
+    loss, grads, _ = tr.loss_and_grads(img.to(DEV), first.to(DEV), pol.initial_state(b), ab.to(DEV), ac.to(DEV))
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(loss_ref)) < 2e-2
+    assert "net.pre_lstm_ln.weight" in grads and "net.pre_lstm_ln.bias" in grads
+    for name in ("net.pre_lstm_ln.weight", "net.pre_lstm_ln.bias", "net.img_process.linear.layer.weight", "net.lastlayer.layer.weight"):
+        mine, ref_g = grads[name].cpu().reshape(grads_ref[name].shape), grads_ref[name]
+        cos = float((mine * ref_g).sum() / (mine.norm() * ref_g.norm()))
+        assert cos > 0.9, (name, cos)
+        assert 0.7 < float(mine.norm() / ref_g.norm()) < 1.4, name

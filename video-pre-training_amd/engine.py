@@ -57,8 +57,6 @@ def check_supported(cfg: dict, idm: bool = False):
     else:
         if not cfg["causal"] or not (1 <= cfg["maxlen"] <= 129):
             raise NotImplementedError("only the clipped_causal mask with 1 <= maxlen <= 129 is implemented")
-        if cfg["use_pre_lstm_ln"]:
-            raise NotImplementedError("use_pre_lstm_ln=True is not used by any released transformer model")
     if cfg["hidsize"] % 256:
         raise NotImplementedError("hidsize must be a multiple of 256")
 
@@ -172,6 +170,8 @@ class PolicyEngine:
             w[p + "mlp0.w"] = ops.pack_linear(f32(sd[p + "mlp0.layer.weight"]), dtype=self.dtype)
             w[p + "mlp1.w"], w[p + "mlp1.b"] = ops.pack_linear(f32(sd[p + "mlp1.layer.weight"]), dtype=self.dtype), f32(sd[p + "mlp1.layer.bias"])
             self.n_qkvr = 3 * hid + nr
+        if cfg["use_pre_lstm_ln"]:    # MinecraftPolicy.pre_lstm_ln (lib/policy.py:186-188,202-203): the reference's default, off in the released models
+            w["prelstm.g"], w["prelstm.b"] = f32(sd["net.pre_lstm_ln.weight"]), f32(sd["net.pre_lstm_ln.bias"])
         w["last.g"], w["last.b"] = f32(sd["net.lastlayer.norm.weight"]), f32(sd["net.lastlayer.norm.bias"])
         w["last.w"] = ops.pack_linear(f32(sd["net.lastlayer.layer.weight"]), dtype=self.dtype)
         w["final.g"], w["final.b"] = f32(sd["net.final_ln.weight"]), f32(sd["net.final_ln.bias"])
@@ -279,8 +279,12 @@ class PolicyEngine:
         hid, heads, maxlen = cfg["hidsize"], cfg["heads"], cfg["maxlen"]
         frames = img_u8.reshape(bsz * t, *img_u8.shape[2:]).contiguous()
         x = self._img_process(frames)
+        if cfg["use_pre_lstm_ln"]:
+            x, _ = ops.layernorm(x, w["prelstm.g"], w["prelstm.b"], out_f32=True, out_bf16=False, dtype=self.dtype)
 
         step = t == 1 and maxlen <= ops.ATTENTION_STEP_MAXLEN     # acting step: attention, memory shift and mask update in one launch
+        if inplace_state and not step:
+            raise ValueError("inplace_state is the acting step's option (T = 1)")
         if step:
             first8 = first[:, 0].contiguous().view(torch.uint8)
         else:
@@ -293,6 +297,8 @@ class PolicyEngine:
                 state_mask = torch.zeros(bsz, 1, maxlen, dtype=torch.bool, device=x.device)
             x1, qkvr, _ = self._ln_linear(x, w[p + "ln1.g"], w[p + "ln1.b"], w[p + "qkvr.w"], self.n_qkvr, bias=w[p + "qkvr.b"], ln_out_f32=True)
             if step:
+                if inplace_state and not (kmem.is_contiguous() and vmem.is_contiguous() and state_mask.is_contiguous()):
+                    raise ValueError("inplace_state needs contiguous state tensors (a .contiguous() copy would receive the update instead of the state)")
                 att, kout, vout, m8 = ops.masked_attention_step(qkvr, kmem.contiguous(), vmem.contiguous(), state_mask.reshape(bsz, maxlen).contiguous(), first8,
                                                                w[p + "b_nd"], bsz, heads, hid, dtype=self.dtype, inplace=inplace_state)
                 new_mask = m8.view(torch.bool).view(bsz, 1, maxlen)
@@ -370,6 +376,8 @@ class IDMEngine(PolicyEngine):
             w[p + "ln2.g"], w[p + "ln2.b"] = f32(sd[p + "mlp0.norm.weight"]), f32(sd[p + "mlp0.norm.bias"])
             w[p + "mlp0.w"] = ops.pack_linear(f32(sd[p + "mlp0.layer.weight"]), dtype=self.dtype)
             w[p + "mlp1.w"], w[p + "mlp1.b"] = ops.pack_linear(f32(sd[p + "mlp1.layer.weight"]), dtype=self.dtype), f32(sd[p + "mlp1.layer.bias"])
+        if cfg["use_pre_lstm_ln"]:
+            w["prelstm.g"], w["prelstm.b"] = f32(sd["net.pre_lstm_ln.weight"]), f32(sd["net.pre_lstm_ln.bias"])
         w["final.g"], w["final.b"] = f32(sd["net.final_ln.weight"]), f32(sd["net.final_ln.bias"])
         for h in ("buttons", "camera"):
             w[h + ".w"] = ops.pack_linear(f32(sd[f"pi_head.{h}.linear_layer.weight"]), dtype=self.dtype)
@@ -403,6 +411,8 @@ class IDMEngine(PolicyEngine):
         p = "net.img_process.linear."
         _, dn = ops.layernorm(d, w[p + "g"], w[p + "b"], relu_in=True, dtype=self.dtype)
         x, _ = ops.linear(dn, w[p + "w"], hid, relu=True)
+        if cfg["use_pre_lstm_ln"]:
+            x, _ = ops.layernorm(x, w["prelstm.g"], w["prelstm.b"], out_f32=True, out_bf16=False, dtype=self.dtype)
         for l in range(cfg["n_layers"]):
             p = f"net.recurrent_layer.blocks.{l}."
             x1, x1b = ops.layernorm(x, w[p + "ln1.g"], w[p + "ln1.b"], out_f32=True, dtype=self.dtype)

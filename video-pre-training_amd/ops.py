@@ -584,6 +584,8 @@ def clip_frames(frames_bgr, cursor_state=None, cursor_bgr=None, cursor_alpha=Non
         out = torch.empty(f, oh, ow, 3, dtype=torch.uint8, device=frames_bgr.device)
     ch = cw = 0
     if cursor_state is not None:
+        if cursor_bgr is None or cursor_alpha is None:
+            raise ValueError("cursor_state needs cursor_bgr and cursor_alpha")
         _chk(cursor_state, torch.int32, "cursor_state"); _chk(cursor_bgr, torch.uint8, "cursor_bgr"); _chk(cursor_alpha, torch.float64, "cursor_alpha")
         if tuple(cursor_state.shape) != (f, 3) or cursor_bgr.dim() != 3 or cursor_bgr.shape[2] != 3 or tuple(cursor_alpha.shape) != tuple(cursor_bgr.shape[:2]):
             raise ValueError("cursor_state must be [F, 3], cursor_bgr [h, w, 3], cursor_alpha [h, w]")

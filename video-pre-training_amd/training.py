@@ -143,6 +143,10 @@ class BCTrainer:
         _, dn = ops.layernorm(d, w[pl + "g"], w[pl + "b"], relu_in=True)          # bf16
         x, x16 = ops.linear(dn, w[pl + "w"], hid, relu=True, out_f32=True, out_bf16=True)
         x_lin16 = x16
+        x_pre = None
+        if cfg["use_pre_lstm_ln"]:     # MinecraftPolicy.pre_lstm_ln (lib/policy.py:202-203)
+            x_pre = x
+            x, _ = ops.layernorm(x_pre, w["prelstm.g"], w["prelstm.b"], out_f32=True, out_bf16=False)
         not_first = ~first[:, 0].reshape(bsz, 1, 1)
         saved: List[dict] = []
         state_out = []
@@ -176,7 +180,7 @@ class BCTrainer:
               for h, n_ in (("buttons", nb), ("camera", nc))}
         lp_b = ops.log_softmax_cols(logits, 0, nb, temp, mask=mk["buttons"])
         lp_c = ops.log_softmax_cols(logits, nb, nc, temp, mask=mk["camera"])
-        return dict(m=m, bsz=bsz, t=t, dev=dev, d=d, dn=dn, x_lin16=x_lin16, saved=saved, x_trunk=x_trunk, xb=xb, y=y, y16=y16, lb=lb,
+        return dict(m=m, bsz=bsz, t=t, dev=dev, d=d, dn=dn, x_lin16=x_lin16, x_pre=x_pre, saved=saved, x_trunk=x_trunk, xb=xb, y=y, y16=y16, lb=lb,
                     logits=logits, lp_b=lp_b, lp_c=lp_c, cnn_saved=cnn_saved, state_out=state_out, ldz=_round_up(nb + nc + 1, 64), mask=mk)
 
     @torch.no_grad()
@@ -261,6 +265,9 @@ class BCTrainer:
             if debug is not None:
                 debug[f'dx_block{l}'] = dx.clone(); debug[f'dx2_block{l}'] = dx2.clone(); debug[f'datt{l}'] = datt.clone(); debug[f'dqkvr{l}'] = dqkvr.clone()
             del dx2, dx2_16, datt, dqkvr, dq16, dx1, dwq
+        if cfg["use_pre_lstm_ln"]:
+            g["net.pre_lstm_ln.weight"], g["net.pre_lstm_ln.bias"] = zeros(hid), zeros(hid)
+            dx = ops.layernorm_backward(S["x_pre"], P["net.pre_lstm_ln.weight"], dx, g["net.pre_lstm_ln.weight"], g["net.pre_lstm_ln.bias"])
         # ImgObsProcess.linear: x = relu(dn Wlin^T)
         dx16 = ops.gate_cast(dx, hid, mask=x_lin16)
         ddn, _, g[pl + "layer.weight"] = linear_backward(dx16, hid, dn, P[pl + "layer.weight"])
