@@ -138,8 +138,8 @@ int vpt_kv_memory_update(const float* qkvr, const float* kmem, const float* vmem
  * vpt_masked_attention_forward(causal = 1, t = 1), vpt_kv_memory_update and the mask bookkeeping of lib/xf.py:366-391
  * (memory visible where state_mask & ~first; next mask = cat(state_mask[1:] & ~first, [True])).  One query per (sequence, head)
  * against the newest maxlen - 1 memory rows and the token itself; the rows it reads are written one row up into kout / vout.
- * state_mask / mask_out: bool bytes [B][maxlen]; first: bool bytes [B].  kout / vout / mask_out MAY alias kmem / vmem /
- * state_mask (in-place state, as the captured acting graph uses it).  maxlen <= 128.  Same formulas as the general kernel
+ * state_mask / mask_out: bool bytes [B][maxlen]; first: bool bytes [B].  kout / vout MAY alias kmem / vmem (in-place state, as
+ * the captured acting graph uses it); mask_out must be a different buffer than state_mask.  maxlen <= 128.  Same formulas as the general kernel
  * (lib/xf.py:18-71, lib/masked_attention.py:161-178); sums in a different order: equal to fp32 rounding. */
 int vpt_masked_attention_step(const float* qkvr, const float* kmem, const float* vmem, const uint8_t* state_mask, const uint8_t* first,
                               const float* b_nd, void* out, float* kout, float* vout, uint8_t* mask_out,

@@ -326,7 +326,8 @@ def test_attention_step_equals_attention_plus_memory_update(batch, heads, maxlen
     k2, v2, m2 = kmem.clone(), vmem.clone(), mv.clone()
     out2, ka, va, ma = ops.masked_attention_step(qkvr, k2, v2, m2, first, b_nd, batch, heads, hid, inplace=True)
     torch.cuda.synchronize()
-    assert ka.data_ptr() == k2.data_ptr() and torch.equal(k2, kref) and torch.equal(v2, vref) and torch.equal(m2, mref) and torch.equal(out2, out)
+    assert ka.data_ptr() == k2.data_ptr() and torch.equal(k2, kref) and torch.equal(v2, vref) and torch.equal(out2, out)
+    assert ma.data_ptr() != m2.data_ptr() and torch.equal(ma, mref) and torch.equal(m2, mv)     # the mask is never updated in place (cross-workgroup read/write)
     with pytest.raises(ValueError):
         ops.masked_attention_step(qkvr.repeat(2, 1), kmem, vmem, mv, first, b_nd, batch, heads, hid)
 

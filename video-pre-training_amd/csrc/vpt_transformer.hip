@@ -239,7 +239,8 @@ extern "C" int vpt_attn_launch(const VptAttnArgs* a, hipStream_t stream) {
 //   thread (key, half of d_head): 16 float4 of its K row -> dot with q, pair-sum by shuffle -> logit (+ rel-pos bias, visibility);
 //   block softmax; thread (d, half of the keys): 64 V values (coalesced over d) x probabilities -> output.
 // Every row is loaded into registers before a barrier and stored after it, and a workgroup owns its head's 128 columns of the
-// memory: kout / vout / mask_out MAY ALIAS kmem / vmem / state_mask (the captured acting graph updates its state in place).
+// memory: kout / vout MAY ALIAS kmem / vmem (the captured acting graph updates its state in place).  mask_out must NOT alias
+// state_mask: every head's workgroup reads the old mask, head 0's writes the new one, and workgroups are not ordered.
 // Same formulas as vpt_attn_kernel (scale 1 / d_head, bias sum_n R[n] b_nd[n][off], invisible rows excluded, all-invisible -> 0);
 // the sums run on the vector ALU in a different order than the matrix cores', so results agree to fp32 rounding, not bit for bit.
 struct VptAttnStepExtra {
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(256) void vpt_attn_step_kernel(VptAttnArgs a, VptAt
 extern "C" int vpt_attn_step_launch(const VptAttnArgs* a, const uint8_t* state_mask, const uint8_t* first, uint8_t* mask_out, float* kout, float* vout,
                                     hipStream_t stream) {
   if (a->hid != a->heads * ATT_DH || a->t != 1 || !a->causal || a->maxlen < 1 || a->maxlen > 128) return -1;
-  if (!kout || !vout || !state_mask || !first || !mask_out) return -1;
+  if (!kout || !vout || !state_mask || !first || !mask_out || mask_out == state_mask) return -1;
   VptAttnStepExtra x;
   x.state_mask = state_mask; x.first = first; x.mask_out = mask_out; x.kout = kout; x.vout = vout;
   hipLaunchKernelGGL(vpt_attn_step_kernel, dim3((unsigned)(a->B * a->heads)), dim3(256), 0, stream, *a, x);

@@ -297,7 +297,7 @@ class PolicyEngine:
                 state_mask = torch.zeros(bsz, 1, maxlen, dtype=torch.bool, device=x.device)
             x1, qkvr, _ = self._ln_linear(x, w[p + "ln1.g"], w[p + "ln1.b"], w[p + "qkvr.w"], self.n_qkvr, bias=w[p + "qkvr.b"], ln_out_f32=True)
             if step:
-                if inplace_state and not (kmem.is_contiguous() and vmem.is_contiguous() and state_mask.is_contiguous()):
+                if inplace_state and not (kmem.is_contiguous() and vmem.is_contiguous()):
                     raise ValueError("inplace_state needs contiguous state tensors (a .contiguous() copy would receive the update instead of the state)")
                 att, kout, vout, m8 = ops.masked_attention_step(qkvr, kmem.contiguous(), vmem.contiguous(), state_mask.reshape(bsz, maxlen).contiguous(), first8,
                                                                w[p + "b_nd"], bsz, heads, hid, dtype=self.dtype, inplace=inplace_state)

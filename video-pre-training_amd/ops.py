@@ -297,7 +297,9 @@ ATTENTION_STEP_MAXLEN = 128
 def masked_attention_step(qkvr, kmem, vmem, state_mask, first, b_nd, batch, heads, hid, dtype=torch.bfloat16, inplace=False):
     """Acting step (t = 1): masked_attention(), kv_memory_update() and the state-mask bookkeeping in one launch.
     state_mask bool/uint8 [batch, maxlen], first bool/uint8 [batch] -> (out 16-bit [batch, hid], kout, vout, new mask uint8 [batch, maxlen]).
-    inplace: the outputs ARE kmem / vmem / state_mask (updated in place: the captured acting graph's static state)."""
+    inplace: kout / vout ARE kmem / vmem (updated in place: the captured acting graph's static state; a workgroup owns its head's
+    columns and holds the rows in registers across a barrier).  The mask is ALWAYS a new tensor: every head's workgroup reads the old
+    mask while one of them writes the new one, and workgroups of one launch are not ordered."""
     _chk(qkvr, torch.float32, "qkvr"); _chk(kmem, torch.float32, "kmem"); _chk(vmem, torch.float32, "vmem"); _chk(b_nd, torch.float32, "b_nd")
     if state_mask.dtype == torch.bool:
         state_mask = state_mask.view(torch.uint8)
@@ -310,10 +312,8 @@ def masked_attention_step(qkvr, kmem, vmem, state_mask, first, b_nd, batch, head
                          f"(got {qkvr.shape[0]} rows for batch {batch}, maxlen {maxlen}, mask {tuple(state_mask.shape)})")
     dt, fmt = _fmt(dtype=dtype)
     out = torch.empty(batch, hid, dtype=dt, device=qkvr.device)
-    if inplace:
-        kout, vout, mout = kmem, vmem, state_mask
-    else:
-        kout, vout, mout = torch.empty_like(kmem), torch.empty_like(vmem), torch.empty_like(state_mask)
+    mout = torch.empty_like(state_mask)
+    kout, vout = (kmem, vmem) if inplace else (torch.empty_like(kmem), torch.empty_like(vmem))
     _call("vpt_masked_attention_step", dict(flops=4.0 * batch * maxlen * hid, bytes=16.0 * batch * maxlen * hid), ptr(qkvr), ptr(kmem), ptr(vmem), ptr(state_mask), ptr(first),
           ptr(b_nd), ptr(out), ptr(kout), ptr(vout), ptr(mout), batch, heads, hid, qkvr.shape[1], maxlen, _stream(), fmt=fmt)
     return out, kout, vout, mout
