@@ -17,7 +17,8 @@ modules/imgproc/src/resize.cpp for CV_8UC3 + INTER_LINEAR (the generic fixed-poi
 HResizeLinear<uchar,int,short,INTER_RESIZE_COEF_SCALE=2048> and VResizeLinear<uchar,int,short,FixedPtCast<int,uchar,22>>,
 including cv::resize's substitution of INTER_AREA for an exact 2 x 2 decimation).  **parity unpinned** for this one
 function: there is no golden vector of cv2.resize in the reference and no cv2 here to produce one; the tests pin the
-properties the algorithm guarantees (identity, constants, hand-computed small cases) and GPU == oracle bit for bit.
+properties the algorithm guarantees (identity, constants, hand-computed small cases), its geometry against an independent
+implementation (torch's float bilinear interpolate with half-pixel centres: every byte within 1) and GPU == oracle bit for bit.
 Only tests/, __graft_entry__.smoke() and tools/ may import this file."""
 import numpy as np
 

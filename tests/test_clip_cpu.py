@@ -104,3 +104,23 @@ def test_process_frame_composes_the_three_steps():
     out = C.process_frame(f, True, 5, 9, image, alpha, resolution=(64, 48))
     assert np.array_equal(out, G["composited"][1][:, :, ::-1])                  # identity resize: composite + BGR -> RGB
     assert np.array_equal(C.process_frame(f, False, 5, 9, image, alpha, resolution=(64, 48)), f[:, :, ::-1])
+
+
+@pytest.mark.parametrize("h,w,dw,dh", [(360, 640, 128, 128), (720, 1280, 128, 128), (100, 37, 128, 128), (45, 80, 31, 17)])
+def test_resize_oracle_geometry_against_an_independent_bilinear(h, w, dw, dh):
+    """cv2 is absent, but torch's bilinear F.interpolate(align_corners=False, antialias=False) samples at the same half-pixel
+    centres with the same edge clamping as cv2.INTER_LINEAR and is an INDEPENDENT implementation (float arithmetic): the
+    fixed-point restatement may differ from its rounded result by at most 1 (11-bit weights, two truncating shifts: a small
+    negative bias, ~0.1) -- a wrong source index, a swapped weight or a half-pixel shift would show up as errors of tens."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(h + w)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    # smooth the noise a little so that a geometric error cannot hide in it, keep hard edges too
+    img[: h // 2] = (np.add.outer(np.arange(h // 2) * 3, np.arange(w) * 2)[:, :, None] % 256).astype(np.uint8)
+    got = C.resize_linear_u8(img, (dw, dh)).astype(np.int64)
+    ref = F.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None].double(), size=(dh, dw), mode="bilinear", align_corners=False, antialias=False)
+    ref = ref[0].permute(1, 2, 0).numpy()
+    diff = got - np.rint(ref)
+    assert np.abs(got - ref).max() <= 1.0 + 1e-9 and np.abs(diff).max() <= 1, (np.abs(got - ref).max(), np.abs(diff).max())
+    assert abs(diff.mean()) < 0.25 and (diff != 0).mean() < 0.3
