@@ -87,3 +87,38 @@ def test_bad_arguments_fail_loudly():
     with pytest.raises((TypeError, ValueError)):
         ops.clip_frames(frames.float())                                          # not uint8
     assert tuple(proc(frames[:0], None).shape) == (0, 128, 128, 3)               # empty batch
+
+
+def test_loader_with_the_device_processor(tmp_path):
+    """clip_loader.DataLoader end to end on the GPU: in-memory decoder, real ClipFrameProcessor (cursor sprite from a PNG file)."""
+    from PIL import Image
+    from vpt_amd import clip_loader
+    with gzip.open(os.path.join(GOLD, "clip_actions_seed0.json.gz"), "rt") as fh:
+        recs = json.load(fh)
+    cur = G["cursor_bgra"]
+    Image.fromarray(np.ascontiguousarray(cur[:, :, [2, 1, 0, 3]]), "RGBA").save(tmp_path / "cursor.png")      # RGBA on disk, BGRA in memory
+    assert np.array_equal(clip_loader.load_cursor_bgra(str(tmp_path / "cursor.png")), cur)
+    rng = np.random.default_rng(9)
+    videos = {}
+    for k, name in enumerate(("r0", "r1", "r2")):
+        steps = recs[k]["steps"][:30]
+        (tmp_path / f"{name}.jsonl").write_text("\n".join(json.dumps(s) for s in steps))
+        (tmp_path / f"{name}.mp4").write_bytes(b"")
+        videos[str(tmp_path / f"{name}.mp4")] = rng.integers(0, 256, (30, 90, 160, 3), dtype=np.uint8)
+    import random
+    random.seed(1)
+    dl = clip_loader.DataLoader(str(tmp_path), n_workers=3, batch_size=3, device=DEV, decoder=lambda p: iter(videos[p]),
+                                cursor_file=str(tmp_path / "cursor.png"), chunk_frames=11)
+    n, seen = 0, {}
+    for frames, actions, ids in dl:
+        for frame, action, tid in zip(frames, actions, ids):
+            assert frame.is_cuda and frame.dtype == torch.uint8 and tuple(frame.shape) == (128, 128, 3)
+            video_path, json_path = dl.demonstration_tuples[tid]
+            steps = clip.clip_steps([json.loads(l) for l in open(json_path)], 90)
+            k = seen.get(tid, 0)                     # this is the k-th kept step of its recording
+            seen[tid] = k + 1
+            want = _oracle_batch(videos[video_path][steps.keep[k]:steps.keep[k] + 1], steps.cursor_state[k:k + 1], cur, (128, 128))[0]
+            assert np.array_equal(frame.cpu().numpy(), want)
+            assert int(action["attack"]) == int(steps.actions[k]["attack"])
+            n += 1
+    assert n >= 9
