@@ -47,12 +47,33 @@ class Rounding:
     """Where the pipeline rounds: MFMA weight operands (w), CNN activations as stored between kernels and fed to the
     MFMAs (a), transformer-trunk GEMM operands / stored activations (t).  Default = what the bf16 kernels do."""
 
-    def __init__(self, w="bf16", a="bf16", t="bf16"):
+    def __init__(self, w="bf16", a="bf16", t="bf16", winograd=False):
         self.names = (w, a, t)
         self.w, self.a, self.t = ROUNDERS[w], ROUNDERS[a], ROUNDERS[t]
+        self.winograd = winograd      # feasibility probe (DESIGN.md section 10): the 3x3 convs as Winograd F(2x2, 3x3) with ROUNDED transformed operands
 
 
 DEFAULT_ROUNDING = Rounding()
+
+
+_WG = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
+_WBT = torch.tensor([[1.0, 0.0, -1.0, 0.0], [0.0, 1.0, 1.0, 0.0], [0.0, -1.0, 1.0, 0.0], [0.0, 1.0, 0.0, -1.0]])
+_WAT = torch.tensor([[1.0, 1.0, 1.0, 0.0], [0.0, 1.0, -1.0, -1.0]])
+
+
+def winograd_conv(x, w, rnd):
+    """3x3 / pad 1 convolution as Winograd F(2x2, 3x3): what a kernel that feeds the matrix cores with the TRANSFORMED operands
+    would compute -- U = G w G^T rounded to the weight format, V = B^T d B (exact in fp32 from the stored activations) rounded to
+    the activation format, fp32 accumulation over the channels, output transform in fp32.  H, W even."""
+    n, c, h, wd = x.shape
+    k = w.shape[0]
+    u = rnd.w(torch.einsum("ia,kcab,jb->kcij", _WG, w, _WG))                      # [K,C,4,4]
+    xp = F.pad(x, (1, 1, 1, 1))
+    tiles = xp.unfold(2, 4, 2).unfold(3, 4, 2)                                      # [N,C,H/2,W/2,4,4]
+    v = rnd.a(torch.einsum("ia,nctuab,jb->nctuij", _WBT, tiles, _WBT))
+    m = torch.einsum("kcij,nctuij->nktuij", u, v)
+    y = torch.einsum("ia,nktuab,jb->nktuij", _WAT, m, _WAT)                         # [N,K,H/2,W/2,2,2]
+    return y.permute(0, 1, 2, 4, 3, 5).reshape(n, k, h, wd)
 
 
 def conv_fold(sd, pfx, x_bf, res=None, rnd=DEFAULT_ROUNDING):
@@ -63,7 +84,7 @@ def conv_fold(sd, pfx, x_bf, res=None, rnd=DEFAULT_ROUNDING):
     mu = flat.mean(1)
     rstd = torch.rsqrt(flat.var(1, unbiased=False) + O.NORM_EPS)
     Wg = rnd.w(W * g.view(1, -1, 1, 1))
-    acc = F.conv2d(x_bf, Wg, padding=1)
+    acc = winograd_conv(x_bf, W * g.view(1, -1, 1, 1), rnd) if rnd.winograd else F.conv2d(x_bf, Wg, padding=1)
     ones = torch.ones(1, x_bf.shape[1], *x_bf.shape[2:])
     sg = F.conv2d(ones, Wg, padding=1)
     sa = F.conv2d(b.view(1, -1, 1, 1) * ones, W, padding=1)

@@ -76,10 +76,15 @@ CASES = [
     ("fp16 hi+lo weights, fp16 acts (2 passes)", ("fp16x2", "fp16", "fp16")),
     ("fp16 hi+lo everywhere (3 passes)", ("fp16x2", "fp16x2", "fp16x2")),
     ("fp32 everywhere (emulator == oracle check)", ("fp32", "fp32", "fp32")),
+    # feasibility probe for DESIGN.md section 10: the fourteen 3x3 convs as Winograd F(2x2, 3x3), transformed operands rounded
+    ("bf16 everywhere, 3x3 convs as Winograd F(2x2,3x3)", ("bf16", "bf16", "bf16", True)),
+    ("fp16 everywhere, 3x3 convs as Winograd F(2x2,3x3)", ("fp16", "fp16", "fp16", True)),
+    ("fp32 Winograd (transform algebra check)", ("fp32", "fp32", "fp32", True)),
 ]
 rows = []
-for name, (w, a, t) in CASES:
-    out = E.policy_forward(sd, cfg, img, first, O.initial_state(cfg, B), rnd=E.Rounding(w, a, t))
+for name, fmt in CASES:
+    w, a, t = fmt[:3]
+    out = E.policy_forward(sd, cfg, img, first, O.initial_state(cfg, B), rnd=E.Rounding(w, a, t, winograd=len(fmt) > 3 and fmt[3]))
     m = metrics(out)
     rows.append((name, m))
     print(f"{name:55s} lp_l2 b/c {m['buttons_lp_l2']:.2e}/{m['camera_lp_l2']:.2e}  centred_l2 b/c {m['buttons_c_l2']:.2e}/{m['camera_c_l2']:.2e} "
