@@ -18,7 +18,8 @@ Extra objects on the line:
                  to the GPU box) timed on 8 host cores on a bounded sample (B=1, T=16) of the same workload, plus
                  BASELINE.json configs[0] (1x); kind "port" (the oracle) only if the archive is missing.
   parity       : log-prob / centred-logit / value errors of the bf16 default and of the fp16 parity mode vs the oracle.
-  fp16_mode    : frames/s of the same workload with precision="fp16".
+  fp16_mode    : the same workload with precision="fp16" (the parity mode) as a full record: timed steps, roofline, per-kernel table.
+  bc_step[_fp16]: BC step (forward + backward + Adam [+ all-reduce]) time, its fraction of the MFMA peak, the three conv passes' TF/s.
 """
 import argparse
 import json
@@ -136,7 +137,116 @@ def parity_block(model: str, dev):
                      "centred_logits_rel_l2": round(max(m["buttons.c_l2"], m["camera.c_l2"]), 5), "value_rel": round(m["v_rel"], 5),
                      "argmax_mismatch_outside_noise_band": m["buttons.argmax_safe_mismatch"] + m["camera.argmax_safe_mismatch"],
                      "within_bounds": all(m[f"{h}.{k}"] < P.BOUNDS[mode][k] for h in ("buttons", "camera") for k in ("lp_l2", "lp_max", "c_l2", "c_max"))}
+    # trained-policy-like ("peaked") heads on frames with low-frequency content: integer actions against the oracle's arg-max
+    sdp = O.synthetic_state_dict(cfg, seed=0, heads="peaked")
+    imgp = P.structured_frames(2, 16, torch.Generator().manual_seed(4))
+    firstp = torch.zeros(2, 16, dtype=torch.bool)
+    refp = O.policy_forward(sdp, cfg, imgp, firstp, O.initial_state(cfg, 2))
+    pol.load_state_dict(sdp, strict=False)
+    out["actions_peaked_heads"] = {"sample": f"{model} model, B=2 T=16 structured frames, oracle.peak_heads weights; deterministic actions of the fused head kernel vs the oracle's arg-max"}
+    for mode in ("bf16", "fp16"):
+        pol.set_precision(mode)
+        with torch.no_grad():
+            o = pol._engine.forward(imgp.to(dev), firstp.to(dev), pol.initial_state(2), sample="deterministic")
+        torch.cuda.synchronize()
+        rec = {}
+        for h in ("buttons", "camera"):
+            hm = P.head_metrics(o[h], refp[h])
+            eq = float((o["action"][h][:, :, 0].cpu() == refp[h].argmax(-1)[:, :, 0]).float().mean())
+            rec[h] = dict(equal_frac=round(eq, 4), outside_noise_band_frac=round(hm["argmax_safe_frac"], 4), mismatches_outside_band=hm["argmax_safe_mismatch"],
+                          logprob_rel_l2=round(hm["lp_l2"], 6))
+        out["actions_peaked_heads"][mode] = rec
     return out
+
+
+def _roofline(ops, pol, step, state, args, B, T, mode):
+    """One extra, instrumented step OUTSIDE the timed region on a single CNN stream (per-kernel durations are only meaningful
+    without cross-stream overlap): HIP events around every launch, on the stream the kernels run on (torch's current stream)."""
+    streams_saved = pol._engine.cnn_streams
+    pol._engine.cnn_streams = 1
+    ops.TIMER.enabled = True
+    ops.TIMER.reset()
+    step(state)
+    summ = ops.TIMER.summary()
+    ops.TIMER.enabled = False
+    pol._engine.cnn_streams = streams_saved
+    c = summ.get("vpt_conv3x3_forward")
+    total_ms = sum(v["ms"] for v in summ.values())
+    kernels = {k: dict(ms=round(v["ms"], 3), calls=v["calls"],
+                       tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] and v["ms"] else None)
+               for k, v in summ.items()}
+    roof = None
+    if c and c["ms"] > 0:
+        ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
+        # HBM traffic cannot be counted live (PMC needs rocprofv3): the committed PMC measurement of this same workload
+        # (separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 per the gfx950 correction), per launch, labelled as such
+        traffic, tsrc = None, None
+        for tp in TRAFFIC_FILES.get(mode, ()):
+            tpath = os.path.join(ROOT, "profiles", tp)
+            if args.model == "2x" and B * T == 8192 and os.path.exists(tpath):
+                try:
+                    traffic, tsrc = round(json.load(open(tpath))["hbm_bytes_per_launch"]), f"committed PMC (profiles/{tp}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, tools/profile_round.sh), not measured by this run"
+                    break
+                except Exception:
+                    traffic = None
+        roof = dict(bound="mfma", kernel="vpt_conv3x3_kernel", achieved=round(ach, 1), peak=2500.0, unit="TFLOP/s",
+                    frac=round(ach / 2500.0, 4), traffic=traffic, traffic_unit="HBM bytes per launch (algorithmic 1.55e9)", traffic_source=tsrc,
+                    launches=c["calls"], avg_launch_ms=round(c["ms"] / c["calls"], 4), share_of_step_time=round(c["ms"] / total_ms, 3),
+                    flop_accounting="direct-convolution FLOPs (2 x H x W x Cout x 9 x Cin per frame and layer) / summed HIP-event durations of the launches")
+    return roof, kernels
+
+
+TRAFFIC_FILES = {"bf16": ("r03_bench_conv3x3_traffic.json", "r02_bench_conv3x3_traffic.json"), "fp16": ("r03_bench_conv3x3_traffic_fp16.json",)}
+
+
+def _bc_leg(pol, args, img, first, g, dev, world, distributed, barrier, dist, mode):
+    """Second half of BASELINE.json's metric: BC-step time (forward + backward through every layer + gradient all-reduce over
+    RCCL when N > 1 + fused Adam), same batch per GPU, KV memory carried between steps; plus one instrumented step (outside the
+    timed region) for the three convolution passes' TF/s."""
+    from vpt_amd import ops
+    from vpt_amd.training import BCTrainer
+    B, T = img.shape[:2]
+    pol.set_precision(mode)
+    tr = BCTrainer(pol, train_cnn=True)
+    ab = torch.randint(0, pol._engine.n_buttons, (B, T), generator=g).to(dev)
+    ac = torch.randint(0, pol._engine.n_camera, (B, T), generator=g).to(dev)
+    st_bc = pol.initial_state(B)
+    losses = []
+    for _ in range(args.bc_warmup):
+        l, st_bc = tr.step(img, first, st_bc, ab, ac)
+        losses.append(l)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.bc_steps):
+        l, st_bc = tr.step(img, first, st_bc, ab, ac)
+        losses.append(l)
+    barrier()
+    bc_el = time.perf_counter() - t0
+    if distributed:
+        tt = torch.tensor([bc_el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        bc_el = float(tt.item())
+    fl = FLOP_PER_FRAME.get(args.model, 0)
+    sec = bc_el / args.bc_steps
+    bc = dict(ms_per_step=round(1e3 * sec, 2), frames_per_s=round(world * B * T / sec, 1),
+              steps=args.bc_steps, warmup=args.bc_warmup, global_batch=world * B, seq_len=T, trained="all parameters (CNN + trunk + heads)",
+              precision=mode, optimizer="Adam lr 1.81e-4 wd 0.039428 (behavioural_cloning.py:38-40)" + (f"; dynamic loss scale {tr.loss_scale:g}, {tr.skipped_steps} skipped steps" if tr.scaled else ""),
+              allreduce=("bucketed all-reduce of the fp32 gradients, trunk + heads overlapped with the CNN backward" if distributed else "none (1 GPU)"),
+              loss_first=round(losses[0], 4), loss_last=round(losses[-1], 4),
+              tflops=round(3 * fl * B * T / sec / 1e12, 1), frac_of_mfma_peak=round(3 * fl * B * T / sec / MFMA_BF16_PEAK, 4),
+              flop_accounting="3 x forward FLOPs (SURVEY 8d) x frames / step time, per GPU",
+              peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1))
+    if int(os.environ.get("RANK", "0")) == 0 and not distributed:
+        ops.TIMER.enabled = True
+        ops.TIMER.reset()
+        tr.step(img, first, st_bc, ab, ac)
+        summ = ops.TIMER.summary()
+        ops.TIMER.enabled = False
+        tf = lambda k: round(summ[k]["flops"] / (summ[k]["ms"] * 1e-3) / 1e12, 1) if k in summ and summ[k]["ms"] > 0 else None
+        bc["conv_passes_tflops"] = dict(forward=tf("vpt_conv3x3_forward"), dgrad=tf("vpt_conv3x3_dgrad"), wgrad=tf("vpt_conv3x3_wgrad"))
+        bc["kernels_ms"] = {k: round(v["ms"], 2) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:12]}
+    del tr
+    return bc
 
 
 def main():
@@ -150,20 +260,28 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bc-steps", type=int, default=10, help="timed behavioural-cloning steps after the forward measurement (0: skip)")
     ap.add_argument("--bc-warmup", type=int, default=1)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"], help="operand format of the HEADLINE value (north star: bf16 tiles); the other format is reported beside it")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
+    dist = None
+    backend = os.environ.get("VPT_DIST_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm; "gloo" lets the N > 1 branch run with every rank on one GPU (tests)
+    n_dev = torch.cuda.device_count()
+    assert torch.cuda.is_available() and n_dev > 0, "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    dev_index = local_rank % n_dev
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     import __graft_entry__ as ge
     if distributed:  # one rank compiles (a no-op when the in-tree .so is current), the others wait
@@ -177,9 +295,10 @@ def main():
     from vpt_amd import ops
     from vpt_amd.lib.policy import MinecraftAgentPolicy
     from vpt_amd.lib.types import minecraft_action_space
-    from vpt_amd import configs   # (oracle/ is only touched by the cpu_baseline leg below)
+    from vpt_amd import configs   # (oracle/ is only touched by the parity / cpu_baseline legs below)
 
-    pol = MinecraftAgentPolicy(minecraft_action_space(), configs.policy_kwargs_for(args.model), dict(temperature=2.0))
+    head, other = args.precision, ("fp16" if args.precision == "bf16" else "bf16")
+    pol = MinecraftAgentPolicy(minecraft_action_space(), configs.policy_kwargs_for(args.model), dict(temperature=2.0), precision=head)
     configs.randomize_(pol, seed=0)
     pol = pol.to(dev)
 
@@ -187,7 +306,6 @@ def main():
     g = torch.Generator().manual_seed(1 + rank)
     img = torch.randint(0, 256, (B, T, 128, 128, 3), generator=g, dtype=torch.uint8).to(dev)
     first = torch.zeros(B, T, dtype=torch.bool, device=dev)
-    state = pol.initial_state(B)
 
     def step(st):
         with torch.no_grad():      # inference path (a grad-enabled call would go through the autograd boundary and keep activations)
@@ -200,117 +318,75 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        state = step(state)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        state = step(state)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def timed_forward(steps, warmup):
+        state = pol.initial_state(B)
+        for _ in range(warmup):
+            state = step(state)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            state = step(state)
+        barrier()
+        el = time.perf_counter() - t0
+        if distributed:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el, state
 
-    # the same workload in the parity mode (precision="fp16": identical kernels built with IEEE-half operands), 1 GPU only
-    fp16_rate = None
+    elapsed, state = timed_forward(args.steps, args.warmup)
+    roof = kernels = None
+    if rank == 0:
+        roof, kernels = _roofline(ops, pol, step, state, args, B, T, head)
+
+    # ---- the same workload in the OTHER operand format, as a full record (timed steps, roofline of the same kernel, per-kernel
+    # table): with --precision bf16 (default) this is the parity mode, the one that meets the north star's 1e-3 ----
+    other_rec = None
     if world == 1 and not args.no_cpu_baseline:
         try:
-            pol.set_precision("fp16")
-            st16 = pol.initial_state(B)
-            st16 = step(step(st16))
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(max(2, args.steps // 2)):
-                st16 = step(st16)
-            torch.cuda.synchronize()
-            fp16_rate = dict(frames_per_s=round(B * T * max(2, args.steps // 2) / (time.perf_counter() - t1), 1),
-                             note="precision='fp16' (libvpt_hip_f16.so), same workload; not the headline value")
-            del st16
+            pol.set_precision(other)
+            el_o, st_o = timed_forward(args.steps, args.warmup)
+            roof_o, kern_o = _roofline(ops, pol, step, st_o, args, B, T, other)
+            fps_o = B * T * args.steps / el_o
+            other_rec = dict(precision=other, frames_per_s=round(fps_o, 1), ms_per_step=round(1e3 * el_o / args.steps, 3), steps=args.steps, warmup=args.warmup,
+                             e2e_frac_of_mfma_peak=round(fps_o * FLOP_PER_FRAME.get(args.model, 0) / MFMA_BF16_PEAK, 4), roofline=roof_o, kernels=kern_o,
+                             note=f"precision='{other}' ({'libvpt_hip_f16.so' if other == 'fp16' else 'libvpt_hip.so'}): identical sources and workload, timed like the headline; not the headline value")
+            del st_o
         except Exception as e:
-            fp16_rate = dict(error=f"{type(e).__name__}: {e}")
+            other_rec = dict(precision=other, error=f"{type(e).__name__}: {e}")
         finally:
-            pol.set_precision("bf16")
+            pol.set_precision(head)
 
-    # instrumented extra step (outside the timed region): per-kernel HIP-event durations
-    roof = None
-    kernels = None
-    if rank == 0:
-        streams_saved = pol._engine.cnn_streams
-        pol._engine.cnn_streams = 1  # per-kernel durations are only meaningful without cross-stream overlap
-        ops.TIMER.enabled = True
-        ops.TIMER.reset()
-        step(state)
-        summ = ops.TIMER.summary()
-        ops.TIMER.enabled = False
-        pol._engine.cnn_streams = streams_saved
-        c = summ.get("vpt_conv3x3_forward")
-        total_ms = sum(v["ms"] for v in summ.values())
-        kernels = {k: dict(ms=round(v["ms"], 3), calls=v["calls"],
-                           tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] and v["ms"] else None)
-                   for k, v in summ.items()}
-        if c and c["ms"] > 0:
-            ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
-            # HBM traffic cannot be counted live (PMC needs rocprofv3): report the committed PMC measurement of this same
-            # workload (profiles/r02_bench_conv3x3_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate passes), per launch
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r02_bench_conv3x3_traffic.json")
-            if args.model == "2x" and B * T == 8192 and os.path.exists(tpath):
-                try:
-                    traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
-                except Exception:
-                    traffic = None
-            roof = dict(bound="mfma", kernel="vpt_conv3x3_kernel", achieved=round(ach, 1), peak=2500.0, unit="TFLOP/s",
-                        frac=round(ach / 2500.0, 4), traffic=traffic, traffic_unit="HBM bytes per launch (committed rocprofv3 PMC pass of this workload, tools/profile_round.sh; algorithmic 1.55e9)", launches=c["calls"],
-                        avg_launch_ms=round(c["ms"] / c["calls"], 4),
-                        share_of_step_time=round(c["ms"] / total_ms, 3))
-
-    # ---- second half of BASELINE.json's metric: BC-step time (forward + backward through every layer + gradient
-    # all-reduce over RCCL when N > 1 + fused Adam), same batch per GPU, KV memory carried between steps ----
-    bc = None
+    bc = bc_other = None
     if args.bc_steps > 0:
         try:
-            from vpt_amd.training import BCTrainer
-            tr = BCTrainer(pol, train_cnn=True)
-            ab = torch.randint(0, pol._engine.n_buttons, (B, T), generator=g).to(dev)
-            ac = torch.randint(0, pol._engine.n_camera, (B, T), generator=g).to(dev)
-            st_bc = pol.initial_state(B)
-            losses = []
-            for _ in range(args.bc_warmup):
-                l, st_bc = tr.step(img, first, st_bc, ab, ac)
-                losses.append(l)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.bc_steps):
-                l, st_bc = tr.step(img, first, st_bc, ab, ac)
-                losses.append(l)
-            barrier()
-            bc_el = time.perf_counter() - t0
-            if distributed:
-                tt = torch.tensor([bc_el], dtype=torch.float64, device=dev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                bc_el = float(tt.item())
-            bc = dict(ms_per_step=round(1e3 * bc_el / args.bc_steps, 2), frames_per_s=round(world * B * T * args.bc_steps / bc_el, 1),
-                      steps=args.bc_steps, warmup=args.bc_warmup, global_batch=world * B, seq_len=T, trained="all parameters (CNN + trunk + heads)",
-                      optimizer="Adam lr 1.81e-4 wd 0.039428 (behavioural_cloning.py:38-40)",
-                      allreduce=("bucketed RCCL all-reduce of the fp32 gradients, trunk + heads overlapped with the CNN backward" if distributed else "none (1 GPU)"),
-                      loss_first=round(losses[0], 4), loss_last=round(losses[-1], 4),
-                      peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1))
+            bc = _bc_leg(pol, args, img, first, g, dev, world, distributed, barrier, dist, head)
         except Exception as e:  # the forward line must survive a failure of the training leg
             bc = dict(error=f"{type(e).__name__}: {e}")
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                import copy
+                a2 = copy.copy(args)
+                a2.bc_steps = max(2, args.bc_steps // 2)
+                bc_other = _bc_leg(pol, a2, img, first, g, dev, world, distributed, barrier, dist, other)
+            except Exception as e:
+                bc_other = dict(precision=other, error=f"{type(e).__name__}: {e}")
+        pol.set_precision(head)
 
     frames_total = world * B * T * args.steps
     fps = frames_total / elapsed
     if rank == 0:
+        par = f"dp{world} replicas (no collective in forward; BC step: gradient all-reduce)"
+        if distributed:
+            par += f"; torch.distributed backend={dist.get_backend()} world_size={dist.get_world_size()}" + (" (RCCL)" if dist.get_backend() == "nccl" else "")
         line = {
             "metric": "frames/sec (fwd) [+ bc_step.ms_per_step], 2x policy, 128x128x3 seq=128",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": head, "data": "synthetic",
             "config": {"workload": f"foundation-model-{args.model} policy forward (IMPALA CNN + 4-layer banded transformer + heads), "
                                    f"batch={B} seq={T} uint8 128x128x3 frames per GPU, KV memory carried, random-init weights",
-                       "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world} replicas (no collective in forward)"},
+                       "global_batch": world * B, "seq_len": T, "parallelism": par},
             "e2e_tflops": round(fps * FLOP_PER_FRAME.get(args.model, 0) / 1e12, 1),
             "e2e_frac_of_mfma_peak": round(fps * FLOP_PER_FRAME.get(args.model, 0) / MFMA_BF16_PEAK, 4),
             "roofline": roof,
@@ -318,7 +394,9 @@ def main():
             "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["fp16_mode"] = fp16_rate
+            line[f"{other}_mode"] = other_rec
+            if bc_other is not None:
+                line["bc_step_" + other] = bc_other
             try:
                 line["parity"] = parity_block(args.model, dev)
             except Exception as e:

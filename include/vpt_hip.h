@@ -169,9 +169,16 @@ int vpt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 /* The same update for EVERY parameter tensor in one launch (th.optim.Adam(policy.parameters()).step(), behavioural_cloning.py:63-67,
  * 122).  `table` is a DEVICE array of `ntensors` descriptors { float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
  * uint64_t n; int64_t first_block; } (48 bytes each), sorted by first_block, where first_block counts 1024-element blocks:
- * first_block[0] = 0, first_block[i+1] = first_block[i] + ceil(n[i] / 1024); total_blocks = the sum. */
+ * first_block[0] = 0, first_block[i+1] = first_block[i] + ceil(n[i] / 1024); total_blocks = the sum.
+ * skip_flag (device int32, optional): when non-zero the launch leaves every tensor untouched -- the found-inf result of
+ * vpt_grads_nonfinite_multi for a loss-scaled step (fp16 operand format), consumed without a host round trip. */
 int vpt_adam_step_multi(const void* table, int ntensors, int64_t total_blocks, int step, float lr, float beta1, float beta2,
-                        float eps, float weight_decay, float grad_scale, void* stream);
+                        float eps, float weight_decay, float grad_scale, const int32_t* skip_flag, void* stream);
+
+/* Sets *flag = 1 (device int32, zeroed by the caller) if any gradient of the table (same layout as above; only `grad`, `n`,
+ * `first_block` are read) is inf or nan.  The reference trains in fp32 and has no counterpart; this is what
+ * torch.cuda.amp.GradScaler.unscale_ computes for an fp16 run of behavioural_cloning.py:117-122. */
+int vpt_grads_nonfinite_multi(const void* table, int ntensors, int64_t total_blocks, int32_t* flag, void* stream);
 
 /* ---- behavioural-cloning step: backward of the heads / trunk / transformer (the reference uses torch autograd,
  * behavioural_cloning.py:117-119).  Linear layers reuse vpt_linear_forward (dgrad: W^T packed; wgrad: A = dY^T). */
@@ -185,20 +192,21 @@ int vpt_bc_nll_backward(const float* lp_buttons, const float* lp_camera, const i
  * MinecraftAgentPolicy.forward / get_output_for_observation (lib/policy.py:252-305) when the caller writes its own loss, as
  * behavioural_cloning.py:101-119 does: g_buttons / g_camera = d loss / d log-prob ([M][nb] / [M][nc], either may be NULL),
  * g_value = d loss / d (raw value-head output) ([M], may be NULL).  dz = (g - exp(lp) * rowsum(g)) / temperature per head,
- * the value column passes through; bf16 [M][ldz], ldz >= nb + nc + 1, padding zero.  mask_* (uint8 [M][n], optional): the
+ * the value column passes through; 16-bit [M][ldz], ldz >= nb + nc + 1, padding zero.  grad_scale multiplies every written value
+ * (the loss scale of the fp16 operand format, whose 16-bit gradient buffers would otherwise underflow; 1 for bf16).  mask_* (uint8 [M][n], optional): the
  * availability masks of the forward -- a masked logit was overwritten with the constant LOG0, so its dz is 0. */
 int vpt_heads_logprob_backward(const float* lp_buttons, const float* lp_camera, const float* g_buttons, const float* g_camera,
                                const float* g_value, const uint8_t* mask_buttons, const uint8_t* mask_camera, void* dz,
-                               int M, int nb, int nc, int ldz, float temperature, void* stream);
+                               int M, int nb, int nc, int ldz, float temperature, float grad_scale, void* stream);
 
 /* nn.LayerNorm backward (optionally through a ReLU on the LayerNorm's input): dx = dx_add + dLN(x, dy);
  * dgain / dbias are accumulated with atomics (caller zeroes). */
 int vpt_layernorm_backward(const float* x, const float* gain, const float* dy, const float* dx_add, float* dx,
                            float* dgain, float* dbias, int M, int D, int relu_in, void* stream);
 
-/* out_bf16[M][ldo] = (mask > 0 ? x : 0) with columns >= N zeroed: the ReLU backward gate (F.relu at lib/util.py:81,
+/* out16[M][ldo] = (mask > 0 ? x : 0) with columns >= N zeroed: the ReLU backward gate (F.relu at lib/util.py:81,
  * lib/policy.py:211) fused with the cast / K-padding that turns an fp32 gradient into a GEMM A operand. */
-int vpt_gate_cast_bf16(const float* x, const void* mask, void* out, int M, int N, int ldx, int ldm, int ldo, void* stream);
+int vpt_gate_cast(const float* x, const void* mask, void* out, int M, int N, int ldx, int ldm, int ldo, void* stream);
 
 /* out[N] += column sums of a bf16 [M][ld] matrix (bias gradients). */
 int vpt_column_sum(const void* x_bf16, float* out, int M, int N, int ld, void* stream);

@@ -12,11 +12,11 @@ pytestmark = pytest.mark.gpu
 import vpt_amd  # noqa: E402,F401
 
 
-def _make(seed=0):
+def _make(seed=0, precision="bf16"):
     from vpt_amd import configs
     from vpt_amd.lib.policy import MinecraftAgentPolicy
     from vpt_amd.lib.types import minecraft_action_space
-    pol = MinecraftAgentPolicy(minecraft_action_space(), configs.policy_kwargs_for("1x"), dict(temperature=2.0))
+    pol = MinecraftAgentPolicy(minecraft_action_space(), configs.policy_kwargs_for("1x"), dict(temperature=2.0), precision=precision)
     configs.randomize_(pol, seed)
     return pol.to("cuda")
 
@@ -30,7 +30,7 @@ def _batch(b=4):
     return img, first, torch.randint(0, 8641, (b, t), generator=g), torch.randint(0, 121, (b, t), generator=g)
 
 
-def _worker(rank, world, port, out_dir, b=4):
+def _worker(rank, world, port, out_dir, b=4, precision="bf16"):
     import torch.distributed as dist
     import __graft_entry__ as ge
     ge.build()
@@ -39,7 +39,7 @@ def _worker(rank, world, port, out_dir, b=4):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        pol = _make()
+        pol = _make(precision=precision)
         tr = BCTrainer(pol, train_cnn=True, weight_decay=0.0)
         img, first, ab, ac = _batch(b)
         b0, b1 = D.shard_range(img.shape[0], rank, world)
@@ -54,18 +54,18 @@ def _worker(rank, world, port, out_dir, b=4):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("b", [4, 5])   # 5 sequences on 2 ranks: shards of 3 and 2 (the mean runs over the true global count)
-def test_two_rank_bc_step_matches_single_process(b):
+@pytest.mark.parametrize("b,precision", [(4, "bf16"), (5, "bf16"), (4, "fp16")])   # 5 sequences on 2 ranks: shards of 3 and 2 (the mean runs
+def test_two_rank_bc_step_matches_single_process(b, precision):                    # over the true global count); fp16: loss-scaled gradients
     import torch.multiprocessing as mp
     from vpt_amd.training import BCTrainer
-    pol = _make()
+    pol = _make(precision=precision)
     tr = BCTrainer(pol, train_cnn=True, weight_decay=0.0)
     img, first, ab, ac = _batch(b)
     loss1, grads1, _ = tr.reduced_loss_and_grads(img.cuda(), first.cuda(), pol.initial_state(b), ab.cuda(), ac.cuda())
     torch.cuda.synchronize()
     grads1 = {k: v.cpu() for k, v in grads1.items()}
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(2, 29533 + b, d, b), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, 29533 + b + (10 if precision == "fp16" else 0), d, b, precision), nprocs=2, join=True)
         r0, r1 = torch.load(os.path.join(d, "rank0.pt")), torch.load(os.path.join(d, "rank1.pt"))
     assert abs(r0["loss"] - float(loss1)) < 1e-4 and abs(r0["loss"] - r1["loss"]) < 1e-6
     # Same frames, same kernels: every per-frame quantity (incl. the GroupNorm statistics, whose cross-tile sums are fp64)

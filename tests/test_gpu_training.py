@@ -1,6 +1,7 @@
-"""Backward kernels and the BC step (heads + trunk + transformer; CNN frozen) against torch autograd
-through the CPU oracle.  Needs an MI355X.  Gradients pass through bf16 MFMA GEMMs (fp32 accumulate): bounds are
-relative L2 per tensor (3e-2; typically 0.5-1.5e-2), fp32 kernels (LN / attention backward) 1e-3."""
+"""Backward kernels and the BC step (every layer, CNN included) against torch autograd through the CPU oracle, in BOTH operand
+formats (fp16 = the parity mode, with loss scaling; bf16).  Needs an MI355X.  Gradients pass through 16-bit MFMA GEMMs (fp32
+accumulate): per-kernel bounds are relative L2 on identical inputs (3e-2; typically 0.5-1.5e-2), fp32 kernels (LN / attention
+backward) 1e-3; end-to-end bounds per format are tests/parity.py:GRAD_BOUNDS, calibrated by the CPU emulator of the rounding points."""
 import numpy as np
 import pytest
 import torch
@@ -13,6 +14,7 @@ from vpt_amd.training import BCTrainer, linear_backward  # noqa: E402
 from vpt_amd.lib.policy import MinecraftAgentPolicy  # noqa: E402
 from vpt_amd.lib.types import minecraft_action_space  # noqa: E402
 from oracle import vpt_oracle as O  # noqa: E402
+from tests import parity as P  # noqa: E402
 
 DEV = "cuda"
 
@@ -113,12 +115,12 @@ def test_attention_backward(bsz, t, first_flags, heads):
     assert _l2(db.cpu(), gb) < 1e-3
 
 
-@pytest.fixture(scope="module")
-def trainer_1x():
+@pytest.fixture(scope="module", params=["bf16", "fp16"])
+def trainer_1x(request):
     pk = O.policy_kwargs_for("1x")
     cfg = O.config_from_policy_kwargs(pk, dict(temperature=2.0))
     sd = O.synthetic_state_dict(cfg, seed=0)
-    pol = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0))
+    pol = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0), precision=request.param)
     pol.load_state_dict(sd, strict=False)
     return pol.to(DEV), cfg, sd
 
@@ -134,6 +136,7 @@ def test_bc_gradients_vs_oracle(trainer_1x, train_cnn):
     oracle/vpt_oracle_bf16.py); the per-kernel tests above check the backward math itself at 1e-3 on identical inputs."""
     from oracle import vpt_oracle_bf16 as OB
     pol, cfg, sd = trainer_1x
+    mode = pol.precision
     tr = BCTrainer(pol, train_cnn=train_cnn)
     b, t = 2, 6
     g = torch.Generator().manual_seed(5)
@@ -144,8 +147,9 @@ def test_bc_gradients_vs_oracle(trainer_1x, train_cnn):
     torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
     if "ref" not in _ORACLE_CACHE:
         _ORACLE_CACHE["ref"] = O.bc_loss_and_grads(sd, cfg, img, first, O.initial_state(cfg, b), ab, ac)[:2]
-        _ORACLE_CACHE["em"] = OB.bc_loss_and_grads(sd, cfg, img, first, O.initial_state(cfg, b), ab, ac)[:2]
-    (loss_ref, grads_ref), (loss_em, grads_em) = _ORACLE_CACHE["ref"], _ORACLE_CACHE["em"]
+    if mode not in _ORACLE_CACHE:      # autograd through the emulator of THIS format's rounding points (same gates as the GPU, up to summation order)
+        _ORACLE_CACHE[mode] = OB.bc_loss_and_grads(sd, cfg, img, first, O.initial_state(cfg, b), ab, ac, rnd=OB.Rounding(mode, mode, mode))[:2]
+    (loss_ref, grads_ref), (loss_em, grads_em) = _ORACLE_CACHE["ref"], _ORACLE_CACHE[mode]
     loss, grads, _ = tr.loss_and_grads(img.to(DEV), first.to(DEV), pol.initial_state(b), ab.to(DEV), ac.to(DEV))
     torch.cuda.synchronize()
     assert abs(float(loss) - loss_ref) < 2e-2 and abs(float(loss) - loss_em) < 1e-2, (float(loss), loss_ref, loss_em)
@@ -157,8 +161,8 @@ def test_bc_gradients_vs_oracle(trainer_1x, train_cnn):
         mine = grads[name].cpu().reshape(ref.shape)
         l2_em[name] = _l2(mine, em)
         cos_ref[name] = float((mine * ref).sum() / (mine.norm() * ref.norm()))
-    print("PARITY BC grads vs bf16-emulating oracle: worst rel-L2", sorted(l2_em.items(), key=lambda kv: -kv[1])[:4])
-    print("PARITY BC grads vs fp32 oracle: worst cosine", sorted(cos_ref.items(), key=lambda kv: kv[1])[:4])
+    print(f"PARITY[{mode}] BC grads vs the {mode}-emulating oracle: worst rel-L2", sorted(l2_em.items(), key=lambda kv: -kv[1])[:4])
+    print(f"PARITY[{mode}] BC grads vs fp32 oracle: worst cosine", sorted(cos_ref.items(), key=lambda kv: kv[1])[:4])
     assert len(l2_em) >= (125 if train_cnn else 60)
     # the CPU emulation and the GPU round at the same points but sum in different orders, so ~1 % of the ReLU
     # gates still differ (tools/bc_grad_diag.py): the bound that holds is on direction and norm, not on L2.
@@ -180,8 +184,13 @@ def test_bc_gradients_vs_oracle(trainer_1x, train_cnn):
     print("PARITY BC grads: largest (GPU-vs-fp32, emulation-vs-fp32) rel-L2", sorted(worst.items(), key=lambda kv: -kv[1][0])[:3])
     mean_gpu = sum(v[0] for v in worst.values()) / len(worst)
     mean_em = sum(v[1] for v in worst.values()) / len(worst)
-    print(f"PARITY BC grads: mean rel-L2 to the fp32 oracle over {len(worst)} tensors: GPU {mean_gpu:.3f}, bf16 emulation {mean_em:.3f}")
+    mean_cos = sum(cos_ref.values()) / len(cos_ref)
+    print(f"PARITY[{mode}] BC grads: mean rel-L2 to the fp32 oracle over {len(worst)} tensors: GPU {mean_gpu:.3f}, {mode} emulation {mean_em:.3f}; "
+          f"cosine to the fp32 oracle: mean {mean_cos:.4f}, worst {min(cos_ref.values()):.3f}")
     assert mean_gpu < 1.15 * mean_em + 0.02, (mean_gpu, mean_em)
+    GB = P.GRAD_BOUNDS[mode]                       # absolute, per format (not relative to our own emulator)
+    assert mean_gpu < GB["l2_mean"] and mean_cos > GB["cos_mean"] and min(cos_ref.values()) > (GB["cos_min"] if mode == "fp16" else 0.4), \
+        (mean_gpu, mean_cos, min(cos_ref.values()))
     bad = {k: v for k, v in l2_em.items() if v > (0.75 if "cnn" in k else 0.4)}
     assert not bad, bad
 
@@ -499,7 +508,8 @@ def test_heads_logprob_backward_matches_autograd():
     assert float(dz2[:, :nb].abs().max()) == 0.0 and _l2(dz2[:, nb:nb + nc], gc) < 6e-3
 
 
-def test_reference_bc_loop_runs_unchanged():
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_reference_bc_loop_runs_unchanged(mode):
     """The statements of behavioural_cloning.py:57-67,99-122, literally, on the HIP policy: get_output_for_observation ->
     get_logprob_of_action -> detach the state -> (-log_prob / BATCH_SIZE).backward() x 8 -> (no-op) clip -> th.optim.Adam.step().
     The accumulated param.grad must equal BCTrainer's hand-driven gradients of the same 8 frames (same kernels) and point
@@ -509,7 +519,7 @@ def test_reference_bc_loop_runs_unchanged():
     pk = O.policy_kwargs_for("1x")
     cfg = O.config_from_policy_kwargs(pk, dict(temperature=2.0))
     sd = O.synthetic_state_dict(cfg, seed=0)
-    policy = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0))
+    policy = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0), precision=mode)
     policy.load_state_dict(sd, strict=False)
     policy = policy.to(DEV)
     BATCH_SIZE, LEARNING_RATE, WEIGHT_DECAY, MAX_GRAD_NORM = 8, 0.000181, 0.039428, 5.0
@@ -550,7 +560,7 @@ def test_reference_bc_loop_runs_unchanged():
     assert moved == len(grads_loop) and len(grads_loop) >= 129
 
     # (1) same kernels driven by hand: BCTrainer on the same 8 frames, T = 1 each, state carried
-    pol2 = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0))
+    pol2 = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0), precision=mode)
     pol2.load_state_dict(sd, strict=False)
     pol2 = pol2.to(DEV)
     tr = BCTrainer(pol2, train_cnn=True, optimizer_state=False)
@@ -569,7 +579,7 @@ def test_reference_bc_loop_runs_unchanged():
             acc_ref[n] = acc_ref.get(n, 0) + v / BATCH_SIZE
     torch.cuda.synchronize()
     assert abs(batch_loss - loss_sum) < 1e-4 and abs(batch_loss - loss_ref) < 2e-2
-    worst, worst_cos = 0.0, 1.0
+    worst, worst_cos, cos_all = 0.0, 1.0, []
     for n, gl in grads_loop.items():
         if float(acc[n].norm()) == 0.0:
             continue
@@ -580,8 +590,10 @@ def test_reference_bc_loop_runs_unchanged():
         if float(ref.norm()) > 0:
             cos = float((gl.cpu() * ref).sum() / (gl.cpu().norm() * ref.norm()))
             worst_cos = min(worst_cos, cos)
-            assert cos > 0.7, (n, cos)               # bf16 ReLU-gate flips: see test_bc_gradients_vs_oracle for the calibrated bounds
-    print(f"PARITY reference BC loop: param.grad vs BCTrainer worst rel-L2 {worst:.2e}; worst cosine vs fp32 oracle autograd {worst_cos:.3f}; "
+            cos_all.append(cos)
+            assert cos > P.GRAD_BOUNDS[mode]["cos_min"], (n, cos)    # per-format bound (tests/parity.py: ReLU-gate flips of a 16-bit forward)
+    assert sum(cos_all) / len(cos_all) > P.GRAD_BOUNDS[mode]["cos_mean"], sum(cos_all) / len(cos_all)
+    print(f"PARITY[{mode}] reference BC loop: mean cosine {sum(cos_all) / len(cos_all):.4f}; param.grad vs BCTrainer worst rel-L2 {worst:.2e}; worst cosine vs fp32 oracle autograd {worst_cos:.3f}; "
           f"loss {batch_loss:.4f} (trainer {loss_sum:.4f}, oracle {loss_ref:.4f})")
 
 

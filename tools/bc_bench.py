@@ -17,7 +17,7 @@ ap.add_argument("--steps", type=int, default=2); ap.add_argument("--no-cnn", act
 a = ap.parse_args()
 dev = "cuda"
 pk = configs.policy_kwargs_for(a.model)
-pol = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0)); configs.randomize_(pol, 0); pol = pol.to(dev)
+pol = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0), precision=__import__("os").environ.get("VPT_PRECISION", "bf16")); configs.randomize_(pol, 0); pol = pol.to(dev)
 tr = BCTrainer(pol, train_cnn=not a.no_cnn)
 g = torch.Generator().manual_seed(1)
 B, T = a.batch, a.seq

@@ -15,7 +15,7 @@ torch.set_num_threads(32)
 DEV = "cuda"
 pk = O.policy_kwargs_for("1x"); cfg = O.config_from_policy_kwargs(pk, dict(temperature=2.0))
 sd = O.synthetic_state_dict(cfg, 0)
-pol = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0)); pol.load_state_dict(sd, strict=False); pol = pol.to(DEV)
+pol = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0), precision=__import__("os").environ.get("VPT_PRECISION", "bf16")); pol.load_state_dict(sd, strict=False); pol = pol.to(DEV)
 tr = BCTrainer(pol)
 b, t = 2, 6
 g = torch.Generator().manual_seed(5)

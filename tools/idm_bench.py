@@ -17,7 +17,7 @@ ap.add_argument("--batch", type=int, default=1); ap.add_argument("--seq", type=i
 ap.add_argument("--model", default="4x")
 a = ap.parse_args()
 kw = configs.idm_kwargs_for(a.model)
-pol = InverseActionPolicy(idm_action_space(), pi_head_kwargs=dict(temperature=2.0), idm_net_kwargs=kw)
+pol = InverseActionPolicy(idm_action_space(), pi_head_kwargs=dict(temperature=2.0), idm_net_kwargs=kw, precision=__import__("os").environ.get("VPT_PRECISION", "bf16"))
 configs.randomize_(pol, 0)
 pol = pol.to("cuda")
 g = torch.Generator().manual_seed(1)

@@ -13,7 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="2x"); ap.add_argument("--steps", type=int, default=200)
 a = ap.parse_args()
 pk = configs.policy_kwargs_for(a.model)
-pol = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0)); configs.randomize_(pol, 0); pol = pol.to("cuda")
+pol = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0), precision=__import__("os").environ.get("VPT_PRECISION", "bf16")); configs.randomize_(pol, 0); pol = pol.to("cuda")
 g = torch.Generator().manual_seed(1)
 frames = torch.randint(0, 256, (a.steps, 1, 128, 128, 3), generator=g, dtype=torch.uint8).to("cuda")
 first = torch.zeros(1, dtype=torch.bool, device="cuda")

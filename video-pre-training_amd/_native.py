@@ -46,13 +46,14 @@ SIGNATURES = {
     "vpt_maxpool_backward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_frame_affine_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_bc_nll_backward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
-    "vpt_heads_logprob_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "vpt_heads_logprob_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P],
     "vpt_layernorm_backward": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
-    "vpt_gate_cast_bf16": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vpt_gate_cast": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_column_sum": [_P, _P, _I, _I, _I, _P],
     "vpt_masked_attention_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vpt_adam_step": [_P, _P, _P, _P, ctypes.c_uint64, _I, _F, _F, _F, _F, _F, _F, _P],
-    "vpt_adam_step_multi": [_P, _I, _L, _I, _F, _F, _F, _F, _F, _F, _P],
+    "vpt_adam_step_multi": [_P, _I, _L, _I, _F, _F, _F, _F, _F, _F, _P, _P],
+    "vpt_grads_nonfinite_multi": [_P, _I, _L, _P, _P],
     "vpt_layernorm_linear_forward": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "vpt_masked_attention_step": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_clip_frames": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _P],

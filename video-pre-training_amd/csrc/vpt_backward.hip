@@ -60,12 +60,12 @@ __global__ __launch_bounds__(256) void vpt_heads_bwd_kernel(VptHeadsBwdArgs a) {
   for (int i = tid; i < a.ldz; i += 256) {
     float g = 0.f;
     if (i < a.nb) {
-      if (gb && !(a.mask_buttons && !a.mask_buttons[(size_t)row * a.nb + i])) g = (gb[i] - expf(lb[i]) * sb) * a.inv_temp;
+      if (gb && !(a.mask_buttons && !a.mask_buttons[(size_t)row * a.nb + i])) g = (gb[i] - expf(lb[i]) * sb) * a.inv_temp * a.grad_scale;
     } else if (i < a.nb + a.nc) {
       const int j = i - a.nb;
-      if (gc && !(a.mask_camera && !a.mask_camera[(size_t)row * a.nc + j])) g = (gc[j] - expf(lc[j]) * sc) * a.inv_temp;
+      if (gc && !(a.mask_camera && !a.mask_camera[(size_t)row * a.nc + j])) g = (gc[j] - expf(lc[j]) * sc) * a.inv_temp * a.grad_scale;
     }
-    else if (i == a.nb + a.nc && a.g_value) g = a.g_value[row];
+    else if (i == a.nb + a.nc && a.g_value) g = a.g_value[row] * a.grad_scale;
     dz[i] = (vpt_op16)g;
   }
 }

@@ -244,7 +244,7 @@ int vpt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
   if (step < 1) return fail(-1, "vpt_adam_step: step counts from 1");
   VptAdamArgs a;
-  a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = (size_t)n;
+  a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = (size_t)n; a.skip_flag = nullptr;
   a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.grad_scale = grad_scale;
   a.step_size = (float)((double)lr / (1.0 - pow((double)beta1, (double)step)));
   a.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
@@ -252,15 +252,20 @@ int vpt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 }
 
 int vpt_adam_step_multi(const void* table, int ntensors, int64_t total_blocks, int step, float lr, float beta1, float beta2,
-                        float eps, float weight_decay, float grad_scale, void* stream) {
+                        float eps, float weight_decay, float grad_scale, const int32_t* skip_flag, void* stream) {
   if (step < 1) return fail(-1, "vpt_adam_step_multi: step counts from 1");
   if (!table && ntensors > 0) return fail(-1, "vpt_adam_step_multi: null table");
   VptAdamArgs a;
-  a.p = nullptr; a.g = nullptr; a.m = nullptr; a.v = nullptr; a.n = 0;
+  a.p = nullptr; a.g = nullptr; a.m = nullptr; a.v = nullptr; a.n = 0; a.skip_flag = (const int*)skip_flag;
   a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.grad_scale = grad_scale;
   a.step_size = (float)((double)lr / (1.0 - pow((double)beta1, (double)step)));
   a.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
   CHECK_LAUNCH(vpt_adam_multi_launch((const VptAdamTensor*)table, ntensors, (long)total_blocks, &a, (hipStream_t)stream), "vpt_adam_step_multi");
+}
+
+int vpt_grads_nonfinite_multi(const void* table, int ntensors, int64_t total_blocks, int32_t* flag, void* stream) {
+  if ((!table && ntensors > 0) || !flag) return fail(-1, "vpt_grads_nonfinite_multi: null table / flag");
+  CHECK_LAUNCH(vpt_grads_nonfinite_launch((const VptAdamTensor*)table, ntensors, (long)total_blocks, (int*)flag, (hipStream_t)stream), "vpt_grads_nonfinite_multi");
 }
 
 int vpt_bc_nll_backward(const float* lp_buttons, const float* lp_camera, const int64_t* act_buttons,
@@ -273,12 +278,12 @@ int vpt_bc_nll_backward(const float* lp_buttons, const float* lp_camera, const i
 
 int vpt_heads_logprob_backward(const float* lp_buttons, const float* lp_camera, const float* g_buttons, const float* g_camera,
                                const float* g_value, const uint8_t* mask_buttons, const uint8_t* mask_camera, void* dz,
-                               int M, int nb, int nc, int ldz, float temperature, void* stream) {
+                               int M, int nb, int nc, int ldz, float temperature, float grad_scale, void* stream) {
   if (!(temperature > 0.f)) return fail(-1, "vpt_heads_logprob_backward: temperature must be positive");
   VptHeadsBwdArgs a;
   a.lp_buttons = lp_buttons; a.lp_camera = lp_camera; a.g_buttons = g_buttons; a.g_camera = g_camera; a.g_value = g_value;
   a.mask_buttons = mask_buttons; a.mask_camera = mask_camera;
-  a.dz = (vpt_op16*)dz; a.M = M; a.nb = nb; a.nc = nc; a.ldz = ldz; a.inv_temp = 1.0f / temperature;
+  a.dz = (vpt_op16*)dz; a.M = M; a.nb = nb; a.nc = nc; a.ldz = ldz; a.inv_temp = 1.0f / temperature; a.grad_scale = grad_scale;
   CHECK_LAUNCH(vpt_heads_bwd_launch(&a, (hipStream_t)stream), "vpt_heads_logprob_backward");
 }
 
@@ -290,10 +295,10 @@ int vpt_layernorm_backward(const float* x, const float* gain, const float* dy, c
   CHECK_LAUNCH(vpt_ln_bwd_launch(&a, (hipStream_t)stream), "vpt_layernorm_backward");
 }
 
-int vpt_gate_cast_bf16(const float* x, const void* mask, void* out, int M, int N, int ldx, int ldm, int ldo, void* stream) {
+int vpt_gate_cast(const float* x, const void* mask, void* out, int M, int N, int ldx, int ldm, int ldo, void* stream) {
   VptGateCastArgs a;
   a.x = x; a.mask = (const vpt_op16*)mask; a.out = (vpt_op16*)out; a.M = M; a.N = N; a.ldx = ldx; a.ldm = ldm; a.ldo = ldo;
-  CHECK_LAUNCH(vpt_gate_cast_launch(&a, (hipStream_t)stream), "vpt_gate_cast_bf16");
+  CHECK_LAUNCH(vpt_gate_cast_launch(&a, (hipStream_t)stream), "vpt_gate_cast");
 }
 
 int vpt_column_sum(const void* x_bf16, float* out, int M, int N, int ld, void* stream) {

@@ -219,6 +219,7 @@ struct VptHeadsBwdArgs {   // generic backward of the two log-softmax heads + th
   const uint8_t* mask_buttons;  // optional [M][nb] / [M][nc]: 0 = the logit was replaced by the constant LOG0 in the forward
   const uint8_t* mask_camera;   //   (lib/action_head.py:170-171): no gradient reaches it
   vpt_op16* dz;            // [M][ldz]: d loss / d (fused head logits), padding columns zero
+  float grad_scale;        // multiplies every written value (fp16 loss scaling; 1 otherwise)
   int M, nb, nc, ldz;
   float inv_temp;          // 1 / temperature
 };
@@ -288,11 +289,14 @@ struct VptAdamArgs {
   float beta1, beta2, eps, weight_decay, grad_scale;
   float step_size;         // lr / (1 - beta1^t)
   float inv_sqrt_bc2;      // 1 / sqrt(1 - beta2^t)
+  const int* skip_flag;    // optional device flag (multi-tensor form): non-zero = leave every tensor untouched (a loss-scaled step
+                           // whose gradients overflowed, vpt_grads_nonfinite_multi)
 };
 
 extern "C" {
 int vpt_adam_launch(const VptAdamArgs* a, hipStream_t s);
 int vpt_adam_multi_launch(const VptAdamTensor* table_dev, int ntensors, long total_blocks, const VptAdamArgs* h, hipStream_t s);
+int vpt_grads_nonfinite_launch(const VptAdamTensor* table_dev, int ntensors, long total_blocks, int* flag, hipStream_t s);
 int vpt_affine_bwd_launch(const VptAffineBwdArgs* a, int pass, hipStream_t s);
 int vpt_pool_bwd_launch(const VptPoolBwdArgs* a, hipStream_t s);
 int vpt_conv_bwd_prep_launch(const VptConvBwdPrepArgs* a, hipStream_t s);

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void vpt_adam_multi_kernel(const VptAdamTensor
     const int mid = (lo + hi + 1) >> 1;
     if (table[mid].first_block <= b) lo = mid; else hi = mid - 1;
   }
+  if (h.skip_flag && *h.skip_flag) return;   // uniform: the whole launch is a no-op when the scaled gradients overflowed
   const VptAdamTensor t = table[lo];
   const size_t i0 = ((size_t)(b - t.first_block) * 256 + threadIdx.x) * 4;
   const float c1 = 1.0f - h.beta1, c2 = 1.0f - h.beta2;
@@ -93,3 +94,34 @@ extern "C" int vpt_adam_multi_launch(const VptAdamTensor* table_dev, int ntensor
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+
+// ---- overflow check of a loss-scaled step (precision = fp16: the 16-bit gradient buffers carry loss_scale x gradient; a value
+// beyond 65504 anywhere in the chain arrives here as inf / nan).  Same table and block mapping as vpt_adam_multi_kernel; the flag
+// is only ever set (caller zeroes it), so the unordered writes are benign.  th.cuda.amp.GradScaler's found_inf, in one launch.
+__global__ __launch_bounds__(256) void vpt_grads_nonfinite_kernel(const VptAdamTensor* __restrict__ table, int ntensors, int* flag) {
+  int lo = 0, hi = ntensors - 1;
+  const long b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].first_block <= b) lo = mid; else hi = mid - 1;
+  }
+  const VptAdamTensor t = table[lo];
+  const size_t i0 = ((size_t)(b - t.first_block) * 256 + threadIdx.x) * 4;
+  bool bad = false;
+  if (i0 + 4 <= t.n) {
+    const f32x4 g = *(const f32x4*)(t.g + i0);
+    // x - x is 0 for finite x and nan for inf / nan
+    const float z = (g.x - g.x) + (g.y - g.y) + (g.z - g.z) + (g.w - g.w);
+    bad = !(z == 0.f);
+  } else {
+    for (size_t i = i0; i < t.n; ++i) { const float g = t.g[i]; bad |= !((g - g) == 0.f); }
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) *flag = 1;
+}
+
+extern "C" int vpt_grads_nonfinite_launch(const VptAdamTensor* table_dev, int ntensors, long total_blocks, int* flag, hipStream_t stream) {
+  if (ntensors <= 0 || total_blocks <= 0) return 0;
+  if (total_blocks > 0x7fffffffL) return -2;
+  hipLaunchKernelGGL(vpt_grads_nonfinite_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream, table_dev, ntensors, flag);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}

@@ -187,9 +187,20 @@ class _PolicyForwardFn(torch.autograd.Function):
         nb, nc = eng.engine.n_buttons, eng.engine.n_camera
         gv = None if g_v is None else g_v.reshape(m).float().contiguous()
         with torch.no_grad():
-            dz = ops.heads_logprob_backward(S["lp_b"], S["lp_c"], flat2(g_b, nb), flat2(g_c, nc), gv, S["ldz"], eng.engine.cfg["temperature"],
-                                            mask_buttons=S["mask"]["buttons"], mask_camera=S["mask"]["camera"])
+            gb, gc = flat2(g_b, nb), flat2(g_c, nc)
+            scale = 1.0
+            if eng.scaled:
+                # fp16 operands: the 16-bit gradient buffers need the incoming gradients lifted into IEEE half's range (a mean
+                # over M frames arrives as 1 / M per element).  Power of two, so un-scaling the fp32 results below is exact.
+                gmax = max([float(x.abs().max()) for x in (gb, gc, gv) if x is not None and x.numel()] or [0.0])
+                if gmax > 0.0 and math.isfinite(gmax):
+                    scale = 2.0 ** math.floor(math.log2(256.0 / gmax))
+            dz = ops.heads_logprob_backward(S["lp_b"], S["lp_c"], gb, gc, gv, S["ldz"], eng.engine.cfg["temperature"],
+                                            mask_buttons=S["mask"]["buttons"], mask_camera=S["mask"]["camera"], dtype=eng.dtype, grad_scale=scale)
             g = eng.backward_from(S, dz, value_grads=gv is not None)
+            if scale != 1.0:
+                for t_ in g.values():
+                    t_.mul_(1.0 / scale)
         grads = tuple(g[n].reshape(shape) if n in g else None for n, shape in zip(ctx.names, ctx.param_shapes))
         return (None, None, None, None, None, None, None) + grads
 
@@ -327,9 +338,9 @@ class MinecraftAgentPolicy(nn.Module):
         img = obs["img"]
         if img.dtype != torch.uint8:
             raise TypeError("obs['img'] must be uint8 [B,T,128,128,3] (the /255 is fused into the first conv)")
-        if torch.is_grad_enabled() and self._engine.precision == "bf16" and any(p.requires_grad for p in self.parameters()):
-            # gradient-enabled call, as the reference's forward is: the outputs join the autograd graph.  (precision="fp16" is
-            # inference only: its outputs carry no grad_fn, so a loss.backward() on them fails in autograd itself.)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # gradient-enabled call, as the reference's forward is: the outputs join the autograd graph (both operand formats;
+            # fp16 scales the incoming gradients into half's range inside the node, _PolicyForwardFn.backward)
             pd_v, state_out = self._forward_differentiable(img, first, state_in, mask)
             return pd_v, state_out, {}
         sg = self._step_graph

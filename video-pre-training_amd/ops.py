@@ -348,12 +348,16 @@ def adam_step_(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.99
           ctypes.c_float(grad_scale), _stream())
 
 
-def adam_step_multi_(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
-    """The Adam update of adam_step_ for a list of tensors in ONE launch (flat fp32 views; same arithmetic per element)."""
+def adam_step_multi_(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0,
+                     found_inf=None):
+    """The Adam update of adam_step_ for a list of tensors in ONE launch (flat fp32 views; same arithmetic per element).
+    found_inf: optional int32 [1] device tensor (loss-scaled fp16 step).  It is zeroed, set by vpt_grads_nonfinite_multi when any
+    gradient is inf / nan, and read by the Adam launch, which then leaves every tensor untouched -- no host round trip."""
     import numpy as np
     n_t = len(params)
     if n_t == 0:
         return
+    _chk(found_inf, torch.int32, "found_inf")
     rec = np.zeros(n_t, dtype=[("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<u8"), ("fb", "<i8")])
     blk = 0
     for i, (p, g, m, v) in enumerate(zip(params, grads, exp_avgs, exp_avg_sqs)):
@@ -365,36 +369,44 @@ def adam_step_multi_(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1=0.9, 
         rec[i] = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, blk)
         blk += (n + 1023) // 1024
     table = torch.from_numpy(rec.view(np.uint8)).to(params[0].device, non_blocking=False)
+    if found_inf is not None:
+        found_inf.zero_()
+        _call("vpt_grads_nonfinite_multi", dict(bytes=4.0 * sum(p.numel() for p in params)), ptr(table), n_t, blk, ptr(found_inf), _stream())
     _call("vpt_adam_step_multi", dict(bytes=28.0 * sum(p.numel() for p in params)), ptr(table), n_t, blk, int(step),
           ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps), ctypes.c_float(weight_decay),
-          ctypes.c_float(grad_scale), _stream())
+          ctypes.c_float(grad_scale), ptr(found_inf), _stream())
     return table   # keep alive until the launch has been enqueued (the caller may drop it afterwards: stream-ordered free)
 
 
 # ---- backward (behavioural-cloning step) ---------------------------------------------------------------
-def nll_backward(lp_buttons, lp_camera, act_buttons, act_camera, ldz, scale):
-    """bf16 [M, ldz] gradient of the BC loss w.r.t. the fused head logits (value column and padding zero)."""
+def nll_backward(lp_buttons, lp_camera, act_buttons, act_camera, ldz, scale, dtype=torch.bfloat16):
+    """16-bit [M, ldz] gradient of the BC loss w.r.t. the fused head logits (value column and padding zero).  `scale` carries
+    1 / (frames x temperature) and, in the fp16 mode, the loss scale (training.BCTrainer)."""
     _chk(lp_buttons, torch.float32, "lp_buttons"); _chk(lp_camera, torch.float32, "lp_camera")
     _chk(act_buttons, torch.int64, "act_buttons"); _chk(act_camera, torch.int64, "act_camera")
     m, nb = lp_buttons.shape
     nc = lp_camera.shape[1]
-    dz = torch.empty(m, ldz, dtype=torch.bfloat16, device=lp_buttons.device)
+    dt, fmt = _fmt(dtype=dtype)
+    dz = torch.empty(m, ldz, dtype=dt, device=lp_buttons.device)
     _call("vpt_bc_nll_backward", dict(bytes=6.0 * m * ldz), ptr(lp_buttons), ptr(lp_camera), ptr(act_buttons), ptr(act_camera),
-          ptr(dz), m, nb, nc, ldz, ctypes.c_float(scale), _stream())
+          ptr(dz), m, nb, nc, ldz, ctypes.c_float(scale), _stream(), fmt=fmt)
     return dz
 
 
-def heads_logprob_backward(lp_buttons, lp_camera, g_buttons, g_camera, g_value, ldz, temperature, mask_buttons=None, mask_camera=None):
-    """bf16 [M, ldz] gradient w.r.t. the fused head logits for arbitrary incoming gradients of the two log-prob tensors and of the
+def heads_logprob_backward(lp_buttons, lp_camera, g_buttons, g_camera, g_value, ldz, temperature, mask_buttons=None, mask_camera=None,
+                           dtype=torch.bfloat16, grad_scale=1.0):
+    """16-bit [M, ldz] gradient w.r.t. the fused head logits for arbitrary incoming gradients of the two log-prob tensors and of the
     raw value output (any of them None = zero).  The autograd boundary of lib/policy.py uses this; the BC fast path uses nll_backward."""
     _chk(lp_buttons, torch.float32, "lp_buttons"); _chk(lp_camera, torch.float32, "lp_camera")
     _chk(g_buttons, torch.float32, "g_buttons"); _chk(g_camera, torch.float32, "g_camera"); _chk(g_value, torch.float32, "g_value")
     _chk(mask_buttons, torch.uint8, "mask_buttons"); _chk(mask_camera, torch.uint8, "mask_camera")
     m, nb = lp_buttons.shape
     nc = lp_camera.shape[1]
-    dz = torch.empty(m, ldz, dtype=torch.bfloat16, device=lp_buttons.device)
+    dt, fmt = _fmt(dtype=dtype)
+    dz = torch.empty(m, ldz, dtype=dt, device=lp_buttons.device)
+    # grad_scale (fp16 loss scaling): d/dz is linear in the incoming gradients and they enter as g / temperature
     _call("vpt_heads_logprob_backward", dict(bytes=10.0 * m * ldz), ptr(lp_buttons), ptr(lp_camera), ptr(g_buttons), ptr(g_camera), ptr(g_value),
-          ptr(mask_buttons), ptr(mask_camera), ptr(dz), m, nb, nc, ldz, ctypes.c_float(temperature), _stream())
+          ptr(mask_buttons), ptr(mask_camera), ptr(dz), m, nb, nc, ldz, ctypes.c_float(temperature), ctypes.c_float(grad_scale), _stream(), fmt=fmt)
     return dz
 
 
@@ -408,18 +420,19 @@ def layernorm_backward(x, gain, dy, dgain, dbias, relu_in=False, dx_add=None):
     return dx
 
 
-def gate_cast(x, ldo, mask=None):
-    """fp32 [M, N] -> bf16 [M, ldo] (zero padded), zeroed where mask <= 0."""
+def gate_cast(x, ldo, mask=None, dtype=torch.bfloat16):
+    """fp32 [M, N] -> 16-bit [M, ldo] (zero padded), zeroed where mask <= 0."""
     _chk(x, torch.float32, "x"); _chk(mask, OP16, "mask")
     m, n = x.shape
-    out = torch.empty(m, ldo, dtype=torch.bfloat16, device=x.device)
-    _call("vpt_gate_cast_bf16", dict(bytes=6.0 * m * ldo), ptr(x), ptr(mask), ptr(out), m, n, n, mask.shape[1] if mask is not None else 0, ldo, _stream())
+    dt, fmt = _fmt(mask, dtype=dtype if mask is None else None)
+    out = torch.empty(m, ldo, dtype=dt, device=x.device)
+    _call("vpt_gate_cast", dict(bytes=6.0 * m * ldo), ptr(x), ptr(mask), ptr(out), m, n, n, mask.shape[1] if mask is not None else 0, ldo, _stream(), fmt=fmt)
     return out
 
 
 def column_sum_(out, x_bf16, n):
     _chk(x_bf16, OP16, "x"); _chk(out, torch.float32, "out")
-    _call("vpt_column_sum", dict(bytes=2.0 * x_bf16.numel()), ptr(x_bf16), ptr(out), x_bf16.shape[0], n, x_bf16.shape[1], _stream())
+    _call("vpt_column_sum", dict(bytes=2.0 * x_bf16.numel()), ptr(x_bf16), ptr(out), x_bf16.shape[0], n, x_bf16.shape[1], _stream(), fmt=_fmt(x_bf16)[1])
 
 
 def masked_attention_backward(qkvr, kmem, vmem, memvalid, b_nd, dout, db_nd, batch, t, heads, hid):
@@ -453,7 +466,7 @@ def conv_backward_prepare(dy, y, res, stats_in, edge_sa, edge_sg, cin, dpooled=N
     scratch = torch.empty(f, 9 * cb * 32 + cb, dtype=torch.float32, device=dev)
     _call("vpt_conv_backward_prepare", dict(bytes=(6.0 if dy is not None else 4.75) * y.numel() + (2.0 * y.numel() if res is not None else 0)),
           ptr(dy), ptr(dpooled), ptr(argmax), ptr(y), ptr(res), ptr(stats_in), ptr(edge_sa), ptr(edge_sg),
-          ptr(dacc), ptr(t12), ptr(coef), ptr(d_sa), ptr(d_sg), ptr(scratch), f, h, w, cin, cb * 32, _stream())
+          ptr(dacc), ptr(t12), ptr(coef), ptr(d_sa), ptr(d_sg), ptr(scratch), f, h, w, cin, cb * 32, _stream(), fmt=_fmt(dy, y, res, dpooled)[1])
     return (dacc, coef, d_sa, d_sg, t12) if want_t12 else (dacc, coef, d_sa, d_sg)
 
 
@@ -462,9 +475,10 @@ def conv3x3_dgrad(dacc, wpk_t, cin, skip=None, xin=None, coef=None):
     _chk(dacc, OP16, "dacc"); _chk(wpk_t, OP16, "wpk_t"); _chk(skip, OP16, "skip")
     _chk(xin, OP16, "xin"); _chk(coef, torch.float32, "coef")
     f, cb, h, w, _ = dacc.shape
-    dx = torch.empty(f, cin // 32, h, w, 32, dtype=torch.bfloat16, device=dacc.device)
+    dt, fmt = _fmt(dacc, wpk_t, skip, xin)
+    dx = torch.empty(f, cin // 32, h, w, 32, dtype=dt, device=dacc.device)
     _call("vpt_conv3x3_dgrad", dict(flops=2.0 * f * h * w * cin * 9 * cb * 32), ptr(dacc), ptr(wpk_t), ptr(skip), ptr(xin), ptr(coef), ptr(dx),
-          f, h, w, cb * 32, cin, _stream())
+          f, h, w, cb * 32, cin, _stream(), fmt=fmt)
     return dx
 
 
@@ -473,7 +487,7 @@ def maxpool_backward(pre, pooled, dpooled):
         _chk(t, OP16, nme)
     f, cb, h, w, _ = pre.shape
     dpre = torch.empty_like(pre)
-    _call("vpt_maxpool_backward", dict(bytes=5.0 * pre.numel()), ptr(pre), ptr(pooled), ptr(dpooled), ptr(dpre), f, cb * 32, h, w, _stream())
+    _call("vpt_maxpool_backward", dict(bytes=5.0 * pre.numel()), ptr(pre), ptr(pooled), ptr(dpooled), ptr(dpre), f, cb * 32, h, w, _stream(), fmt=_fmt(pre, pooled, dpooled)[1])
     return dpre
 
 
@@ -485,10 +499,11 @@ def frame_affine_backward(x, dy, gain, stats_in, dgain, dbias, per_element=False
     ab = torch.zeros(f, 2, dtype=torch.float64, device=x.device)
     dx = torch.empty_like(x)
     args = (ptr(x), ptr(dy), ptr(dx_add), ptr(dx), ptr(gain), ptr(stats_in), ptr(ab), ptr(dgain), ptr(dbias), f, cb * 32, h * w, 1 if per_element else 0)
-    _call("vpt_frame_affine_backward", dict(bytes=4.0 * x.numel()), *args, 1, _stream())
-    _call("vpt_frame_affine_backward", dict(bytes=6.0 * x.numel()), *args, 2, _stream())
+    fmt = _fmt(x, dy, dx_add)[1]
+    _call("vpt_frame_affine_backward", dict(bytes=4.0 * x.numel()), *args, 1, _stream(), fmt=fmt)
+    _call("vpt_frame_affine_backward", dict(bytes=6.0 * x.numel()), *args, 2, _stream(), fmt=fmt)
     if per_element:
-        _call("vpt_frame_affine_backward", dict(bytes=4.0 * x.numel()), *args, 3, _stream())
+        _call("vpt_frame_affine_backward", dict(bytes=4.0 * x.numel()), *args, 3, _stream(), fmt=fmt)
     return dx
 
 
@@ -498,8 +513,9 @@ def conv3x3_wgrad(dacc, x, out=None):
     f, cbo, h, w, _ = dacc.shape
     cbi = x.shape[1]
     dw = out if out is not None else torch.zeros(cbo * 32, 9, cbi * 32, dtype=torch.float32, device=x.device)
-    scratch = torch.empty(_native.load().vpt_conv3x3_wgrad_scratch_floats(f, cbi * 32, cbo * 32), dtype=torch.float32, device=x.device)
-    _call("vpt_conv3x3_wgrad", dict(flops=2.0 * f * h * w * cbo * 32 * 9 * cbi * 32), ptr(dacc), ptr(x), ptr(dw), ptr(scratch), f, h, w, cbi * 32, cbo * 32, _stream())
+    fmt = _fmt(dacc, x)[1]
+    scratch = torch.empty(_native.load(fmt).vpt_conv3x3_wgrad_scratch_floats(f, cbi * 32, cbo * 32), dtype=torch.float32, device=x.device)
+    _call("vpt_conv3x3_wgrad", dict(flops=2.0 * f * h * w * cbo * 32 * 9 * cbi * 32), ptr(dacc), ptr(x), ptr(dw), ptr(scratch), f, h, w, cbi * 32, cbo * 32, _stream(), fmt=fmt)
     return dw
 
 
@@ -513,7 +529,7 @@ def conv_first_backward(img_u8, wfrag, dpooled, cout, out=None):
     dw, db = out
     _chk(dw, torch.float32, "dw"); _chk(db, torch.float32, "db")
     _call("vpt_conv_first_backward", dict(flops=2.0 * f * (h // 2) * (w // 2) * cout * 27), ptr(img_u8), ptr(wfrag), ptr(dpooled), ptr(dw), ptr(db),
-          f, h, w, cout, _stream())
+          f, h, w, cout, _stream(), fmt=_fmt(wfrag, dpooled)[1])
     return dw, db
 
 

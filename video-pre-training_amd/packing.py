@@ -57,12 +57,12 @@ def edge_tap_matrix(device, dtype=torch.float64):
     return _EDGE_TAP[key]
 
 
-def pack_conv3x3_dgrad(weight, gain):
-    """Weights of the input-gradient convolution of a normed conv layer: Wd[c, o, kh, kw] = bf16(W * gain)[o, c, 2-kh, 2-kw]
+def pack_conv3x3_dgrad(weight, gain, dtype=torch.bfloat16):
+    """Weights of the input-gradient convolution of a normed conv layer: Wd[c, o, kh, kw] = op16(W * gain)[o, c, 2-kh, 2-kw]
     in the same packed format (a conv with Cin' = Cout, Cout' = Cin, no further gain)."""
-    wg = (weight * gain.view(1, -1, 1, 1)).to(torch.bfloat16).float()
+    wg = (weight * gain.view(1, -1, 1, 1)).to(dtype).float()
     wd = wg.permute(1, 0, 2, 3).flip(2, 3).contiguous()
-    wpk, _, _ = pack_conv3x3(wd, torch.ones(wd.shape[1], device=weight.device), None, tables=False)
+    wpk, _, _ = pack_conv3x3(wd, torch.ones(wd.shape[1], device=weight.device), None, tables=False, dtype=dtype)
     return wpk
 
 

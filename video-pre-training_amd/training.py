@@ -43,7 +43,7 @@ def linear_backward(dy16: torch.Tensor, n: int, x16: Optional[torch.Tensor], wei
     dev = dy16.device
     dx32 = dx16 = dw = None
     if need_dx:   # W^T packed straight from the fp32 master by one kernel (was: zero, transpose, cast, permute -- four tensor ops)
-        wt = ops.pack_linear(weight.contiguous(), transposed=True, k_pad=np_)
+        wt = ops.pack_linear(weight.contiguous(), transposed=True, k_pad=np_, dtype=dy16.dtype)
         dx32, dx16 = ops.linear(dy16, wt, k, res=res, mask=mask, out_f32=dx_f32,
                                 out_bf16=dx_bf16_ld is not None, out_bf16_ld=dx_bf16_ld)
         del wt
@@ -54,15 +54,26 @@ def linear_backward(dy16: torch.Tensor, n: int, x16: Optional[torch.Tensor], wei
 
 class BCTrainer:
     def __init__(self, policy, lr: float = 0.000181, weight_decay: float = 0.039428, betas=(0.9, 0.999), eps: float = 1e-8,
-                 train_cnn: bool = True, optimizer_state: bool = True):
+                 train_cnn: bool = True, optimizer_state: bool = True, loss_scale: Optional[float] = None,
+                 scale_growth_interval: int = 200):
         """train_cnn=True (default, as the reference: behavioural_cloning.py:57-63 optimises policy.parameters(), i.e. every
         parameter) or False to freeze `net.img_process.cnn.*` and fine-tune trunk + heads only (no CNN activations kept).
-        optimizer_state=False: gradients only (the autograd boundary of lib/policy.py), no Adam moments allocated."""
+        optimizer_state=False: gradients only (the autograd boundary of lib/policy.py), no Adam moments allocated.
+
+        Both operand formats train.  precision="fp16" (the parity mode) keeps every 16-bit gradient buffer -- dz, the GEMM /
+        conv operands dacc, the inter-layer dx -- inside IEEE half's range by LOSS SCALING: the loss gradient is written as
+        (loss_scale / temperature) x (softmax - one-hot) per frame, i.e. the 1 / global_frames of the mean is left out as well, so
+        the magnitudes in the 16-bit buffers do not depend on the batch size; vpt_adam_step_multi multiplies the fp32 gradients by
+        1 / (loss_scale x global_frames).  `loss_scale` (default 256 for fp16, 1 = off for bf16) is dynamic as in
+        torch.cuda.amp.GradScaler: vpt_grads_nonfinite_multi checks the (all-reduced) gradients; an overflowed step is skipped on
+        the device (the Adam launch reads the flag) and the scale halves, it doubles after `scale_growth_interval` clean steps."""
         self.train_cnn = bool(train_cnn)
         self.policy = policy
         self.engine = policy._engine
-        if self.engine.precision != "bf16":
-            raise NotImplementedError("BCTrainer: the hand-written backward supports precision='bf16' only (fp16 gradients would need loss scaling)")
+        self.dtype = self.engine.dtype
+        self.scaled = self.engine.precision == "fp16"
+        self.loss_scale = float(loss_scale) if loss_scale is not None else (256.0 if self.scaled else 1.0)
+        self.scale_growth_interval, self._clean_steps, self.skipped_steps = int(scale_growth_interval), 0, 0
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.step_count = 0
         self.params: Dict[str, torch.nn.Parameter] = dict(policy.named_parameters())
@@ -74,11 +85,19 @@ class BCTrainer:
     def state_dict(self) -> dict:
         """Optimizer state next to the policy's own `.weights` state_dict (behavioural_cloning.py:131-132 saves only the
         latter): Adam moments keyed by the reference's parameter names, the step count and the hyper-parameters."""
+        self._need_optimizer_state()
         return dict(step=self.step_count, lr=self.lr, weight_decay=self.wd, betas=tuple(self.betas), eps=self.eps,
-                    train_cnn=self.train_cnn, exp_avg={n: t.detach().clone() for n, t in self.m.items()},
+                    loss_scale=self.loss_scale, train_cnn=self.train_cnn, exp_avg={n: t.detach().clone() for n, t in self.m.items()},
                     exp_avg_sq={n: t.detach().clone() for n, t in self.v.items()})
 
+    def _need_optimizer_state(self):
+        if not self.m and self.trainable:
+            raise RuntimeError("this BCTrainer was built with optimizer_state=False (gradients only): step / state_dict / load_state_dict need the Adam moments")
+
     def load_state_dict(self, sd: dict):
+        self._need_optimizer_state()
+        if self.scaled and "loss_scale" in sd:
+            self.loss_scale = float(sd["loss_scale"])
         if set(sd["exp_avg"]) != set(self.m):
             raise KeyError(f"optimizer state does not match the trainable parameters: {sorted(set(sd['exp_avg']) ^ set(self.m))[:4]} ...")
         self.step_count = int(sd["step"])
@@ -97,9 +116,11 @@ class BCTrainer:
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
     def loss_and_grads(self, img_u8, first, state_in, act_buttons, act_camera, global_frames: Optional[int] = None, debug: Optional[dict] = None,
-                       on_trunk_grads=None):
+                       on_trunk_grads=None, unscaled: bool = True):
         """Forward (saving activations) + backward.  Returns (loss of this rank's frames, grads dict, state_out).
         global_frames: number of frames in the global (all-rank) batch the mean runs over (default: local).
+        unscaled=True: the gradients of the mean loss in both operand formats.  False (what step() uses): in the fp16 mode they are
+        left multiplied by 1 / grad_unscale(global_frames) -- the optimiser launch folds that factor in, no extra pass.
         on_trunk_grads(g): called once the gradients of everything behind the CNN (88 % of the parameters) are final and
         before the CNN's backward starts -- the data-parallel step starts their all-reduce there."""
         S = self.forward_saving(img_u8, first, state_in)
@@ -108,9 +129,20 @@ class BCTrainer:
         ac = act_camera.reshape(m).to(torch.int64).contiguous()
         loss = -(S["lp_b"].gather(1, ab[:, None]) + S["lp_c"].gather(1, ac[:, None])).mean()
         gf = global_frames or m
-        dz = ops.nll_backward(S["lp_b"], S["lp_c"], ab, ac, S["ldz"], 1.0 / (gf * self.engine.cfg["temperature"]))
+        # bf16: the gradient of the global mean.  fp16: loss_scale x the gradient of the SUM over frames (see __init__); grad_unscale()
+        # is the factor that turns the returned gradients into those of the mean.
+        scale = (self.loss_scale if self.scaled else 1.0 / gf) / self.engine.cfg["temperature"]
+        dz = ops.nll_backward(S["lp_b"], S["lp_c"], ab, ac, S["ldz"], scale, dtype=self.dtype)
         g = self.backward_from(S, dz, on_trunk_grads=on_trunk_grads, debug=debug)
+        if unscaled and self.scaled:
+            f = self.grad_unscale(gf)
+            for t_ in g.values():
+                t_.mul_(f)
         return loss, g, S["state_out"]
+
+    def grad_unscale(self, global_frames: int) -> float:
+        """What loss_and_grads' gradients must be multiplied by to be d(mean loss)/d(parameter): 1 in bf16."""
+        return 1.0 / (self.loss_scale * global_frames) if self.scaled else 1.0
 
     @torch.no_grad()
     def forward_saving(self, img_u8, first, state_in, mask: Optional[dict] = None) -> dict:
@@ -140,13 +172,14 @@ class BCTrainer:
             del xn
         d = outs[0] if len(outs) == 1 else torch.cat(outs, 0)                     # [M,256] pre-ReLU dense output
         pl = "net.img_process.linear."
-        _, dn = ops.layernorm(d, w[pl + "g"], w[pl + "b"], relu_in=True)          # bf16
+        dt = self.dtype
+        _, dn = ops.layernorm(d, w[pl + "g"], w[pl + "b"], relu_in=True, dtype=dt)          # 16-bit
         x, x16 = ops.linear(dn, w[pl + "w"], hid, relu=True, out_f32=True, out_bf16=True)
         x_lin16 = x16
         x_pre = None
         if cfg["use_pre_lstm_ln"]:     # MinecraftPolicy.pre_lstm_ln (lib/policy.py:202-203)
             x_pre = x
-            x, _ = ops.layernorm(x_pre, w["prelstm.g"], w["prelstm.b"], out_f32=True, out_bf16=False)
+            x, _ = ops.layernorm(x_pre, w["prelstm.g"], w["prelstm.b"], out_f32=True, out_bf16=False, dtype=dt)
         not_first = ~first[:, 0].reshape(bsz, 1, 1)
         saved: List[dict] = []
         state_out = []
@@ -157,12 +190,12 @@ class BCTrainer:
                 state_mask = torch.zeros(bsz, 1, maxlen, dtype=torch.bool, device=dev)
             memvalid = (state_mask & not_first).reshape(bsz, maxlen).to(torch.uint8).contiguous()
             kmem, vmem = kmem.contiguous(), vmem.contiguous()
-            x1, x1b = ops.layernorm(x, w[p + "ln1.g"], w[p + "ln1.b"], out_f32=True)
+            x1, x1b = ops.layernorm(x, w[p + "ln1.g"], w[p + "ln1.b"], out_f32=True, dtype=dt)
             qkvr, _ = ops.linear(x1b, w[p + "qkvr.w"], eng.n_qkvr, bias=w[p + "qkvr.b"])
-            att = ops.masked_attention(qkvr, kmem, vmem, memvalid, w[p + "b_nd"], bsz, t, heads, hid)
+            att = ops.masked_attention(qkvr, kmem, vmem, memvalid, w[p + "b_nd"], bsz, t, heads, hid, dtype=dt)
             kout, vout = ops.kv_memory_update(qkvr, kmem, vmem, bsz, t, hid)
             x2, _ = ops.linear(att, w[p + "proj.w"], hid, bias=w[p + "proj.b"], res=x1)
-            _, hb = ops.layernorm(x2, w[p + "ln2.g"], w[p + "ln2.b"])
+            _, hb = ops.layernorm(x2, w[p + "ln2.g"], w[p + "ln2.b"], dtype=dt)
             _, h2 = ops.linear(hb, w[p + "mlp0.w"], hid * ratio, relu=True, out_f32=False, out_bf16=True)
             xo, _ = ops.linear(h2, w[p + "mlp1.w"], hid, bias=w[p + "mlp1.b"], res=x2)
             saved.append(dict(x=x, x1b=x1b, qkvr=qkvr, kmem=kmem, vmem=vmem, memvalid=memvalid, att=att, x2=x2, hb=hb, h2=h2))
@@ -171,9 +204,9 @@ class BCTrainer:
             state_out.append((new_mask, (kout, vout)))
             x = xo
         x_trunk = x
-        _, xb = ops.layernorm(x_trunk, w["last.g"], w["last.b"], relu_in=True)
+        _, xb = ops.layernorm(x_trunk, w["last.g"], w["last.b"], relu_in=True, dtype=dt)
         y, y16 = ops.linear(xb, w["last.w"], hid, relu=True, out_f32=True, out_bf16=True)
-        _, lb = ops.layernorm(y, w["final.g"], w["final.b"])
+        _, lb = ops.layernorm(y, w["final.g"], w["final.b"], dtype=dt)
         logits, _ = ops.linear(lb, w["heads.w"], nb + nc + 1, bias=w["heads.b"])
         temp = cfg["temperature"]
         mk = {h: (mask[h].reshape(m, n_).to(torch.uint8).contiguous() if mask is not None and mask.get(h) is not None else None)
@@ -231,7 +264,7 @@ class BCTrainer:
             p = f"net.recurrent_layer.blocks.{l}."
             o = p + "r.orc_block."
             s = saved[l]
-            dout16 = ops.gate_cast(dx, hid)
+            dout16 = ops.gate_cast(dx, hid, dtype=self.dtype)
             # mlp1: out = x2 + h2 W1^T + b1
             _, dh16, g[p + "mlp1.layer.weight"] = linear_backward(dout16, hid, s["h2"], P[p + "mlp1.layer.weight"], mask=s["h2"],
                                                                   dx_f32=False, dx_bf16_ld=hid * ratio)
@@ -243,7 +276,7 @@ class BCTrainer:
             dx2 = ops.layernorm_backward(s["x2"], P[p + "mlp0.norm.weight"], dhb, g[p + "mlp0.norm.weight"], g[p + "mlp0.norm.bias"], dx_add=dx)
             del dh16, dhb, dout16
             # proj: x2 = x1 + att Wp^T + bp
-            dx2_16 = ops.gate_cast(dx2, hid)
+            dx2_16 = ops.gate_cast(dx2, hid, dtype=self.dtype)
             datt, _, g[o + "proj_layer.weight"] = linear_backward(dx2_16, hid, s["att"], P[o + "proj_layer.weight"])
             g[o + "proj_layer.bias"] = zeros(hid)
             ops.column_sum_(g[o + "proj_layer.bias"], dx2_16, hid)
@@ -252,7 +285,7 @@ class BCTrainer:
             dqkvr = ops.masked_attention_backward(s["qkvr"], s["kmem"], s["vmem"], s["memvalid"], w[p + "b_nd"], datt,
                                                   g[o + "b_nd"], bsz, t, heads, hid)
             nq = eng.n_qkvr
-            dq16 = ops.gate_cast(dqkvr, _round_up(nq, 64))
+            dq16 = ops.gate_cast(dqkvr, _round_up(nq, 64), dtype=self.dtype)
             wq = torch.cat([P[o + "q_layer.weight"], P[o + "k_layer.weight"], P[o + "v_layer.weight"], P[o + "r_layer.weight"]], 0)
             dx1, _, dwq = linear_backward(dq16, nq, s["x1b"], wq, res=dx2)   # dx1 = dx2 (skip) + dqkvr Wqkvr
             g[o + "q_layer.weight"], g[o + "k_layer.weight"] = dwq[:hid], dwq[hid:2 * hid]
@@ -347,10 +380,10 @@ class BCTrainer:
         c2 = cfg["chans"][-1]
         acc = dict(wt={}, raw={}, n={}, dense=None)
         for q in self._conv_names():
-            acc["wt"][q] = packing.pack_conv3x3_dgrad(P[q + ".layer.weight"].float(), P[q + ".norm.weight"].float())
+            acc["wt"][q] = packing.pack_conv3x3_dgrad(P[q + ".layer.weight"].float(), P[q + ".norm.weight"].float(), dtype=self.dtype)
         pd = "net.img_process.cnn.dense."
         wd_blk = packing.chw_to_blocked_columns(P[pd + "layer.weight"].float(), c2, 16, 16)      # [256, K] in activation order
-        acc["dense_wt"] = packing.pack_linear(wd_blk.t().contiguous())                           # dgrad operand: N = K, K = 256
+        acc["dense_wt"] = packing.pack_linear(wd_blk.t().contiguous(), dtype=self.dtype)                           # dgrad operand: N = K, K = 256
         k = wd_blk.shape[1]
         acc["dense_dwT"] = torch.zeros(k, 256, dtype=torch.float32, device=dev)
         acc["dense_dg"], acc["dense_db"] = torch.zeros(k, dtype=torch.float32, device=dev), torch.zeros(k, dtype=torch.float32, device=dev)
@@ -384,7 +417,7 @@ class BCTrainer:
         f = x_last.shape[0]
         k = x_last[0].numel()
         # dense: d = xn Wd^T.   dxn = dd Wd ;  dWd^T += xn^T dd  (GEMM rows = the K activations, reduction over frames)
-        dd16 = ops.gate_cast(dd, 256)
+        dd16 = ops.gate_cast(dd, 256, dtype=self.dtype)
         _, dxn = ops.linear(dd16, acc["dense_wt"], k, out_f32=False, out_bf16=True)
         xn = ops.frame_affine(x_last, w[pd + "g"], w[pd + "b"], s_last, per_element=True)
         ops.linear_wgrad(xn.view(f, k), dd16, k, out=acc["dense_dwT"])      # dWd^T [K, 256] += xn^T dd
@@ -430,6 +463,8 @@ class BCTrainer:
     @torch.no_grad()
     def reduced_loss_and_grads(self, img_u8, first, state_in, act_buttons, act_camera):
         """This rank's shard of the batch -> (global mean loss, gradients of the GLOBAL mean loss summed over ranks, state_out).
+        (fp16 mode: the gradients stay loss-scaled, i.e. are those of the mean divided by grad_unscale(global frames); step() hands
+        that factor to the optimiser launch.)
         The loss gradient already carries 1 / global_frames, so the exchange is a plain sum, in two bucketed all-reduces:
         the trunk + head gradients (final before the CNN backward starts) travel over RCCL WHILE the CNN backward -- two
         thirds of the step's compute -- runs; the CNN's own gradients (a tenth of the bytes) follow at the end.  A rank
@@ -437,14 +472,15 @@ class BCTrainer:
         (loss, healthy-rank count) reduction, so all ranks raise together instead of blocking in an all-reduce."""
         world = dist.get_world_size() if dist.is_initialized() else 1
         m_local = img_u8.shape[0] * img_u8.shape[1]
+        self._global_frames = m_local
         if world == 1:
-            return self.loss_and_grads(img_u8, first, state_in, act_buttons, act_camera, global_frames=m_local)
+            return self.loss_and_grads(img_u8, first, state_in, act_buttons, act_camera, global_frames=m_local, unscaled=False)
         dev = img_u8.device
         # Shards may differ by one sequence when B % world != 0 (distributed.shard_range): the mean runs over the TRUE global
         # frame count, and the reported loss is the frame-weighted mean of the ranks' losses.
         count = torch.tensor([float(m_local)], dtype=torch.float64, device=dev)
         dist.all_reduce(count)
-        m_global = int(round(float(count.item())))
+        m_global = self._global_frames = int(round(float(count.item())))
         early = [n for n in self.trainable if not n.startswith("net.img_process.cnn.")]   # final before the CNN backward
         late = [n for n in self.trainable if n.startswith("net.img_process.cnn.")]
         pending, state = [], dict(early_sent=False)
@@ -458,7 +494,7 @@ class BCTrainer:
         err, loss, grads, state_out = None, None, None, None
         try:
             loss, grads, state_out = self.loss_and_grads(img_u8, first, state_in, act_buttons, act_camera,
-                                                         global_frames=m_global, on_trunk_grads=start_trunk_exchange)
+                                                         global_frames=m_global, on_trunk_grads=start_trunk_exchange, unscaled=False)
             for n in late:
                 grads[n] = grads[n].contiguous()
             pending.extend(D.bucketed_all_reduce_start([grads[n] for n in late]))
@@ -478,15 +514,29 @@ class BCTrainer:
     @torch.no_grad()
     def step(self, img_u8, first, state_in, act_buttons, act_camera):
         """One optimiser step on this rank's shard of the batch.  Returns (global mean loss, state_out)."""
+        self._need_optimizer_state()
         loss, grads, state_out = self.reduced_loss_and_grads(img_u8, first, state_in, act_buttons, act_camera)
         names = [n for n in self.trainable if n in grads]
-        self.step_count += 1
-        # one launch for all tensors (th.optim.Adam(policy.parameters()).step(), behavioural_cloning.py:122)
+        found_inf = torch.zeros(1, dtype=torch.int32, device=img_u8.device) if self.scaled else None
+        # one launch for all tensors (th.optim.Adam(policy.parameters()).step(), behavioural_cloning.py:122); in the fp16 mode it
+        # un-scales the gradients and is a no-op on the device when the overflow check (same table, one launch before) fired
         ops.adam_step_multi_([self.params[n].data.view(-1) for n in names], [grads[n].contiguous().view(-1) for n in names],
-                             [self.m[n].view(-1) for n in names], [self.v[n].view(-1) for n in names], self.step_count,
-                             lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.wd)
+                             [self.m[n].view(-1) for n in names], [self.v[n].view(-1) for n in names], self.step_count + 1,
+                             lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.wd,
+                             grad_scale=self.grad_unscale(self._global_frames), found_inf=found_inf)
+        loss = float(loss)                     # (synchronises: the flag below is ready)
+        if self.scaled and int(found_inf.item()):
+            self.skipped_steps += 1            # the ranks agree: every rank checked the same all-reduced gradients
+            self._clean_steps = 0
+            self.loss_scale = max(self.loss_scale * 0.5, 1.0)
+            return loss, state_out
+        self.step_count += 1
+        if self.scaled:
+            self._clean_steps += 1
+            if self._clean_steps >= self.scale_growth_interval:
+                self._clean_steps, self.loss_scale = 0, min(self.loss_scale * 2.0, 65536.0)
         self.policy._packed_key = None  # weights changed: re-pack before the next forward
-        return float(loss), state_out
+        return loss, state_out
 
 
 # ---------------------------------------------------------------------------------------------------------
