@@ -5,7 +5,10 @@
 //     composite_images_with_alpha(frame, cursor_image, cursor_alpha, cursor_x, cursor_y)      (:34-46, only while a GUI is open)
 //     cv2.cvtColor(frame, COLOR_BGR2RGB);  np.clip(.., 0, 255)                                (:120-121; the clip is a no-op on uint8)
 //     resize_image(frame, AGENT_RESOLUTION) = cv2.resize(frame, (128, 128), INTER_LINEAR)     (agent.py:100-103)
-// Everything is integer / IEEE arithmetic restated exactly, so the result is BIT-IDENTICAL to the CPU path:
+// Everything is integer / IEEE arithmetic, restated.  What is PINNED: the cursor blend is bit-identical to the live reference's
+// composite_images_with_alpha (golden vectors, tests/golden/make_golden_clip.py).  What is NOT: the resize restates OpenCV's
+// published algorithm and is bit-identical to oracle/clip_oracle.py, but neither has been checked against real cv2 output
+// (opencv-python is absent from this image) -- "parity unpinned" for that one function.
 //   * the cursor blend is numpy's  uint8(img * (1 - alpha) + cursor * alpha)  in fp64, each product and the sum rounded
 //     separately (no FMA contraction), truncated toward zero;
 //   * the resize is OpenCV's fixed-point INTER_LINEAR for 8-bit images (imgproc/resize.cpp: 11-bit weights from

@@ -34,6 +34,14 @@
 #ifndef VPT_EPI_ABLATE
 #define VPT_EPI_ABLATE 0   // profiling builds: 1 = no output stores, 2 = no residual loads inside the epilogue
 #endif
+// Profiling switches (VPT_CONV_ABLATE = 1: skip the epilogue, 2: skip the main loop; VPT_CONV_EXTRA_LDS: dynamic LDS to force one
+// workgroup per CU) exist ONLY in builds made with -DVPT_CONV_PROFILE (tools/build_variant.sh): the shipped library reads no
+// environment variable and its kernel carries no ablation branch -- a stray variable cannot change results.
+#ifdef VPT_CONV_PROFILE
+#define CONV_ABLATE (a.ablate)
+#else
+#define CONV_ABLATE 0
+#endif
 
 #define A_RS 80
 #define A_BYTES (324 * A_RS)            // 25920
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   } while (0)
 
   if (TRACE && tid == 0) t_trace[1] = wall_clock64();
-  if (a.ablate != 2) {
+  if (CONV_ABLATE != 2) {
     FB_LD(0, 0, 0, 0); FA_LD(0, 0, 0, 0); FB_LD(0, 0, 1, 0); FA_LD(0, 0, 0, 1); FA_LD(0, 0, 0, 2); FA_LD(0, 0, 0, 3);
     SB();
     if (NCB > 1) {   // first channel block peeled: its first eight MFMAs take C = 0 instead of 128 zeroed registers
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
 
   // ---------------- epilogue ----------------
   if (TRACE && tid == 0) t_trace[2] = wall_clock64();
-  if (a.ablate == 1) {  // profiling: keep the accumulators live, skip the epilogue
+  if (CONV_ABLATE == 1) {  // profiling: keep the accumulators live, skip the epilogue
     float t = 0.f;
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -367,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     if (t == 12345.678f) a.y[0] = (vpt_op16)t;
     return;
   }
-  if (HAS_RES && a.ablate == 2) { LOAD_RES(0); LOAD_RES(1); }
+  if (HAS_RES && CONV_ABLATE == 2) { LOAD_RES(0); LOAD_RES(1); }
   SB();
 
   f32x2 s_sum2 = {0.f, 0.f}, s_sq2 = {0.f, 0.f};   // packed fp32 (v_pk_add_f32 / v_pk_fma_f32): two values per VALU issue
@@ -527,17 +535,21 @@ static long long* g_conv_trace = nullptr;
 extern "C" void vpt_conv3x3_set_trace(void* buf) { g_conv_trace = (long long*)buf; }  // profiling: [grid][12] int64, or null
 
 extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream) {
-  static int ablate = -1, extra_lds = 0;
-  if (ablate < 0) {
+  int ablate = 0, extra_lds = 0;
+#ifdef VPT_CONV_PROFILE
+  static int ablate_env = -1, extra_lds_env = 0;
+  if (ablate_env < 0) {
     const char* e = getenv("VPT_CONV_ABLATE");
-    ablate = e ? atoi(e) : 0;
-    const char* xl = getenv("VPT_CONV_EXTRA_LDS");  // profiling: dynamic LDS bytes (> 2 KB forces one workgroup per CU)
-    extra_lds = xl ? atoi(xl) : 0;
-    if (extra_lds > 0) {
-      (void)hipFuncSetAttribute((const void*)vpt_conv3x3_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds);
-      (void)hipFuncSetAttribute((const void*)vpt_conv3x3_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds);
+    ablate_env = e ? atoi(e) : 0;
+    const char* xl = getenv("VPT_CONV_EXTRA_LDS");  // dynamic LDS bytes (> 2 KB forces one workgroup per CU)
+    extra_lds_env = xl ? atoi(xl) : 0;
+    if (extra_lds_env > 0) {
+      (void)hipFuncSetAttribute((const void*)vpt_conv3x3_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds_env);
+      (void)hipFuncSetAttribute((const void*)vpt_conv3x3_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds_env);
     }
   }
+  ablate = ablate_env; extra_lds = extra_lds_env;
+#endif
   VptConv3x3Args a_copy = *a_in;
   a_copy.ablate = ablate;
   a_copy.trace = g_conv_trace;

@@ -283,7 +283,9 @@ class MinecraftAgentPolicy(nn.Module):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             # arg-max + its log-prob ride in the graph; the recurrent state is updated in place (no copies back into the static buffers)
-            out = eng.forward(sg["img"], sg["first"], sg["state"], sample="deterministic", inplace_state=True)
+            from .. import ops
+            inplace = cfg["maxlen"] <= ops.ATTENTION_STEP_MAXLEN     # the fused step kernel's limit; longer memories go through copies (below)
+            out = eng.forward(sg["img"], sg["first"], sg["state"], sample="deterministic", inplace_state=inplace)
             for (m_in, (k_in, v_in)), (m_out, (k_out, v_out)) in zip(sg["state"], out["state_out"]):
                 if m_out.data_ptr() != m_in.data_ptr():
                     m_in.copy_(m_out)

@@ -590,7 +590,9 @@ def action_to_factored(joint_buttons, joint_camera, n_camera_bins=11):
 # ---- clip data path (data_loader.py:113-122 on the device) --------------------------------------------------------
 def clip_frames(frames_bgr, cursor_state=None, cursor_bgr=None, cursor_alpha=None, out_hw=(128, 128), out=None):
     """uint8 BGR [F,H,W,3] (+ int32 [F,3] (gui open, x, y), uint8 cursor [h,w,3] BGR, fp64 alpha [h,w]) -> uint8 RGB [F,oh,ow,3]:
-    cursor compositing, BGR->RGB and cv2.INTER_LINEAR resize in one launch, bit-identical to the reference's CPU path."""
+    cursor compositing, BGR->RGB and the cv2.INTER_LINEAR resize in one launch.  The compositing is bit-identical to the live
+    reference's function (golden vectors); the resize restates OpenCV's 8-bit fixed-point algorithm and is bit-identical to
+    oracle/clip_oracle.py, which is NOT pinned against real cv2 (absent from this image)."""
     _chk(frames_bgr, torch.uint8, "frames_bgr")
     if frames_bgr.dim() != 4 or frames_bgr.shape[3] != 3:
         raise ValueError("frames_bgr must be [F, H, W, 3]")
@@ -598,6 +600,10 @@ def clip_frames(frames_bgr, cursor_state=None, cursor_bgr=None, cursor_alpha=Non
     oh, ow = int(out_hw[0]), int(out_hw[1])
     if out is None:
         out = torch.empty(f, oh, ow, 3, dtype=torch.uint8, device=frames_bgr.device)
+    else:
+        _chk(out, torch.uint8, "out")
+        if tuple(out.shape) != (f, oh, ow, 3) or out.device != frames_bgr.device:
+            raise ValueError(f"clip_frames: out must be uint8 [{f}, {oh}, {ow}, 3] on {frames_bgr.device}, got {tuple(out.shape)} on {out.device}")
     ch = cw = 0
     if cursor_state is not None:
         if cursor_bgr is None or cursor_alpha is None:
