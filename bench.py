@@ -146,6 +146,7 @@ def parity_block(model: str, dev):
     out["actions_peaked_heads"] = {"sample": f"{model} model, B=2 T=16 structured frames, oracle.peak_heads weights; deterministic actions of the fused head kernel vs the oracle's arg-max"}
     for mode in ("bf16", "fp16"):
         pol.set_precision(mode)
+        pol._ensure_packed()
         with torch.no_grad():
             o = pol._engine.forward(imgp.to(dev), firstp.to(dev), pol.initial_state(2), sample="deterministic")
         torch.cuda.synchronize()

@@ -99,9 +99,13 @@ def test_minerl_agent_runs_unchanged_over_hip_policy(R, tmp_path):
     # ---- the unmodified acting loop (stochastic, as run_agent.py:22-24): a valid MineRL action every step -------------------
     n = 16
     frames = _pov_frames(n, seed=7)
+    with torch.no_grad():
+        ref_keys = set(ref_agent.get_action({"pov": frames[0]}).keys())     # what ActionTransformer.policy2env emits (a subset of the env's keys)
+    ref_agent.reset()
+    assert ref_keys <= set(ag_mod.TARGET_ACTION_SPACE.keys()) and {"camera", "attack", "forward", "inventory"} <= ref_keys
     for i in range(4):
         a = agent.get_action({"pov": frames[i]})
-        assert set(a.keys()) == set(ag_mod.TARGET_ACTION_SPACE.keys())
+        assert set(a.keys()) == ref_keys
         assert a["camera"].shape == (1, 2) and all(np.asarray(v).shape[0] == 1 for v in a.values())
         assert all(int(np.asarray(a[k]).ravel()[0]) in (0, 1) for k in a if k != "camera")
     # ---- side by side, arg-max actions, state carried inside the agents -------------------------------------------
@@ -159,7 +163,7 @@ def test_idm_agent_runs_unchanged_over_hip_policy(R, tmp_path):
     assert set(got.keys()) == set(want.keys())
     agree = {k: float((np.asarray(got[k]) == np.asarray(want[k])).mean()) for k in got}
     print("DROP-IN IDMAgent[fp16]: fraction of the 128 frames with the same predicted env action per key:", {k: round(v, 3) for k, v in agree.items()})
-    assert np.asarray(got["camera"]).shape == (n, 2)
+    assert np.asarray(got["camera"]).shape == np.asarray(want["camera"]).shape == (1, n, 2)
     assert min(agree.values()) >= 0.97
 
 

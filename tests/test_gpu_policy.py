@@ -89,7 +89,7 @@ def test_deterministic_actions_equal_reference(pol_1x):
     pol, cfg, sd = pol_1x
     mode = pol.precision
     b, t = 4, 16
-    img = _inputs(555, b, t)
+    img = P.structured_frames(b, t, torch.Generator().manual_seed(555))     # low-frequency content: the arg-max varies from frame to frame
     first = torch.zeros(b, t, dtype=torch.bool)
     ref = O.policy_forward(sd, cfg, img, first, O.initial_state(cfg, b))
     st = pol.initial_state(b)
@@ -109,7 +109,7 @@ def test_deterministic_actions_equal_reference(pol_1x):
         top2 = ref[h].topk(2, -1).values[:, :, 0]
         safe = (top2[..., 0] - top2[..., 1]) > 4 * err
         print(f"ACTIONS[{mode}] {h}: agree {float((got == want).float().mean()):.3f} overall, {int(safe.sum())}/{safe.numel()} positions outside "
-              f"the noise band (4 x {err:.2e}), mismatches there: {int(((got != want) & safe).sum())}")
+              f"the noise band (4 x {err:.2e}), mismatches there: {int(((got != want) & safe).sum())}; distinct oracle actions {len(set(want.flatten().tolist()))}")
         assert bool((got[safe] == want[safe]).all())
         if mode == "fp16":
             assert float(safe.float().mean()) > 0.5, "fp16 mode should resolve most positions"

@@ -1,5 +1,8 @@
 #!/bin/bash
-out=gpurun_out/r02_full; mkdir -p $out
-timeout 3000 python -m pytest tests/ -x -q -m gpu --durations=8 > $out/gpu_tests.log 2>&1; echo "rc=$?" >> $out/gpu_tests.log
-grep -E "passed|failed|Error|rc=|s call|assert" $out/gpu_tests.log | cut -c1-300 | tail -24
-timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"; tail -c 6000 $out/bench.json; tail -5 $out/bench.err
+# One GPU round: the -m gpu tests (all of them, failures collected), smoke(), bench.py.  tools/gpu_round.sh [tag] [pytest args...]
+tag=${1:-r03_full}; shift
+out=gpurun_out/$tag; mkdir -p $out
+timeout 2400 python -m pytest tests/ -q -m gpu --durations=12 -s "$@" > $out/gpu_tests.log 2>&1; echo "rc=$?" >> $out/gpu_tests.log
+grep -E "passed|failed|^FAILED|^ERROR|rc=" $out/gpu_tests.log | cut -c1-400 | tail -40
+timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; echo "smoke rc=$?"; tail -8 $out/smoke.log | cut -c1-400
+timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"; tail -c 9000 $out/bench.json; tail -5 $out/bench.err
