@@ -238,6 +238,7 @@ def _bc_leg(pol, args, img, first, g, dev, world, distributed, barrier, dist, mo
               flop_accounting="3 x forward FLOPs (SURVEY 8d) x frames / step time, per GPU",
               peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1))
     if int(os.environ.get("RANK", "0")) == 0 and not distributed:
+        tr.cnn_streams = 1          # per-kernel durations are only meaningful without cross-stream overlap
         ops.TIMER.enabled = True
         ops.TIMER.reset()
         tr.step(img, first, st_bc, ab, ac)

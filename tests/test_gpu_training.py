@@ -486,9 +486,9 @@ def test_bc_gradients_independent_of_cnn_chunking(trainer_1x):
             continue
         e = _l2(g2[k].float().cpu(), v.float().cpu())
         worst = max(worst, e)
-        # (the first conv's dW is a heavily cancelling sum over every pixel of the batch, flushed by fp32 atomics whose order follows
+        # (the first conv's dW / db are heavily cancelling sums over every pixel of the batch, flushed by fp32 atomics whose order follows
         # the persistent workgroups' tile ranges: measured 1.2e-4 in fp16, 5e-5 in bf16)
-        assert e < (3e-4 if k == "net.img_process.cnn.stacks.0.firstconv.layer.weight" else 1e-4), (k, e)
+        assert e < (3e-4 if k.startswith("net.img_process.cnn.stacks.0.firstconv.layer.") else 1e-4), (k, e)
     print(f"PARITY BC gradients, 3 CNN chunks vs 1: worst rel-L2 {worst:.2e}")
 
 

@@ -11,6 +11,7 @@ import __graft_entry__ as ge
 ge.build()
 from vpt_amd import ops, packing  # noqa: E402
 
+DT = {"bf16": torch.bfloat16, "fp16": torch.float16}[os.environ.get("VPT_PRECISION", "bf16")]   # operand format (library) under test
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = "cuda"
@@ -23,9 +24,9 @@ for name, hw, cin, cout, use_res in shapes:
     f = frames * (64 * 64) // (hw * hw) if hw < 64 else frames
     f = min(f, frames * 4)
     W = torch.randn(cout, cin, 3, 3, generator=g) * (1.6 / (cin * 9) ** 0.5)
-    wpk, sa, sg = packing.pack_conv3x3(W.to(dev), torch.ones(cin, device=dev), torch.zeros(cin, device=dev))
-    x = torch.relu(torch.randn(f, cin // 32, hw, hw, 32, device=dev)).to(torch.bfloat16)
-    res = torch.randn(f, cout // 32, hw, hw, 32, device=dev).to(torch.bfloat16) if use_res else None
+    wpk, sa, sg = packing.pack_conv3x3(W.to(dev), torch.ones(cin, device=dev), torch.zeros(cin, device=dev), dtype=DT)
+    x = torch.relu(torch.randn(f, cin // 32, hw, hw, 32, device=dev)).to(DT)
+    res = torch.randn(f, cout // 32, hw, hw, 32, device=dev).to(DT) if use_res else None
     if os.environ.get("VPT_BENCH_ZERO") == "1":  # DVFS probe: same instruction stream, no operand toggling (MI355X_MICROARCH.md "DVFS give-back")
         x.zero_(); wpk.zero_()
         if res is not None:
@@ -33,7 +34,7 @@ for name, hw, cin, cout, use_res in shapes:
     xf = x.float().reshape(f, -1).double()
     st_in = torch.stack([xf.sum(1), (xf * xf).sum(1)], 1).contiguous()
     st_out = None if os.environ.get("VPT_BENCH_NOSTATS") == "1" else torch.zeros(f, 2, dtype=torch.float64, device=dev)
-    out = torch.empty(f, cout // 32, hw, hw, 32, dtype=torch.bfloat16, device=dev)
+    out = torch.empty(f, cout // 32, hw, hw, 32, dtype=DT, device=dev)
     for _ in range(2):
         ops.conv3x3(x, wpk, sa, sg, st_in, cout, res=res, stats_out=st_out, out=out)
     torch.cuda.synchronize()
@@ -50,4 +51,4 @@ for name, hw, cin, cout, use_res in shapes:
     ms, best = times[2], times[0]
     flops = 2.0 * f * hw * hw * cout * 9 * cin
     tag = " ".join(f"{k[9:].lower()}={v}" for k, v in os.environ.items() if k.startswith("VPT_CONV_"))
-    print(f"{name:9s} frames={f:5d} {hw}x{hw} {cin}->{cout}: median {ms:7.3f} ms {flops / ms / 1e9:7.1f} TF/s | best {flops / best / 1e9:7.1f} TF/s  {tag}")
+    print(f"[{os.environ.get('VPT_PRECISION', 'bf16')}] {name:9s} frames={f:5d} {hw}x{hw} {cin}->{cout}: median {ms:7.3f} ms {flops / ms / 1e9:7.1f} TF/s | best {flops / best / 1e9:7.1f} TF/s  {tag}")

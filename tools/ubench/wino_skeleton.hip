@@ -1,0 +1,179 @@
+// Micro-benchmark (gfx950): the MAIN LOOP of a fused Winograd F(2x2, 3x3) convolution, without its transforms -- an upper bound
+// for what such a kernel could reach, measured before building it (time-boxed, kill below 1.25x).
+//
+// F(2x2, 3x3) replaces the 9 * Cin multiply-accumulates per output by 4 * Cin (2.25x fewer MFMA passes) at the price of SIXTEEN
+// independent accumulator sets (one per Winograd position xi): M_xi[tiles][couts] += V_xi[tiles][Cin] * U_xi[Cin][couts].  The
+// accumulators decide everything: 16 positions x (32 tiles x 32 couts) is already 256 registers per lane, so a wave's register
+// tile per position is ONE 32x32 MFMA tile and every MFMA needs a fresh A fragment (V_xi, 1 KB) and a fresh B fragment (U_xi, 1 KB)
+// from LDS: 2 KB of LDS reads per MFMA, against 0.75 KB in the direct kernel (4 x 2 register tile: 6 reads feed 8 MFMAs).  LDS
+// delivers 128 B / clock / CU, a 32x32x16 MFMA takes 32 clocks per SIMD: four SIMDs at 2 KB / MFMA are LDS-bound at 50 % of the
+// MFMA rate BEFORE the input transform writes V (+ 25 %), reads the halo tile (+ 25 %) and spends its 128 packed adds per thread
+// and channel block in the same issue slots.
+//
+// Variants (same random bf16 operands in LDS, 4 waves per workgroup, persistent loop, everything resident):
+//   wino16 : 16 positions x one 32x32 tile per wave, 256 accumulator registers (AGPRs), 1 workgroup / CU      -> 2 KB / MFMA
+//   wino8x2: 8 positions (half a pass) x 32 tiles x 64 couts per wave, 256 accumulators, 1 workgroup / CU      -> 1.5 KB / MFMA
+//   direct : the direct kernel's 4 x 2 register tile (128 accumulators), 2 workgroups / CU                     -> 0.75 KB / MFMA
+// Output: MFMA TF/s actually issued, and for the Winograd variants the "effective" direct-convolution rate (x 2.25).
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench/wino_skeleton.hip -o tools/ubench/wino_skeleton && tools/ubench/wino_skeleton
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define LDS_BYTES (128 * 1024)
+
+// MODE 0: wino16, 1: wino8x2, 2: direct 4x2
+template <int MODE>
+__global__ __launch_bounds__(256, MODE == 2 ? 2 : 1) void skeleton(const uint4* __restrict__ init, float* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  constexpr int BYTES = MODE == 2 ? 64 * 1024 : LDS_BYTES;
+  for (int i = tid; i < BYTES / 16; i += 256) ((uint4*)lds)[i] = init[i];
+  __syncthreads();
+  // fragment reads: conflict-free 16-byte-per-lane rows (64 lanes x 16 B = 1 KB contiguous per fragment)
+  const unsigned char* base = lds + lane * 16;
+  float s = 0.f;
+  if (MODE == 0) {
+    f32x16 acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const unsigned char* av = base + (w >> 1) * 32768;          // this wave's 32 tiles: 16 positions x 2 k-steps x 1 KB
+    const unsigned char* bu = base + 65536 + (w & 1) * 32768;   // this wave's 32 couts
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+          const bf16x8 a = *(const bf16x8*)(av + (ks * 16 + xi) * 1024);
+          const bf16x8 b = *(const bf16x8*)(bu + (ks * 16 + xi) * 1024);
+          acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[xi], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[j][r];
+  } else if (MODE == 1) {
+    f32x16 acc[8][2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.f;
+    const unsigned char* av = base + (w >> 1) * 16384;
+    const unsigned char* bu = base + 65536 + (w & 1) * 32768;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int xi = 0; xi < 8; ++xi) {
+          const bf16x8 a = *(const bf16x8*)(av + (ks * 8 + xi) * 1024);
+          const bf16x8 b0 = *(const bf16x8*)(bu + (ks * 16 + 2 * xi) * 1024);
+          const bf16x8 b1 = *(const bf16x8*)(bu + (ks * 16 + 2 * xi + 1) * 1024);
+          acc[xi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[xi][0], 0, 0, 0);
+          acc[xi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[xi][1], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[j][n][r];
+  } else {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    const unsigned char* av = base + (w >> 1) * 16384;
+    const unsigned char* bu = base + 32768 + (w & 1) * 16384;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {   // 4 groups of 8 MFMAs = the same 32 MFMAs per iteration as the other variants
+        bf16x8 a[4], b[2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[m] = *(const bf16x8*)(av + ((g * 4 + m) & 15) * 1024);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) b[n] = *(const bf16x8*)(bu + ((g * 2 + n) & 15) * 1024);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[m][n][r];
+  }
+  out[blockIdx.x * 256 + tid] = s;
+}
+
+template <int MODE>
+static double run(const uint4* init, float* out, int grid, int iters, int reps) {
+  const int bytes = MODE == 2 ? 64 * 1024 : LDS_BYTES;
+  hipFuncSetAttribute((const void*)skeleton<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(skeleton<MODE>, dim3(grid), dim3(256), bytes, 0, init, out, iters);
+  hipDeviceSynchronize();
+  double best = 1e30;
+  for (int r = 0; r < reps; ++r) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(skeleton<MODE>, dim3(grid), dim3(256), bytes, 0, init, out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  return best;
+}
+
+int main(int argc, char** argv) {
+  const int zero = argc > 1 ? atoi(argv[1]) : 0;   // 1: all-zero operands (clock / power probe)
+  std::vector<unsigned short> h(LDS_BYTES / 2);
+  srand(1);
+  for (auto& v : h) {   // bf16 bit patterns of roughly N(0, 1) values (post-ReLU-like: half of them zero)
+    float f = zero ? 0.f : ((rand() & 1) ? 0.f : (float)(rand() % 2001 - 1000) / 500.f);
+    unsigned u; memcpy(&u, &f, 4);
+    v = (unsigned short)(u >> 16);
+  }
+  uint4* init; float* out;
+  hipMalloc(&init, LDS_BYTES); hipMalloc(&out, 4 * 256 * 1024);
+  hipMemcpy(init, h.data(), LDS_BYTES, hipMemcpyHostToDevice);
+  const int iters = 2000, reps = 5;
+  const double flop_per_mfma = 2.0 * 32 * 32 * 16;
+  {
+    const int grid = 256;   // one workgroup per CU
+    const double ms = run<0>(init, out, grid, iters, reps);
+    const double tf = (double)grid * 4 * iters * 32 * flop_per_mfma / (ms * 1e-3) / 1e12;
+    printf("wino16  (2 KB LDS / MFMA, 1 wg/CU, 256 acc regs): %.3f ms  %.1f TF/s issued  -> %.1f TF/s effective (x2.25), transforms NOT included\n", ms, tf, tf * 2.25);
+  }
+  {
+    const int grid = 256;
+    const double ms = run<1>(init, out, grid, iters, reps);
+    const double tf = (double)grid * 4 * iters * 32 * flop_per_mfma / (ms * 1e-3) / 1e12;
+    printf("wino8x2 (1.5 KB LDS / MFMA, 1 wg/CU, 256 acc regs): %.3f ms  %.1f TF/s issued  -> %.1f TF/s effective (x2.25) if the second half-pass re-staged nothing\n", ms, tf, tf * 2.25);
+  }
+  {
+    const int grid = 512;   // two workgroups per CU
+    const double ms = run<2>(init, out, grid, iters, reps);
+    const double tf = (double)grid * 4 * iters * 32 * flop_per_mfma / (ms * 1e-3) / 1e12;
+    printf("direct  (0.75 KB LDS / MFMA, 2 wg/CU, 128 acc regs): %.3f ms  %.1f TF/s issued (= effective)\n", ms, tf);
+  }
+  return 0;
+}

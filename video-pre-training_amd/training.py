@@ -16,6 +16,7 @@ fused first conv (vpt_conv_first_bwd_kernel).  train_cnn=False freezes `net.img_
 trunk and heads only (71 % of the 2x model's parameters).  Data parallelism: one process per GPU, sequences sharded by rank, the
 gradients summed over RCCL in buckets -- trunk + heads while the CNN backward runs, the CNN's at the end
 (BCTrainer.reduced_loss_and_grads); the 1 / global_frames factor is already in the loss gradient."""
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -24,6 +25,14 @@ import torch.distributed as dist
 from . import distributed as D
 from . import ops, packing
 from .engine import DENSE_SPLITK
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
 
 
 def _round_up(x: int, m: int) -> int:
@@ -76,6 +85,13 @@ class BCTrainer:
         self.scale_growth_interval, self._clean_steps, self.skipped_steps = int(scale_growth_interval), 0, 0
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.step_count = 0
+        # Frame chunks of the CNN (forward-saving AND backward) alternate over this many HIP streams, chunk ci always on stream
+        # ci % n: one chunk's HBM-bound passes (conv_backward_prepare, the affine backward, pool) and launch tails overlap the
+        # other chunks' MFMA-bound convolutions, as in the inference engine.  Each stream accumulates its weight-gradient pieces in
+        # its own buffers (summed in a fixed order at the end: deterministic); a chunk's saved activations are allocated, used and
+        # released on ONE stream, so the caching allocator's per-stream pools need no cross-stream bookkeeping.
+        self.cnn_streams = int(os.environ.get("VPT_BC_STREAMS", self.engine.cnn_streams))
+        self._streams: List[torch.cuda.Stream] = []
         self.params: Dict[str, torch.nn.Parameter] = dict(policy.named_parameters())
         self.trainable = [n for n in self.params if self._is_trainable(n)]
         self.m = {n: torch.zeros_like(self.params[n], dtype=torch.float32) for n in self.trainable} if optimizer_state else {}
@@ -161,15 +177,19 @@ class BCTrainer:
 
         # ---------------- forward, keeping what the backward needs ----------------
         outs, cnn_saved = [], []
-        for i in range(0, m, eng.cnn_chunk):
-            if self.train_cnn:
-                xn, sv = self._cnn_forward_saving(frames[i:i + eng.cnn_chunk])
-                cnn_saved.append(sv)
-            else:
-                xn = eng._cnn_chunk(frames[i:i + eng.cnn_chunk])
-            d32, _ = ops.linear(xn.view(xn.shape[0], -1), w["net.img_process.cnn.dense.w"], 256, splitk=DENSE_SPLITK)
-            outs.append(d32)
-            del xn
+        streams, main = self._chunk_streams((m + eng.cnn_chunk - 1) // eng.cnn_chunk)
+        for ci, i in enumerate(range(0, m, eng.cnn_chunk)):
+            with (torch.cuda.stream(streams[ci % len(streams)]) if streams else _NullCtx()):
+                if self.train_cnn:
+                    xn, sv = self._cnn_forward_saving(frames[i:i + eng.cnn_chunk])
+                    cnn_saved.append(sv)
+                else:
+                    xn = eng._cnn_chunk(frames[i:i + eng.cnn_chunk])
+                d32, _ = ops.linear(xn.view(xn.shape[0], -1), w["net.img_process.cnn.dense.w"], 256, splitk=DENSE_SPLITK)
+                outs.append(d32)
+                del xn
+        for st in streams:
+            main.wait_stream(st)
         d = outs[0] if len(outs) == 1 else torch.cat(outs, 0)                     # [M,256] pre-ReLU dense output
         pl = "net.img_process.linear."
         dt = self.dtype
@@ -310,11 +330,58 @@ class BCTrainer:
             on_trunk_grads(g)
         if self.train_cnn:
             acc = self._cnn_backward_begin(P)
+            n_acc = max(1, min(self.cnn_streams, len(cnn_saved)))
+            accs = [acc] + [self._cnn_backward_accumulators(acc) for _ in range(n_acc - 1)]     # operands shared, accumulators per stream
+            streams, main = self._chunk_streams(len(cnn_saved))                                   # (after the zero-fills above were enqueued)
             for ci, i in enumerate(range(0, m, eng.cnn_chunk)):
-                self._cnn_backward_chunk(cnn_saved[ci], dd[i:i + eng.cnn_chunk].contiguous(), acc)
-                cnn_saved[ci] = None
+                with (torch.cuda.stream(streams[ci % len(streams)]) if streams else _NullCtx()):
+                    self._cnn_backward_chunk(cnn_saved[ci], dd[i:i + eng.cnn_chunk].contiguous(), accs[ci % len(accs)])
+                    cnn_saved[ci] = None
+            for st in streams:
+                main.wait_stream(st)
+            self._cnn_backward_merge(accs)
             self._cnn_backward_finish(acc, P, g)
         return g
+
+    def _chunk_streams(self, n_chunks: int):
+        """-> (the side streams the CNN chunks alternate over -- [] = everything on the current stream --, the current stream);
+        the side streams have been made to wait for the work enqueued so far."""
+        main = torch.cuda.current_stream()
+        n = min(self.cnn_streams, n_chunks)
+        if n <= 1:
+            return [], main
+        if len(self._streams) < n:
+            self._streams = [torch.cuda.Stream() for _ in range(n)]
+        for st in self._streams[:n]:
+            st.wait_stream(main)
+        return self._streams[:n], main
+
+    def _cnn_backward_accumulators(self, acc):
+        """A second set of zeroed accumulators next to `acc` (same read-only operands)."""
+        z = torch.zeros_like
+        other = dict(wt=acc["wt"], dense_wt=acc["dense_wt"], raw={}, n={s: (z(a), z(b)) for s, (a, b) in acc["n"].items()}, dense=None,
+                     dense_dwT=z(acc["dense_dwT"]), dense_dg=z(acc["dense_dg"]), dense_db=z(acc["dense_db"]))
+        return other
+
+    def _cnn_backward_merge(self, accs):
+        """Sum the per-stream accumulators into accs[0], in stream order."""
+        a0 = accs[0]
+        for a in accs[1:]:
+            for q, r in a["raw"].items():
+                if q in a0["raw"]:
+                    for t0, t1 in zip(a0["raw"][q], r):
+                        t0.add_(t1)
+                else:
+                    a0["raw"][q] = r
+            for s, (dg_, db_) in a["n"].items():
+                a0["n"][s][0].add_(dg_); a0["n"][s][1].add_(db_)
+            for k in ("dense_dwT", "dense_dg", "dense_db"):
+                a0[k].add_(a[k])
+            if a.get("first") is not None:
+                if a0.get("first") is None:
+                    a0["first"] = a["first"]
+                else:
+                    a0["first"][0].add_(a["first"][0]); a0["first"][1].add_(a["first"][1])
 
     # ------------------------------------------------------------------------------------------
     # IMPALA CNN: forward that keeps every activation (6.2 MB / frame on the 2x model: a 64 x 128 batch is 50 GB of
