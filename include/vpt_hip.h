@@ -13,7 +13,9 @@
  *   - return 0 on success, <0 on a rejected argument or a launch failure (vpt_last_error() explains);
  *   - "blocked" activations are bf16 [frames][C/32][H][W][32]; "stats" are double[frames][2] holding the
  *     running (sum, sum of squares) of a frame, accumulated with atomics -- the caller zeroes them;
- *   - packed weight formats are produced by video-pre-training_amd/packing.py (documented in DESIGN.md).
+ *   - packed weight formats are produced by the vpt_pack_* / vpt_chw_to_blocked entry points below from the
+ *     reference's fp32 tensors: a host without torch can prepare a model (video-pre-training_amd/packing.py is the CPU restatement
+ *     the tests compare them with, bit for bit).
  */
 #ifndef VPT_HIP_H
 #define VPT_HIP_H
@@ -33,7 +35,7 @@ const char* vpt_operand_format(void);
 const char* vpt_last_error(void);
 
 /* ---- weight re-packing (the `.weights` state_dict, fp32, reference shapes -> what the kernels stream) ------------------
- * A host needs nothing else to prepare a model: sizes from the three queries, then one launch per layer.
+ * A host needs nothing else to prepare a model: sizes from the queries, then one launch per layer.
  *   vpt_pack_conv3x3: Conv2d weight [Cout][Cin][3][3] of a FanInInitReLULayer with GroupNorm(1, Cin) (lib/util.py:58-82,
  *     lib/impala_cnn.py:30-52,86-97) -> wpk (16-bit, vpt_conv3x3_packed_elems elements: round(W * gain) in the swizzled LDS
  *     image of vpt_conv3x3_forward) and, when edge_sa / edge_sg are given (forward use; both or neither), the tables of the
@@ -42,10 +44,32 @@ const char* vpt_last_error(void);
  *   vpt_pack_linear: nn.Linear weight [N][K] (row stride ldw) -> [ceil(N/128)][K/32][128][32] 16-bit, rows >= N zero,
  *     K % 64 == 0.  With transposed = 1 the packed matrix is the TRANSPOSE of a [src_rows][ldw] source (element (n, k) =
  *     source[k][n], zero for k >= src_rows): the operand of the input-gradient GEMM dx = dy W, with the reduction dimension
- *     (the layer's output width) padded to K. */
+ *     (the layer's output width) padded to K.
+ *   vpt_pack_conv_first: stack-0 firstconv weight [Cout][3][3][3] + bias [Cout] (lib/impala_cnn.py:86-97 with lib/util.py:64-65: no
+ *     norm => bias) -> the MFMA A-operand fragments vpt_conv_first_forward / _backward read (16-bit, vpt_conv_first_packed_elems):
+ *     W / 255 (the pixel operand is the raw byte; ImgPreprocessing's x / 255, lib/policy.py:39-45, is folded in here) and the bias
+ *     as two 16-bit halves in the spare K slots.
+ *   vpt_pack_conv3d_t5: IDM Conv3d weight [O][3][5][1][1] + bias [O] (lib/policy.py:364-372) -> fragments (16-bit,
+ *     vpt_conv3d_t5_packed_elems) + the bias zero-padded to ceil(O/128)*128 floats.
+ *   vpt_chw_to_blocked: fp32 [rows][C*H*W] in the reference's C,H,W flatten order (lib/impala_cnn.py:192-193) -> the blocked
+ *     activation order [rows][C/32][H][W][32]: the dense layer's weight columns (rows = 256) and its LayerNorm gain / bias
+ *     (rows = 1) before vpt_pack_linear / vpt_frame_affine_forward.  Out of place. */
 long vpt_conv3x3_packed_elems(int Cout, int Cin);
 long vpt_conv3x3_table_floats(int Cout);
 long vpt_linear_packed_elems(int N, int K);
+long vpt_conv_first_packed_elems(int Cout);
+long vpt_conv3d_t5_packed_elems(int O);
+int vpt_pack_conv_first(const float* weight, const float* bias, void* wfrag, int Cout, void* stream);
+int vpt_pack_conv3d_t5(const float* weight, const float* bias, void* wfrag, float* bias_padded, int O, void* stream);
+int vpt_chw_to_blocked(const float* src, float* dst, int64_t rows, int C, int H, int W, void* stream);
+
+/* Workspace query: bytes of caller-owned scratch for the entry points that take a `scratch` / partial-sum buffer.
+ *   VPT_WS_CONV3X3_WGRAD         (frames, -, -, Cin, Cout)   vpt_conv3x3_wgrad's scratch
+ *   VPT_WS_CONV_BACKWARD_PREPARE (frames, -, -, -, Cout)     vpt_conv_backward_prepare's scratch
+ *   VPT_WS_LINEAR_SPLITK         (splitk, M, N, -, -)        the [splitk][M][N] fp32 slices vpt_linear_forward writes when splitk > 1
+ * Returns -1 for an unknown op. */
+enum { VPT_WS_CONV3X3_WGRAD = 1, VPT_WS_CONV_BACKWARD_PREPARE = 2, VPT_WS_LINEAR_SPLITK = 3 };
+int64_t vpt_workspace_bytes(int op, int frames, int H, int W, int Cin, int Cout);
 int vpt_pack_conv3x3(const float* weight, const float* gain, const float* bias, void* wpk, float* edge_sa, float* edge_sg,
                      int Cout, int Cin, void* stream);
 int vpt_pack_linear(const float* weight, void* wpk, int N, int K, int transposed, int ldw, int src_rows, void* stream);

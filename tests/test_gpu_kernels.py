@@ -410,3 +410,30 @@ def test_device_pack_linear_bit_exact(n, k):
         wt = torch.zeros(k, np_, device=DEV)
         wt[:, :n] = W.t()
         assert torch.equal(ops.pack_linear(W, transposed=True, k_pad=np_).view(torch.int16), packing.pack_linear(wt).view(torch.int16))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_device_pack_first_convs_and_permutes_bit_exact(dtype):
+    """vpt_pack_conv_first / vpt_pack_conv3d_t5 / vpt_chw_to_blocked (what finishes "a torch-free host can prepare a model") ==
+    the packing.py restatements, bit for bit; and vpt_workspace_bytes agrees with the sizes ops.py allocates."""
+    from vpt_amd import _native
+    g = torch.Generator().manual_seed(9)
+    for cout in (128, 64, 192):
+        W = (torch.randn(cout, 3, 3, 3, generator=g) * 0.3).to(DEV)
+        b = (torch.randn(cout, generator=g) * 0.1).to(DEV)
+        assert torch.equal(ops.pack_conv_first(W, b, dtype=dtype).view(torch.int16), packing.pack_conv_first(W, b, dtype=dtype).view(torch.int16))
+    for o in (128, 96):
+        W = (torch.randn(o, 3, 5, 1, 1, generator=g) * 0.3).to(DEV)
+        b = (torch.randn(o, generator=g) * 0.1).to(DEV)
+        f1, b1 = ops.pack_conv3d_t5(W, b, dtype=dtype)
+        f2, b2 = packing.pack_conv3d_t5(W, b, dtype=dtype)
+        assert torch.equal(f1.view(torch.int16), f2.view(torch.int16)) and torch.equal(b1, b2)
+    c, h, w = 64, 16, 16
+    m = torch.randn(7, c * h * w, generator=g).to(DEV)
+    assert torch.equal(ops.chw_to_blocked(m, c, h, w), packing.chw_to_blocked_columns(m, c, h, w))
+    v = torch.randn(c * h * w, generator=g).to(DEV)
+    assert torch.equal(ops.chw_to_blocked(v, c, h, w), packing.chw_to_blocked_vector(v, c, h, w))
+    lib = _native.load("bf16")
+    assert lib.vpt_workspace_bytes(1, 8, 0, 0, 64, 128) == 4 * lib.vpt_conv3x3_wgrad_scratch_floats(8, 64, 128)
+    assert lib.vpt_workspace_bytes(2, 8, 0, 0, 0, 128) == 4 * 8 * (9 * 128 + 4)
+    assert lib.vpt_workspace_bytes(3, 16, 1024, 256, 0, 0) == 4 * 16 * 1024 * 256 and lib.vpt_workspace_bytes(99, 1, 1, 1, 1, 1) == -1

@@ -123,6 +123,103 @@ __global__ __launch_bounds__(256, MODE == 2 ? 2 : 1) void skeleton(const uint4* 
   out[blockIdx.x * 256 + tid] = s;
 }
 
+
+// ---- where does the direct kernel's main loop lose against its own skeleton?  The same 4 x 2 register tile and 0.75 KB / MFMA,
+// plus, step by step, what the real vpt_conv3x3_kernel does per K step (48 MFMAs per wave = one kernel row of a 32-channel block):
+//   LVL 1: one workgroup barrier per step (in front of the step's last group, as in the kernel)
+//   LVL 2: + the next step's 24 KB weight tile by LDS-DMA (6 x global_load_lds of 1 KB per wave) into the other half of a double
+//          buffer, counted wait in front of the barrier; fragments are read from the half that landed one step earlier
+//   LVL 3: + every third step the 26 KB halo tile: 6 x 16-byte global loads per lane, written with ds_write_b128 behind a
+//          second barrier
+template <int LVL>
+__global__ __launch_bounds__(256, 2) void direct_steps(const uint4* __restrict__ init, const uint4* __restrict__ wsrc, float* out, int steps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [0, 26 KB) halo, [26 KB, 74 KB) two weight buffers
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int i = tid; i < 76 * 1024 / 16; i += 256) ((uint4*)lds)[i] = init[i];
+  __syncthreads();
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  const unsigned char* av = lds + lane * 16 + (w >> 1) * 8192;                  // halo region: 4 fragments x 3 taps
+  const unsigned char* bbase = lds + 26 * 1024 + lane * 16 + (w & 1) * 2048;
+  uint4 hreg[6];
+  for (int st = 0; st < steps; ++st) {
+    const unsigned char* bu = bbase + (st & 1) * 24576;
+    unsigned char* bdst = lds + 26 * 1024 + ((st + 1) & 1) * 24576 + w * 1024;
+    const uint4* wp = wsrc + (size_t)((st * 37 + blockIdx.x) & 63) * 1536 + w * 64 + lane;    // a 24 KB slab of an L2-resident 1.5 MB pack
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+      bf16x8 a[4], b[2];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) a[m] = *(const bf16x8*)(av + ((g >> 1) * 4 + m) * 1024 * 0 + ((g * 4 + m) % 16) * 1024);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) b[n] = *(const bf16x8*)(bu + ((g * 2 + n) % 11) * 4096 % 20480);
+      if (LVL >= 2 && g < 3) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp + (g * 2 + q) * 256),
+                                           (__attribute__((address_space(3))) void*)(bdst + (g * 2 + q) * 4096), 16, 0, 0);
+      }
+      if (LVL >= 3 && (st % 3) == 0 && g >= 3 && g < 5) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) hreg[(g - 3) * 3 + q] = wsrc[98304 + (size_t)(((st + blockIdx.x * 7) & 31) * 1536 + ((g - 3) * 3 + q) * 256 + tid)];
+      }
+      if (LVL >= 1 && g == 5) {
+        if (LVL >= 3 && (st % 3) == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+    if (LVL >= 3 && (st % 3) == 2) {   // the next channel block's halo replaces the current one
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int q = 0; q < 6; ++q) *(uint4*)(lds + ((q * 256 + tid) * 16) % (25 * 1024)) = hreg[q];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[m][n][r];
+  out[blockIdx.x * 256 + tid] = s;
+}
+
+template <int LVL>
+static double run_steps(const uint4* init, const uint4* wsrc, float* out, int steps, int reps) {
+  const int bytes = 76 * 1024, grid = 512;
+  hipFuncSetAttribute((const void*)direct_steps<LVL>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(direct_steps<LVL>, dim3(grid), dim3(256), bytes, 0, init, wsrc, out, steps);
+  hipDeviceSynchronize();
+  double best = 1e30;
+  for (int r = 0; r < reps; ++r) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(direct_steps<LVL>, dim3(grid), dim3(256), bytes, 0, init, wsrc, out, steps);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  const double tf = (double)grid * 4 * steps * 48 * 2.0 * 32 * 32 * 16 / (best * 1e-3) / 1e12;
+  printf("direct main loop, level %d (%s): %.3f ms  %.1f TF/s\n", LVL,
+         LVL == 0 ? "fragments + MFMAs only" : LVL == 1 ? "+ one barrier per 48 MFMAs" : LVL == 2 ? "+ 24 KB weight LDS-DMA per step" : "+ halo loads / ds_write_b128 / second barrier every third step",
+         best, tf);
+  return best;
+}
+
 template <int MODE>
 static double run(const uint4* init, float* out, int grid, int iters, int reps) {
   const int bytes = MODE == 2 ? 64 * 1024 : LDS_BYTES;
@@ -174,6 +271,18 @@ int main(int argc, char** argv) {
     const double ms = run<2>(init, out, grid, iters, reps);
     const double tf = (double)grid * 4 * iters * 32 * flop_per_mfma / (ms * 1e-3) / 1e12;
     printf("direct  (0.75 KB LDS / MFMA, 2 wg/CU, 128 acc regs): %.3f ms  %.1f TF/s issued (= effective)\n", ms, tf);
+  }
+  {   // the direct kernel's K step, feature by feature (random operands unless argv[1] == 1)
+    uint4* wsrc;
+    const size_t wbytes = (size_t)(98304 + 32 * 1536 + 2048) * 16;
+    hipMalloc(&wsrc, wbytes);
+    std::vector<unsigned short> hw(wbytes / 2);
+    for (auto& v : hw) { float f = zero ? 0.f : (float)(rand() % 2001 - 1000) / 4000.f; unsigned u; memcpy(&u, &f, 4); v = (unsigned short)(u >> 16); }
+    hipMemcpy(wsrc, hw.data(), wbytes, hipMemcpyHostToDevice);
+    run_steps<0>(init, wsrc, out, 1200, reps);
+    run_steps<1>(init, wsrc, out, 1200, reps);
+    run_steps<2>(init, wsrc, out, 1200, reps);
+    run_steps<3>(init, wsrc, out, 1200, reps);
   }
   return 0;
 }

@@ -23,6 +23,9 @@ SIGNATURES = {
     "vpt_conv3d_t5_forward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_pack_conv3x3": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
     "vpt_pack_linear": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "vpt_pack_conv_first": [_P, _P, _P, _I, _P],
+    "vpt_pack_conv3d_t5": [_P, _P, _P, _P, _I, _P],
+    "vpt_chw_to_blocked": [_P, _P, ctypes.c_int64, _I, _I, _I, _P],
     "vpt_conv3x3_forward": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_maxpool_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_frame_affine_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -87,7 +90,9 @@ def load(fmt: str = "bf16"):
     lib.vpt_version.restype = ctypes.c_char_p
     lib.vpt_operand_format.restype = ctypes.c_char_p
     lib.vpt_conv3x3_wgrad_scratch_floats.restype = ctypes.c_long
-    for q, at in (("vpt_conv3x3_packed_elems", [_I, _I]), ("vpt_conv3x3_table_floats", [_I]), ("vpt_linear_packed_elems", [_I, _I])):
+    lib.vpt_workspace_bytes.argtypes, lib.vpt_workspace_bytes.restype = [_I] * 6, ctypes.c_int64
+    for q, at in (("vpt_conv3x3_packed_elems", [_I, _I]), ("vpt_conv3x3_table_floats", [_I]), ("vpt_linear_packed_elems", [_I, _I]),
+                  ("vpt_conv_first_packed_elems", [_I]), ("vpt_conv3d_t5_packed_elems", [_I])):
         getattr(lib, q).argtypes, getattr(lib, q).restype = at, ctypes.c_long
     lib.vpt_last_error.restype = ctypes.c_char_p
     if lib.vpt_operand_format().decode() != fmt:

@@ -37,6 +37,34 @@ int vpt_pack_linear(const float* weight, void* wpk, int N, int K, int transposed
   CHECK_LAUNCH(vpt_pack_linear_launch(weight, wpk, N, K, transposed, ldw, src_rows, (hipStream_t)stream), "vpt_pack_linear");
 }
 
+long vpt_conv_first_packed_elems(int Cout) { return (long)((Cout + 127) / 128) * 4 * 2 * 64 * 8; }
+long vpt_conv3d_t5_packed_elems(int O) { return (long)((O + 127) / 128) * 4 * 64 * 8; }
+
+int vpt_pack_conv_first(const float* weight, const float* bias, void* wfrag, int Cout, void* stream) {
+  if (!weight || !bias || !wfrag) return fail(-1, "vpt_pack_conv_first: null pointer");
+  CHECK_LAUNCH(vpt_pack_conv_first_launch(weight, bias, wfrag, Cout, (hipStream_t)stream), "vpt_pack_conv_first");
+}
+
+int vpt_pack_conv3d_t5(const float* weight, const float* bias, void* wfrag, float* bias_padded, int O, void* stream) {
+  if (!weight || !bias || !wfrag || !bias_padded) return fail(-1, "vpt_pack_conv3d_t5: null pointer");
+  CHECK_LAUNCH(vpt_pack_conv3d_t5_launch(weight, bias, wfrag, bias_padded, O, (hipStream_t)stream), "vpt_pack_conv3d_t5");
+}
+
+int vpt_chw_to_blocked(const float* src, float* dst, int64_t rows, int C, int H, int W, void* stream) {
+  if (!src || !dst || src == dst) return fail(-1, "vpt_chw_to_blocked: null or aliased pointers");
+  CHECK_LAUNCH(vpt_chw_to_blocked_launch(src, dst, (long)rows, C, H, W, (hipStream_t)stream), "vpt_chw_to_blocked");
+}
+
+/* Bytes of caller-owned scratch an entry point needs (every buffer is the caller's: the library never allocates). */
+int64_t vpt_workspace_bytes(int op, int frames, int H, int W, int Cin, int Cout) {
+  switch (op) {
+    case VPT_WS_CONV3X3_WGRAD: return 4 * (int64_t)vpt_conv3x3_wgrad_scratch_floats(frames, Cin, Cout);
+    case VPT_WS_CONV_BACKWARD_PREPARE: return 4 * (int64_t)frames * (9LL * Cout + Cout / 32);
+    case VPT_WS_LINEAR_SPLITK: return 4 * (int64_t)frames * H * (int64_t)W;   /* splitk (= frames) x M (= H) x N (= W) fp32 partial slices */
+    default: return -1;
+  }
+}
+
 int vpt_conv_first_forward(const uint8_t* img, const void* wfrag, void* y, double* stats_out,
                            int frames, int H, int W, int Cout, void* stream) {
   VptConvFirstArgs a;

@@ -294,6 +294,9 @@ struct VptAdamArgs {
 };
 
 extern "C" {
+int vpt_pack_conv_first_launch(const float* w, const float* bias, void* out, int Cout, hipStream_t s);
+int vpt_pack_conv3d_t5_launch(const float* w, const float* bias, void* out, float* bias_pad, int O, hipStream_t s);
+int vpt_chw_to_blocked_launch(const float* src, float* dst, long rows, int C, int H, int W, hipStream_t s);
 int vpt_adam_launch(const VptAdamArgs* a, hipStream_t s);
 int vpt_adam_multi_launch(const VptAdamTensor* table_dev, int ntensors, long total_blocks, const VptAdamArgs* h, hipStream_t s);
 int vpt_grads_nonfinite_launch(const VptAdamTensor* table_dev, int ntensors, long total_blocks, int* flag, hipStream_t s);

@@ -7,7 +7,12 @@
 //                            = round(W * gain), 16-byte chunks of each 64-byte row XOR-swizzled by ((cout >> 2) & 3): the LDS
 //                            image vpt_conv3x3_kernel DMAs) + the edge tables SA / SG [9][NT*128] fp32 of its GroupNorm fold.
 //  vpt_pack_linear_kernel  : nn.Linear weight [N][K] -> [ceil(N/128)][K/32][128][32] (16-bit, rows >= N zero).
-// Both reproduce video-pre-training_amd/packing.py bit for bit (tests/test_gpu_kernels.py): sums in fp64, round to nearest even.
+//  vpt_pack_conv_first_kernel : stack-0 firstconv weight [Cout][3][3][3] + bias -> the MFMA A-operand fragments of
+//                            vpt_conv_first_kernel ([NT][4][2][64][8]: W / 255 at k = (kh*3+kw)*3+ch, the bias as hi / lo halves at k = 27 / 28).
+//  vpt_pack_conv3d_t5_kernel : IDM Conv3d weight [O][3][5][1][1] -> fragments [NT][4][64][8] (k = dt*3+ch, k = 15 zero) + padded bias.
+//  vpt_chw_to_blocked_kernel : fp32 [rows][C*H*W] in the reference's C,H,W flatten order (lib/impala_cnn.py:192-193) -> the blocked
+//                            activation order [rows][C/32][H][W][32] (dense-layer weight columns, its LayerNorm gain / bias).
+// All reproduce video-pre-training_amd/packing.py bit for bit (tests/test_gpu_kernels.py): sums in fp64, round to nearest even.
 #include "vpt_common.h"
 #include "vpt_kernels.h"
 
@@ -91,5 +96,77 @@ extern "C" int vpt_pack_linear_launch(const float* w, void* out, int N, int K, i
   size_t blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(vpt_pack_linear_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, (op16_t*)out, N, K, transposed, ldw, src_rows);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// ---- stack-0 first conv: W[o][ch][kh][kw], bias[o] -> frag[nt][cs][ks][hi][l31][8]  (o = nt*128 + cs*32 + l31, k = ks*16 + hi*8 + e)
+__global__ __launch_bounds__(256) void vpt_pack_conv_first_kernel(const float* __restrict__ w, const float* __restrict__ bias, op16_t* __restrict__ out, int Cout, int NT) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= NT * 128 * 32) return;
+  const int e = i & 7, l31 = (i >> 3) & 31, hi = (i >> 8) & 1, ks = (i >> 9) & 1, cs = (i >> 10) & 3, nt = i >> 12;
+  const int o = nt * 128 + cs * 32 + l31, k = ks * 16 + hi * 8 + e;
+  float v = 0.f;
+  if (o < Cout) {
+    if (k < 27) {
+      const int tap = k / 3, ch = k - 3 * tap;              // tap = kh*3 + kw
+      v = w[(size_t)o * 27 + ch * 9 + tap] / 255.0f;         // (the pixel operand is the raw byte 0..255)
+    } else if (k == 27 || k == 28) {
+      const float b = bias[o];
+      const float bh = (float)(op16_t)b;
+      v = (k == 27) ? bh : (b - bh);                         // hi / lo halves: the bias enters the fp32 accumulator to ~16 mantissa bits
+    }
+  }
+  asm volatile("" : "+v"(v));                                // the quotient / difference is an fp32 value of its own before the 16-bit rounding
+  out[i] = (op16_t)v;
+}
+
+extern "C" int vpt_pack_conv_first_launch(const float* w, const float* bias, void* out, int Cout, hipStream_t stream) {
+  if (Cout <= 0 || (Cout & 31)) return -1;
+  const int NT = (Cout + 127) / 128;
+  hipLaunchKernelGGL(vpt_pack_conv_first_kernel, dim3(NT * 16), dim3(256), 0, stream, w, bias, (op16_t*)out, Cout, NT);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// ---- IDM temporal conv: W[o][ch][dt], bias[o] -> frag[nt][cs][hi][l31][8] (k = hi*8 + e = dt*3 + ch; k = 15 zero), bias_pad[NT*128]
+__global__ __launch_bounds__(256) void vpt_pack_conv3d_t5_kernel(const float* __restrict__ w, const float* __restrict__ bias, op16_t* __restrict__ out,
+                                                                float* __restrict__ bias_pad, int O, int NT) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= NT * 128 * 16) return;
+  const int e = i & 7, l31 = (i >> 3) & 31, hi = (i >> 8) & 1, cs = (i >> 9) & 3, nt = i >> 11;
+  const int o = nt * 128 + cs * 32 + l31, k = hi * 8 + e;
+  float v = 0.f;
+  if (o < O && k < 15) {
+    const int dt = k / 3, ch = k - 3 * dt;
+    v = w[(size_t)o * 15 + ch * 5 + dt];
+  }
+  out[i] = (op16_t)v;
+  if (k == 0) bias_pad[o] = (o < O) ? bias[o] : 0.f;
+}
+
+extern "C" int vpt_pack_conv3d_t5_launch(const float* w, const float* bias, void* out, float* bias_pad, int O, hipStream_t stream) {
+  if (O <= 0 || (O & 31)) return -1;
+  const int NT = (O + 127) / 128;
+  hipLaunchKernelGGL(vpt_pack_conv3d_t5_kernel, dim3(NT * 8), dim3(256), 0, stream, w, bias, (op16_t*)out, bias_pad, O, NT);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// ---- C,H,W flatten order -> blocked activation order, per row: dst[r][cb][h][w][j] = src[r][(cb*32 + j)*H*W + h*W + w]
+__global__ __launch_bounds__(256) void vpt_chw_to_blocked_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows, int C, int HW) {
+  const size_t per = (size_t)C * HW, total = (size_t)rows * per;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / per, q = i - r * per;
+    const int j = (int)(q & 31);
+    const size_t p = q >> 5;                 // cb * HW + (h*W + w)
+    const int cb = (int)(p / HW), hw = (int)(p - (size_t)cb * HW);
+    dst[i] = src[r * per + (size_t)(cb * 32 + j) * HW + hw];
+  }
+}
+
+extern "C" int vpt_chw_to_blocked_launch(const float* src, float* dst, long rows, int C, int H, int W, hipStream_t stream) {
+  if (rows <= 0 || C <= 0 || (C & 31) || H <= 0 || W <= 0) return -1;
+  const size_t total = (size_t)rows * C * H * W;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(vpt_chw_to_blocked_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, dst, rows, C, H * W);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

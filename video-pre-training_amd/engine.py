@@ -139,7 +139,7 @@ class PolicyEngine:
         for s, c in enumerate(cfg["chans"]):
             p = f"net.img_process.cnn.stacks.{s}."
             if s == 0:
-                w[p + "firstconv"] = packing.pack_conv_first(f32(sd[p + "firstconv.layer.weight"]), f32(sd[p + "firstconv.layer.bias"]), dtype=self.dtype)
+                w[p + "firstconv"] = ops.pack_conv_first(f32(sd[p + "firstconv.layer.weight"]), f32(sd[p + "firstconv.layer.bias"]), dtype=self.dtype)
             else:
                 w[p + "firstconv"] = ops.pack_conv3x3(f32(sd[p + "firstconv.layer.weight"]), f32(sd[p + "firstconv.norm.weight"]), f32(sd[p + "firstconv.norm.bias"]), dtype=self.dtype)
             w[p + "n.g"], w[p + "n.b"] = f32(sd[p + "n.weight"]), f32(sd[p + "n.bias"])
@@ -150,9 +150,9 @@ class PolicyEngine:
             cin = c
         c2 = cfg["chans"][-1]
         p = "net.img_process.cnn.dense."
-        w[p + "g"] = packing.chw_to_blocked_vector(f32(sd[p + "norm.weight"]), c2, 16, 16)
-        w[p + "b"] = packing.chw_to_blocked_vector(f32(sd[p + "norm.bias"]), c2, 16, 16)
-        w[p + "w"] = ops.pack_linear(packing.chw_to_blocked_columns(f32(sd[p + "layer.weight"]), c2, 16, 16), dtype=self.dtype)
+        w[p + "g"] = ops.chw_to_blocked(f32(sd[p + "norm.weight"]), c2, 16, 16)
+        w[p + "b"] = ops.chw_to_blocked(f32(sd[p + "norm.bias"]), c2, 16, 16)
+        w[p + "w"] = ops.pack_linear(ops.chw_to_blocked(f32(sd[p + "layer.weight"]), c2, 16, 16), dtype=self.dtype)
         p = "net.img_process.linear."
         w[p + "g"], w[p + "b"] = f32(sd[p + "norm.weight"]), f32(sd[p + "norm.bias"])
         w[p + "w"] = ops.pack_linear(f32(sd[p + "layer.weight"]), dtype=self.dtype)
@@ -348,7 +348,7 @@ class IDMEngine(PolicyEngine):
     def pack(self, sd):
         cfg, w = self.cfg, {}
         f32 = lambda t: t.detach().float().contiguous()
-        w["conv3d"] = packing.pack_conv3d_t5(f32(sd["net.conv3d_layer.layer.weight"]), f32(sd["net.conv3d_layer.layer.bias"]), dtype=self.dtype)
+        w["conv3d"] = ops.pack_conv3d_t5(f32(sd["net.conv3d_layer.layer.weight"]), f32(sd["net.conv3d_layer.layer.bias"]), dtype=self.dtype)
         self.c3d_out = sd["net.conv3d_layer.layer.weight"].shape[0]
         for s, c in enumerate(cfg["chans"]):
             p = f"net.img_process.cnn.stacks.{s}."
@@ -360,9 +360,9 @@ class IDMEngine(PolicyEngine):
                     w[q] = ops.pack_conv3x3(f32(sd[q + ".layer.weight"]), f32(sd[q + ".norm.weight"]), f32(sd[q + ".norm.bias"]), dtype=self.dtype)
         c2 = cfg["chans"][-1]
         p = "net.img_process.cnn.dense."
-        w[p + "g"] = packing.chw_to_blocked_vector(f32(sd[p + "norm.weight"]), c2, 16, 16)
-        w[p + "b"] = packing.chw_to_blocked_vector(f32(sd[p + "norm.bias"]), c2, 16, 16)
-        w[p + "w"] = ops.pack_linear(packing.chw_to_blocked_columns(f32(sd[p + "layer.weight"]), c2, 16, 16), dtype=self.dtype)
+        w[p + "g"] = ops.chw_to_blocked(f32(sd[p + "norm.weight"]), c2, 16, 16)
+        w[p + "b"] = ops.chw_to_blocked(f32(sd[p + "norm.bias"]), c2, 16, 16)
+        w[p + "w"] = ops.pack_linear(ops.chw_to_blocked(f32(sd[p + "layer.weight"]), c2, 16, 16), dtype=self.dtype)
         p = "net.img_process.linear."
         w[p + "g"], w[p + "b"] = f32(sd[p + "norm.weight"]), f32(sd[p + "norm.bias"])
         w[p + "w"] = ops.pack_linear(f32(sd[p + "layer.weight"]), dtype=self.dtype)

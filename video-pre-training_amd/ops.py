@@ -120,6 +120,44 @@ def pack_linear(weight, dtype=torch.bfloat16, transposed=False, k_pad=None):
     return out
 
 
+def pack_conv_first(weight, bias, dtype=torch.bfloat16):
+    """Device re-pack of the stack-0 firstconv (vpt_pack_conv_first) -> fragments [NT][4][2][64][8], exactly as packing.pack_conv_first."""
+    _chk(weight, torch.float32, "weight"); _chk(bias, torch.float32, "bias")
+    cout = weight.shape[0]
+    if tuple(weight.shape[1:]) != (3, 3, 3):
+        raise ValueError(f"pack_conv_first: weight must be [Cout, 3, 3, 3], got {tuple(weight.shape)}")
+    dt, fmt = _fmt(dtype=dtype)
+    out = torch.empty((cout + 127) // 128, 4, 2, 64, 8, dtype=dt, device=weight.device)
+    assert out.numel() == _native.load(fmt).vpt_conv_first_packed_elems(cout)
+    _call("vpt_pack_conv_first", None, ptr(weight), ptr(bias), ptr(out), cout, _stream(), fmt=fmt)
+    return out
+
+
+def pack_conv3d_t5(weight, bias, dtype=torch.bfloat16):
+    """Device re-pack of the IDM's temporal conv (vpt_pack_conv3d_t5) -> (fragments [NT][4][64][8], bias fp32 [NT*128])."""
+    _chk(weight, torch.float32, "weight"); _chk(bias, torch.float32, "bias")
+    o = weight.shape[0]
+    if tuple(weight.shape[1:]) != (3, 5, 1, 1):
+        raise ValueError(f"pack_conv3d_t5: weight must be [O, 3, 5, 1, 1], got {tuple(weight.shape)}")
+    dt, fmt = _fmt(dtype=dtype)
+    nt = (o + 127) // 128
+    out = torch.empty(nt, 4, 64, 8, dtype=dt, device=weight.device)
+    bp = torch.empty(nt * 128, dtype=torch.float32, device=weight.device)
+    _call("vpt_pack_conv3d_t5", None, ptr(weight), ptr(bias), ptr(out), ptr(bp), o, _stream(), fmt=fmt)
+    return out, bp
+
+
+def chw_to_blocked(x, c, h, w):
+    """fp32 [rows, c*h*w] (or [c*h*w]) in C,H,W flatten order -> the same shape in blocked activation order (vpt_chw_to_blocked)."""
+    _chk(x, torch.float32, "x")
+    rows = 1 if x.dim() == 1 else x.shape[0]
+    if x.numel() != rows * c * h * w:
+        raise ValueError(f"chw_to_blocked: {tuple(x.shape)} is not [rows, {c}*{h}*{w}]")
+    out = torch.empty_like(x)
+    _call("vpt_chw_to_blocked", None, ptr(x), ptr(out), ctypes.c_int64(rows), c, h, w, _stream())
+    return out
+
+
 def conv_first(img_u8, wfrag, cout, stats_out=None):
     """img_u8 [F,H,W,3] uint8 -> pooled blocked bf16 [F, cout/32, H/2, W/2, 32]."""
     _chk(img_u8, torch.uint8, "img"); _chk(wfrag, OP16, "wfrag"); _chk(stats_out, torch.float64, "stats_out")
