@@ -96,6 +96,14 @@ int vpt_conv3d_t5_forward(const uint8_t* img, const void* wfrag, const float* bi
 int vpt_conv3x3_forward(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg,
                         const double* stats_in, const void* res, void* y, double* stats_out,
                         int frames, int H, int W, int Cin, int Cout, void* stream);
+/* The same call with the workgroup tiling chosen by the caller instead of by the grid size: 1 = the throughput kernel (16x16
+ * pixels x 128 output channels per workgroup: batches of frames, what bench.py measures), 2 = the latency kernel (x 32 output
+ * channels: 4x the workgroups, a quarter of the serial MFMA chain each -- the acting path of agent.py:190-206, where one frame
+ * would otherwise occupy 2-32 of the 256 CUs), 0 = throughput unless that grid has fewer workgroups than the chip has CUs.
+ * Same layouts, same arithmetic, same K order. */
+int vpt_conv3x3_forward_tiled(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg,
+                              const double* stats_in, const void* res, void* y, double* stats_out,
+                              int frames, int H, int W, int Cin, int Cout, int tiling, void* stream);
 
 /* F.max_pool2d(x, 3, 2, 1) on a post-ReLU blocked tensor (lib/impala_cnn.py:117, stacks 1..2).  argmax (optional, for
  * training): uint8, shaped like y, the window position kh*3+kw of the first maximum (15 when the window is all zero). */

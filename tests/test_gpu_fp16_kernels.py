@@ -37,7 +37,8 @@ def test_mixed_formats_rejected():
 
 
 @pytest.mark.parametrize("frames,h,w,cin,cout,use_res", [(2, 16, 16, 128, 128, True), (1, 32, 32, 64, 160, False), (2, 32, 32, 256, 256, True)])
-def test_conv3x3_fp16(frames, h, w, cin, cout, use_res):
+@pytest.mark.parametrize("tiling", ["throughput", "latency"])
+def test_conv3x3_fp16(frames, h, w, cin, cout, use_res, tiling):
     g = torch.Generator().manual_seed(1)
     W = torch.randn(cout, cin, 3, 3, generator=g) * (1.6 / (cin * 9) ** 0.5)
     gain = 1 + 0.2 * torch.randn(cin, generator=g)
@@ -50,7 +51,7 @@ def test_conv3x3_fp16(frames, h, w, cin, cout, use_res):
     wpk, sa, sg = packing.pack_conv3x3(W.to(DEV), gain.to(DEV), bias.to(DEV), dtype=H)
     st_out = torch.zeros(frames, 2, dtype=torch.float64, device=DEV)
     y = ops.conv3x3(packing.nchw_to_blocked(xh.float(), dtype=H).to(DEV), wpk, sa, sg, _stats_of(xh.float()).to(DEV), cout,
-                    res=packing.nchw_to_blocked(res.float(), dtype=H).to(DEV) if use_res else None, stats_out=st_out)
+                    res=packing.nchw_to_blocked(res.float(), dtype=H).to(DEV) if use_res else None, stats_out=st_out, tiling=tiling)
     torch.cuda.synchronize()
     assert y.dtype == H
     err = _relerr(packing.blocked_to_nchw(y.cpu(), cout, h, w), ref)

@@ -39,7 +39,8 @@ def _stats_of(x_nchw):
     (2, 64, 64, 64, 128, False),    # 1x stack-1 firstconv
     (2, 16, 16, 32, 64, True),      # a single 32-channel block: no peeled first block, the last one starts from zeroed accumulators
 ])
-def test_conv3x3(frames, h, w, cin, cout, use_res):
+@pytest.mark.parametrize("tiling", ["throughput", "latency"])   # both workgroup tilings of the same convolution (vpt_conv3x3_forward_tiled)
+def test_conv3x3(frames, h, w, cin, cout, use_res, tiling):
     g = torch.Generator().manual_seed(1)
     W = torch.randn(cout, cin, 3, 3, generator=g) * (1.6 / (cin * 9) ** 0.5)
     gain = 1 + 0.2 * torch.randn(cin, generator=g)
@@ -55,11 +56,16 @@ def test_conv3x3(frames, h, w, cin, cout, use_res):
     st_in = _stats_of(xb.float()).to(DEV)
     st_out = torch.zeros(frames, 2, dtype=torch.float64, device=DEV)
     y = ops.conv3x3(packing.nchw_to_blocked(xb.float()).to(DEV), wpk, sa, sg, st_in, cout,
-                    res=packing.nchw_to_blocked(res.float()).to(DEV) if use_res else None, stats_out=st_out)
+                    res=packing.nchw_to_blocked(res.float()).to(DEV) if use_res else None, stats_out=st_out, tiling=tiling)
     torch.cuda.synchronize()
     out = packing.blocked_to_nchw(y.cpu(), cout, h, w)
     err = _relerr(out, ref)
     assert err < 2e-2, f"conv3x3 rel err {err}"
+    if tiling == "latency":     # same arithmetic and K order as the throughput kernel: equal up to the last 16-bit rounding of a few outputs
+        y2 = ops.conv3x3(packing.nchw_to_blocked(xb.float()).to(DEV), wpk, sa, sg, st_in, cout,
+                         res=packing.nchw_to_blocked(res.float()).to(DEV) if use_res else None, tiling="throughput")
+        torch.cuda.synchronize()
+        assert _relerr(y.float().cpu(), y2.float().cpu()) < 1e-3
     st_ref = _stats_of(ref)
     assert torch.allclose(st_out.cpu(), st_ref, rtol=5e-3, atol=1.0), (st_out.cpu(), st_ref)
 

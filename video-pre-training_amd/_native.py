@@ -27,6 +27,7 @@ SIGNATURES = {
     "vpt_pack_conv3d_t5": [_P, _P, _P, _P, _I, _P],
     "vpt_chw_to_blocked": [_P, _P, ctypes.c_int64, _I, _I, _I, _P],
     "vpt_conv3x3_forward": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vpt_conv3x3_forward_tiled": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vpt_maxpool_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_frame_affine_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_linear_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],

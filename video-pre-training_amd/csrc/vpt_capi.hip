@@ -84,8 +84,16 @@ int vpt_conv3d_t5_forward(const uint8_t* img, const void* wfrag, const float* bi
 int vpt_conv3x3_forward(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg,
                         const double* stats_in, const void* res, void* y, double* stats_out,
                         int frames, int H, int W, int Cin, int Cout, void* stream) {
+  return vpt_conv3x3_forward_tiled(x, wpk, edge_sa, edge_sg, stats_in, res, y, stats_out, frames, H, W, Cin, Cout, 0, stream);
+}
+
+int vpt_conv3x3_forward_tiled(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg,
+                              const double* stats_in, const void* res, void* y, double* stats_out,
+                              int frames, int H, int W, int Cin, int Cout, int tiling, void* stream) {
   if (!stats_in) return fail(-1, "vpt_conv3x3_forward: stats_in is required");
+  if (tiling < 0 || tiling > 2) return fail(-1, "vpt_conv3x3_forward_tiled: tiling must be 0 (auto), 1 (throughput) or 2 (latency)");
   VptConv3x3Args a;
+  a.tiling = tiling;
   a.x = (const vpt_op16*)x; a.wpk = (const vpt_op16*)wpk; a.edge_sa = edge_sa; a.edge_sg = edge_sg;
   a.stats_in = stats_in; a.res = (const vpt_op16*)res; a.y = (vpt_op16*)y; a.stats_out = stats_out;
   a.frames = frames; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
@@ -102,7 +110,7 @@ int vpt_conv3x3_dgrad(const void* dacc, const void* wpk_t, const void* skip, con
   a.stats_in = nullptr; a.res = (const vpt_op16*)skip; a.y = (vpt_op16*)dx; a.stats_out = nullptr;
   a.frames = frames; a.H = H; a.W = W; a.Cin = Cout; a.Cout = Cin;   // roles swap in the transposed convolution
   a.NT = (Cin + 127) / 128; a.CoutPad = a.NT * 128; a.inv_count_in = 1.0;
-  a.bwd = 1; a.xin = (const vpt_op16*)xin; a.coef = coef;
+  a.bwd = 1; a.xin = (const vpt_op16*)xin; a.coef = coef; a.tiling = 1;
   CHECK_LAUNCH(vpt_conv3x3_launch(&a, (hipStream_t)stream), "vpt_conv3x3_dgrad");
 }
 

@@ -37,6 +37,9 @@
 // Profiling switches (VPT_CONV_ABLATE = 1: skip the epilogue, 2: skip the main loop; VPT_CONV_EXTRA_LDS: dynamic LDS to force one
 // workgroup per CU) exist ONLY in builds made with -DVPT_CONV_PROFILE (tools/build_variant.sh): the shipped library reads no
 // environment variable and its kernel carries no ablation branch -- a stray variable cannot change results.
+#ifndef VPT_CONV_SMALL_GRID
+#define VPT_CONV_SMALL_GRID 256   // throughput-kernel grids below this (less than one workgroup per CU) take vpt_conv3x3_small_kernel
+#endif
 #ifdef VPT_CONV_PROFILE
 #define CONV_ABLATE (a.ablate)
 #else
@@ -531,6 +534,161 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Small-batch (acting path, agent.py:190-206: B = 1 .. 8 frames) instantiation: the SAME convolution, layouts and arithmetic, tiled
+// for LATENCY.  One frame of the 2x model gives the throughput kernel above 16 / 8 / 2 workgroups per layer, each walking the whole
+// K = 1152 ... 2304 chain alone (26-28 us per launch on 2-32 of 256 CUs: profiles/r02_t1_step_kernel_stats.csv).  Here a workgroup
+// takes 16 x 16 pixels x 32 output channels (4x the workgroups, a quarter of the serial MFMA chain each: 36 MFMAs per wave and
+// channel block), wave w = pixel rows 4w .. 4w+3 = two 2 x 16-pixel subtiles.  Halo and the 18 KB weight slice of a channel block
+// are double-buffered in LDS (one workgroup per CU is plenty), one barrier per channel block, plain epilogue.  Same K order
+// (channel block, kernel row, kernel column, 16-channel half) as the throughput kernel.
+#define S_W_BYTES (9 * 32 * 64)                       // 18432: 9 taps x 32 couts x 32 cin
+#define S_KK_OFF (2 * A_BYTES + 2 * S_W_BYTES)        // 88704
+#define S_BYTES (S_KK_OFF + 9 * 32 * 4 + 32)
+
+template <bool HAS_RES>
+__global__ __launch_bounds__(256, 1) void vpt_conv3x3_small_kernel(VptConv3x3Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[S_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int tilesX = a.W >> 4, tilesY = a.H >> 4;
+  const int CB_out = a.Cout >> 5;
+  int L = blockIdx.x;
+  const int cbo = L % CB_out; L /= CB_out;
+  const int tx = L % tilesX; L /= tilesX;
+  const int ty = L % tilesY;
+  const int f = L / tilesY;
+  const int nt = cbo >> 2, qo = cbo & 3;
+  const int tx0 = tx * 16, ty0 = ty * 16;
+  const int NCB = a.Cin >> 5;
+  const int HW = a.H * a.W;
+
+  int a_loff[6];
+  unsigned a_gbyte[6];
+  unsigned a_inside = 0;
+#pragma unroll
+  for (int m = 0; m < 6; ++m) {
+    const int q = tid + 256 * m;
+    const int P = ((q >> 5) << 3) + (q & 7), part = (q >> 3) & 3;
+    a_loff[m] = -1;
+    a_gbyte[m] = 0u;
+    if (P < 324) {
+      const int hy = P / 18, hx = P - hy * 18;
+      const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
+      a_loff[m] = P * A_RS + part * 16;
+      if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
+        a_gbyte[m] = (unsigned)((y * a.W + x) * 32 + part * 8) * 2u;
+        a_inside |= 1u << m;
+      }
+    }
+  }
+  const op16_t* xplane = a.x + (size_t)f * NCB * HW * 32;
+  // weight slice of one channel block: 18 pieces of 1 KB (tap, 16-row half); wave w moves pieces w, w + 4, ...
+  const op16_t* wbase = a.wpk + (size_t)nt * NCB * 9 * 4096 + (size_t)(qo * 32) * 32 + (size_t)lane * 8;
+  u32x4 areg[6];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#define S_ISSUE_W(cb_, buf_)                                                                              \
+  _Pragma("unroll") for (int p_ = w; p_ < 18; p_ += 4)                                                    \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase + ((size_t)(cb_) * 9 + (p_ >> 1)) * 4096 + (p_ & 1) * 512), \
+                                     (__attribute__((address_space(3))) void*)(smem + 2 * A_BYTES + (buf_) * S_W_BYTES + (p_ >> 1) * 2048 + (p_ & 1) * 1024), 16, 0, 0)
+#define S_LOAD_A(cb_)                                                                                     \
+  _Pragma("unroll") for (int m_ = 0; m_ < 6; ++m_) areg[m_] = *(const u32x4*)((const char*)xplane + ((size_t)(cb_) * HW * 64 + a_gbyte[m_]))
+#define S_WRITE_A(buf_)                                                                                   \
+  _Pragma("unroll") for (int m_ = 0; m_ < 6; ++m_)                                                        \
+    if (a_loff[m_] >= 0) *(u32x4*)(smem + (buf_) * A_BYTES + a_loff[m_]) = ((a_inside >> m_) & 1u) ? areg[m_] : zero4
+
+  S_ISSUE_W(0, 0);
+  S_LOAD_A(0);
+  float mean, rstd;
+  frame_mean_rstd(a.stats_in, f, a.inv_count_in, mean, rstd);
+  {
+    float* kk = (float*)(smem + S_KK_OFF);
+    for (int idx = tid; idx < 9 * 32; idx += 256) {
+      const int o = (idx >> 5) * a.CoutPad + cbo * 32 + (idx & 31);
+      kk[idx] = a.edge_sa[o] - rstd * mean * a.edge_sg[o];
+    }
+  }
+  S_WRITE_A(0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+  const int bsw = (l31 >> 2) & 3;
+  for (int cb = 0; cb < NCB; ++cb) {
+    const int cur = cb & 1;
+    if (cb + 1 < NCB) { S_ISSUE_W(cb + 1, 1 - cur); S_LOAD_A(cb + 1); }
+    const unsigned char* aL = smem + cur * A_BYTES + ((w * 4 + sub_row(l31)) * 18 + (l31 & 15)) * A_RS + hi * 16;
+    const unsigned char* bL = smem + 2 * A_BYTES + cur * S_W_BYTES + l31 * 64;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const op16x8 fb = *(const op16x8*)(bL + (dy * 3 + dx) * 2048 + (((2 * ks + hi) ^ bsw) << 4));
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const op16x8 fa = *(const op16x8*)(aL + (dy * 18 + dx) * A_RS + m * (2 * 18 * A_RS) + ks * 32);
+            acc[m] = VPT_MFMA_32X32X16(fb, fa, acc[m], 0, 0, 0);
+          }
+        }
+    if (cb + 1 < NCB) {
+      S_WRITE_A(1 - cur);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+  }
+#undef S_ISSUE_W
+#undef S_LOAD_A
+#undef S_WRITE_A
+
+  // ---- epilogue: GroupNorm fold + ReLU (+ residual), 8-byte pieces (4 consecutive output channels of one pixel), statistics ----
+  const float* kk = (const float*)(smem + S_KK_OFF);
+  float s_sum = 0.f, s_sq = 0.f;
+  const size_t obase = (size_t)(f * CB_out + cbo) * HW * 32;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int y = ty0 + w * 4 + 2 * m + sub_row(l31);
+    const int x = tx0 + (l31 & 15);
+    const int ey = (y == 0) ? 0 : ((y == a.H - 1) ? 2 : 1);
+    const int ex = (x == 0) ? 0 : ((x == a.W - 1) ? 2 : 1);
+    const float* ke = kk + (ey * 3 + ex) * 32 + 4 * hi;
+    const size_t poff = obase + (size_t)(y * a.W + x) * 32 + 4 * hi;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 k4 = *(const f32x4*)(ke + 8 * g);
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(rstd, acc[m][4 * g + j], k4[j]), 0.f);
+      if (HAS_RES) {
+        const u32x2 r2 = *(const u32x2*)(a.res + poff + 8 * g);
+        v[0] += op16_lo_to_f32(r2.x); v[1] += op16_hi_to_f32(r2.x);
+        v[2] += op16_lo_to_f32(r2.y); v[3] += op16_hi_to_f32(r2.y);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s_sum += v[j]; s_sq = fmaf(v[j], v[j], s_sq); }
+      const u32x2 pk = {pack_op16x2(v[0], v[1]), pack_op16x2(v[2], v[3])};
+      *(u32x2*)(a.y + poff + 8 * g) = pk;
+    }
+  }
+  if (a.stats_out) {
+    float* red = (float*)(smem + S_KK_OFF + 9 * 32 * 4);
+    s_sum = wave_sum(s_sum);
+    s_sq = wave_sum(s_sq);
+    if (lane == 0) { red[w] = s_sum; red[4 + w] = s_sq; }
+    __syncthreads();
+    if (tid == 0) {
+      atomicAdd(a.stats_out + 2 * f, (double)((red[0] + red[1]) + (red[2] + red[3])));
+      atomicAdd(a.stats_out + 2 * f + 1, (double)((red[4] + red[5]) + (red[6] + red[7])));
+    }
+  }
+}
+
 static long long* g_conv_trace = nullptr;
 extern "C" void vpt_conv3x3_set_trace(void* buf) { g_conv_trace = (long long*)buf; }  // profiling: [grid][12] int64, or null
 
@@ -559,6 +717,13 @@ extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream
   if (grid > 0x7fffffffL) return -2;
   const int mode = a->bwd ? (a->res ? 3 : 2) : (a->res ? 1 : 0);
   if (a->bwd && (!a->xin || !a->coef)) return -1;   // dgrad always carries the GroupNorm-statistics terms (c0 + c1 * xin)
+  // fewer workgroups than CUs (a handful of frames: the acting path): the latency tiling, 32 output channels per workgroup
+  if (!a->bwd && !a->trace && (a->tiling == 2 || (a->tiling == 0 && grid < VPT_CONV_SMALL_GRID))) {
+    const long sgrid = (long)a->frames * (a->H >> 4) * (a->W >> 4) * (a->Cout >> 5);
+    if (a->res) hipLaunchKernelGGL((vpt_conv3x3_small_kernel<true>), dim3((unsigned)sgrid), dim3(256), 0, stream, *a);
+    else hipLaunchKernelGGL((vpt_conv3x3_small_kernel<false>), dim3((unsigned)sgrid), dim3(256), 0, stream, *a);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+  }
 #define LAUNCH_(T_, M_) hipLaunchKernelGGL((vpt_conv3x3_kernel<T_, M_>), dim3((unsigned)grid), dim3(256), extra_lds, stream, *a)
   if (a->trace) { if (mode == 0) LAUNCH_(true, 0); else if (mode == 1) LAUNCH_(true, 1); else if (mode == 2) LAUNCH_(true, 2); else LAUNCH_(true, 3); }
   else { if (mode == 0) LAUNCH_(false, 0); else if (mode == 1) LAUNCH_(false, 1); else if (mode == 2) LAUNCH_(false, 2); else LAUNCH_(false, 3); }

@@ -21,6 +21,7 @@ struct VptConv3x3Args {
   double* stats_out;       // optional [F][2], accumulated (caller zeroes)
   int frames, H, W, Cin, Cout, CoutPad, NT;
   double inv_count_in;     // 1 / (Cin*H*W)
+  int tiling;              // forward only: 0 = by grid size, 1 = throughput kernel (16x16 px x 128 couts), 2 = latency kernel (x 32 couts)
   int ablate;              // profiling only (env VPT_CONV_ABLATE)
   long long* trace;        // profiling only: per-workgroup phase timestamps (vpt_conv3x3_set_trace)
   // dgrad mode (bwd != 0): no GroupNorm fold, no ReLU; out = conv + res + coef[f][0] + coef[f][1] * xin

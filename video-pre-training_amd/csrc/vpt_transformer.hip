@@ -375,42 +375,66 @@ extern "C" int vpt_kv_update_launch(const VptKvUpdateArgs* a, hipStream_t stream
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void vpt_logsoftmax_kernel(VptLogSoftmaxArgs a) {
-  __shared__ float red[12];
-  __shared__ int redi[4];
+// NW waves per row.  The scaled logits of a thread (the first LSM_CAP it owns) stay in registers for the three passes -- one
+// load and ONE division by the temperature per element (the reference divides: z / T, not z * (1 / T)).  Rows are independent:
+// a batch of rows (M >= 64: training / chunked inference) takes 4 waves per row, the acting path's one or two rows of 8641
+// classes take 16 (34 elements and three dependent passes per thread were 17-31 us per launch of a 1 ms step).
+#define LSM_CAP 9
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void vpt_logsoftmax_kernel(VptLogSoftmaxArgs a) {
+  constexpr int NT = 64 * NW;
+  __shared__ float red[3 * NW];
+  __shared__ int redi[NW];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const float* z = a.logits + (size_t)row * a.ld + a.col0;
   const uint8_t* mk = a.mask ? a.mask + (size_t)row * a.n : nullptr;
   const float T = a.temperature;
 #define SCALED(i_) ((mk && !mk[i_]) ? -100.0f : z[i_] / T)   /* shaped_out /= T; shaped_out[~mask] = LOG0 */
+  float c[LSM_CAP];
   float m = -3.0e38f;
-  for (int i = tid; i < a.n; i += 256) m = fmaxf(m, SCALED(i));
+#pragma unroll
+  for (int k = 0; k < LSM_CAP; ++k) {
+    const int i = tid + NT * k;
+    c[k] = (i < a.n) ? SCALED(i) : -3.0e38f;
+    m = fmaxf(m, c[k]);
+  }
+  for (int i = tid + NT * LSM_CAP; i < a.n; i += NT) m = fmaxf(m, SCALED(i));
   m = wave_max(m);
   if (lane == 0) red[w] = m;
   __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  m = red[0];
+#pragma unroll
+  for (int k = 1; k < NW; ++k) m = fmaxf(m, red[k]);
   float s = 0.f;
-  for (int i = tid; i < a.n; i += 256) s += expf(SCALED(i) - m);
+#pragma unroll
+  for (int k = 0; k < LSM_CAP; ++k) s += (tid + NT * k < a.n) ? expf(c[k] - m) : 0.f;
+  for (int i = tid + NT * LSM_CAP; i < a.n; i += NT) s += expf(SCALED(i) - m);
   s = wave_sum(s);
-  if (lane == 0) red[4 + w] = s;
+  if (lane == 0) red[NW + w] = s;
   __syncthreads();
-  const float lse = m + logf((red[4] + red[5]) + (red[6] + red[7]));
+  float tot = 0.f;
+#pragma unroll
+  for (int k = 0; k < NW; ++k) tot += red[NW + k];
+  const float lse = m + logf(tot);
   float* o = a.out + (size_t)row * a.n;
   // CategoricalActionHead.sample (lib/action_head.py:195-207) on the way out: argmax of the log-probs, or of
   // log-probs - log(-log u) (Gumbel-max; u == 1 -> 0.999 as the reference guards); FIRST maximum, as torch.argmax.
   const float* u = a.noise ? a.noise + (size_t)row * a.n : nullptr;
   float best = -3.0e38f;
   int besti = 0x7fffffff;
-  for (int i = tid; i < a.n; i += 256) {
-    const float lp = SCALED(i) - lse;
+  auto emit = [&](int i, float sc_) __attribute__((always_inline)) {
+    const float lp = sc_ - lse;
     o[i] = lp;
     if (a.action) {
       float sc = lp;
       if (u) { float ui = u[i]; if (ui == 1.0f) ui = 0.999f; sc = lp - logf(-logf(ui)); }
       if (sc > best) { best = sc; besti = i; }     // ascending i per thread: keeps the first maximum
     }
-  }
-#undef SCALED
+  };
+#pragma unroll
+  for (int k = 0; k < LSM_CAP; ++k)
+    if (tid + NT * k < a.n) emit(tid + NT * k, c[k]);
+  for (int i = tid + NT * LSM_CAP; i < a.n; i += NT) emit(i, SCALED(i));
   if (a.action) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -418,19 +442,21 @@ __global__ __launch_bounds__(256) void vpt_logsoftmax_kernel(VptLogSoftmaxArgs a
       const int oi = __shfl_xor(besti, off, 64);
       if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
     }
-    if (lane == 0) { red[8 + w] = best; redi[w] = besti; }
+    if (lane == 0) { red[2 * NW + w] = best; redi[w] = besti; }
     __syncthreads();
     if (tid == 0) {
-      for (int k = 1; k < 4; ++k)
-        if (red[8 + k] > best || (red[8 + k] == best && redi[k] < besti)) { best = red[8 + k]; besti = redi[k]; }
+      for (int k = 1; k < NW; ++k)
+        if (red[2 * NW + k] > best || (red[2 * NW + k] == best && redi[k] < besti)) { best = red[2 * NW + k]; besti = redi[k]; }
       a.action[row] = besti;
       if (a.action_logp) a.action_logp[row] = ((mk && !mk[besti]) ? -100.0f : z[besti] / T) - lse;
     }
   }
+#undef SCALED
 }
 
 extern "C" int vpt_logsoftmax_launch(const VptLogSoftmaxArgs* a, hipStream_t stream) {
   if (a->M <= 0 || a->n <= 0) return -1;
-  hipLaunchKernelGGL(vpt_logsoftmax_kernel, dim3(a->M), dim3(256), 0, stream, *a);
+  if (a->M < 64 && a->n > 1024) hipLaunchKernelGGL((vpt_logsoftmax_kernel<16>), dim3(a->M), dim3(1024), 0, stream, *a);
+  else hipLaunchKernelGGL((vpt_logsoftmax_kernel<4>), dim3(a->M), dim3(256), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

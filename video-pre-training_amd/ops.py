@@ -168,8 +168,12 @@ def conv_first(img_u8, wfrag, cout, stats_out=None):
     return y
 
 
-def conv3x3(x, wpk, edge_sa, edge_sg, stats_in, cout, res=None, stats_out=None, out=None):
-    """x blocked bf16 [F,Cin/32,H,W,32] -> blocked bf16 [F,cout/32,H,W,32] (GN fold + ReLU [+res])."""
+CONV_TILING = {"auto": 0, "throughput": 1, "latency": 2}
+
+
+def conv3x3(x, wpk, edge_sa, edge_sg, stats_in, cout, res=None, stats_out=None, out=None, tiling="auto"):
+    """x blocked bf16 [F,Cin/32,H,W,32] -> blocked bf16 [F,cout/32,H,W,32] (GN fold + ReLU [+res]).
+    tiling: "auto" (by grid size), "throughput" or "latency" (vpt_conv3x3_forward_tiled)."""
     _chk(x, OP16, "x"); _chk(wpk, OP16, "wpk"); _chk(edge_sa, torch.float32, "edge_sa")
     _chk(edge_sg, torch.float32, "edge_sg"); _chk(stats_in, torch.float64, "stats_in")
     _chk(res, OP16, "res"); _chk(stats_out, torch.float64, "stats_out")
@@ -177,8 +181,13 @@ def conv3x3(x, wpk, edge_sa, edge_sg, stats_in, cout, res=None, stats_out=None, 
     dt, fmt = _fmt(x, wpk, res, out)
     if out is None:
         out = torch.empty(f, cout // 32, h, w, 32, dtype=dt, device=x.device)
-    _call("vpt_conv3x3_forward", dict(flops=2.0 * f * h * w * cout * 9 * cb * 32, bytes=2.0 * f * h * w * (cb * 32 + cout * (2 if res is not None else 1))), ptr(x), ptr(wpk), ptr(edge_sa), ptr(edge_sg), ptr(stats_in), ptr(res),
-                 ptr(out), ptr(stats_out), f, h, w, cb * 32, cout, _stream(), fmt=fmt)
+    meta = dict(flops=2.0 * f * h * w * cout * 9 * cb * 32, bytes=2.0 * f * h * w * (cb * 32 + cout * (2 if res is not None else 1)))
+    if tiling == "auto":
+        _call("vpt_conv3x3_forward", meta, ptr(x), ptr(wpk), ptr(edge_sa), ptr(edge_sg), ptr(stats_in), ptr(res),
+              ptr(out), ptr(stats_out), f, h, w, cb * 32, cout, _stream(), fmt=fmt)
+    else:
+        _call("vpt_conv3x3_forward_tiled", meta, ptr(x), ptr(wpk), ptr(edge_sa), ptr(edge_sg), ptr(stats_in), ptr(res),
+              ptr(out), ptr(stats_out), f, h, w, cb * 32, cout, CONV_TILING[tiling], _stream(), fmt=fmt)
     return out
 
 
