@@ -427,7 +427,9 @@ def test_device_pack_first_convs_and_permutes_bit_exact(dtype):
     for cout in (128, 64, 192):
         W = (torch.randn(cout, 3, 3, 3, generator=g) * 0.3).to(DEV)
         b = (torch.randn(cout, generator=g) * 0.1).to(DEV)
-        assert torch.equal(ops.pack_conv_first(W, b, dtype=dtype).view(torch.int16), packing.pack_conv_first(W, b, dtype=dtype).view(torch.int16))
+        got, want = ops.pack_conv_first(W, b, dtype=dtype), packing.pack_conv_first(W, b, dtype=dtype)
+        bad = (got.view(torch.int16) != want.view(torch.int16)).nonzero()
+        assert bad.numel() == 0, (cout, bad[:6].tolist(), got.view(-1)[:0].dtype, [(float(got[tuple(i)]), float(want[tuple(i)])) for i in bad[:6].tolist()])
     for o in (128, 96):
         W = (torch.randn(o, 3, 5, 1, 1, generator=g) * 0.3).to(DEV)
         b = (torch.randn(o, generator=g) * 0.1).to(DEV)

@@ -199,6 +199,16 @@ def test_step_graph_matches_eager(pol_1x):
     try:
         graphed, st_g = rollout()
         graphed2, _ = rollout()                 # second episode: initial_state copied over the aliased buffers
+        # the graph against the ORACLE (not only against our own eager launches): the same 7 steps, T = 1 each, state carried,
+        # `first` raised at step 3 -- log-probs within the mode's bounds, value de-normalised as lib/normalize_ewma.py does
+        so = O.initial_state(cfg, 1)
+        for i, g_ in enumerate(graphed):
+            ref = O.policy_forward(sd, cfg, frames[i].cpu()[None], torch.tensor([[firsts[i]]]), so)
+            so = ref["state_out"]
+            m = P.policy_metrics(dict(buttons=g_[2][None], camera=g_[3][None]), dict(buttons=ref["buttons"], camera=ref["camera"]))
+            P.check(m, pol.precision, f"graphed step {i} vs oracle")
+            v_ref = float(O.denormalize_value(sd, "value_head.", ref["vpred"]).reshape(-1)[0])
+            assert abs(g_[4] - v_ref) < P.BOUNDS[pol.precision]["v_rel"] * max(1.0, abs(v_ref)) * 1.3, (i, g_[4], v_ref)
         for e, g_, g2 in zip(eager, graphed, graphed2):
             assert e[0] == g_[0] == g2[0] and e[1] == g_[1] == g2[1]
             assert torch.allclose(e[2], g_[2], atol=2e-4) and torch.allclose(e[3], g_[3], atol=2e-4) and abs(e[4] - g_[4]) < 1e-3

@@ -543,7 +543,8 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
 // are double-buffered in LDS (one workgroup per CU is plenty), one barrier per channel block, plain epilogue.  Same K order
 // (channel block, kernel row, kernel column, 16-channel half) as the throughput kernel.
 #define S_W_BYTES (9 * 32 * 64)                       // 18432: 9 taps x 32 couts x 32 cin
-#define S_KK_OFF (2 * A_BYTES + 2 * S_W_BYTES)        // 88704
+#define S_NBUF 3                                      // stages in LDS: the loads of channel block cb + 2 are in flight while cb computes
+#define S_KK_OFF (S_NBUF * (A_BYTES + S_W_BYTES))     // 133056
 #define S_BYTES (S_KK_OFF + 9 * 32 * 4 + 32)
 
 template <bool HAS_RES>
@@ -584,22 +585,35 @@ __global__ __launch_bounds__(256, 1) void vpt_conv3x3_small_kernel(VptConv3x3Arg
     }
   }
   const op16_t* xplane = a.x + (size_t)f * NCB * HW * 32;
-  // weight slice of one channel block: 18 pieces of 1 KB (tap, 16-row half); wave w moves pieces w, w + 4, ...
+  // weight slice of one channel block: 18 pieces of 1 KB (tap, 16-row half); wave w moves pieces w, w + 4, ... (5 for waves 0 / 1,
+  // 4 for waves 2 / 3).  A stage = those pieces by LDS-DMA + the halo's six 16-byte loads per lane into one of two register sets.
   const op16_t* wbase = a.wpk + (size_t)nt * NCB * 9 * 4096 + (size_t)(qo * 32) * 32 + (size_t)lane * 8;
-  u32x4 areg[6];
+  u32x4 areg[2][6];
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
-#define S_ISSUE_W(cb_, buf_)                                                                              \
-  _Pragma("unroll") for (int p_ = w; p_ < 18; p_ += 4)                                                    \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase + ((size_t)(cb_) * 9 + (p_ >> 1)) * 4096 + (p_ & 1) * 512), \
-                                     (__attribute__((address_space(3))) void*)(smem + 2 * A_BYTES + (buf_) * S_W_BYTES + (p_ >> 1) * 2048 + (p_ & 1) * 1024), 16, 0, 0)
-#define S_LOAD_A(cb_)                                                                                     \
-  _Pragma("unroll") for (int m_ = 0; m_ < 6; ++m_) areg[m_] = *(const u32x4*)((const char*)xplane + ((size_t)(cb_) * HW * 64 + a_gbyte[m_]))
-#define S_WRITE_A(buf_)                                                                                   \
+  unsigned char* const wlds = smem + S_NBUF * A_BYTES;
+#define S_ISSUE(cb_, SET_)                                                                                \
+  do {                                                                                                    \
+    unsigned char* wd_ = wlds + ((cb_) % S_NBUF) * S_W_BYTES;                                             \
+    _Pragma("unroll") for (int p_ = w; p_ < 18; p_ += 4)                                                  \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase + ((size_t)(cb_) * 9 + (p_ >> 1)) * 4096 + (p_ & 1) * 512), \
+                                       (__attribute__((address_space(3))) void*)(wd_ + (p_ >> 1) * 2048 + (p_ & 1) * 1024), 16, 0, 0); \
+    _Pragma("unroll") for (int m_ = 0; m_ < 6; ++m_)                                                      \
+      areg[SET_][m_] = *(const u32x4*)((const char*)xplane + ((size_t)(cb_) * HW * 64 + a_gbyte[m_]));    \
+  } while (0)
+#define S_WRITE_A(cb_, SET_)                                                                              \
   _Pragma("unroll") for (int m_ = 0; m_ < 6; ++m_)                                                        \
-    if (a_loff[m_] >= 0) *(u32x4*)(smem + (buf_) * A_BYTES + a_loff[m_]) = ((a_inside >> m_) & 1u) ? areg[m_] : zero4
+    if (a_loff[m_] >= 0) *(u32x4*)(smem + ((cb_) % S_NBUF) * A_BYTES + a_loff[m_]) = ((a_inside >> m_) & 1u) ? areg[SET_][m_] : zero4
+  // counted wait: everything up to and including stage `older` has landed, the stage issued after it (if any) stays in flight.
+  // Loads retire in issue order; a stage is 11 vector-memory instructions for waves 0 / 1 and 10 for waves 2 / 3.
+#define S_WAIT_OLDER(YOUNGER_ISSUED)                                                                      \
+  do {                                                                                                    \
+    if (!(YOUNGER_ISSUED)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               \
+    else if (w < 2) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");                                     \
+    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                                \
+  } while (0)
 
-  S_ISSUE_W(0, 0);
-  S_LOAD_A(0);
+  S_ISSUE(0, 0);
+  if (NCB > 1) S_ISSUE(1, 1);
   float mean, rstd;
   frame_mean_rstd(a.stats_in, f, a.inv_count_in, mean, rstd);
   {
@@ -609,8 +623,9 @@ __global__ __launch_bounds__(256, 1) void vpt_conv3x3_small_kernel(VptConv3x3Arg
       kk[idx] = a.edge_sa[o] - rstd * mean * a.edge_sg[o];
     }
   }
-  S_WRITE_A(0);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the statistics / table loads above were issued after the stages: drain once)
+  S_WRITE_A(0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
 
   f32x16 acc[2];
@@ -619,33 +634,40 @@ __global__ __launch_bounds__(256, 1) void vpt_conv3x3_small_kernel(VptConv3x3Arg
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
   const int bsw = (l31 >> 2) & 3;
-  for (int cb = 0; cb < NCB; ++cb) {
-    const int cur = cb & 1;
-    if (cb + 1 < NCB) { S_ISSUE_W(cb + 1, 1 - cur); S_LOAD_A(cb + 1); }
-    const unsigned char* aL = smem + cur * A_BYTES + ((w * 4 + sub_row(l31)) * 18 + (l31 & 15)) * A_RS + hi * 16;
-    const unsigned char* bL = smem + 2 * A_BYTES + cur * S_W_BYTES + l31 * 64;
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const op16x8 fb = *(const op16x8*)(bL + (dy * 3 + dx) * 2048 + (((2 * ks + hi) ^ bsw) << 4));
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            const op16x8 fa = *(const op16x8*)(aL + (dy * 18 + dx) * A_RS + m * (2 * 18 * A_RS) + ks * 32);
-            acc[m] = VPT_MFMA_32X32X16(fb, fa, acc[m], 0, 0, 0);
-          }
-        }
-    if (cb + 1 < NCB) {
-      S_WRITE_A(1 - cur);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
+  // iteration cb: issue stage cb + 2 (its halo into the register set stage cb used), compute stage cb, then move the halo of stage
+  // cb + 1 -- issued one iteration EARLIER, so it has had two compute phases to land; the counted wait leaves stage cb + 2 in flight
+  // -- from its registers into LDS for the next iteration.  One barrier per channel block.
+#define S_ITER(cb_, SET_)                                                                                 \
+  do {                                                                                                    \
+    const bool more_ = (cb_) + 2 < NCB;                                                                   \
+    if (more_) S_ISSUE((cb_) + 2, SET_);                                                                  \
+    const unsigned char* aL = smem + ((cb_) % S_NBUF) * A_BYTES + ((w * 4 + sub_row(l31)) * 18 + (l31 & 15)) * A_RS + hi * 16; \
+    const unsigned char* bL = wlds + ((cb_) % S_NBUF) * S_W_BYTES + l31 * 64;                             \
+    _Pragma("unroll") for (int dy = 0; dy < 3; ++dy)                                                      \
+      _Pragma("unroll") for (int dx = 0; dx < 3; ++dx)                                                    \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                \
+          const op16x8 fb = *(const op16x8*)(bL + (dy * 3 + dx) * 2048 + (((2 * ks + hi) ^ bsw) << 4));   \
+          _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                                 \
+            const op16x8 fa = *(const op16x8*)(aL + (dy * 18 + dx) * A_RS + m * (2 * 18 * A_RS) + ks * 32); \
+            acc[m] = VPT_MFMA_32X32X16(fb, fa, acc[m], 0, 0, 0);                                          \
+          }                                                                                               \
+        }                                                                                                 \
+    if ((cb_) + 1 < NCB) {                                                                                \
+      S_WAIT_OLDER(more_);                                                                                \
+      S_WRITE_A((cb_) + 1, 1 - (SET_));                                                                   \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
+    }                                                                                                     \
+    __builtin_amdgcn_s_barrier();                                                                         \
+    asm volatile("" ::: "memory");                                                                        \
+  } while (0)
+  for (int cb = 0; cb < NCB; cb += 2) {
+    S_ITER(cb, 0);
+    if (cb + 1 < NCB) S_ITER(cb + 1, 1);
   }
-#undef S_ISSUE_W
-#undef S_LOAD_A
+#undef S_ITER
+#undef S_ISSUE
 #undef S_WRITE_A
+#undef S_WAIT_OLDER
 
   // ---- epilogue: GroupNorm fold + ReLU (+ residual), 8-byte pieces (4 consecutive output channels of one pixel), statistics ----
   const float* kk = (const float*)(smem + S_KK_OFF);

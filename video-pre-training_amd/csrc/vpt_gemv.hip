@@ -8,13 +8,13 @@
 // ROWS rows x 32 k one contiguous ROWS * 64-byte run; lane = (k block within the instruction, row, 8-k chunk), so one
 // 16-byte load per lane covers 64 / (4 ROWS) consecutive k blocks; the 4 waves interleave over the k blocks; fp32 accumulate;
 // reduce over the chunk / k-block lanes by shuffles and over the waves through LDS.  grid = ceil(N / ROWS) x splitk.
-// ROWS = 16 when that already gives >= 512 workgroups, else 4: at N = 2048 sixteen rows per workgroup put 128 workgroups on
-// 256 CUs with 2 MB of loads in flight chip-wide -- 1 TB/s, 24 us per trunk layer of the T = 1 step; with four rows every byte
-// of the matrix is requested up front by 512+ workgroups.
+// ROWS (16 / 4 / 2) is chosen so that every CU holds several workgroups (vpt_gemv_launch): at N = 2048 sixteen rows per workgroup
+// put 128 workgroups on 256 CUs with 2 MB of loads in flight chip-wide -- 1 TB/s, 24 us per trunk layer of the T = 1 step.
 #include "vpt_common.h"
 #include "vpt_kernels.h"
 
 #define GEMV_LN_MAXK 3072   // hidsize of the largest policy (3x); 8 rows x 3072 x 2 B = 48 KB of LDS
+#define GEMV_PRE 8          // 16-byte weight loads in flight per lane
 
 // Fused LayerNorm prologue (LN = true): the acting step's LayerNorms all feed a linear layer, and at M = 1 a LayerNorm launch
 // is a 10 us link in a serial chain of 60 kernels for 8 KB of data.  Every workgroup normalises the M rows itself -- wave w takes
@@ -40,35 +40,50 @@ __global__ __launch_bounds__(256) void vpt_gemv_kernel(VptGemmArgs a) {
 #pragma unroll
   for (int m = 0; m < MR; ++m) acc[m] = 0.f;
   const int kbf = kb0 + w * KPI + ksub;        // this lane's first k block
-  u32x4 wpre[4];
-  if (LN) {
-    // the first four weight loads of the lane go out BEFORE the normalisation (they do not depend on it)
+  // The weight matrix is read exactly once, by one CU: nontemporal loads (MI355X_MICROARCH.md "nt-weights": issued -> landed -18 %),
+  // GEMV_PRE of them (128 bytes per lane, 32 KB per workgroup) in flight before anything else happens -- at M = 1 the layer is HBM
+  // latency x bytes in flight, nothing else (round 2 kept 4: 1.4-1.9 TB/s on the 26-34 MB layers of the 2x trunk).
+  u32x4 wpre[GEMV_PRE];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int kb = min(kbf + j * 4 * KPI, kbs - 1);
-      wpre[j] = *(const u32x4*)(wp + (size_t)kb * 4096);
-    }
+  for (int j = 0; j < GEMV_PRE; ++j) {
+    const int kb = kbf + j * 4 * KPI;
+    wpre[j] = (u32x4){0u, 0u, 0u, 0u};
+    if (kb < kb1) wpre[j] = __builtin_nontemporal_load((const u32x4*)(wp + (size_t)kb * 4096));
+  }
+  if (LN) {
+    // (the loads above do not depend on the normalisation: they are in flight while it runs).  The row is read ONCE into
+    // registers (K <= 3072: 12 float4 per lane) and the three passes of vpt_layernorm_kernel run on them -- same lane -> element
+    // map, same operation order, so the result stays bit-identical to the two-kernel path, at one memory round trip instead of three.
     const int n4 = a.K >> 2;
     for (int m = w; m < a.M; m += 4) {
       const float* x = a.ln_x + (size_t)m * a.K;
-      float s = 0.f;
-      for (int i = lane; i < n4; i += 64) {
-        f32x4 v = *(const f32x4*)(x + 4 * i);
+      f32x4 xv[GEMV_LN_MAXK / 256];
+#pragma unroll
+      for (int q = 0; q < GEMV_LN_MAXK / 256; ++q) {
+        const int i = lane + 64 * q;
+        f32x4 v = (i < n4) ? *(const f32x4*)(x + 4 * i) : (f32x4){0.f, 0.f, 0.f, 0.f};
         if (a.ln_relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        s += (v.x + v.y) + (v.z + v.w);
+        xv[q] = v;
       }
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < GEMV_LN_MAXK / 256; ++q)
+        if (lane + 64 * q < n4) s += (xv[q].x + xv[q].y) + (xv[q].z + xv[q].w);
       const float mean = wave_sum(s) / (float)a.K;
       float ss = 0.f;
-      for (int i = lane; i < n4; i += 64) {
-        f32x4 v = *(const f32x4*)(x + 4 * i);
-        if (a.ln_relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-        ss += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-      }
+#pragma unroll
+      for (int q = 0; q < GEMV_LN_MAXK / 256; ++q)
+        if (lane + 64 * q < n4) {
+          const f32x4 v = xv[q];
+          const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+          ss += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
       const float rstd = rsqrtf(wave_sum(ss) / (float)a.K + VPT_NORM_EPS);
-      for (int i = lane; i < n4; i += 64) {
-        f32x4 v = *(const f32x4*)(x + 4 * i);
-        if (a.ln_relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+#pragma unroll
+      for (int q = 0; q < GEMV_LN_MAXK / 256; ++q) {
+        const int i = lane + 64 * q;
+        if (i >= n4) continue;
+        const f32x4 v = xv[q];
         const f32x4 g = *(const f32x4*)(a.ln_gain + 4 * i), b = *(const f32x4*)(a.ln_bias + 4 * i);
         f32x4 y;
         y.x = fmaf((v.x - mean) * rstd, g.x, b.x);
@@ -94,13 +109,17 @@ __global__ __launch_bounds__(256) void vpt_gemv_kernel(VptGemmArgs a) {
       for (int k = 0; k < 8; ++k) acc[m] = fmaf(wv[k], av[k], acc[m]);
     }
   };
-  if (LN) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (kbf + j * 4 * KPI < kb1) mac(wpre[j], kbf + j * 4 * KPI);
+  for (int j = 0; j < GEMV_PRE; ++j)
+    if (kbf + j * 4 * KPI < kb1) mac(wpre[j], kbf + j * 4 * KPI);
+  for (int kb = kbf + GEMV_PRE * 4 * KPI; kb < kb1; kb += GEMV_PRE * 4 * KPI) {   // further rounds of GEMV_PRE loads per lane (K >= 4096)
+#pragma unroll
+    for (int j = 0; j < GEMV_PRE; ++j)
+      if (kb + j * 4 * KPI < kb1) wpre[j] = __builtin_nontemporal_load((const u32x4*)(wp + (size_t)(kb + j * 4 * KPI) * 4096));
+#pragma unroll
+    for (int j = 0; j < GEMV_PRE; ++j)
+      if (kb + j * 4 * KPI < kb1) mac(wpre[j], kb + j * 4 * KPI);
   }
-#pragma unroll 4
-  for (int kb = kbf + (LN ? 16 * KPI : 0); kb < kb1; kb += 4 * KPI) mac(*(const u32x4*)(wp + (size_t)kb * 4096), kb);
 #pragma unroll
   for (int m = 0; m < MR; ++m) {
     acc[m] += __shfl_xor(acc[m], 1, 64);
@@ -137,12 +156,16 @@ extern "C" int vpt_gemv_launch(const VptGemmArgs* a, hipStream_t stream) {
   if (!a->ln_x && (a->lda & 7)) return -1;
   if (a->ln_x && (a->K > GEMV_LN_MAXK || a->splitk != 1 || !a->ln_gain || !a->ln_bias)) return -1;
   if (a->splitk > 1 && (!a->atomic_out || a->relu || a->res || a->out_bf16 || a->mask)) return -1;
-  const int rows = ((a->N + 15) >> 4) * a->splitk >= 512 ? 16 : 4;
+  // workgroups per CU decide the bytes in flight: ROWS = 16 only when that still leaves >= 8 workgroups per CU (N >= 32768 rows x splits),
+  // 2 when four rows would give fewer than 4 per CU (N <= 4096: the trunk's hid -> hid layers)
+  const long units = (long)a->N * a->splitk;
+  const int rows = units >= 32768 ? 16 : (units > 4096 ? 4 : 2);
   const long grid = (long)((a->N + rows - 1) / rows) * a->splitk;
   if (grid > 0x7fffffffL) return -2;
   const dim3 g((unsigned)grid), b(256);
 #define GEMV__(MR_, LN_) do { if (rows == 16) hipLaunchKernelGGL((vpt_gemv_kernel<MR_, 16, LN_>), g, b, 0, stream, *a); \
-                              else hipLaunchKernelGGL((vpt_gemv_kernel<MR_, 4, LN_>), g, b, 0, stream, *a); } while (0)
+                              else if (rows == 4) hipLaunchKernelGGL((vpt_gemv_kernel<MR_, 4, LN_>), g, b, 0, stream, *a); \
+                              else hipLaunchKernelGGL((vpt_gemv_kernel<MR_, 2, LN_>), g, b, 0, stream, *a); } while (0)
 #define GEMV_(MR_) do { if (a->ln_x) GEMV__(MR_, true); else GEMV__(MR_, false); } while (0)
   if (a->M == 1) GEMV_(1);
   else if (a->M == 2) GEMV_(2);

@@ -137,6 +137,19 @@ class NormalizeEwma(nn.Module):
         mean, var = self.running_mean_var()
         return x * torch.sqrt(var)[(None,) * 2] + mean[(None,) * 2]
 
+    def affine(self):
+        """denormalize(x) = x * scale + shift with (scale, shift) as host floats, recomputed only when the statistics change
+        (lib/normalize_ewma.py:27-31,57-60 with output size 1): the acting step applies it with one fused multiply-add inside
+        its graph instead of the half-dozen small kernels of running_mean_var() per step."""
+        key = (self.running_mean._version, self.running_mean_sq._version, self.debiasing_term._version,
+               self.running_mean.data_ptr(), str(self.running_mean.device))
+        if getattr(self, "_affine_key", None) != key:
+            mean, var = self.running_mean_var()
+            if mean.numel() != 1:
+                raise NotImplementedError("NormalizeEwma.affine(): scalar value head only")
+            self._affine, self._affine_key = (float(torch.sqrt(var).reshape(-1)[0]), float(mean.reshape(-1)[0])), key
+        return self._affine
+
 
 class ScaledMSEHead(nn.Module):
     """lib/scaled_mse_head.py:11-50: the Linear(hid -> 1) lives in the fused heads GEMM."""
@@ -281,11 +294,19 @@ class MinecraftAgentPolicy(nn.Module):
                 eng.forward(sg["img"], sg["first"], sg["state"], sample="deterministic")
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
+        scale, shift = self.value_head.normalizer.affine()
         with torch.cuda.graph(graph):
             # arg-max + its log-prob ride in the graph; the recurrent state is updated in place (no copies back into the static buffers)
             from .. import ops
             inplace = cfg["maxlen"] <= ops.ATTENTION_STEP_MAXLEN     # the fused step kernel's limit; longer memories go through copies (below)
             out = eng.forward(sg["img"], sg["first"], sg["state"], sample="deterministic", inplace_state=inplace)
+            # act()'s glue rides in the graph too: the value de-normalisation (one fused multiply-add) and the NaN check of the
+            # action log-prob (lib/policy.py:320-321 asserts it every step) as a flag the host reads with the action
+            out["vpred_denorm"] = torch.add(torch.full_like(out["vpred"][:, 0], shift), out["vpred"][:, 0], alpha=scale)
+            out["nan_flag"] = torch.isnan(out["action_log_prob"]).any()
+            # everything the caller keeps beyond the next replay, packed: two small tensors to clone per step instead of four
+            out["_keep_i"] = torch.cat([out["action"][k].reshape(b, 1) for k in ("buttons", "camera")], 1)                # int64 [B, 2]
+            out["_keep_f"] = torch.cat([out["action_log_prob"].reshape(b, 1), out["vpred_denorm"].reshape(b, 1)], 1)      # fp32 [B, 2]
             for (m_in, (k_in, v_in)), (m_out, (k_out, v_out)) in zip(sg["state"], out["state_out"]):
                 if m_out.data_ptr() != m_in.data_ptr():
                     m_in.copy_(m_out)
@@ -312,8 +333,11 @@ class MinecraftAgentPolicy(nn.Module):
         out = dict(sg["out"])
         out["state_out"] = sg["state"]
         if "action" in out:      # handed to the caller: must survive the next replay (the other outputs are consumed at once)
-            out["action"] = {k: v.clone() for k, v in out["action"].items()}
-            out["action_log_prob"] = out["action_log_prob"].clone()
+            ki, kf = out["_keep_i"].clone(), out["_keep_f"].clone()
+            bsz = ki.shape[0]
+            out["action"] = {"buttons": ki[:, 0].reshape(bsz, 1, 1), "camera": ki[:, 1].reshape(bsz, 1, 1)}
+            out["action_log_prob"] = kf[:, 0].reshape(out["action_log_prob"].shape)
+            out["vpred_denorm"] = kf[:, 1].reshape(bsz, 1)
         return out
 
     def initial_state(self, batch_size: int):
@@ -353,7 +377,7 @@ class MinecraftAgentPolicy(nn.Module):
         else:
             out = self._engine.forward(img, first, state_in, mask=mask, sample=sample)
         pi_logits = {"camera": out["camera"], "buttons": out["buttons"]}
-        extra = {k: out[k] for k in ("action", "action_log_prob") if k in out}
+        extra = {k: out[k] for k in ("action", "action_log_prob", "vpred_denorm", "nan_flag") if k in out}
         return (pi_logits, out["vpred"], None), out["state_out"], extra
 
     def _forward_differentiable(self, img, first, state_in, mask=None):
@@ -403,8 +427,13 @@ class MinecraftAgentPolicy(nn.Module):
             else:
                 ac = tree_map(lambda x: x.unsqueeze(1), taken_action)
             log_prob = self.pi_head.logprob(ac, pd)
-        assert not torch.isnan(log_prob).any()
-        result = {"log_prob": log_prob[:, 0], "vpred": self.value_head.denormalize(vpred)[:, 0]}
+        if "nan_flag" in extra and taken_action is None and "action" in extra:
+            assert not bool(extra["nan_flag"])            # computed inside the step graph
+            vp = extra["vpred_denorm"]
+        else:
+            assert not torch.isnan(log_prob).any()
+            vp = self.value_head.denormalize(vpred)[:, 0]
+        result = {"log_prob": log_prob[:, 0], "vpred": vp}
         if return_pd:
             result["pd"] = tree_map(lambda x: x[:, 0], pd)
         ac = tree_map(lambda x: x[:, 0], ac)
