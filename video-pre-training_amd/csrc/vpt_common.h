@@ -54,6 +54,18 @@ __device__ __forceinline__ uint32_t pack_op16x2_exact(float lo, float hi) {
 }
 #endif
 
+// packed pair dot product with fp32 accumulate: c + a.lo * b.lo + a.hi * b.hi (v_dot2c_f32_bf16 / v_dot2c_f32_f16) -- the
+// weight-streaming linears of the acting path: one instruction per two MACs, no 16-bit -> fp32 conversions
+__device__ __forceinline__ float dot2_op16(uint32_t a, uint32_t b, float c) {
+#ifdef VPT_OPERAND_F16
+  typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_, a), __builtin_bit_cast(h2_, b), c, false);
+#else
+  typedef __bf16 b2_ __attribute__((ext_vector_type(2)));
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2_, a), __builtin_bit_cast(b2_, b), c, false);
+#endif
+}
+
 // LDS transpose read (ds_read_b64_tr_b16): 4 consecutive 16-bit elements of this lane's column
 __device__ __forceinline__ op16x4 lds_tr16_read(const unsigned char* p) {
   return __builtin_bit_cast(op16x4, VPT_DS_READ_TR16_B64((__attribute__((address_space(3))) tr16x4*)(p)));

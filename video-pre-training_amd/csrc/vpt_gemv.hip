@@ -26,6 +26,8 @@ __global__ __launch_bounds__(256) void vpt_gemv_kernel(VptGemmArgs a) {
   constexpr int KPI = 64 / (4 * ROWS);          // k blocks covered by one wave-wide load instruction
   __shared__ float part_[4][ROWS][MR];
   __shared__ __attribute__((aligned(16))) vpt_op16 arow_[LN ? MR * GEMV_LN_MAXK : 8];
+  constexpr int XS_ROWS = MR < 4 ? MR : 4;      // fp32 staging rows of the LayerNorm prologue: one per wave that has a row
+  __shared__ __attribute__((aligned(16))) float xs_[LN ? XS_ROWS * GEMV_LN_MAXK : 4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int NB = (a.N + ROWS - 1) / ROWS;
   const int nb = blockIdx.x % NB, split = blockIdx.x / NB;
@@ -51,39 +53,34 @@ __global__ __launch_bounds__(256) void vpt_gemv_kernel(VptGemmArgs a) {
     if (kb < kb1) wpre[j] = __builtin_nontemporal_load((const u32x4*)(wp + (size_t)kb * 4096));
   }
   if (LN) {
-    // (the loads above do not depend on the normalisation: they are in flight while it runs).  The row is read ONCE into
-    // registers (K <= 3072: 12 float4 per lane) and the three passes of vpt_layernorm_kernel run on them -- same lane -> element
-    // map, same operation order, so the result stays bit-identical to the two-kernel path, at one memory round trip instead of three.
+    // (the loads above do not depend on the normalisation: they are in flight while it runs).  The row is read from global memory
+    // ONCE, into a per-wave LDS staging row, and the three passes of vpt_layernorm_kernel run on that copy -- same lane -> element
+    // map, same operation order, so the result stays bit-identical to the two-kernel path, at one memory round trip instead of
+    // three and without holding the row in registers (a register-resident row cost the kernel its occupancy: 172 VGPRs).
     const int n4 = a.K >> 2;
+    float* xs = xs_ + (size_t)(w % XS_ROWS) * GEMV_LN_MAXK;
     for (int m = w; m < a.M; m += 4) {
       const float* x = a.ln_x + (size_t)m * a.K;
-      f32x4 xv[GEMV_LN_MAXK / 256];
-#pragma unroll
-      for (int q = 0; q < GEMV_LN_MAXK / 256; ++q) {
-        const int i = lane + 64 * q;
-        f32x4 v = (i < n4) ? *(const f32x4*)(x + 4 * i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int i = lane; i < n4; i += 64) {
+        f32x4 v = *(const f32x4*)(x + 4 * i);
         if (a.ln_relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        xv[q] = v;
+        *(f32x4*)(xs + 4 * i) = v;
       }
       float s = 0.f;
-#pragma unroll
-      for (int q = 0; q < GEMV_LN_MAXK / 256; ++q)
-        if (lane + 64 * q < n4) s += (xv[q].x + xv[q].y) + (xv[q].z + xv[q].w);
+      for (int i = lane; i < n4; i += 64) {
+        const f32x4 v = *(const f32x4*)(xs + 4 * i);
+        s += (v.x + v.y) + (v.z + v.w);
+      }
       const float mean = wave_sum(s) / (float)a.K;
       float ss = 0.f;
-#pragma unroll
-      for (int q = 0; q < GEMV_LN_MAXK / 256; ++q)
-        if (lane + 64 * q < n4) {
-          const f32x4 v = xv[q];
-          const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-          ss += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-        }
+      for (int i = lane; i < n4; i += 64) {
+        const f32x4 v = *(const f32x4*)(xs + 4 * i);
+        const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+        ss += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
       const float rstd = rsqrtf(wave_sum(ss) / (float)a.K + VPT_NORM_EPS);
-#pragma unroll
-      for (int q = 0; q < GEMV_LN_MAXK / 256; ++q) {
-        const int i = lane + 64 * q;
-        if (i >= n4) continue;
-        const f32x4 v = xv[q];
+      for (int i = lane; i < n4; i += 64) {
+        const f32x4 v = *(const f32x4*)(xs + 4 * i);
         const f32x4 g = *(const f32x4*)(a.ln_gain + 4 * i), b = *(const f32x4*)(a.ln_bias + 4 * i);
         f32x4 y;
         y.x = fmaf((v.x - mean) * rstd, g.x, b.x);
@@ -97,16 +94,16 @@ __global__ __launch_bounds__(256) void vpt_gemv_kernel(VptGemmArgs a) {
     }
     __syncthreads();
   }
-  auto mac = [&](const u32x4& wraw, int kb) {
-    float wv[8];
-    unpack8(wraw, wv);
+  auto mac = [&](const u32x4& wraw, int kb) {   // 8 MACs per row: four packed-pair dot products, fp32 accumulate, k ascending
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
-      float av[8];
-      if (LN) unpack8(*(const u32x4*)(arow_ + (size_t)min(m, a.M - 1) * a.K + kb * 32 + chunk * 8), av);
-      else unpack8(*(const u32x4*)(ap + (size_t)min(m, a.M - 1) * a.lda + kb * 32), av);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) acc[m] = fmaf(wv[k], av[k], acc[m]);
+      u32x4 av;
+      if (LN) av = *(const u32x4*)(arow_ + (size_t)min(m, a.M - 1) * a.K + kb * 32 + chunk * 8);
+      else av = *(const u32x4*)(ap + (size_t)min(m, a.M - 1) * a.lda + kb * 32);
+      acc[m] = dot2_op16(wraw.x, av.x, acc[m]);
+      acc[m] = dot2_op16(wraw.y, av.y, acc[m]);
+      acc[m] = dot2_op16(wraw.z, av.z, acc[m]);
+      acc[m] = dot2_op16(wraw.w, av.w, acc[m]);
     }
   };
 #pragma unroll

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void vpt_pack_conv_first_kernel(const float* _
   if (o < Cout) {
     if (k < 27) {
       const int tap = k / 3, ch = k - 3 * tap;              // tap = kh*3 + kw
-      v = w[(size_t)o * 27 + ch * 9 + tap] / 255.0f;         // (the pixel operand is the raw byte 0..255)
+      v = __fdiv_rn(w[(size_t)o * 27 + ch * 9 + tap], 255.0f);   // correctly rounded fp32 quotient, as torch's W / 255 (the pixel operand is the raw byte)
     } else if (k == 27 || k == 28) {
       const float b = bias[o];
       const float bh = (float)(op16_t)b;

@@ -186,7 +186,7 @@ class PolicyEngine:
         self.packed = True
 
     # ------------------------------------------------------------------------------------------
-    def _cnn_chunk(self, img: torch.Tensor, x0=None, s_x0=None) -> torch.Tensor:
+    def _cnn_chunk(self, img: torch.Tensor, x0=None, s_x0=None, tiling: str = "throughput") -> torch.Tensor:
         """img uint8 [F,128,128,3] -> blocked bf16 [F, C2/32, 16, 16, 32] normalised for the dense layer,
         i.e. everything of ImpalaCNN.forward up to (and including) dense.norm.  With (x0, s_x0) given (IDM:
         the temporal conv's blocked output and its frame statistics) stack 0 uses the normed conv3x3 path."""
@@ -209,7 +209,7 @@ class PolicyEngine:
                 pooled = ops.conv_first(img, w[p + "firstconv"], c, stats_out=s_pool)
             else:
                 wpk, sa, sg = w[p + "firstconv"]
-                pre = ops.conv3x3(x, wpk, sa, sg, s_x, c)
+                pre = ops.conv3x3(x, wpk, sa, sg, s_x, c, tiling=tiling)
                 pooled = ops.maxpool(pre, stats_out=s_pool)
                 del pre
             s_x = nxt()
@@ -217,10 +217,10 @@ class PolicyEngine:
             for b in range(2):
                 wpk, sa, sg = w[f"{p}blocks.{b}.conv0"]
                 s_y = nxt()
-                y = ops.conv3x3(x, wpk, sa, sg, s_x, c, stats_out=s_y)
+                y = ops.conv3x3(x, wpk, sa, sg, s_x, c, stats_out=s_y, tiling=tiling)
                 wpk, sa, sg = w[f"{p}blocks.{b}.conv1"]
                 s_n = nxt()
-                x = ops.conv3x3(y, wpk, sa, sg, s_y, c, res=x, stats_out=s_n)
+                x = ops.conv3x3(y, wpk, sa, sg, s_y, c, res=x, stats_out=s_n, tiling=tiling)
                 s_x = s_n
                 del y
         p = "net.img_process.cnn.dense."
@@ -236,8 +236,8 @@ class PolicyEngine:
         o32, o16 = ops.linear(ln16, wpk, n, bias=bias, res=res, relu=relu, out_f32=out_f32, out_bf16=out_bf16)
         return ln32, o32, o16
 
-    def _img_process(self, frames: torch.Tensor) -> torch.Tensor:
-        """uint8 [N,128,128,3] -> fp32 [N,hid]  (ImgObsProcess.forward, lib/policy.py:79-80)."""
+    def _img_process(self, frames: torch.Tensor, tiling: str = "throughput") -> torch.Tensor:
+        """uint8 [N,128,128,3] -> fp32 [N,hid]  (ImgObsProcess.forward, lib/policy.py:79-80).  tiling: see ops.conv3x3."""
         cfg, w = self.cfg, self.w
         n = frames.shape[0]
         outs = []
@@ -254,7 +254,7 @@ class PolicyEngine:
         for ci, i in enumerate(range(0, n, self.cnn_chunk)):
             ctx = torch.cuda.stream(self._streams[ci % n_streams]) if n_streams > 1 else _NullCtx()
             with ctx:
-                xn = self._cnn_chunk(frames[i:i + self.cnn_chunk])
+                xn = self._cnn_chunk(frames[i:i + self.cnn_chunk], tiling=tiling)
                 flat = xn.view(xn.shape[0], -1)
                 d32, _ = ops.linear(flat, w["net.img_process.cnn.dense.w"], 256, splitk=DENSE_SPLITK)
                 outs.append(d32)
@@ -280,7 +280,8 @@ class PolicyEngine:
         bsz, t = img_u8.shape[:2]
         hid, heads, maxlen = cfg["hidsize"], cfg["heads"], cfg["maxlen"]
         frames = img_u8.reshape(bsz * t, *img_u8.shape[2:]).contiguous()
-        x = self._img_process(frames)
+        # the acting step (agent.py:190-206: T = 1, a handful of environments) runs the convolutions on the latency tiling
+        x = self._img_process(frames, tiling="latency" if (t == 1 and bsz <= ops.LN_LINEAR_MAX_ROWS) else "throughput")
         if cfg["use_pre_lstm_ln"]:
             x, _ = ops.layernorm(x, w["prelstm.g"], w["prelstm.b"], out_f32=True, out_bf16=False, dtype=self.dtype)
 

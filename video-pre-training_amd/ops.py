@@ -171,9 +171,11 @@ def conv_first(img_u8, wfrag, cout, stats_out=None):
 CONV_TILING = {"auto": 0, "throughput": 1, "latency": 2}
 
 
-def conv3x3(x, wpk, edge_sa, edge_sg, stats_in, cout, res=None, stats_out=None, out=None, tiling="auto"):
+def conv3x3(x, wpk, edge_sa, edge_sg, stats_in, cout, res=None, stats_out=None, out=None, tiling="throughput"):
     """x blocked bf16 [F,Cin/32,H,W,32] -> blocked bf16 [F,cout/32,H,W,32] (GN fold + ReLU [+res]).
-    tiling: "auto" (by grid size), "throughput" or "latency" (vpt_conv3x3_forward_tiled)."""
+    tiling: "throughput" (default: a frame's result must not depend on how many frames share the launch -- chunking, sharding
+    over ranks and the batch size are free choices of the caller; the two tilings sum a tile's statistics in different orders),
+    "latency" (the acting step asks for it explicitly) or "auto" (by grid size) -- vpt_conv3x3_forward_tiled."""
     _chk(x, OP16, "x"); _chk(wpk, OP16, "wpk"); _chk(edge_sa, torch.float32, "edge_sa")
     _chk(edge_sg, torch.float32, "edge_sg"); _chk(stats_in, torch.float64, "stats_in")
     _chk(res, OP16, "res"); _chk(stats_out, torch.float64, "stats_out")
