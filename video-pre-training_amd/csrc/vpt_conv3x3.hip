@@ -637,21 +637,37 @@ __global__ __launch_bounds__(256, 1) void vpt_conv3x3_small_kernel(VptConv3x3Arg
   // iteration cb: issue stage cb + 2 (its halo into the register set stage cb used), compute stage cb, then move the halo of stage
   // cb + 1 -- issued one iteration EARLIER, so it has had two compute phases to land; the counted wait leaves stage cb + 2 in flight
   // -- from its registers into LDS for the next iteration.  One barrier per channel block.
+  op16x8 sfb[3], sfa[3][2];
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define S_LOADG(g__)                                                                                      \
+  do {                                                                                                    \
+    const int gg_ = (g__);   /* a constant after unrolling: the register-set index gg_ % 3 must fold */ \
+    const int tap_ = gg_ >> 1, ks_ = gg_ & 1, dy_ = tap_ / 3, dx_ = tap_ - 3 * dy_;                       \
+    sfb[gg_ % 3] = *(const op16x8*)(bL + tap_ * 2048 + (((2 * ks_ + hi) ^ bsw) << 4));                    \
+    sfa[gg_ % 3][0] = *(const op16x8*)(aL + (dy_ * 18 + dx_) * A_RS + ks_ * 32);                          \
+    sfa[gg_ % 3][1] = *(const op16x8*)(aL + (dy_ * 18 + dx_) * A_RS + (2 * 18 * A_RS) + ks_ * 32);        \
+  } while (0)
 #define S_ITER(cb_, SET_)                                                                                 \
   do {                                                                                                    \
     const bool more_ = (cb_) + 2 < NCB;                                                                   \
     if (more_) S_ISSUE((cb_) + 2, SET_);                                                                  \
     const unsigned char* aL = smem + ((cb_) % S_NBUF) * A_BYTES + ((w * 4 + sub_row(l31)) * 18 + (l31 & 15)) * A_RS + hi * 16; \
     const unsigned char* bL = wlds + ((cb_) % S_NBUF) * S_W_BYTES + l31 * 64;                             \
-    _Pragma("unroll") for (int dy = 0; dy < 3; ++dy)                                                      \
-      _Pragma("unroll") for (int dx = 0; dx < 3; ++dx)                                                    \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                \
-          const op16x8 fb = *(const op16x8*)(bL + (dy * 3 + dx) * 2048 + (((2 * ks + hi) ^ bsw) << 4));   \
-          _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                                 \
-            const op16x8 fa = *(const op16x8*)(aL + (dy * 18 + dx) * A_RS + m * (2 * 18 * A_RS) + ks * 32); \
-            acc[m] = VPT_MFMA_32X32X16(fb, fa, acc[m], 0, 0, 0);                                          \
-          }                                                                                               \
-        }                                                                                                 \
+    /* 18 groups (kernel row, kernel column, 16-channel half) of one weight fragment, two pixel fragments, two MFMAs.  One wave \
+       per SIMD and nobody to hide an LDS round trip behind: the fragments of group g + 2 are requested before the MFMAs of group \
+       g issue (three register sets, order pinned; left alone the compiler reads each group right before its use and waits). */ \
+    S_LOADG(0); S_LOADG(1); SB();                                                                         \
+    _Pragma("unroll") for (int g_ = 0; g_ < 18; ++g_) {                                                   \
+      if (g_ + 2 < 18) { S_LOADG(g_ + 2); }                                                               \
+      /* LDS reads return in order: group g_ has landed once at most the 3 (2) younger groups' reads are outstanding */ \
+      if (g_ < 16) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");                                     \
+      else if (g_ == 16) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");                               \
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+      SB();                                                                                               \
+      acc[0] = VPT_MFMA_32X32X16(sfb[g_ % 3], sfa[g_ % 3][0], acc[0], 0, 0, 0);                           \
+      acc[1] = VPT_MFMA_32X32X16(sfb[g_ % 3], sfa[g_ % 3][1], acc[1], 0, 0, 0);                           \
+      SB();                                                                                               \
+    }                                                                                                     \
     if ((cb_) + 1 < NCB) {                                                                                \
       S_WAIT_OLDER(more_);                                                                                \
       S_WRITE_A((cb_) + 1, 1 - (SET_));                                                                   \
@@ -665,6 +681,8 @@ __global__ __launch_bounds__(256, 1) void vpt_conv3x3_small_kernel(VptConv3x3Arg
     if (cb + 1 < NCB) S_ITER(cb + 1, 1);
   }
 #undef S_ITER
+#undef S_LOADG
+#undef SB
 #undef S_ISSUE
 #undef S_WRITE_A
 #undef S_WAIT_OLDER

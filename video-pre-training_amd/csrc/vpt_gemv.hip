@@ -52,11 +52,72 @@ __global__ __launch_bounds__(256) void vpt_gemv_kernel(VptGemmArgs a) {
     wpre[j] = (u32x4){0u, 0u, 0u, 0u};
     if (kb < kb1) wpre[j] = __builtin_nontemporal_load((const u32x4*)(wp + (size_t)kb * 4096));
   }
-  if (LN) {
-    // (the loads above do not depend on the normalisation: they are in flight while it runs).  The row is read from global memory
-    // ONCE, into a per-wave LDS staging row, and the three passes of vpt_layernorm_kernel run on that copy -- same lane -> element
-    // map, same operation order, so the result stays bit-identical to the two-kernel path, at one memory round trip instead of
-    // three and without holding the row in registers (a register-resident row cost the kernel its occupancy: 172 VGPRs).
+  if (LN && MR <= 4) {
+    // (the weight loads above do not depend on the normalisation: they are in flight while it runs).  Up to four rows (the acting
+    // path): the whole workgroup shares the work -- every thread fetches its slice of the rows, of the gain and of the bias at
+    // once (one memory round trip), wave m then runs the two statistics passes of row m on the LDS copy with EXACTLY the lane ->
+    // element map, operation order and butterfly sums of vpt_layernorm_kernel, and the element-wise apply is spread over all 256
+    // threads again: bit-identical to the two-kernel path.  (One wave doing all of it cost 3.8 us per launch, 11 launches a step.)
+    const int n4 = a.K >> 2;
+    __shared__ float stat_[4][2];
+    f32x4 gv[GEMV_LN_MAXK / 1024], bv[GEMV_LN_MAXK / 1024];
+#pragma unroll
+    for (int q = 0; q < GEMV_LN_MAXK / 1024; ++q) {
+      const int i4 = tid + 256 * q;
+      if (i4 < n4) {
+        gv[q] = *(const f32x4*)(a.ln_gain + 4 * i4);
+        bv[q] = *(const f32x4*)(a.ln_bias + 4 * i4);
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+          if (m < a.M) {
+            f32x4 v = *(const f32x4*)(a.ln_x + (size_t)m * a.K + 4 * i4);
+            if (a.ln_relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *(f32x4*)(xs_ + (size_t)m * GEMV_LN_MAXK + 4 * i4) = v;
+          }
+      }
+    }
+    __syncthreads();
+    if (w < a.M) {
+      const float* xs = xs_ + (size_t)w * GEMV_LN_MAXK;
+      float s = 0.f;
+      for (int i4 = lane; i4 < n4; i4 += 64) {
+        const f32x4 v = *(const f32x4*)(xs + 4 * i4);
+        s += (v.x + v.y) + (v.z + v.w);
+      }
+      const float mean = wave_sum(s) / (float)a.K;
+      float ss = 0.f;
+      for (int i4 = lane; i4 < n4; i4 += 64) {
+        const f32x4 v = *(const f32x4*)(xs + 4 * i4);
+        const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+        ss += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
+      const float rstd = rsqrtf(wave_sum(ss) / (float)a.K + VPT_NORM_EPS);
+      if (lane == 0) { stat_[w][0] = mean; stat_[w][1] = rstd; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      if (m >= a.M) break;
+      const float mean = stat_[m][0], rstd = stat_[m][1];
+#pragma unroll
+      for (int q = 0; q < GEMV_LN_MAXK / 1024; ++q) {
+        const int i4 = tid + 256 * q;
+        if (i4 >= n4) continue;
+        const f32x4 v = *(const f32x4*)(xs_ + (size_t)m * GEMV_LN_MAXK + 4 * i4);
+        const f32x4 g = gv[q], b = bv[q];
+        f32x4 y;
+        y.x = fmaf((v.x - mean) * rstd, g.x, b.x);
+        y.y = fmaf((v.y - mean) * rstd, g.y, b.y);
+        y.z = fmaf((v.z - mean) * rstd, g.z, b.z);
+        y.w = fmaf((v.w - mean) * rstd, g.w, b.w);
+        if (a.ln_out_f32 && blockIdx.x == 0) *(f32x4*)(a.ln_out_f32 + (size_t)m * a.K + 4 * i4) = y;
+        u32x2 p = {pack_op16x2(y.x, y.y), pack_op16x2(y.z, y.w)};
+        *(u32x2*)(arow_ + (size_t)m * a.K + 4 * i4) = p;
+      }
+    }
+    __syncthreads();
+  } else if (LN) {
+    // five to eight rows: wave w takes rows w, w + 4 on its own (per-wave staging row), same arithmetic
     const int n4 = a.K >> 2;
     float* xs = xs_ + (size_t)(w % XS_ROWS) * GEMV_LN_MAXK;
     for (int m = w; m < a.M; m += 4) {
@@ -148,6 +209,9 @@ __global__ __launch_bounds__(256) void vpt_gemv_kernel(VptGemmArgs a) {
   }
 }
 
+static int g_gemv_rows = 0;
+extern "C" void vpt_gemv_set_rows(int rows) { g_gemv_rows = rows; }   // profiling hook (tools/gemv_bench.py): force ROWS, 0 = automatic
+
 extern "C" int vpt_gemv_launch(const VptGemmArgs* a, hipStream_t stream) {
   if (a->M <= 0 || a->M > 8 || a->N <= 0 || (a->K & 31) || a->splitk < 1) return -1;
   if (!a->ln_x && (a->lda & 7)) return -1;
@@ -156,11 +220,14 @@ extern "C" int vpt_gemv_launch(const VptGemmArgs* a, hipStream_t stream) {
   // workgroups per CU decide the bytes in flight: ROWS = 16 only when that still leaves >= 8 workgroups per CU (N >= 32768 rows x splits),
   // 2 when four rows would give fewer than 4 per CU (N <= 4096: the trunk's hid -> hid layers)
   const long units = (long)a->N * a->splitk;
-  const int rows = units >= 32768 ? 16 : (units > 4096 ? 4 : 2);
+  int rows = 2;                                   // the fewest rows per workgroup that still fit the grid into ONE round of
+  while (rows < 16 && units > 1280L * rows) rows *= 2;   // resident workgroups (5 per CU at the LayerNorm variant's 96 VGPRs)
+  if (g_gemv_rows == 2 || g_gemv_rows == 4 || g_gemv_rows == 8 || g_gemv_rows == 16) rows = g_gemv_rows;
   const long grid = (long)((a->N + rows - 1) / rows) * a->splitk;
   if (grid > 0x7fffffffL) return -2;
   const dim3 g((unsigned)grid), b(256);
 #define GEMV__(MR_, LN_) do { if (rows == 16) hipLaunchKernelGGL((vpt_gemv_kernel<MR_, 16, LN_>), g, b, 0, stream, *a); \
+                              else if (rows == 8) hipLaunchKernelGGL((vpt_gemv_kernel<MR_, 8, LN_>), g, b, 0, stream, *a); \
                               else if (rows == 4) hipLaunchKernelGGL((vpt_gemv_kernel<MR_, 4, LN_>), g, b, 0, stream, *a); \
                               else hipLaunchKernelGGL((vpt_gemv_kernel<MR_, 2, LN_>), g, b, 0, stream, *a); } while (0)
 #define GEMV_(MR_) do { if (a->ln_x) GEMV__(MR_, true); else GEMV__(MR_, false); } while (0)
