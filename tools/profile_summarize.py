@@ -26,7 +26,7 @@ def last_json_line(path):
 
 
 # (1) / (2) kernel-trace stats + the bench lines of the profiled runs
-for sub, name in (("fwd1", "fwd_singlestream"), ("fwdbc", "fwd_bc")):
+for sub, name in (("fwd1", "fwd_singlestream"), ("fwd1_fp16", "fwd_singlestream_fp16"), ("fwdbc", "fwd_bc")):
     f = one(f"{sub}/**/*_kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(DST, f"{TAG}_bench_{name}_kernel_stats.csv"))
@@ -42,47 +42,54 @@ for sub, name in (("fwd1", "fwd_singlestream"), ("fwdbc", "fwd_bc")):
 # (3) PMC of the conv micro-benchmark: per-launch averages by (grid size, kernel instantiation)
 SHAPES = {1048576: "s0.block 64x64 128->128 (256 frames)", 2097152: "256-cout layers (s1.first / s1.block / s2.first)",
           524288: "s2.block 16x16 256->256"}
-pmc = defaultdict(lambda: defaultdict(list))
-dur = defaultdict(lambda: defaultdict(list))
-for sub in ("pmc_sq", "pmc_grbm"):
-    f = one(f"{sub}/**/*_counter_collection.csv")
-    if not f:
+import glob as _g
+_variants = [("", "bf16", "")] if _g.glob(os.path.join(SRC, "pmc_sq", "**", "*_counter_collection.csv"), recursive=True) else []
+_variants += [("_bf16", "bf16", ""), ("_fp16", "fp16", "_fp16")]
+for SFX, FMT, FSFX in _variants:
+    if not _g.glob(os.path.join(SRC, f"pmc_sq{SFX}", "**", "*_counter_collection.csv"), recursive=True):
         continue
-    seen = set()
-    for r in csv.DictReader(open(f)):
-        if "vpt_conv3x3_kernel" not in r["Kernel_Name"]:
+    pmc = defaultdict(lambda: defaultdict(list))
+    dur = defaultdict(lambda: defaultdict(list))
+    for sub in (f"pmc_sq{SFX}", f"pmc_grbm{SFX}"):
+        f = one(f"{sub}/**/*_counter_collection.csv")
+        if not f:
             continue
-        res = "res" if ", 1>" in r["Kernel_Name"] else "nores"
-        key = f"grid{r['Grid_Size']}_{res}"
-        pmc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
-        if (sub, r["Dispatch_Id"]) not in seen:
-            seen.add((sub, r["Dispatch_Id"]))
-            dur[key][sub].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
-out = {"kernel": "vpt_conv3x3_kernel (end of round 2)", "counters": {}}
-for key, cs in sorted(pmc.items()):
-    d = {k: sum(v) / len(v) for k, v in cs.items()}
-    d["_dur_ns_sq_pass"] = sum(dur[key]["pmc_sq"]) / max(len(dur[key]["pmc_sq"]), 1)
-    d["_dur_ns_grbm_pass"] = sum(dur[key]["pmc_grbm"]) / max(len(dur[key]["pmc_grbm"]), 1)
-    grid = int(key[4:].split("_")[0])
-    d["shape"] = SHAPES.get(grid, f"grid {grid}")
-    d["residual"] = key.endswith("_res")
-    if d.get("GRBM_GUI_ACTIVE") and d["_dur_ns_grbm_pass"]:
-        d["effective_clock_ghz"] = d["GRBM_GUI_ACTIVE"] / 8.0 / d["_dur_ns_grbm_pass"]   # the counter is summed over the 8 XCDs
-    # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs (256 CUs x 4); cycles of the SQ pass = GRBM cycles per XCD scaled by
-    # the two passes' durations
-    if d.get("SQ_VALU_MFMA_BUSY_CYCLES") and d.get("GRBM_GUI_ACTIVE"):
-        d["mfma_busy_frac_of_cycles"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] * d["_dur_ns_sq_pass"] / d["_dur_ns_grbm_pass"] * 128.0)
-    if d.get("SQ_WAVE_CYCLES"):
-        d["wait_inst_any_frac_of_wave_cycles"] = d.get("SQ_WAIT_INST_ANY", 0.0) / d["SQ_WAVE_CYCLES"]
-        d["wait_any_frac_of_wave_cycles"] = d.get("SQ_WAIT_ANY", 0.0) / d["SQ_WAVE_CYCLES"]
-    if d.get("SQ_LDS_IDX_ACTIVE"):
-        d["lds_conflict_frac"] = d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"]
-    out["counters"][key] = d
-if out["counters"]:
-    json.dump(out, open(os.path.join(DST, f"{TAG}_conv3x3_pmc.json"), "w"), indent=1)
-    for k, d in out["counters"].items():
-        print(f"pmc {k}: clock {d.get('effective_clock_ghz', 0):.2f} GHz  MFMA busy {100 * d.get('mfma_busy_frac_of_cycles', 0):.1f} %  "
-              f"wait_inst_any {100 * d.get('wait_inst_any_frac_of_wave_cycles', 0):.0f} %  LDS conflicts {100 * d.get('lds_conflict_frac', 0):.1f} %")
+        seen = set()
+        for r in csv.DictReader(open(f)):
+            if "vpt_conv3x3_kernel" not in r["Kernel_Name"]:
+                continue
+            res = "res" if ", 1>" in r["Kernel_Name"] else "nores"
+            key = f"grid{r['Grid_Size']}_{res}"
+            pmc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if (sub, r["Dispatch_Id"]) not in seen:
+                seen.add((sub, r["Dispatch_Id"]))
+                dur[key][sub].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    out = {"kernel": f"vpt_conv3x3_kernel ({TAG}, operand format {FMT})", "counters": {}}
+    for key, cs in sorted(pmc.items()):
+        d = {k: sum(v) / len(v) for k, v in cs.items()}
+        d["_dur_ns_sq_pass"] = sum(dur[key][f"pmc_sq{SFX}"]) / max(len(dur[key][f"pmc_sq{SFX}"]), 1)
+        d["_dur_ns_grbm_pass"] = sum(dur[key][f"pmc_grbm{SFX}"]) / max(len(dur[key][f"pmc_grbm{SFX}"]), 1)
+        grid = int(key[4:].split("_")[0])
+        d["shape"] = SHAPES.get(grid, f"grid {grid}")
+        d["residual"] = key.endswith("_res")
+        if d.get("GRBM_GUI_ACTIVE") and d["_dur_ns_grbm_pass"]:
+            d["effective_clock_ghz"] = d["GRBM_GUI_ACTIVE"] / 8.0 / d["_dur_ns_grbm_pass"]   # the counter is summed over the 8 XCDs
+        # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs (256 CUs x 4); cycles of the SQ pass = GRBM cycles per XCD scaled by
+        # the two passes' durations
+        if d.get("SQ_VALU_MFMA_BUSY_CYCLES") and d.get("GRBM_GUI_ACTIVE"):
+            d["mfma_busy_frac_of_cycles"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] * d["_dur_ns_sq_pass"] / d["_dur_ns_grbm_pass"] * 128.0)
+        if d.get("SQ_WAVE_CYCLES"):
+            d["wait_inst_any_frac_of_wave_cycles"] = d.get("SQ_WAIT_INST_ANY", 0.0) / d["SQ_WAVE_CYCLES"]
+            d["wait_any_frac_of_wave_cycles"] = d.get("SQ_WAIT_ANY", 0.0) / d["SQ_WAVE_CYCLES"]
+        if d.get("SQ_LDS_IDX_ACTIVE"):
+            d["lds_conflict_frac"] = d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"]
+        out["counters"][key] = d
+    if out["counters"]:
+        json.dump(out, open(os.path.join(DST, f"{TAG}_conv3x3_pmc{FSFX}.json"), "w"), indent=1)
+        for k, d in out["counters"].items():
+            print(f"pmc[{FMT}] {k}: clock {d.get('effective_clock_ghz', 0):.2f} GHz  MFMA busy {100 * d.get('mfma_busy_frac_of_cycles', 0):.1f} %  "
+                  f"wait_inst_any {100 * d.get('wait_inst_any_frac_of_wave_cycles', 0):.0f} %  LDS conflicts {100 * d.get('lds_conflict_frac', 0):.1f} %")
+
 
 # (4) HBM traffic of the conv kernel over the bench workload
 tot = {}

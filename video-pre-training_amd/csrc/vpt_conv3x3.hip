@@ -248,9 +248,13 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   do {                                                                                                    \
     _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_) { MM(set_, m_, 0); MM(set_, m_, 1); }                \
   } while (0)
+#ifndef VPT_CONV_DMA_PIECES
+#define VPT_CONV_DMA_PIECES 6   // profiling builds: fewer weight-DMA pieces per wave and step (the results are then wrong; timing only)
+#endif
 #define GLDS(m_)                                                                                          \
+  do { if ((m_) < VPT_CONV_DMA_PIECES)                                                                    \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp_ + (m_) * 2048),    \
-                                   (__attribute__((address_space(3))) void*)(bd_ + (m_) * 4096), 16, 0, 0)
+                                   (__attribute__((address_space(3))) void*)(bd_ + (m_) * 4096), 16, 0, 0); } while (0)
 #define XA(m_) areg[m_] = *(const u32x4*)((const char*)xplane + (cbo_ + a_gbyte[m_]))
 #define XR(m_, n2_, p_) rq[m_][n2_][p_] = EPI_LD(resp, m_, n2_, p_)
 #define NOP_() ((void)0)
