@@ -41,13 +41,13 @@ class KernelTimer:
 TIMER = KernelTimer()
 
 
-def _call(name, meta, *args, fmt="bf16"):
+def _call(name, meta, *args, fmt="bf16", label=None):
     if TIMER.enabled:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         _native.call(name, *args, fmt=fmt)
         b.record()
-        TIMER.records.append((name, a, b, meta or {}))
+        TIMER.records.append((label or name, a, b, meta or {}))
     else:
         _native.call(name, *args, fmt=fmt)
 
@@ -189,7 +189,8 @@ def conv3x3(x, wpk, edge_sa, edge_sg, stats_in, cout, res=None, stats_out=None, 
               ptr(out), ptr(stats_out), f, h, w, cb * 32, cout, _stream(), fmt=fmt)
     else:
         _call("vpt_conv3x3_forward_tiled", meta, ptr(x), ptr(wpk), ptr(edge_sa), ptr(edge_sg), ptr(stats_in), ptr(res),
-              ptr(out), ptr(stats_out), f, h, w, cb * 32, cout, CONV_TILING[tiling], _stream(), fmt=fmt)
+              ptr(out), ptr(stats_out), f, h, w, cb * 32, cout, CONV_TILING[tiling], _stream(), fmt=fmt,
+              label="vpt_conv3x3_forward" if tiling == "throughput" else "vpt_conv3x3_forward_latency")
     return out
 
 
