@@ -80,12 +80,6 @@ int vpt_pack_linear(const float* weight, void* wpk, int N, int K, int transposed
  * img: uint8 [frames][H][W][3]; wfrag: bf16 [NT][4][2][64][8]; y: blocked [frames][Cout/32][H/2][W/2][32]. */
 int vpt_conv_first_forward(const uint8_t* img, const void* wfrag, void* y, double* stats_out,
                            int frames, int H, int W, int Cout, void* stream);
-/* The training forward: additionally records, per pooled value, which of the nine window positions won the max-pool
- * (argmax: uint8, shaped like y: kh*3+kw of the FIRST maximum in scan order -- torch's rule --, 15 when the window's maximum is 0,
- * i.e. no gradient passes the ReLU), so that vpt_conv_first_backward_argmax need not recompute and search the pre-pool tile
- * (what autograd keeps as F.max_pool2d's indices and the ReLU mask, lib/impala_cnn.py:115-117). */
-int vpt_conv_first_forward_train(const uint8_t* img, const void* wfrag, void* y, double* stats_out, uint8_t* argmax,
-                                 int frames, int H, int W, int Cout, void* stream);
 
 /* IDM temporal conv + ingest + bias + ReLU.
  * Replaces ImgPreprocessing.forward (lib/policy.py:39-45) and InverseActionNet._conv3d_forward
@@ -281,10 +275,6 @@ int vpt_conv3x3_dgrad(const void* dacc, const void* wpk_t, const void* skip, con
  * and db[Cout] (fp32 atomics; caller zeroes). */
 int vpt_conv_first_backward(const uint8_t* img, const void* wfrag, const void* dpooled, float* dw, float* db,
                             int frames, int H, int W, int Cout, void* stream);
-/* The same with the arg-max codes of vpt_conv_first_forward_train: no recompute, no search (3.5x faster); argmax = NULL is
- * vpt_conv_first_backward. */
-int vpt_conv_first_backward_argmax(const uint8_t* img, const void* wfrag, const void* dpooled, const uint8_t* argmax, float* dw, float* db,
-                                   int frames, int H, int W, int Cout, void* stream);
 
 /* Weight gradient of the folded convolution: dw[o][tap][c] += sum_{f,p} dacc[f][o][p] * x[f][c][p + tap] (fp32; caller
  * zeroes or accumulates).  W in {16, 32, 64}.  scratch: fp32 work buffer of vpt_conv3x3_wgrad_scratch_floats() elements

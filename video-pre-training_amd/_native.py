@@ -20,8 +20,6 @@ _D = ctypes.c_double
 # name -> argtypes, exactly as declared in include/vpt_hip.h
 SIGNATURES = {
     "vpt_conv_first_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "vpt_conv_first_forward_train": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "vpt_conv_first_backward_argmax": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_conv3d_t5_forward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_pack_conv3x3": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
     "vpt_pack_linear": [_P, _P, _I, _I, _I, _I, _I, _P],

@@ -67,13 +67,8 @@ int64_t vpt_workspace_bytes(int op, int frames, int H, int W, int Cin, int Cout)
 
 int vpt_conv_first_forward(const uint8_t* img, const void* wfrag, void* y, double* stats_out,
                            int frames, int H, int W, int Cout, void* stream) {
-  return vpt_conv_first_forward_train(img, wfrag, y, stats_out, nullptr, frames, H, W, Cout, stream);
-}
-
-int vpt_conv_first_forward_train(const uint8_t* img, const void* wfrag, void* y, double* stats_out, uint8_t* argmax,
-                                 int frames, int H, int W, int Cout, void* stream) {
   VptConvFirstArgs a;
-  a.img = img; a.wfrag = (const vpt_op16*)wfrag; a.y = (vpt_op16*)y; a.stats_out = stats_out; a.argmax = argmax;
+  a.img = img; a.wfrag = (const vpt_op16*)wfrag; a.y = (vpt_op16*)y; a.stats_out = stats_out;
   a.frames = frames; a.H = H; a.W = W; a.Cout = Cout; a.NT = (Cout + 127) / 128;
   CHECK_LAUNCH(vpt_conv_first_launch(&a, (hipStream_t)stream), "vpt_conv_first_forward");
 }
@@ -134,13 +129,8 @@ int vpt_conv_backward_prepare(const void* dy, const void* dpooled, const uint8_t
 
 int vpt_conv_first_backward(const uint8_t* img, const void* wfrag, const void* dpooled, float* dw, float* db,
                             int frames, int H, int W, int Cout, void* stream) {
-  return vpt_conv_first_backward_argmax(img, wfrag, dpooled, nullptr, dw, db, frames, H, W, Cout, stream);
-}
-
-int vpt_conv_first_backward_argmax(const uint8_t* img, const void* wfrag, const void* dpooled, const uint8_t* argmax, float* dw, float* db,
-                                   int frames, int H, int W, int Cout, void* stream) {
   VptConvFirstBwdArgs a;
-  a.img = img; a.wfrag = (const vpt_op16*)wfrag; a.dpooled = (const vpt_op16*)dpooled; a.dw = dw; a.db = db; a.argmax = argmax;
+  a.img = img; a.wfrag = (const vpt_op16*)wfrag; a.dpooled = (const vpt_op16*)dpooled; a.dw = dw; a.db = db;
   a.frames = frames; a.H = H; a.W = W; a.Cout = Cout;
   CHECK_LAUNCH(vpt_conv_first_bwd_launch(&a, (hipStream_t)stream), "vpt_conv_first_backward");
 }

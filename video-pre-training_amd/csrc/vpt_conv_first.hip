@@ -24,10 +24,6 @@
 
 typedef short i16x8 __attribute__((ext_vector_type(8)));
 
-// ARGMAX (training forward): the pool also records WHICH of the nine window positions won -- first maximum in scan order, 15 when
-// the window's maximum is 0 (no gradient through the ReLU) -- one byte per pooled value, so that the backward pass neither
-// recomputes the pre-pool tile nor searches it (that search was 58 % of vpt_conv_first_bwd_kernel, the recompute another 30 %).
-template <bool ARGMAX>
 __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[CT_BYTES + IN_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -158,27 +154,15 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
     const int cg = nt * 128 + cbl * 32 + oct4 * 8;
     const unsigned char* src = smem + ((2 * pyl) * 17 + 2 * pxl) * CT_RS + (cbl * 32 + oct4 * 8) * 2;
     i16x8 m = {0, 0, 0, 0, 0, 0, 0, 0};    // = ReLU: positive bf16 patterns order like signed 16-bit integers, negative ones stay below 0
-    i16x8 code = {15, 15, 15, 15, 15, 15, 15, 15};
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         const i16x8 v = *(const i16x8*)(src + (dy * 17 + dx) * CT_RS);
-        if (ARGMAX) {   // packed: (m - v) saturating, sign-extended = all ones where v > m (strict: the first maximum stays)
-          const i16x8 gt = __builtin_elementwise_sub_sat(m, v) >> 15;
-          const short kk = (short)(dy * 3 + dx);
-          const i16x8 kv = {kk, kk, kk, kk, kk, kk, kk, kk};
-          code = (gt & kv) | (~gt & code);
-        }
         m = __builtin_elementwise_max(m, v);
       }
     if (cg < a.Cout) {
       const u32x4 mv = __builtin_bit_cast(u32x4, m);
-      if (ARGMAX) {
-        typedef unsigned char u8x8 __attribute__((ext_vector_type(8)));
-        const size_t offa = ((size_t)(f * CB_out + (cg >> 5)) * PH * PW + (size_t)((py0 + pyl) * PW + px0 + pxl)) * 32 + (cg & 31);
-        *(u8x8*)(a.argmax + offa) = __builtin_convertvector(code, u8x8);
-      }
       float vals[8];
       unpack8(mv, vals);
 #pragma unroll
@@ -213,7 +197,6 @@ extern "C" int vpt_conv_first_launch(const VptConvFirstArgs* a, hipStream_t stre
   }
   long grid = (long)a->frames * (a->H >> 4) * (a->W >> 4) * a->NT;
   if (grid > 2L * num_cu) grid = 2L * num_cu;
-  if (a->argmax) hipLaunchKernelGGL((vpt_conv_first_kernel<true>), dim3((unsigned)grid), dim3(256), 0, stream, *a);
-  else hipLaunchKernelGGL((vpt_conv_first_kernel<false>), dim3((unsigned)grid), dim3(256), 0, stream, *a);
+  hipLaunchKernelGGL(vpt_conv_first_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -29,9 +29,6 @@
 #define IN_OFF CT_BYTES
 #define IN_BYTES 1088
 
-// AM = true: the forward stored the arg-max code of every pooled value (vpt_conv_first_forward_train): steps 1 and 2 -- 30 % and
-// 58 % of the recomputing kernel's time (profiles/r03_experiments.md section 7) -- are replaced by 32 byte loads per thread.
-template <bool AM>
 __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirstBwdArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[CT_BYTES + IN_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index: scalar (slice / pixel arithmetic of step 4 stays off the vector ALU)
@@ -43,12 +40,10 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
   const int CB_out = a.Cout >> 5;
 
   op16x8 wfr[4][2];
-  if (!AM) {
 #pragma unroll
-    for (int cs = 0; cs < 4; ++cs)
+  for (int cs = 0; cs < 4; ++cs)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) wfr[cs][ks] = *((const op16x8*)a.wfrag + ((nt * 4 + cs) * 2 + ks) * 64 + lane);
-  }
+    for (int ks = 0; ks < 2; ++ks) wfr[cs][ks] = *((const op16x8*)a.wfrag + ((nt * 4 + cs) * 2 + ks) * 64 + lane);
 
   const int oc = tid & 127, half = tid >> 7;   // backward role: output channel within the N tile, pooled-pixel half
   const int og = nt * 128 + oc;
@@ -112,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
     };
     uint32_t dreg[4][4];     // this thread's 32 pooled gradients, two bf16 per register (requested after the search)
     // ---- recompute the post-ReLU conv tile (identical to the forward kernel) ----
-    if (!AM && !(VPT_CFB_ABLATE & 16))
+    if (!(VPT_CFB_ABLATE & 16))
     for (int sub = w; sub < 10; sub += 4) {
       const int p = sub * 32 + l31;
       const bool pv = p < 289;
@@ -169,26 +164,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
     uint32_t cpk[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) cpk[k] = 0xffffffffu;
-    if (AM) {
-      if (ovalid) {   // the forward's codes: window position kh * 3 + kw of the first maximum, 15 = no gradient
-        const uint8_t* am = a.argmax + ((size_t)(f * CB_out + (og >> 5)) * PH * PW) * 32 + (og & 31);
-        uint8_t codes[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-          const int pp = half * 32 + k;
-          codes[k] = am[(size_t)((py0 + (pp >> 3)) * PW + px0 + (pp & 7)) * 32];
-        }
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-          const int pp = half * 32 + k;
-          const int pyl = pp >> 3, pxl = pp & 7;
-          const uint32_t c = codes[k];
-          const uint32_t kh = (c >= 6u) ? 2u : ((c >= 3u) ? 1u : 0u);
-          const uint32_t cpos = (c > 8u) ? 0xffffu : (uint32_t)((2 * pyl) * 17 + 2 * pxl) + kh * 17u + (c - 3u * kh);
-          cpk[k >> 1] = (k & 1) ? ((cpk[k >> 1] & 0x0000ffffu) | (cpos << 16)) : ((cpk[k >> 1] & 0xffff0000u) | cpos);
-        }
-      }
-    } else if (ovalid && !(VPT_CFB_ABLATE & 1)) {
+    if (ovalid && !(VPT_CFB_ABLATE & 1)) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -347,7 +323,6 @@ extern "C" int vpt_conv_first_bwd_launch(const VptConvFirstBwdArgs* a, hipStream
   const long tiles = (long)a->frames * (a->H >> 4) * (a->W >> 4);
   long gx = (long)num_cu * 2;
   if (tiles < gx) gx = tiles;
-  if (a->argmax) hipLaunchKernelGGL((vpt_conv_first_bwd_kernel<true>), dim3((unsigned)gx, (a->Cout + 127) / 128), dim3(256), 0, stream, *a);
-  else hipLaunchKernelGGL((vpt_conv_first_bwd_kernel<false>), dim3((unsigned)gx, (a->Cout + 127) / 128), dim3(256), 0, stream, *a);
+  hipLaunchKernelGGL(vpt_conv_first_bwd_kernel, dim3((unsigned)gx, (a->Cout + 127) / 128), dim3(256), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -46,7 +46,6 @@ struct VptConvFirstArgs {
   vpt_op16* y;             // pooled output [F][Cout/32][H/2][W/2][32]
   double* stats_out;       // [F][2]
   int frames, H, W, Cout, NT;
-  uint8_t* argmax;         // optional (training) [F][Cout/32][H/2][W/2][32]: window position kh*3+kw of the first maximum, 15 = the window's maximum is 0
 };
 
 struct VptConv3dArgs {
@@ -191,7 +190,6 @@ struct VptConvFirstBwdArgs {
   float* dw;               // [Cout][27] in (kh, kw, ch) order, accumulated
   float* db;               // [Cout] accumulated
   int frames, H, W, Cout;
-  const uint8_t* argmax;   // optional: the forward's arg-max codes (vpt_conv_first_forward_train); null = recompute the pre-pool tile and search
 };
 
 struct VptConvWgradArgs {

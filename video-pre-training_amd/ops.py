@@ -158,20 +158,14 @@ def chw_to_blocked(x, c, h, w):
     return out
 
 
-def conv_first(img_u8, wfrag, cout, stats_out=None, want_argmax=False):
-    """img_u8 [F,H,W,3] uint8 -> pooled blocked bf16 [F, cout/32, H/2, W/2, 32]; with want_argmax (training) -> (pooled, argmax uint8 of
-    the same shape: the winning window position of every pooled value, for conv_first_backward)."""
+def conv_first(img_u8, wfrag, cout, stats_out=None):
+    """img_u8 [F,H,W,3] uint8 -> pooled blocked bf16 [F, cout/32, H/2, W/2, 32]."""
     _chk(img_u8, torch.uint8, "img"); _chk(wfrag, OP16, "wfrag"); _chk(stats_out, torch.float64, "stats_out")
     f, h, w, _ = img_u8.shape
     dt, fmt = _fmt(wfrag)
     y = torch.empty(f, cout // 32, h // 2, w // 2, 32, dtype=dt, device=img_u8.device)
-    meta = dict(flops=2.0 * f * h * w * cout * 27, bytes=f * (h * w * 3 + h * w * cout // 2))
-    if not want_argmax:
-        _call("vpt_conv_first_forward", meta, ptr(img_u8), ptr(wfrag), ptr(y), ptr(stats_out), f, h, w, cout, _stream(), fmt=fmt)
-        return y
-    am = torch.empty(f, cout // 32, h // 2, w // 2, 32, dtype=torch.uint8, device=img_u8.device)
-    _call("vpt_conv_first_forward_train", meta, ptr(img_u8), ptr(wfrag), ptr(y), ptr(stats_out), ptr(am), f, h, w, cout, _stream(), fmt=fmt, label="vpt_conv_first_forward")
-    return y, am
+    _call("vpt_conv_first_forward", dict(flops=2.0 * f * h * w * cout * 27, bytes=f * (h * w * 3 + h * w * cout // 2)), ptr(img_u8), ptr(wfrag), ptr(y), ptr(stats_out), f, h, w, cout, _stream(), fmt=fmt)
+    return y
 
 
 CONV_TILING = {"auto": 0, "throughput": 1, "latency": 2}
@@ -575,24 +569,17 @@ def conv3x3_wgrad(dacc, x, out=None):
     return dw
 
 
-def conv_first_backward(img_u8, wfrag, dpooled, cout, out=None, argmax=None):
+def conv_first_backward(img_u8, wfrag, dpooled, cout, out=None):
     """-> (dW fp32 [cout, 27] in (kh, kw, ch) tap order, db fp32 [cout]); accumulated into out=(dW, db) when given.
-    conv_first_grad_to_reference() maps dW to the reference's [cout, 3, 3, 3] (o, ch, kh, kw).
-    argmax: the codes of conv_first(..., want_argmax=True) -- no recompute / search in the kernel; None = recompute."""
-    _chk(img_u8, torch.uint8, "img"); _chk(wfrag, OP16, "wfrag"); _chk(dpooled, OP16, "dpooled"); _chk(argmax, torch.uint8, "argmax")
-    if argmax is not None and tuple(argmax.shape) != tuple(dpooled.shape):
-        raise ValueError(f"conv_first_backward: argmax {tuple(argmax.shape)} must be shaped like dpooled {tuple(dpooled.shape)}")
+    conv_first_grad_to_reference() maps dW to the reference's [cout, 3, 3, 3] (o, ch, kh, kw)."""
+    _chk(img_u8, torch.uint8, "img"); _chk(wfrag, OP16, "wfrag"); _chk(dpooled, OP16, "dpooled")
     f, h, w, _ = img_u8.shape
     if out is None:
         out = (torch.zeros(cout, 27, dtype=torch.float32, device=img_u8.device), torch.zeros(cout, dtype=torch.float32, device=img_u8.device))
     dw, db = out
     _chk(dw, torch.float32, "dw"); _chk(db, torch.float32, "db")
-    if argmax is None:
-        _call("vpt_conv_first_backward", dict(flops=2.0 * f * (h // 2) * (w // 2) * cout * 27), ptr(img_u8), ptr(wfrag), ptr(dpooled), ptr(dw), ptr(db),
-              f, h, w, cout, _stream(), fmt=_fmt(wfrag, dpooled)[1])
-    else:
-        _call("vpt_conv_first_backward_argmax", dict(flops=2.0 * f * (h // 2) * (w // 2) * cout * 27), ptr(img_u8), ptr(wfrag), ptr(dpooled), ptr(argmax), ptr(dw), ptr(db),
-              f, h, w, cout, _stream(), fmt=_fmt(wfrag, dpooled)[1], label="vpt_conv_first_backward")
+    _call("vpt_conv_first_backward", dict(flops=2.0 * f * (h // 2) * (w // 2) * cout * 27), ptr(img_u8), ptr(wfrag), ptr(dpooled), ptr(dw), ptr(db),
+          f, h, w, cout, _stream(), fmt=_fmt(wfrag, dpooled)[1])
     return dw, db
 
 

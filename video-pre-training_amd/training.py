@@ -407,7 +407,7 @@ class BCTrainer:
             rec = dict(x_prev=x, s_prev=s_x)
             s_pool = nxt()
             if s == 0:
-                pooled, rec["argmax"] = ops.conv_first(img, w[p + "firstconv"], c, stats_out=s_pool, want_argmax=True)
+                pooled = ops.conv_first(img, w[p + "firstconv"], c, stats_out=s_pool)
             else:
                 wpk, sa, sg = w[p + "firstconv"]
                 rec["pre"] = ops.conv3x3(x, wpk, sa, sg, s_x, c)
@@ -503,7 +503,7 @@ class BCTrainer:
             dpooled = ops.frame_affine_backward(rec["pooled"], dx, w[p + "n.g"], rec["s_pool"], dgn, dbn)
             if s == 0:
                 c = cfg["chans"][0]
-                acc["first"] = ops.conv_first_backward(sv["img"], w[p + "firstconv"], dpooled, c, out=acc.get("first"), argmax=rec["argmax"])
+                acc["first"] = ops.conv_first_backward(sv["img"], w[p + "firstconv"], dpooled, c, out=acc.get("first"))
             else:
                 dx = self._conv_layer_backward(p + "firstconv", acc, None, rec["pre"], None, rec["x_prev"], rec["s_prev"], None,
                                                pool=(dpooled, rec["argmax"]))
