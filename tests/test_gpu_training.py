@@ -486,9 +486,15 @@ def test_bc_gradients_independent_of_cnn_chunking(trainer_1x):
             continue
         e = _l2(g2[k].float().cpu(), v.float().cpu())
         worst = max(worst, e)
-        # (the first conv's dW / db are heavily cancelling sums over every pixel of the batch, flushed by fp32 atomics whose order follows
-        # the persistent workgroups' tile ranges: measured 1.2e-4 in fp16, 5e-5 in bf16)
-        assert e < (3e-4 if k.startswith("net.img_process.cnn.stacks.0.firstconv.layer.") else 1e-4), (k, e)
+        # bf16: chunked == unchunked to the order of fp32 additions (5e-7; 7e-5 on the heavily cancelling sums of the stack-0 tensors when
+        # three chunks accumulate into ONE buffer).  fp16: two runs of the SAME configuration already differ by ~1e-4 on the stack-0
+        # tensors (tools/diag_chunking.py).  Not a race: the bias-like gradients there are sums of ~1e5 signed 16-bit values that cancel
+        # to ~1e-3 of their absolute mass, accumulated by fp32 atomics in arrival order.  Values with bf16's 8 significant bits add
+        # EXACTLY in fp32 over that range (8 + ~9 bits of growth + the values' spread < 24), so the order is immaterial (5e-7);
+        # fp16's 11 bits do not, and the order-dependent fp32 rounding (1e-7) is seen through the 1000x cancellation.  Chunking adds
+        # nothing on top of that run-to-run figure, which is what this bound states.
+        stack0 = k.startswith("net.img_process.cnn.stacks.0.")
+        assert e < ((5e-4 if stack0 else 1e-4) if pol.precision == "fp16" else (3e-4 if k.startswith("net.img_process.cnn.stacks.0.firstconv.layer.") else 1e-4)), (k, e)
     print(f"PARITY BC gradients, 3 CNN chunks vs 1: worst rel-L2 {worst:.2e}")
 
 
