@@ -636,3 +636,35 @@ def test_autograd_boundary_with_logit_mask():
     gref, = torch.autograd.grad(loss_ref, [leaves["pi_head.buttons.linear_layer.bias"]])
     assert abs(float(loss) - float(loss_ref)) < 2e-2
     assert _l2(gb, gref) < 5e-2, _l2(gb, gref)
+
+
+def test_fp16_loss_scale_overflow_skips_the_step_on_the_device():
+    """precision="fp16": a loss scale far beyond IEEE half's range makes the 16-bit gradient buffers overflow; vpt_grads_nonfinite_multi
+    must flag it, the Adam launch must leave EVERY tensor (weights and moments) untouched, the step count must not advance and the scale
+    must halve -- then, at a sane scale, the same trainer trains.  (What torch.cuda.amp.GradScaler does for an fp16 run of
+    behavioural_cloning.py:117-122; the skip decision never leaves the device.)"""
+    pk = O.policy_kwargs_for("1x")
+    cfg = O.config_from_policy_kwargs(pk, dict(temperature=2.0))
+    sd = O.synthetic_state_dict(cfg, seed=0)
+    pol = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0), precision="fp16")
+    pol.load_state_dict(sd, strict=False)
+    pol = pol.to(DEV)
+    g = torch.Generator().manual_seed(61)
+    b, t = 2, 3
+    img = torch.randint(0, 256, (b, t, 128, 128, 3), generator=g, dtype=torch.uint8).to(DEV)
+    first = torch.zeros(b, t, dtype=torch.bool, device=DEV)
+    ab, ac = torch.randint(0, 8641, (b, t), generator=g).to(DEV), torch.randint(0, 121, (b, t), generator=g).to(DEV)
+    tr = BCTrainer(pol, lr=1e-4, weight_decay=0.0, loss_scale=2.0 ** 30)
+    before = {k: v.detach().clone() for k, v in pol.named_parameters()}
+    loss, _ = tr.step(img, first, pol.initial_state(b), ab, ac)
+    torch.cuda.synchronize()
+    assert tr.skipped_steps == 1 and tr.step_count == 0 and tr.loss_scale == 2.0 ** 29
+    assert abs(loss - 13.8) < 0.5                                                   # the forward (and the reported loss) are unaffected
+    assert all(torch.equal(v.detach(), before[k]) for k, v in pol.named_parameters())
+    assert all(float(m.abs().max()) == 0.0 for m in tr.m.values()) and all(float(v.abs().max()) == 0.0 for v in tr.v.values())
+    tr.loss_scale = 256.0
+    losses = [tr.step(img, first, pol.initial_state(b), ab, ac)[0] for _ in range(4)]
+    torch.cuda.synchronize()
+    assert tr.skipped_steps == 1 and tr.step_count == 4 and losses[-1] < losses[0] - 0.1
+    moved = sum(int(not torch.equal(v.detach(), before[k])) for k, v in pol.named_parameters() if k in tr.m)
+    assert moved == len(tr.m)
