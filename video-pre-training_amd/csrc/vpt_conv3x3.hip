@@ -542,17 +542,18 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
 // Small-batch (acting path, agent.py:190-206: B = 1 .. 8 frames) instantiation: the SAME convolution, layouts and arithmetic, tiled
 // for LATENCY.  One frame of the 2x model gives the throughput kernel above 16 / 8 / 2 workgroups per layer, each walking the whole
 // K = 1152 ... 2304 chain alone (26-28 us per launch on 2-32 of 256 CUs: profiles/r02_t1_step_kernel_stats.csv).  Here a workgroup
-// takes 16 x 16 pixels x 32 output channels (4x the workgroups, a quarter of the serial MFMA chain each: 36 MFMAs per wave and
-// channel block), wave w = pixel rows 4w .. 4w+3 = two 2 x 16-pixel subtiles.  Halo and the 18 KB weight slice of a channel block
+// takes 16 x 16 pixels x 32 output channels (4x the workgroups) with EIGHT waves -- wave w = pixel rows 2w, 2w+1 = one 2 x 16-pixel
+// subtile, 18 MFMAs per wave and channel block: an eighth of the throughput kernel's serial chain, and two waves per SIMD to hide
+// each other's LDS round trips.  Halo and the 18 KB weight slice of a channel block
 // are double-buffered in LDS (one workgroup per CU is plenty), one barrier per channel block, plain epilogue.  Same K order
 // (channel block, kernel row, kernel column, 16-channel half) as the throughput kernel.
 #define S_W_BYTES (9 * 32 * 64)                       // 18432: 9 taps x 32 couts x 32 cin
 #define S_NBUF 3                                      // stages in LDS: the loads of channel block cb + 2 are in flight while cb computes
 #define S_KK_OFF (S_NBUF * (A_BYTES + S_W_BYTES))     // 133056
-#define S_BYTES (S_KK_OFF + 9 * 32 * 4 + 32)
+#define S_BYTES (S_KK_OFF + 9 * 32 * 4 + 64)
 
 template <bool HAS_RES>
-__global__ __launch_bounds__(256, 1) void vpt_conv3x3_small_kernel(VptConv3x3Args a) {
+__global__ __launch_bounds__(512, 1) void vpt_conv3x3_small_kernel(VptConv3x3Args a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[S_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -569,12 +570,12 @@ __global__ __launch_bounds__(256, 1) void vpt_conv3x3_small_kernel(VptConv3x3Arg
   const int NCB = a.Cin >> 5;
   const int HW = a.H * a.W;
 
-  int a_loff[6];
-  unsigned a_gbyte[6];
+  int a_loff[3];
+  unsigned a_gbyte[3];
   unsigned a_inside = 0;
 #pragma unroll
-  for (int m = 0; m < 6; ++m) {
-    const int q = tid + 256 * m;
+  for (int m = 0; m < 3; ++m) {
+    const int q = tid + 512 * m;
     const int P = ((q >> 5) << 3) + (q & 7), part = (q >> 3) & 3;
     a_loff[m] = -1;
     a_gbyte[m] = 0u;
@@ -589,31 +590,31 @@ __global__ __launch_bounds__(256, 1) void vpt_conv3x3_small_kernel(VptConv3x3Arg
     }
   }
   const op16_t* xplane = a.x + (size_t)f * NCB * HW * 32;
-  // weight slice of one channel block: 18 pieces of 1 KB (tap, 16-row half); wave w moves pieces w, w + 4, ... (5 for waves 0 / 1,
-  // 4 for waves 2 / 3).  A stage = those pieces by LDS-DMA + the halo's six 16-byte loads per lane into one of two register sets.
+  // weight slice of one channel block: 18 pieces of 1 KB (tap, 16-row half); wave w moves pieces w, w + 8, w + 16 (3 for waves 0 / 1,
+  // 2 for the others).  A stage = those pieces by LDS-DMA + the halo's three 16-byte loads per lane into one of two register sets.
   const op16_t* wbase = a.wpk + (size_t)nt * NCB * 9 * 4096 + (size_t)(qo * 32) * 32 + (size_t)lane * 8;
-  u32x4 areg[2][6];
+  u32x4 areg[2][3];
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
   unsigned char* const wlds = smem + S_NBUF * A_BYTES;
 #define S_ISSUE(cb_, SET_)                                                                                \
   do {                                                                                                    \
     unsigned char* wd_ = wlds + ((cb_) % S_NBUF) * S_W_BYTES;                                             \
-    _Pragma("unroll") for (int p_ = w; p_ < 18; p_ += 4)                                                  \
+    _Pragma("unroll") for (int p_ = w; p_ < 18; p_ += 8)                                                  \
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase + ((size_t)(cb_) * 9 + (p_ >> 1)) * 4096 + (p_ & 1) * 512), \
                                        (__attribute__((address_space(3))) void*)(wd_ + (p_ >> 1) * 2048 + (p_ & 1) * 1024), 16, 0, 0); \
-    _Pragma("unroll") for (int m_ = 0; m_ < 6; ++m_)                                                      \
+    _Pragma("unroll") for (int m_ = 0; m_ < 3; ++m_)                                                      \
       areg[SET_][m_] = *(const u32x4*)((const char*)xplane + ((size_t)(cb_) * HW * 64 + a_gbyte[m_]));    \
   } while (0)
 #define S_WRITE_A(cb_, SET_)                                                                              \
-  _Pragma("unroll") for (int m_ = 0; m_ < 6; ++m_)                                                        \
+  _Pragma("unroll") for (int m_ = 0; m_ < 3; ++m_)                                                        \
     if (a_loff[m_] >= 0) *(u32x4*)(smem + ((cb_) % S_NBUF) * A_BYTES + a_loff[m_]) = ((a_inside >> m_) & 1u) ? areg[SET_][m_] : zero4
   // counted wait: everything up to and including stage `older` has landed, the stage issued after it (if any) stays in flight.
-  // Loads retire in issue order; a stage is 11 vector-memory instructions for waves 0 / 1 and 10 for waves 2 / 3.
+  // Loads retire in issue order; a stage is 6 vector-memory instructions for waves 0 / 1 and 5 for the others.
 #define S_WAIT_OLDER(YOUNGER_ISSUED)                                                                      \
   do {                                                                                                    \
     if (!(YOUNGER_ISSUED)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               \
-    else if (w < 2) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");                                     \
-    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                                \
+    else if (w < 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                      \
+    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                                                 \
   } while (0)
 
   S_ISSUE(0, 0);
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(256, 1) void vpt_conv3x3_small_kernel(VptConv3x3Arg
   frame_mean_rstd(a.stats_in, f, a.inv_count_in, mean, rstd);
   {
     float* kk = (float*)(smem + S_KK_OFF);
-    for (int idx = tid; idx < 9 * 32; idx += 256) {
+    for (int idx = tid; idx < 9 * 32; idx += 512) {
       const int o = (idx >> 5) * a.CoutPad + cbo * 32 + (idx & 31);
       kk[idx] = a.edge_sa[o] - rstd * mean * a.edge_sg[o];
     }
@@ -632,44 +633,40 @@ __global__ __launch_bounds__(256, 1) void vpt_conv3x3_small_kernel(VptConv3x3Arg
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
 
-  f32x16 acc[2];
+  f32x16 acc;
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int bsw = (l31 >> 2) & 3;
   // iteration cb: issue stage cb + 2 (its halo into the register set stage cb used), compute stage cb, then move the halo of stage
   // cb + 1 -- issued one iteration EARLIER, so it has had two compute phases to land; the counted wait leaves stage cb + 2 in flight
   // -- from its registers into LDS for the next iteration.  One barrier per channel block.
-  op16x8 sfb[3], sfa[3][2];
+  op16x8 sfb[3], sfa[3];
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define S_LOADG(g__)                                                                                      \
   do {                                                                                                    \
     const int gg_ = (g__);   /* a constant after unrolling: the register-set index gg_ % 3 must fold */ \
     const int tap_ = gg_ >> 1, ks_ = gg_ & 1, dy_ = tap_ / 3, dx_ = tap_ - 3 * dy_;                       \
     sfb[gg_ % 3] = *(const op16x8*)(bL + tap_ * 2048 + (((2 * ks_ + hi) ^ bsw) << 4));                    \
-    sfa[gg_ % 3][0] = *(const op16x8*)(aL + (dy_ * 18 + dx_) * A_RS + ks_ * 32);                          \
-    sfa[gg_ % 3][1] = *(const op16x8*)(aL + (dy_ * 18 + dx_) * A_RS + (2 * 18 * A_RS) + ks_ * 32);        \
+    sfa[gg_ % 3] = *(const op16x8*)(aL + (dy_ * 18 + dx_) * A_RS + ks_ * 32);                             \
   } while (0)
 #define S_ITER(cb_, SET_)                                                                                 \
   do {                                                                                                    \
     const bool more_ = (cb_) + 2 < NCB;                                                                   \
     if (more_) S_ISSUE((cb_) + 2, SET_);                                                                  \
-    const unsigned char* aL = smem + ((cb_) % S_NBUF) * A_BYTES + ((w * 4 + sub_row(l31)) * 18 + (l31 & 15)) * A_RS + hi * 16; \
+    const unsigned char* aL = smem + ((cb_) % S_NBUF) * A_BYTES + ((w * 2 + sub_row(l31)) * 18 + (l31 & 15)) * A_RS + hi * 16; \
     const unsigned char* bL = wlds + ((cb_) % S_NBUF) * S_W_BYTES + l31 * 64;                             \
-    /* 18 groups (kernel row, kernel column, 16-channel half) of one weight fragment, two pixel fragments, two MFMAs.  One wave \
-       per SIMD and nobody to hide an LDS round trip behind: the fragments of group g + 2 are requested before the MFMAs of group \
-       g issue (three register sets, order pinned; left alone the compiler reads each group right before its use and waits). */ \
+    /* 18 groups (kernel row, kernel column, 16-channel half) of one weight fragment, one pixel fragment, one MFMA: the fragments \
+       of group g + 2 are requested before the MFMA of group g issues (three register sets, order pinned; left alone the compiler \
+       reads each group right before its use and waits for it). */ \
     S_LOADG(0); S_LOADG(1); SB();                                                                         \
     _Pragma("unroll") for (int g_ = 0; g_ < 18; ++g_) {                                                   \
       if (g_ + 2 < 18) { S_LOADG(g_ + 2); }                                                               \
-      /* LDS reads return in order: group g_ has landed once at most the 3 (2) younger groups' reads are outstanding */ \
-      if (g_ < 16) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");                                     \
-      else if (g_ == 16) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");                               \
+      /* LDS reads return in order: group g_ has landed once at most the two younger groups' four reads are outstanding */ \
+      if (g_ < 16) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                     \
+      else if (g_ == 16) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");                               \
       else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
       SB();                                                                                               \
-      acc[0] = VPT_MFMA_32X32X16(sfb[g_ % 3], sfa[g_ % 3][0], acc[0], 0, 0, 0);                           \
-      acc[1] = VPT_MFMA_32X32X16(sfb[g_ % 3], sfa[g_ % 3][1], acc[1], 0, 0, 0);                           \
+      acc = VPT_MFMA_32X32X16(sfb[g_ % 3], sfa[g_ % 3], acc, 0, 0, 0);                                    \
       SB();                                                                                               \
     }                                                                                                     \
     if ((cb_) + 1 < NCB) {                                                                                \
@@ -695,24 +692,27 @@ __global__ __launch_bounds__(256, 1) void vpt_conv3x3_small_kernel(VptConv3x3Arg
   const float* kk = (const float*)(smem + S_KK_OFF);
   float s_sum = 0.f, s_sq = 0.f;
   const size_t obase = (size_t)(f * CB_out + cbo) * HW * 32;
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int y = ty0 + w * 4 + 2 * m + sub_row(l31);
+  {
+    const int y = ty0 + w * 2 + sub_row(l31);
     const int x = tx0 + (l31 & 15);
     const int ey = (y == 0) ? 0 : ((y == a.H - 1) ? 2 : 1);
     const int ex = (x == 0) ? 0 : ((x == a.W - 1) ? 2 : 1);
     const float* ke = kk + (ey * 3 + ex) * 32 + 4 * hi;
     const size_t poff = obase + (size_t)(y * a.W + x) * 32 + 4 * hi;
+    u32x2 r2[4];
+    if (HAS_RES) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) r2[g] = *(const u32x2*)(a.res + poff + 8 * g);
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const f32x4 k4 = *(const f32x4*)(ke + 8 * g);
       float v[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(rstd, acc[m][4 * g + j], k4[j]), 0.f);
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(rstd, acc[4 * g + j], k4[j]), 0.f);
       if (HAS_RES) {
-        const u32x2 r2 = *(const u32x2*)(a.res + poff + 8 * g);
-        v[0] += op16_lo_to_f32(r2.x); v[1] += op16_hi_to_f32(r2.x);
-        v[2] += op16_lo_to_f32(r2.y); v[3] += op16_hi_to_f32(r2.y);
+        v[0] += op16_lo_to_f32(r2[g].x); v[1] += op16_hi_to_f32(r2[g].x);
+        v[2] += op16_lo_to_f32(r2[g].y); v[3] += op16_hi_to_f32(r2[g].y);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) { s_sum += v[j]; s_sq = fmaf(v[j], v[j], s_sq); }
@@ -724,11 +724,11 @@ __global__ __launch_bounds__(256, 1) void vpt_conv3x3_small_kernel(VptConv3x3Arg
     float* red = (float*)(smem + S_KK_OFF + 9 * 32 * 4);
     s_sum = wave_sum(s_sum);
     s_sq = wave_sum(s_sq);
-    if (lane == 0) { red[w] = s_sum; red[4 + w] = s_sq; }
+    if (lane == 0) { red[w] = s_sum; red[8 + w] = s_sq; }
     __syncthreads();
     if (tid == 0) {
-      atomicAdd(a.stats_out + 2 * f, (double)((red[0] + red[1]) + (red[2] + red[3])));
-      atomicAdd(a.stats_out + 2 * f + 1, (double)((red[4] + red[5]) + (red[6] + red[7])));
+      atomicAdd(a.stats_out + 2 * f, (double)(((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]))));
+      atomicAdd(a.stats_out + 2 * f + 1, (double)(((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]))));
     }
   }
 }
@@ -764,8 +764,8 @@ extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream
   // fewer workgroups than CUs (a handful of frames: the acting path): the latency tiling, 32 output channels per workgroup
   if (!a->bwd && !a->trace && (a->tiling == 2 || (a->tiling == 0 && grid < VPT_CONV_SMALL_GRID))) {
     const long sgrid = (long)a->frames * (a->H >> 4) * (a->W >> 4) * (a->Cout >> 5);
-    if (a->res) hipLaunchKernelGGL((vpt_conv3x3_small_kernel<true>), dim3((unsigned)sgrid), dim3(256), 0, stream, *a);
-    else hipLaunchKernelGGL((vpt_conv3x3_small_kernel<false>), dim3((unsigned)sgrid), dim3(256), 0, stream, *a);
+    if (a->res) hipLaunchKernelGGL((vpt_conv3x3_small_kernel<true>), dim3((unsigned)sgrid), dim3(512), 0, stream, *a);
+    else hipLaunchKernelGGL((vpt_conv3x3_small_kernel<false>), dim3((unsigned)sgrid), dim3(512), 0, stream, *a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
   }
 #define LAUNCH_(T_, M_) hipLaunchKernelGGL((vpt_conv3x3_kernel<T_, M_>), dim3((unsigned)grid), dim3(256), extra_lds, stream, *a)
