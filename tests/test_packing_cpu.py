@@ -54,14 +54,16 @@ def test_conv_first_pack():
     b = 0.1 * torch.randn(cout, generator=g)
     frag = packing.pack_conv_first(W, b)
     assert frag.shape == (1, 4, 2, 64, 8)
-    # undo the fragment order: lane -> (row = l&31, k-half = l>>5)
+    # undo the fragment order: lane -> (row = l&31, slot half = l>>5), slot -> k through packing.CONV_FIRST_SLOT_K
     wk = torch.zeros(128, 32)
+    assert sorted(packing.CONV_FIRST_SLOT_K) == list(range(32))
     for cs in range(4):
         for ks in range(2):
             for lane in range(64):
                 o = cs * 32 + (lane & 31)
-                k0 = ks * 16 + (lane >> 5) * 8
-                wk[o, k0:k0 + 8] = frag[0, cs, ks, lane].float()
+                s0 = ks * 16 + (lane >> 5) * 8
+                for e in range(8):
+                    wk[o, packing.CONV_FIRST_SLOT_K[s0 + e]] = frag[0, cs, ks, lane, e].float()
     assert wk[cout:].abs().max() == 0
     img = torch.randint(0, 256, (1, 8, 8, 3), generator=g, dtype=torch.uint8)
     # emulate: acc = sum_k wk[o,k] * pix[k] with wk = W / 255 and pix the raw bytes, pix[27] = pix[28] = 1 (bias hi / lo), then relu

@@ -7,8 +7,9 @@
 //
 // Formulation: K = 27 (+2 bias slots) padded to 32 -> two MFMA 32x32x16 k-steps with SWAPPED operands:
 // the weights are the MFMA A operand (rows = output channels, resident in registers for the whole
-// workgroup), the pixels are the B operand (built on the fly from the uint8 tile in LDS; 0..255 are exact
-// in bf16; the 1/255 is folded into the packed weights).  With the swap each lane ends up holding 4 consecutive
+// workgroup), the pixels are the B operand: the input tile is converted ONCE to 16-bit operands in LDS (0..255 are
+// exact in bf16 and fp16; the 1/255 is folded into the packed weights) and the K slots are ordered so that a lane's
+// fragment is one 16-byte LDS read (vpt_conv_first_tile.h).  With the swap each lane ends up holding 4 consecutive
 // output channels of one pixel, so the conv tile is written to LDS with packed 8-byte stores, and the
 // pool is a packed signed-16-bit max over the raw bf16 bit patterns starting from 0, which is max-pool and
 // ReLU in one (positive bf16 patterns order like integers; negative ones are negative integers).
@@ -16,32 +17,22 @@
 // One workgroup = 8x8 pooled pixels (17x17 conv pixels, 19x19 input pixels) x 128 output channels.
 #include "vpt_common.h"
 #include "vpt_kernels.h"
-
-#define CT_RS 272
-#define CT_BYTES (289 * CT_RS)  // 78608
-#define IN_OFF CT_BYTES
-#define IN_BYTES 1088
+#include "vpt_conv_first_tile.h"
 
 typedef short i16x8 __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[CT_BYTES + IN_BYTES];
-  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5, l31 = lane & 31;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[CF_SMEM_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
   const int PH = a.H >> 1, PW = a.W >> 1;
   const int tilesX = PW >> 3, tilesY = PH >> 3;
   const long T = (long)a.frames * tilesY * tilesX * a.NT;
-  unsigned char* in = smem + IN_OFF;
   const int CB_out = a.Cout >> 5;
 
   // persistent workgroups (2 per CU): the next tile's 19 x 19 x 3 input bytes are fetched into registers while the
   // current tile computes, so the global-load latency is off the per-tile critical path
   unsigned char nxt[5];
-  auto fetch = [&](long tile) {
-    long L = tile / a.NT;
-    const int tx = (int)(L % tilesX); L /= tilesX;
-    const int ty = (int)(L % tilesY);
-    const int f = (int)(L / tilesY);
+  auto fetch = [&](int f, int ty, int tx) {
     const int iy0 = 2 * (ty * 8) - 2, ix0 = 2 * (tx * 8) - 2;
     const uint8_t* img = a.img + (size_t)f * a.H * a.W * 3;
 #pragma unroll
@@ -50,7 +41,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
       const int r = idx / 57, rem = idx - r * 57;
       const int y = iy0 + r, x = ix0 + rem / 3;
       const bool ok = idx < 19 * 57 && y >= 0 && y < a.H && x >= 0 && x < a.W;
-      const unsigned char v = img[ok ? ((long)y * a.W + ix0) * 3 + rem : 0];
+      const unsigned char v = img[ok ? (y * a.W + ix0) * 3 + rem : 0];
       nxt[m] = ok ? v : (unsigned char)0;
     }
   };
@@ -58,22 +49,31 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
   // summed in registers and flushed with one atomic pair per (workgroup, frame)
   const long per = (T + gridDim.x - 1) / gridDim.x;
   const long t_begin = blockIdx.x * per, t_end = min(t_begin + per, T);
-  if (t_begin < t_end) fetch(t_begin);
+  // tile coordinates (frame, tile row, tile column, channel tile) are decoded once and then counted up: the 64-bit
+  // divisions of a per-tile decode were ~1000 scalar instructions per tile
+  int nt, tx, ty, f;
+  {
+    long L = t_begin;
+    nt = (int)(L % a.NT); L /= a.NT;
+    tx = (int)(L % tilesX); L /= tilesX;
+    ty = (int)(L % tilesY);
+    f = (int)(L / tilesY);
+  }
+  int nnt = nt, ntx = tx, nty = ty, nf = f;   // the tile after the current one
+  auto advance = [&]() {
+    if (++nnt == a.NT) { nnt = 0; if (++ntx == tilesX) { ntx = 0; if (++nty == tilesY) { nty = 0; ++nf; } } }
+  };
+  if (t_begin < t_end) fetch(f, ty, tx);
   // (per tile the sums are fp32 in a fixed order; ACROSS tiles they are added in fp64, so a frame's statistics do not
   // depend on how the tile list happens to be cut into workgroup ranges, i.e. on the batch size)
   int nt_loaded = -1, stat_f = -1;
   double d_sum = 0.0, d_sq = 0.0;
   op16x8 wfr[4][2];
-  for (long tile = t_begin; tile < t_end; ++tile) {
-    long L = tile;
-    const int nt = (int)(L % a.NT); L /= a.NT;
-    const int tx = (int)(L % tilesX); L /= tilesX;
-    const int ty = (int)(L % tilesY);
-    const int f = (int)(L / tilesY);
+  for (long tile = t_begin; tile < t_end; ++tile, nt = nnt, tx = ntx, ty = nty, f = nf) {
     const int py0 = ty * 8, px0 = tx * 8;
-#pragma unroll
-    for (int m = 0; m < 5; ++m)
-      if (tid + 256 * m < 19 * 57) in[tid + 256 * m] = nxt[m];
+    advance();
+    cf_stage_input(smem, nxt, tid);
+    if (tid == 0) *(int*)(smem + CTR_OFF) = 0;
     if (nt != nt_loaded) {   // weight fragments [nt][cs][ks][lane][8] stay in registers across tiles
 #pragma unroll
       for (int cs = 0; cs < 4; ++cs)
@@ -82,61 +82,9 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
       nt_loaded = nt;
     }
     __syncthreads();
-    if (tile + 1 < t_end) fetch(tile + 1);
-
-  for (int sub = w; sub < 10; sub += 4) {
-    const int p = sub * 32 + l31;
-    const bool pv = p < 289;
-    const int pc = pv ? p : 288;
-    const int cr = pc / 17, cc = pc - cr * 17;
-    const int gy = 2 * py0 - 1 + cr, gx = 2 * px0 - 1 + cc;
-    const bool inimg = pv && gy >= 0 && gx >= 0 && gy < a.H && gx < a.W;
-    const unsigned char* ib = in + (cr * 19 + cc) * 3;
-
-    op16x8 pf[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      float h[8];      // the byte as fp32: exact in either 16-bit operand format
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int kA = ks * 16 + e, kB = ks * 16 + 8 + e;     // k for lanes 0-31 / 32-63
-        const int offA = kA + 48 * (kA / 9);                   // byte offset of tap (k/9, (k%9)/3), channel k%3
-        const int offB = (kB < 27) ? (kB + 48 * (kB / 9)) : 0;
-        float v = (float)ib[hi ? offB : offA];
-        if (kB >= 27) v = hi ? ((kB <= 28) ? 1.0f : 0.0f) : v; // bias slots (k = 27, 28) carry 1.0, the rest 0
-        h[e] = v;
-      }
-      u32x4 pk;
-      pk.x = pack_op16x2_exact(h[0], h[1]);
-      pk.y = pack_op16x2_exact(h[2], h[3]);
-      pk.z = pack_op16x2_exact(h[4], h[5]);
-      pk.w = pack_op16x2_exact(h[6], h[7]);
-      pf[ks] = __builtin_bit_cast(op16x8, pk);
-    }
-    f32x16 acc[4];
-#pragma unroll
-    for (int cs = 0; cs < 4; ++cs) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[cs][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) acc[cs] = VPT_MFMA_32X32X16(wfr[cs][ks], pf[ks], acc[cs], 0, 0, 0);
-    }
-    // conv + bias (1/255 is folded into the weights), rounded to bf16 and stored RAW: the ReLU commutes with the
-    // max-pool, so it is applied once per pooled value instead of once per conv value; pixels outside the image -> 0
-    const uint32_t keep = inimg ? 0xffffffffu : 0u;
-    if (pv) {
-      unsigned char* dst = smem + p * CT_RS + hi * 8;
-#pragma unroll
-      for (int cs = 0; cs < 4; ++cs) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          u32x2 pk2 = {pack_op16x2(acc[cs][4 * g + 0], acc[cs][4 * g + 1]) & keep, pack_op16x2(acc[cs][4 * g + 2], acc[cs][4 * g + 3]) & keep};
-          *(u32x2*)(dst + (cs * 32 + g * 8) * 2) = pk2;
-        }
-      }
-    }
-  }
-  __syncthreads();
+    if (tile + 1 < t_end) fetch(nf, nty, ntx);
+    cf_conv_tile(smem, wfr, lane, py0, px0, ty == 0 || tx == 0);
+    __syncthreads();
 
   // ---- 3x3 / stride 2 max-pool over the conv tile, store + statistics ----
   if (a.stats_out && f != stat_f) {
@@ -196,6 +144,7 @@ extern "C" int vpt_conv_first_launch(const VptConvFirstArgs* a, hipStream_t stre
                  ? prop.multiProcessorCount : 256;
   }
   long grid = (long)a->frames * (a->H >> 4) * (a->W >> 4) * a->NT;
+  if ((long)a->frames * a->H * a->W * 3 > 0x7fffffffL) return -2;   // 32-bit pixel offsets inside a launch
   if (grid > 2L * num_cu) grid = 2L * num_cu;
   hipLaunchKernelGGL(vpt_conv_first_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -3;

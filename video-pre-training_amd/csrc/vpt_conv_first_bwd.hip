@@ -24,13 +24,10 @@
 #ifndef VPT_CFB_ABLATE
 #define VPT_CFB_ABLATE 0   // profiling builds: 1 no search, 2 no zero fill, 4 no scatter, 8 no MFMA contraction, 16 no recompute
 #endif
-#define CT_RS 272
-#define CT_BYTES (289 * CT_RS)
-#define IN_OFF CT_BYTES
-#define IN_BYTES 1088
+#include "vpt_conv_first_tile.h"
 
 __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirstBwdArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[CT_BYTES + IN_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[CF_SMEM_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index: scalar (slice / pixel arithmetic of step 4 stays off the vector ALU)
   const int hi = lane >> 5, l31 = lane & 31;
   const int PH = a.H >> 1, PW = a.W >> 1;
@@ -57,16 +54,12 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
   const int g16 = lane >> 4, i16 = lane & 15;
   const int tr_off = (8 * (g16 >> 1) + (i16 >> 2)) * CT_RS + (16 * (g16 & 1) + 4 * (i16 & 3)) * 2;
   const int tap = l31;                                   // B operand row of this lane
-  const int tap_off = min(tap, 26) + 48 * (min(tap, 26) / 9);   // byte offset of tap (kh, kw, ch) inside the 19-pixel-wide input tile (taps >= 27: any valid byte)
-  unsigned char* in = smem + IN_OFF;
+  const int tap_off = min(tap, 26) + 48 * (min(tap, 26) / 9);   // element offset of tap (kh, kw, ch) inside the 19-pixel-wide input tile (taps >= 27: any valid element)
+  const unsigned short* in16 = (const unsigned short*)(smem + IN_OFF);
 
   // next tile's input bytes are fetched into registers while the current tile computes (as in the forward kernel)
   unsigned char nxt[5];
-  auto fetch = [&](long tile) {
-    long L = tile;
-    const int tx = (int)(L % tilesX); L /= tilesX;
-    const int ty = (int)(L % tilesY);
-    const int f = (int)(L / tilesY);
+  auto fetch = [&](int f, int ty, int tx) {
     const int iy0 = 2 * (ty * 8) - 2, ix0 = 2 * (tx * 8) - 2;
     const uint8_t* img = a.img + (size_t)f * a.H * a.W * 3;
 #pragma unroll
@@ -75,25 +68,30 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
       const int r = idx / 57, rem = idx - r * 57;
       const int y = iy0 + r, x = ix0 + rem / 3;
       const bool ok = idx < 19 * 57 && y >= 0 && y < a.H && x >= 0 && x < a.W;
-      const unsigned char v = img[ok ? ((long)y * a.W + ix0) * 3 + rem : 0];
+      const unsigned char v = img[ok ? (y * a.W + ix0) * 3 + rem : 0];
       nxt[m] = ok ? v : (unsigned char)0;
     }
   };
   const long per = (T + gridDim.x - 1) / gridDim.x;
   const long t_begin = blockIdx.x * per, t_end = min(t_begin + per, T);
-  if (t_begin < t_end) fetch(t_begin);
+  // tile coordinates are decoded once and then counted up (no 64-bit divisions per tile)
+  int tx, ty, f;
+  {
+    long L = t_begin;
+    tx = (int)(L % tilesX); L /= tilesX;
+    ty = (int)(L % tilesY);
+    f = (int)(L / tilesY);
+  }
+  int ntx = tx, nty = ty, nf = f;
+  if (t_begin < t_end) fetch(f, ty, tx);
 
-  for (long tile = t_begin; tile < t_end; ++tile) {
-    long L = tile;
-    const int tx = (int)(L % tilesX); L /= tilesX;
-    const int ty = (int)(L % tilesY);
-    const int f = (int)(L / tilesY);
+  for (long tile = t_begin; tile < t_end; ++tile, tx = ntx, ty = nty, f = nf) {
     const int py0 = ty * 8, px0 = tx * 8;
-#pragma unroll
-    for (int m = 0; m < 5; ++m)
-      if (tid + 256 * m < 19 * 57) in[tid + 256 * m] = nxt[m];
+    if (++ntx == tilesX) { ntx = 0; if (++nty == tilesY) { nty = 0; ++nf; } }
+    cf_stage_input(smem, nxt, tid);
+    if (tid == 0) *(int*)(smem + CTR_OFF) = 0;
     __syncthreads();
-    if (tile + 1 < t_end) fetch(tile + 1);
+    if (tile + 1 < t_end) fetch(nf, nty, ntx);
     // this thread's 32 pooled gradients, two bf16 per register, fetched in four groups of 8: group 0 now (its latency
     // hides behind the recompute), group g + 1 while group g is routed
     const unsigned short* dP = (const unsigned short*)a.dpooled + ((size_t)(f * CB_out + ((ovalid ? og : 0) >> 5)) * PH * PW) * 32 + ((ovalid ? og : 0) & 31);
@@ -106,60 +104,9 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
       }
     };
     uint32_t dreg[4][4];     // this thread's 32 pooled gradients, two bf16 per register (requested after the search)
-    // ---- recompute the post-ReLU conv tile (identical to the forward kernel) ----
-    if (!(VPT_CFB_ABLATE & 16))
-    for (int sub = w; sub < 10; sub += 4) {
-      const int p = sub * 32 + l31;
-      const bool pv = p < 289;
-      const int pc = pv ? p : 288;
-      const int cr = pc / 17, cc = pc - cr * 17;
-      const int gy = 2 * py0 - 1 + cr, gx = 2 * px0 - 1 + cc;
-      const bool inimg = pv && gy >= 0 && gx >= 0 && gy < a.H && gx < a.W;
-      const unsigned char* ib = in + (cr * 19 + cc) * 3;
-      op16x8 pf[2];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        float h[8];      // the byte as fp32: exact, so its bf16 is the upper half of the fp32 pattern
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int kA = ks * 16 + e, kB = ks * 16 + 8 + e;     // k for lanes 0-31 / 32-63
-        const int offA = kA + 48 * (kA / 9);                   // byte offset of tap (k/9, (k%9)/3), channel k%3
-        const int offB = (kB < 27) ? (kB + 48 * (kB / 9)) : 0;
-        float v = (float)ib[hi ? offB : offA];
-        if (kB >= 27) v = hi ? ((kB <= 28) ? 1.0f : 0.0f) : v; // bias slots (k = 27, 28) carry 1.0, the rest 0
-        h[e] = v;
-      }
-      u32x4 pk;
-      pk.x = pack_op16x2_exact(h[0], h[1]);
-      pk.y = pack_op16x2_exact(h[2], h[3]);
-      pk.z = pack_op16x2_exact(h[4], h[5]);
-      pk.w = pack_op16x2_exact(h[6], h[7]);
-      pf[ks] = __builtin_bit_cast(op16x8, pk);
-      }
-      f32x16 acc[4];
-#pragma unroll
-      for (int cs = 0; cs < 4; ++cs) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[cs][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) acc[cs] = VPT_MFMA_32X32X16(wfr[cs][ks], pf[ks], acc[cs], 0, 0, 0);
-      }
-      // conv + bias (1/255 is folded into the weights), rounded to bf16 and stored RAW: the ReLU commutes with the
-    // max-pool, so it is applied once per pooled value instead of once per conv value; pixels outside the image -> 0
-    const uint32_t keep = inimg ? 0xffffffffu : 0u;
-    if (pv) {
-      unsigned char* dst = smem + p * CT_RS + hi * 8;
-#pragma unroll
-      for (int cs = 0; cs < 4; ++cs) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          u32x2 pk2 = {pack_op16x2(acc[cs][4 * g + 0], acc[cs][4 * g + 1]) & keep, pack_op16x2(acc[cs][4 * g + 2], acc[cs][4 * g + 3]) & keep};
-          *(u32x2*)(dst + (cs * 32 + g * 8) * 2) = pk2;
-        }
-      }
-    }
-  }
-  __syncthreads();
+    // ---- 1. recompute the conv tile (vpt_conv_first_tile.h: the forward kernel's code) ----
+    if (!(VPT_CFB_ABLATE & 16)) cf_conv_tile(smem, wfr, lane, py0, px0, ty == 0 || tx == 0);
+    __syncthreads();
     // ---- 2. arg-max search: conv pixel (0..288) of every pooled pixel, 0xffff = no gradient (ReLU gate / zero gradient) ----
     uint32_t cpk[16];
 #pragma unroll
@@ -252,23 +199,23 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
     // ---- 4. dW^T += G^T x patches on the matrix cores: wave w takes the 16-pixel slices w, w + 4, ... ----
     if (!(VPT_CFB_ABLATE & 8))
     for (int ks = w; ks < 19; ks += 4) {
-      // B fragment: row = tap, k = conv pixels 16 ks + 8 hi .. + 7.  ks is wave-uniform, so the input-tile byte offset of every
-      // (pixel, hi) pair is scalar arithmetic; per element one select (hi), one byte read (the lane's tap offset is in the base
-      // pointer), one conversion.  Pixels beyond 288 need no masking here: the A side is exactly zero for them and bytes are
+      // B fragment: row = tap, k = conv pixels 16 ks + 8 hi .. + 7.  ks is wave-uniform, so the input-tile offset of every
+      // (pixel, hi) pair is scalar arithmetic; per element one select (hi) and one 16-bit read of the converted input tile (the
+      // lane's tap offset is in the base pointer).  Pixels beyond 288 need no masking here: the A side is exactly zero for them and bytes are
       // finite; taps 28..31 produce columns that are never flushed; tap 27 is the column of ones (db).
       u32x4 pk;
       uint32_t pw[4];
-      const unsigned char* inl = in + tap_off;
+      const unsigned short* inl = in16 + tap_off;
 #pragma unroll
       for (int e2 = 0; e2 < 4; ++e2) {
-        float v2[2];
+        uint32_t v2[2];
 #pragma unroll
         for (int e1 = 0; e1 < 2; ++e1) {
           const int c0 = min(ks * 16 + e2 * 2 + e1, 288), c1 = min(ks * 16 + 8 + e2 * 2 + e1, 288);
           const int o0 = ((c0 / 17) * 19 + (c0 % 17)) * 3, o1 = ((c1 / 17) * 19 + (c1 % 17)) * 3;
-          v2[e1] = (float)inl[hi ? o1 : o0];
+          v2[e1] = inl[hi ? o1 : o0];
         }
-        pw[e2] = pack_op16x2_exact(v2[0], v2[1]);
+        pw[e2] = v2[0] | (v2[1] << 16);
       }
       const uint32_t ones = pack_op16x2_exact(1.0f, 1.0f);
       pk.x = (tap == 27) ? ones : pw[0]; pk.y = (tap == 27) ? ones : pw[1]; pk.z = (tap == 27) ? ones : pw[2]; pk.w = (tap == 27) ? ones : pw[3];
@@ -321,6 +268,7 @@ extern "C" int vpt_conv_first_bwd_launch(const VptConvFirstBwdArgs* a, hipStream
                  ? prop.multiProcessorCount : 256;
   }
   const long tiles = (long)a->frames * (a->H >> 4) * (a->W >> 4);
+  if ((long)a->frames * a->H * a->W * 3 > 0x7fffffffL) return -2;   // 32-bit pixel offsets inside a launch
   long gx = (long)num_cu * 2;
   if (tiles < gx) gx = tiles;
   hipLaunchKernelGGL(vpt_conv_first_bwd_kernel, dim3((unsigned)gx, (a->Cout + 127) / 128), dim3(256), 0, stream, *a);

@@ -38,23 +38,19 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
   const int s_end = min(s_begin + per, nsteps_total);
   if (s_begin >= s_end) return;
 
-  // staging maps: A row (m0 + arow + 32 m), 16-byte part apart; one 32-bit offset + a validity mask instead of eight pointers
+  // staging maps: A row (m0 + arow + 32 m), 16-byte part apart.  Rows beyond M re-read row M - 1 (clamped offset, no branch and
+  // no select in the main loop): an output row depends on its own A row only, and the epilogue never stores rows >= M.
   const int arow = tid >> 3, apart = tid & 7;
   const char* abase = (const char*)(a.A + (size_t)m0 * a.lda);           // wave-uniform
-  const unsigned astride = 32u * (unsigned)a.lda * 2u;                   // bytes between staged rows
-  const unsigned aoff0 = (unsigned)arow * (unsigned)a.lda * 2u + apart * 16u;
-  unsigned avmask = 0;
+  unsigned aoff[8];
 #pragma unroll
-  for (int m = 0; m < 8; ++m) avmask |= (m0 + arow + 32 * m < a.M) ? (1u << m) : 0u;
-  // rows beyond M read row m0 (always valid) and are zeroed
-#define A_LOAD(m_, s_) ((((avmask >> (m_)) & 1u) != 0u) ? *(const u32x4*)(abase + (size_t)(s_) * 128 + (aoff0 + (m_) * astride)) \
-                                                         : zero4)
+  for (int m = 0; m < 8; ++m) aoff[m] = (unsigned)min(arow + 32 * m, a.M - 1 - m0) * (unsigned)a.lda * 2u + apart * 16u;
+#define A_LOAD(m_, s_) (*(const u32x4*)(abase + (size_t)(s_) * 128 + aoff[m_]))
   unsigned char* ast = smem + arow * GA_RS + apart * 16;
   const vpt_op16* wbase = a.wpk + (size_t)nt * (a.K >> 5) * 4096 + tid * 8;
   unsigned char* bst = smem + GA_BYTES + (tid >> 2) * GB_RS + (tid & 3) * 16;
 
   u32x4 areg[8], breg[4];
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
 #pragma unroll
   for (int m = 0; m < 8; ++m) areg[m] = A_LOAD(m, s_begin);
 #pragma unroll

@@ -8,7 +8,8 @@
 //                            image vpt_conv3x3_kernel DMAs) + the edge tables SA / SG [9][NT*128] fp32 of its GroupNorm fold.
 //  vpt_pack_linear_kernel  : nn.Linear weight [N][K] -> [ceil(N/128)][K/32][128][32] (16-bit, rows >= N zero).
 //  vpt_pack_conv_first_kernel : stack-0 firstconv weight [Cout][3][3][3] + bias -> the MFMA A-operand fragments of
-//                            vpt_conv_first_kernel ([NT][4][2][64][8]: W / 255 at k = (kh*3+kw)*3+ch, the bias as hi / lo halves at k = 27 / 28).
+//                            vpt_conv_first_kernel ([NT][4][2][64][8]: W / 255 at k = (kh*3+kw)*3+ch, the bias as hi / lo halves at k = 27 / 28; the 32 K
+//                            slots in the order of vpt_conv_first_tile.h: per kernel row eight contiguous values, the ninth ones + bias last).
 //  vpt_pack_conv3d_t5_kernel : IDM Conv3d weight [O][3][5][1][1] -> fragments [NT][4][64][8] (k = dt*3+ch, k = 15 zero) + padded bias.
 //  vpt_chw_to_blocked_kernel : fp32 [rows][C*H*W] in the reference's C,H,W flatten order (lib/impala_cnn.py:192-193) -> the blocked
 //                            activation order [rows][C/32][H][W][32] (dense-layer weight columns, its LayerNorm gain / bias).
@@ -99,12 +100,14 @@ extern "C" int vpt_pack_linear_launch(const float* w, void* out, int N, int K, i
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-// ---- stack-0 first conv: W[o][ch][kh][kw], bias[o] -> frag[nt][cs][ks][hi][l31][8]  (o = nt*128 + cs*32 + l31, k = ks*16 + hi*8 + e)
+// ---- stack-0 first conv: W[o][ch][kh][kw], bias[o] -> frag[nt][cs][ks][hi][l31][8]  (o = nt*128 + cs*32 + l31, slot = ks*16 + hi*8 + e;
+// slots 0..23 hold k = 9 * (slot / 8) + slot % 8 (values 0..7 of kernel row 0, 1, 2), slots 24..26 k = 8, 17, 26, slots 27.. k = slot)
 __global__ __launch_bounds__(256) void vpt_pack_conv_first_kernel(const float* __restrict__ w, const float* __restrict__ bias, op16_t* __restrict__ out, int Cout, int NT) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= NT * 128 * 32) return;
   const int e = i & 7, l31 = (i >> 3) & 31, hi = (i >> 8) & 1, ks = (i >> 9) & 1, cs = (i >> 10) & 3, nt = i >> 12;
-  const int o = nt * 128 + cs * 32 + l31, k = ks * 16 + hi * 8 + e;
+  const int o = nt * 128 + cs * 32 + l31, slot = ks * 16 + hi * 8 + e;
+  const int k = (slot < 24) ? 9 * (slot >> 3) + (slot & 7) : (slot < 27) ? 9 * (slot - 24) + 8 : slot;
   float v = 0.f;
   if (o < Cout) {
     if (k < 27) {

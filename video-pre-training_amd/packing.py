@@ -77,10 +77,16 @@ def swizzle_rows64(t):
     return torch.gather(v, -2, idx).reshape(t.shape).contiguous()
 
 
+# K slot -> k of the first conv's two MFMA k-steps (vpt_conv_first_tile.h): values 0..7 of kernel row 0, 1, 2 (each one 16-byte
+# read of the 16-bit input tile), then the ninth value of the three rows, the two bias slots and three zero slots.
+CONV_FIRST_SLOT_K = [9 * (s >> 3) + (s & 7) for s in range(24)] + [8, 17, 26, 27, 28, 29, 30, 31]
+
+
 def pack_conv_first(weight, bias, dtype=torch.bfloat16):
     """Stack-0 firstconv weight [Cout,3,3,3] + bias [Cout] -> MFMA A-operand fragments
     bf16 [NT][4][2][64][8] (vpt_conv_first.hip).  k = (kh*3+kw)*3 + ch for k < 27 holds W / 255 (the pixel operand is
-    the raw byte 0..255); k = 27 / 28 carry the hi / lo bf16 halves of the bias (the pixel operand holds 1.0 there)."""
+    the raw byte 0..255); k = 27 / 28 carry the hi / lo bf16 halves of the bias (the pixel operand holds 1.0 there);
+    the 32 values of a row are stored in the slot order CONV_FIRST_SLOT_K."""
     cout = weight.shape[0]
     assert weight.shape[1:] == (3, 3, 3) and cout % 32 == 0
     nt = _ceil_div(cout, 128)
@@ -91,6 +97,7 @@ def pack_conv_first(weight, bias, dtype=torch.bfloat16):
     lo = (bias - hi).to(dtype).float()
     wk[:cout, 27] = hi
     wk[:cout, 28] = lo
+    wk = wk[:, torch.tensor(CONV_FIRST_SLOT_K, device=wk.device)].contiguous()
     # [nt][cs][l31][ks][hi][e] -> [nt][cs][ks][hi][l31][e]
     frag = wk.view(nt, 4, 32, 2, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous().view(nt, 4, 2, 64, 8)
     return frag.to(dtype).contiguous()
