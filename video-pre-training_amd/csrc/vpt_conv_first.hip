@@ -20,8 +20,12 @@
 #include "vpt_conv_first_tile.h"
 
 typedef short i16x8 __attribute__((ext_vector_type(8)));
+// Eight waves per workgroup, two workgroups per CU (the 79 KB conv tile decides that): four waves per SIMD.  With four waves per
+// workgroup (round 2) a tile took ~11 k cycles against ~5 k of issued work -- LDS round trips, the slice counter and three
+// barriers per tile with nothing else to run.
+#define CF_THREADS 512
 
-__global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs a) {
+__global__ __launch_bounds__(CF_THREADS, 4) void vpt_conv_first_kernel(VptConvFirstArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[CF_SMEM_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int PH = a.H >> 1, PW = a.W >> 1;
@@ -31,19 +35,9 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
 
   // persistent workgroups (2 per CU): the next tile's 19 x 19 x 3 input bytes are fetched into registers while the
   // current tile computes, so the global-load latency is off the per-tile critical path
-  unsigned char nxt[5];
+  u32x2 nxt[CF_FETCH(CF_THREADS)];
   auto fetch = [&](int f, int ty, int tx) {
-    const int iy0 = 2 * (ty * 8) - 2, ix0 = 2 * (tx * 8) - 2;
-    const uint8_t* img = a.img + (size_t)f * a.H * a.W * 3;
-#pragma unroll
-    for (int m = 0; m < 5; ++m) {
-      const int idx = tid + 256 * m;
-      const int r = idx / 57, rem = idx - r * 57;
-      const int y = iy0 + r, x = ix0 + rem / 3;
-      const bool ok = idx < 19 * 57 && y >= 0 && y < a.H && x >= 0 && x < a.W;
-      const unsigned char v = img[ok ? (y * a.W + ix0) * 3 + rem : 0];
-      nxt[m] = ok ? v : (unsigned char)0;
-    }
+    cf_fetch_input<CF_THREADS>(a.img + (size_t)f * a.H * a.W * 3, a.H, a.W, 2 * (ty * 8) - 2, 2 * (tx * 8) - 2, tid, nxt);
   };
   // contiguous tile range per workgroup: consecutive tiles belong to the same frame, so the frame statistics are
   // summed in registers and flushed with one atomic pair per (workgroup, frame)
@@ -63,17 +57,22 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
   auto advance = [&]() {
     if (++nnt == a.NT) { nnt = 0; if (++ntx == tilesX) { ntx = 0; if (++nty == tilesY) { nty = 0; ++nf; } } }
   };
-  if (t_begin < t_end) fetch(f, ty, tx);
   // (per tile the sums are fp32 in a fixed order; ACROSS tiles they are added in fp64, so a frame's statistics do not
   // depend on how the tile list happens to be cut into workgroup ranges, i.e. on the batch size)
   int nt_loaded = -1, stat_f = -1;
   double d_sum = 0.0, d_sq = 0.0;
   op16x8 wfr[4][2];
+  // Two barriers per tile: [records(t) staged, counter 0] -> fetch(t + 1) into registers, conv slices -> barrier -> stage
+  // records(t + 1) (the slices were their last readers), reset the counter, pool the conv tile -> barrier.
+  if (t_begin < t_end) {
+    fetch(f, ty, tx);
+    cf_stage_input<CF_THREADS>(smem, nxt, tid);
+    if (tid == 0) *(int*)(smem + CTR_OFF) = 0;
+  }
+  __syncthreads();
   for (long tile = t_begin; tile < t_end; ++tile, nt = nnt, tx = ntx, ty = nty, f = nf) {
     const int py0 = ty * 8, px0 = tx * 8;
     advance();
-    cf_stage_input(smem, nxt, tid);
-    if (tid == 0) *(int*)(smem + CTR_OFF) = 0;
     if (nt != nt_loaded) {   // weight fragments [nt][cs][ks][lane][8] stay in registers across tiles
 #pragma unroll
       for (int cs = 0; cs < 4; ++cs)
@@ -81,10 +80,11 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
         for (int ks = 0; ks < 2; ++ks) wfr[cs][ks] = *((const op16x8*)a.wfrag + ((nt * 4 + cs) * 2 + ks) * 64 + lane);
       nt_loaded = nt;
     }
-    __syncthreads();
     if (tile + 1 < t_end) fetch(nf, nty, ntx);
     cf_conv_tile(smem, wfr, lane, py0, px0, ty == 0 || tx == 0);
     __syncthreads();
+    if (tile + 1 < t_end) cf_stage_input<CF_THREADS>(smem, nxt, tid);
+    if (tid == 0) *(int*)(smem + CTR_OFF) = 0;
 
   // ---- 3x3 / stride 2 max-pool over the conv tile, store + statistics ----
   if (a.stats_out && f != stat_f) {
@@ -96,9 +96,12 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
   }
   float s_sum = 0.f, s_sq = 0.f;
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int item = tid + 256 * it;
-    const int oct4 = item & 3, pxl = (item >> 2) & 7, pyl = (item >> 5) & 7, cbl = item >> 8;
+  for (int it = 0; it < 1024 / CF_THREADS; ++it) {
+    const int item = tid + CF_THREADS * it;
+    // A ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} (+32): the four lane quads of a
+    // group take pooled columns 0, 2, 4, 6 or 1, 3, 5, 7 -- neighbouring pooled pixels are 2 * CT_RS = 8 banks apart and a quad
+    // covers 16, so consecutive columns collide two by two (576 conflict cycles per tile, profiles/r03_experiments.md section 8)
+    const int oct4 = item & 3, pxl = (0x76452310u >> (4 * ((item >> 2) & 7))) & 7, pyl = (item >> 5) & 7, cbl = item >> 8;
     const int cg = nt * 128 + cbl * 32 + oct4 * 8;
     const unsigned char* src = smem + ((2 * pyl) * 17 + 2 * pxl) * CT_RS + (cbl * 32 + oct4 * 8) * 2;
     i16x8 m = {0, 0, 0, 0, 0, 0, 0, 0};    // = ReLU: positive bf16 patterns order like signed 16-bit integers, negative ones stay below 0
@@ -111,12 +114,11 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_kernel(VptConvFirstArgs
       }
     if (cg < a.Cout) {
       const u32x4 mv = __builtin_bit_cast(u32x4, m);
-      float vals[8];
-      unpack8(mv, vals);
+      const uint32_t ones = CF_ONE_BITS | (CF_ONE_BITS << 16);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        s_sum += vals[k];
-        s_sq = fmaf(vals[k], vals[k], s_sq);
+      for (int k = 0; k < 4; ++k) {     // packed pairs: one dot2 per two values for the sum, one for the sum of squares (products of 16-bit operands are exact in fp32)
+        s_sum = dot2_op16(mv[k], ones, s_sum);
+        s_sq = dot2_op16(mv[k], mv[k], s_sq);
       }
       const size_t off = ((size_t)(f * CB_out + (cg >> 5)) * PH * PW + (size_t)((py0 + pyl) * PW + px0 + pxl)) * 32 + (cg & 31);
       *(u32x4*)(a.y + off) = mv;
@@ -146,6 +148,6 @@ extern "C" int vpt_conv_first_launch(const VptConvFirstArgs* a, hipStream_t stre
   long grid = (long)a->frames * (a->H >> 4) * (a->W >> 4) * a->NT;
   if ((long)a->frames * a->H * a->W * 3 > 0x7fffffffL) return -2;   // 32-bit pixel offsets inside a launch
   if (grid > 2L * num_cu) grid = 2L * num_cu;
-  hipLaunchKernelGGL(vpt_conv_first_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *a);
+  hipLaunchKernelGGL(vpt_conv_first_kernel, dim3((unsigned)grid), dim3(CF_THREADS), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

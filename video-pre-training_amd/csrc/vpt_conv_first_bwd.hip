@@ -54,23 +54,14 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
   const int g16 = lane >> 4, i16 = lane & 15;
   const int tr_off = (8 * (g16 >> 1) + (i16 >> 2)) * CT_RS + (16 * (g16 & 1) + 4 * (i16 & 3)) * 2;
   const int tap = l31;                                   // B operand row of this lane
-  const int tap_off = min(tap, 26) + 48 * (min(tap, 26) / 9);   // element offset of tap (kh, kw, ch) inside the 19-pixel-wide input tile (taps >= 27: any valid element)
-  const unsigned short* in16 = (const unsigned short*)(smem + IN_OFF);
+  const int tap_c = min(tap, 26);
+  const int tap_off = ((tap_c / 9) * 19 + (tap_c % 9) / 3) * 8 + tap_c % 3;   // byte of tap (kh, kw, ch) relative to the pixel's record: record (kh, kw), byte ch (taps >= 27: any valid byte)
+  const unsigned char* in8 = smem + IN_OFF;
 
   // next tile's input bytes are fetched into registers while the current tile computes (as in the forward kernel)
-  unsigned char nxt[5];
+  u32x2 nxt[CF_FETCH(256)];
   auto fetch = [&](int f, int ty, int tx) {
-    const int iy0 = 2 * (ty * 8) - 2, ix0 = 2 * (tx * 8) - 2;
-    const uint8_t* img = a.img + (size_t)f * a.H * a.W * 3;
-#pragma unroll
-    for (int m = 0; m < 5; ++m) {
-      const int idx = tid + 256 * m;
-      const int r = idx / 57, rem = idx - r * 57;
-      const int y = iy0 + r, x = ix0 + rem / 3;
-      const bool ok = idx < 19 * 57 && y >= 0 && y < a.H && x >= 0 && x < a.W;
-      const unsigned char v = img[ok ? (y * a.W + ix0) * 3 + rem : 0];
-      nxt[m] = ok ? v : (unsigned char)0;
-    }
+    cf_fetch_input<256>(a.img + (size_t)f * a.H * a.W * 3, a.H, a.W, 2 * (ty * 8) - 2, 2 * (tx * 8) - 2, tid, nxt);
   };
   const long per = (T + gridDim.x - 1) / gridDim.x;
   const long t_begin = blockIdx.x * per, t_end = min(t_begin + per, T);
@@ -88,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
   for (long tile = t_begin; tile < t_end; ++tile, tx = ntx, ty = nty, f = nf) {
     const int py0 = ty * 8, px0 = tx * 8;
     if (++ntx == tilesX) { ntx = 0; if (++nty == tilesY) { nty = 0; ++nf; } }
-    cf_stage_input(smem, nxt, tid);
+    cf_stage_input<256>(smem, nxt, tid);
     if (tid == 0) *(int*)(smem + CTR_OFF) = 0;
     __syncthreads();
     if (tile + 1 < t_end) fetch(nf, nty, ntx);
@@ -200,22 +191,22 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
     if (!(VPT_CFB_ABLATE & 8))
     for (int ks = w; ks < 19; ks += 4) {
       // B fragment: row = tap, k = conv pixels 16 ks + 8 hi .. + 7.  ks is wave-uniform, so the input-tile offset of every
-      // (pixel, hi) pair is scalar arithmetic; per element one select (hi) and one 16-bit read of the converted input tile (the
-      // lane's tap offset is in the base pointer).  Pixels beyond 288 need no masking here: the A side is exactly zero for them and bytes are
+      // (pixel, hi) pair is scalar arithmetic; per element one select (hi), one byte read of the pixel's record (the lane's tap
+      // offset is in the base pointer) and one conversion.  Pixels beyond 288 need no masking here: the A side is exactly zero for them and bytes are
       // finite; taps 28..31 produce columns that are never flushed; tap 27 is the column of ones (db).
       u32x4 pk;
       uint32_t pw[4];
-      const unsigned short* inl = in16 + tap_off;
+      const unsigned char* inl = in8 + tap_off;
 #pragma unroll
       for (int e2 = 0; e2 < 4; ++e2) {
-        uint32_t v2[2];
+        float v2[2];
 #pragma unroll
         for (int e1 = 0; e1 < 2; ++e1) {
           const int c0 = min(ks * 16 + e2 * 2 + e1, 288), c1 = min(ks * 16 + 8 + e2 * 2 + e1, 288);
-          const int o0 = ((c0 / 17) * 19 + (c0 % 17)) * 3, o1 = ((c1 / 17) * 19 + (c1 % 17)) * 3;
-          v2[e1] = inl[hi ? o1 : o0];
+          const int o0 = ((c0 / 17) * 19 + (c0 % 17)) * 8, o1 = ((c1 / 17) * 19 + (c1 % 17)) * 8;
+          v2[e1] = (float)inl[hi ? o1 : o0];
         }
-        pw[e2] = v2[0] | (v2[1] << 16);
+        pw[e2] = pack_op16x2_exact(v2[0], v2[1]);
       }
       const uint32_t ones = pack_op16x2_exact(1.0f, 1.0f);
       pk.x = (tap == 27) ? ones : pw[0]; pk.y = (tap == 27) ? ones : pw[1]; pk.z = (tap == 27) ? ones : pw[2]; pk.w = (tap == 27) ? ones : pw[3];

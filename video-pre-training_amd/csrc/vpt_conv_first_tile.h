@@ -2,22 +2,25 @@
 // backward kernel's recompute (vpt_conv_first_bwd.hip): both must produce the SAME 16-bit values.
 //
 // LDS image of one tile:   [0, CT_BYTES)          conv tile  [289 conv pixels][128 channels] 16-bit, pixel pitch CT_RS
-//                          [IN_OFF, +IN_BYTES)    input tile [19][19][3] as 16-bit operands (the bytes 0..255, exact), +5 pad
+//                          [IN_OFF, +IN_BYTES)    input tile as 19 x 19 eight-byte RECORDS: record (y, x) = the 8 input bytes that
+//                                                 start at pixel (y, x), channel 0 (pixels x, x + 1 and two channels of x + 2)
 //                          [CTR_OFF, +16)         work counter of the tile's 32-pixel slices
-// A conv pixel's K vector is three runs of nine consecutive input values (kernel row dy: (kw, ch) contiguous at element
-// ((cr + dy) * 19 + cc) * 3).  The 32 K slots of the two MFMA k-steps are ORDERED FOR THAT (vpt_pack.hip / packing.py use
-// the same table):   ks 0, lanes 0-31 : row 0 values 0..7        ks 0, lanes 32-63 : row 1 values 0..7
-//                    ks 1, lanes 0-31 : row 2 values 0..7        ks 1, lanes 32-63 : row 0 / 1 / 2 value 8, bias hi, bias lo, 0, 0, 0
-// so a lane's fragment is one (2-byte aligned) 16-byte LDS read -- round 2 built it from 16 byte reads, 16 conversions and 8
-// packs per k-step, 122 vector instructions per 8 MFMAs, and the kernel was vector-issue bound.
+// A conv pixel's K vector is three runs of nine consecutive input bytes (kernel row dy: (kw, ch) contiguous).  The 32 K slots of
+// the two MFMA k-steps are ORDERED FOR THAT (vpt_pack.hip / packing.py use the same table):
+//     ks 0, lanes 0-31 : row 0 values 0..7        ks 0, lanes 32-63 : row 1 values 0..7
+//     ks 1, lanes 0-31 : row 2 values 0..7        ks 1, lanes 32-63 : row 0 / 1 / 2 value 8, bias hi, bias lo, 0, 0, 0
+// so a lane's fragment is one ALIGNED 8-byte LDS read of a record + eight byte -> operand conversions (values 8: byte 2 of
+// record (y, x + 2)).  History: round 2 built it from 16 byte reads, 16 conversions and 8 packs per k-step; a 16-bit tile in its
+// natural [y][x][ch] order read with 2-byte-aligned ds_read_b128 cost 1170 cycles of SQ_LDS_UNALIGNED_STALL per tile (PMC:
+// profiles/r03_experiments.md section 8) -- the LDS pipe, 61 % busy with 30 % of that in stalls, is what bounds this kernel.
 #pragma once
 #include "vpt_common.h"
 
 #define CT_RS 272
 #define CT_BYTES (289 * CT_RS)  // 78608
 #define IN_OFF CT_BYTES
-#define IN_ELEMS (19 * 57)      // 1083
-#define IN_BYTES 2176
+#define IN_RECS (19 * 19)       // 361
+#define IN_BYTES (IN_RECS * 8)  // 2888
 #define CTR_OFF (IN_OFF + IN_BYTES)
 #define CF_SMEM_BYTES (CTR_OFF + 16)
 
@@ -27,15 +30,52 @@
 #define CF_ONE_BITS 0x3f80u
 #endif
 
-// a byte 0..255 as the 16-bit operand's bit pattern (exact in both formats)
-__device__ __forceinline__ unsigned short cf_byte_bits(unsigned char v) { return (unsigned short)(pack_op16x2_exact((float)v, 0.f) & 0xffffu); }
+// four bytes of a dword -> four 16-bit operands (0..255 are exact in both formats): v_cvt_f32_ubyteN + one pack per pair
+__device__ __forceinline__ u32x2 cf_bytes4(uint32_t w) {
+  u32x2 r;
+  r.x = pack_op16x2_exact((float)(w & 0xffu), (float)((w >> 8) & 0xffu));
+  r.y = pack_op16x2_exact((float)((w >> 16) & 0xffu), (float)(w >> 24));
+  return r;
+}
+__device__ __forceinline__ u32x4 cf_bytes8(u32x2 rec) {
+  const u32x2 a = cf_bytes4(rec.x), b = cf_bytes4(rec.y);
+  return (u32x4){a.x, a.y, b.x, b.y};
+}
 
-// this thread's five bytes of the 19 x 19 x 3 input tile (fetched one tile ahead) -> 16-bit LDS image
-__device__ __forceinline__ void cf_stage_input(unsigned char* smem, const unsigned char (&nxt)[5], int tid) {
-  unsigned short* in16 = (unsigned short*)(smem + IN_OFF);
+// Fetch (one tile ahead, into registers) and staging of the input records.  Thread t < 361 owns record (t / 19, t % 19) of the
+// tile whose input window starts at image pixel (iy0, ix0) = (2 py0 - 2, 2 px0 - 2): one unaligned 8-byte global load when
+// pixels x .. x + 2 of the row are inside the image, byte loads with zero fill on the image border (the conv's zero padding).
+#define CF_FETCH(THREADS) ((IN_RECS + (THREADS) - 1) / (THREADS))   // 2 per thread at 256 threads, 1 at 512
+template <int THREADS>
+__device__ __forceinline__ void cf_fetch_input(const uint8_t* img, int H, int W, int iy0, int ix0, int tid, u32x2 (&nxt)[CF_FETCH(THREADS)]) {
 #pragma unroll
-  for (int m = 0; m < 5; ++m)
-    if (tid + 256 * m < IN_ELEMS + 5) in16[tid + 256 * m] = (tid + 256 * m < IN_ELEMS) ? cf_byte_bits(nxt[m]) : (unsigned short)0;
+  for (int m = 0; m < CF_FETCH(THREADS); ++m) {
+    const int t = tid + THREADS * m;
+    const int y = t / 19, x = t - y * 19;
+    const int gy = iy0 + y, gx = ix0 + x;
+    u32x2 v = {0u, 0u};
+    if (t < IN_RECS && gy >= 0 && gy < H) {
+      const uint8_t* src = img + (gy * W + gx) * 3;
+      if (gx >= 0 && gx + 2 < W) {
+        __builtin_memcpy(&v, src, 8);
+      } else {
+        uint64_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int q = gx + j / 3;
+          if (q >= 0 && q < W) acc |= (uint64_t)src[j] << (8 * j);
+        }
+        v.x = (uint32_t)acc; v.y = (uint32_t)(acc >> 32);
+      }
+    }
+    nxt[m] = v;
+  }
+}
+template <int THREADS>
+__device__ __forceinline__ void cf_stage_input(unsigned char* smem, const u32x2 (&nxt)[CF_FETCH(THREADS)], int tid) {
+#pragma unroll
+  for (int m = 0; m < CF_FETCH(THREADS); ++m)
+    if (tid + THREADS * m < IN_RECS) *(u32x2*)(smem + IN_OFF + (tid + THREADS * m) * 8) = nxt[m];
 }
 
 // One 32-pixel slice `sub` of the tile: conv + bias (1/255 is folded into the weights), rounded to 16 bits and stored RAW into
@@ -47,44 +87,46 @@ __device__ __forceinline__ void cf_conv_slice(unsigned char* smem, const op16x8 
   const bool pv = p < 289;
   const int pc = pv ? p : 288;
   const int cr = pc / 17, cc = pc - cr * 17;
-  const unsigned short* ib = (const unsigned short*)(smem + IN_OFF) + (cr * 19 + cc) * 3;
-  op16x8 pf[2];
-  u32x4 y, l;
-  __builtin_memcpy(&pf[0], ib + (hi ? 57 : 0), 16);
-  __builtin_memcpy(&y, ib + 114, 16);
-  l.x = (uint32_t)ib[8] | ((uint32_t)ib[57 + 8] << 16);
-  l.y = (uint32_t)ib[114 + 8] | (CF_ONE_BITS << 16);
+  const unsigned char* ib = smem + IN_OFF + (cr * 19 + cc) * 8;
+  const u32x2 x = *(const u32x2*)(ib + (hi ? 19 * 8 : 0));
+  const u32x2 y = *(const u32x2*)(ib + 2 * 19 * 8);
+  const float n0 = (float)ib[2 * 8 + 2], n1 = (float)ib[(19 + 2) * 8 + 2], n2 = (float)ib[(2 * 19 + 2) * 8 + 2];
+  u32x4 l;
+  l.x = pack_op16x2_exact(n0, n1);
+  l.y = pack_op16x2_exact(n2, 1.0f);
   l.z = CF_ONE_BITS;
   l.w = 0u;
-  pf[1] = __builtin_bit_cast(op16x8, hi ? l : y);
-  f32x16 acc[4];
-#pragma unroll
-  for (int cs = 0; cs < 4; ++cs) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[cs][r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) acc[cs] = VPT_MFMA_32X32X16(wfr[cs][ks], pf[ks], acc[cs], 0, 0, 0);
-  }
-  if (!pv) return;
+  op16x8 pf[2];
+  pf[0] = __builtin_bit_cast(op16x8, cf_bytes8(x));
+  pf[1] = __builtin_bit_cast(op16x8, hi ? l : cf_bytes8(y));
   unsigned char* dst = smem + p * CT_RS + hi * 8;
-  if (edge) {
+  uint32_t keep = 0xffffffffu;
+  if (edge) {   // H, W are multiples of 16: a tile never crosses the bottom / right border
     const int gy = 2 * py0 - 1 + cr, gx = 2 * px0 - 1 + cc;
-    const uint32_t keep = (gy >= 0 && gx >= 0) ? 0xffffffffu : 0u;   // H, W are multiples of 16: the tile never crosses the bottom / right border
+    keep = (gy >= 0 && gx >= 0) ? 0xffffffffu : 0u;
+  }
+  // two 32-channel blocks at a time: 32 live accumulator registers (the forward kernel runs four waves per SIMD, 128 registers)
 #pragma unroll
-    for (int cs = 0; cs < 4; ++cs)
+  for (int ch = 0; ch < 2; ++ch) {
+    f32x16 acc[2];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u32x2 pk2 = {pack_op16x2(acc[cs][4 * g + 0], acc[cs][4 * g + 1]) & keep, pack_op16x2(acc[cs][4 * g + 2], acc[cs][4 * g + 3]) & keep};
-        *(u32x2*)(dst + (cs * 32 + g * 8) * 2) = pk2;
-      }
-  } else {
+    for (int c2 = 0; c2 < 2; ++c2) {
 #pragma unroll
-    for (int cs = 0; cs < 4; ++cs)
+      for (int r = 0; r < 16; ++r) acc[c2][r] = 0.f;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u32x2 pk2 = {pack_op16x2(acc[cs][4 * g + 0], acc[cs][4 * g + 1]), pack_op16x2(acc[cs][4 * g + 2], acc[cs][4 * g + 3])};
-        *(u32x2*)(dst + (cs * 32 + g * 8) * 2) = pk2;
-      }
+      for (int ks = 0; ks < 2; ++ks) acc[c2] = VPT_MFMA_32X32X16(wfr[2 * ch + c2][ks], pf[ks], acc[c2], 0, 0, 0);
+    }
+    if (pv) {
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          u32x2 pk2 = {pack_op16x2(acc[c2][4 * g + 0], acc[c2][4 * g + 1]), pack_op16x2(acc[c2][4 * g + 2], acc[c2][4 * g + 3])};
+          if (edge) { pk2.x &= keep; pk2.y &= keep; }
+          *(u32x2*)(dst + ((2 * ch + c2) * 32 + g * 8) * 2) = pk2;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
