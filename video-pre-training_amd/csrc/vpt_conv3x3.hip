@@ -248,6 +248,9 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   do {                                                                                                    \
     _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_) { MM(set_, m_, 0); MM(set_, m_, 1); }                \
   } while (0)
+#ifndef VPT_CONV_HALO_ABLATE
+#define VPT_CONV_HALO_ABLATE 0  // profiling builds (wrong results, timing only): 1 = halo written without the zero-fill selects, 2 = no halo loads / writes after block 0
+#endif
 #ifndef VPT_CONV_DMA_PIECES
 #define VPT_CONV_DMA_PIECES 6   // profiling builds: fewer weight-DMA pieces per wave and step (the results are then wrong; timing only)
 #endif
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   do { if ((m_) < VPT_CONV_DMA_PIECES)                                                                    \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp_ + (m_) * 2048),    \
                                    (__attribute__((address_space(3))) void*)(bd_ + (m_) * 4096), 16, 0, 0); } while (0)
-#define XA(m_) areg[m_] = *(const u32x4*)((const char*)xplane + (cbo_ + a_gbyte[m_]))
+#define XA(m_) do { if (VPT_CONV_HALO_ABLATE != 2) areg[m_] = *(const u32x4*)((const char*)xplane + (cbo_ + a_gbyte[m_])); } while (0)
 #define XR(m_, n2_, p_) rq[m_][n2_][p_] = EPI_LD(resp, m_, n2_, p_)
 #define NOP_() ((void)0)
 #define WAIT_BARRIER(n_late_)                                                                             \
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     if (PRE_A) {                                                                                          \
       GROUP(1, dy_, 4, boff_, do { XA(0); XA(1); } while (0), do { XA(2); } while (0));                   \
       GROUP(0, dy_, 5, boff_, do { XA(3); XA(4); } while (0), do { XA(5); } while (0));                   \
-      WAIT_BARRIER(6);                                                                                    \
+      if (VPT_CONV_HALO_ABLATE == 2) WAIT_BARRIER(0); else WAIT_BARRIER(6);                               \
     } else if ((PRE_R) && HAS_RES) { /* compile-time: without a residual the loads would be dead code and the count wrong */ \
       GROUP(1, dy_, 4, boff_, do { XR(0, 0, 0); XR(0, 0, 1); } while (0), do { XR(0, 1, 0); XR(0, 1, 1); } while (0)); \
       GROUP(0, dy_, 5, boff_, do { XR(1, 0, 0); XR(1, 0, 1); } while (0), do { XR(1, 1, 0); XR(1, 1, 1); } while (0)); \
@@ -305,8 +308,13 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     }                                                                                                     \
     if (WR_A) {   /* the halo of the next channel block replaces the current one: second barrier before its first read */ \
       _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_) {                                                  \
-        if (a_loff[m_] >= 0) *(u32x4*)(smem + a_loff[m_]) = ((a_inside >> m_) & 1u) ? areg[m_] : zero4;   \
-        if (m_ + 4 < 6 && a_loff[m_ + 4] >= 0) *(u32x4*)(smem + a_loff[m_ + 4]) = ((a_inside >> (m_ + 4)) & 1u) ? areg[m_ + 4] : zero4; \
+        if (VPT_CONV_HALO_ABLATE == 0) {                                                                  \
+          if (a_loff[m_] >= 0) *(u32x4*)(smem + a_loff[m_]) = ((a_inside >> m_) & 1u) ? areg[m_] : zero4; \
+          if (m_ + 4 < 6 && a_loff[m_ + 4] >= 0) *(u32x4*)(smem + a_loff[m_ + 4]) = ((a_inside >> (m_ + 4)) & 1u) ? areg[m_ + 4] : zero4; \
+        } else if (VPT_CONV_HALO_ABLATE == 1) {                                                           \
+          if (a_loff[m_] >= 0) *(u32x4*)(smem + a_loff[m_]) = areg[m_];                                   \
+          if (m_ + 4 < 6 && a_loff[m_ + 4] >= 0) *(u32x4*)(smem + a_loff[m_ + 4]) = areg[m_ + 4];         \
+        }                                                                                                 \
         SB(); MM(1, m_, 0); SB();                                                                         \
       }                                                                                                   \
       WAIT_BARRIER(0);                                                                                    \
