@@ -177,6 +177,20 @@ int vpt_masked_attention_step(const float* qkvr, const float* kmem, const float*
                               const float* b_nd, void* out, float* kout, float* vout, uint8_t* mask_out,
                               int B, int heads, int hid, int ld, int maxlen, void* stream);
 
+/* The same step with EVERYTHING updated in place (what the captured acting graph uses: no copies of the recurrent state at all):
+ * kmem / vmem / state_mask are read and overwritten.  The mask is safe to overwrite because the workgroup that arrives last at
+ * done_counter ([B] ints, zero before the first launch; the kernel leaves them zero) writes it, after every other one has read it. */
+int vpt_masked_attention_step_inplace(const float* qkvr, float* kmem, float* vmem, uint8_t* state_mask, const uint8_t* first,
+                                      const float* b_nd, void* out, int* done_counter, int B, int heads, int hid, int ld, int maxlen, void* stream);
+
+/* Tail of MinecraftAgentPolicy.act for the acting step (lib/policy.py:307-327) in one launch: log_prob = logp_buttons + logp_camera
+ * (lib/action_head.py:227-237 sums the heads), value de-normalisation v * scale + shift (lib/normalize_ewma.py:27-31 with
+ * scale = sqrt(var + eps), shift = mean), the NaN assertion of lib/policy.py:320-321 as a byte flag, and one packed record per
+ * environment:  keep[b][4] (int64) = { buttons action, camera action, float bits of log_prob, float bits of the de-normalised value
+ * (low half) | float bits of the raw value-head output (high half) }.  value_col: column of the value head in logits[B][ld]. */
+int vpt_act_epilogue(const int64_t* action_buttons, const int64_t* action_camera, const float* logp_buttons, const float* logp_camera,
+                     const float* logits, int ld, int value_col, float scale, float shift, int64_t* keep, uint8_t* nan_flag, int B, void* stream);
+
 /* CategoricalActionHead.forward tail (lib/action_head.py:170-174): out[M][n] = log_softmax(logits[:, col0:col0+n] / T). */
 int vpt_log_softmax_forward(const float* logits, float* out, int M, int ld, int col0, int n, float temperature,
                             void* stream);

@@ -333,9 +333,44 @@ def test_attention_step_equals_attention_plus_memory_update(batch, heads, maxlen
     out2, ka, va, ma = ops.masked_attention_step(qkvr, k2, v2, m2, first, b_nd, batch, heads, hid, inplace=True)
     torch.cuda.synchronize()
     assert ka.data_ptr() == k2.data_ptr() and torch.equal(k2, kref) and torch.equal(v2, vref) and torch.equal(out2, out)
-    assert ma.data_ptr() != m2.data_ptr() and torch.equal(ma, mref) and torch.equal(m2, mv)     # the mask is never updated in place (cross-workgroup read/write)
+    assert ma.data_ptr() != m2.data_ptr() and torch.equal(ma, mref) and torch.equal(m2, mv)     # without a counter the mask is a new tensor (cross-workgroup read/write)
+    # everything in place (vpt_masked_attention_step_inplace): the workgroup that arrives last writes the mask and re-zeroes the counter;
+    # two chained steps = two chained steps of the copying variant
+    k3, v3, m3 = kmem.clone(), vmem.clone(), mv.clone()
+    done = torch.zeros(64, dtype=torch.int32, device=DEV)
+    out3, kb, vb, mb = ops.masked_attention_step(qkvr, k3, v3, m3, first, b_nd, batch, heads, hid, inplace=True, done=done)
+    torch.cuda.synchronize()
+    assert mb.data_ptr() == m3.data_ptr() and torch.equal(m3, mref) and torch.equal(k3, kref) and torch.equal(v3, vref) and torch.equal(out3, out)
+    assert int(done.abs().sum()) == 0
+    nofirst = torch.zeros_like(first)
+    o4r, k4r, v4r, m4r = ops.masked_attention_step(qkvr, kref, vref, mref, nofirst, b_nd, batch, heads, hid)
+    o4, _, _, _ = ops.masked_attention_step(qkvr, k3, v3, m3, nofirst, b_nd, batch, heads, hid, inplace=True, done=done)
+    torch.cuda.synchronize()
+    assert torch.equal(o4, o4r) and torch.equal(k3, k4r) and torch.equal(v3, v4r) and torch.equal(m3, m4r) and int(done.abs().sum()) == 0
+    with pytest.raises(ValueError):
+        ops.masked_attention_step(qkvr, k3, v3, m3, first, b_nd, batch, heads, hid, inplace=False, done=done)
     with pytest.raises(ValueError):
         ops.masked_attention_step(qkvr.repeat(2, 1), kmem, vmem, mv, first, b_nd, batch, heads, hid)
+
+
+@pytest.mark.parametrize("m", [1, 5])
+def test_act_epilogue(m):
+    """vpt_act_epilogue: summed head log-probs, de-normalised value, NaN flag and the packed record (MinecraftAgentPolicy.act's tail)."""
+    g = torch.Generator().manual_seed(m)
+    ab = torch.randint(0, 8641, (m,), generator=g).to(DEV); ac = torch.randint(0, 121, (m,), generator=g).to(DEV)
+    lb = -torch.rand(m, generator=g).to(DEV) * 9; lc = -torch.rand(m, generator=g).to(DEV) * 5
+    logits = torch.randn(m, 8763, generator=g).to(DEV)
+    scale, shift = 1.7320508, -0.25
+    keep, flag = ops.act_epilogue(ab, ac, lb, lc, logits, 8762, scale, shift)
+    b2, c2, lp, vd, v = ops.unpack_act_keep(keep)
+    torch.cuda.synchronize()
+    assert torch.equal(b2, ab) and torch.equal(c2, ac) and int(flag) == 0
+    assert torch.equal(lp, lb + lc) and torch.equal(v, logits[:, 8762])
+    ref = torch.addcmul(torch.full((m,), shift, device=DEV), logits[:, 8762], torch.full((m,), scale, device=DEV))
+    assert torch.allclose(vd, ref, rtol=1e-6, atol=1e-6)
+    lb[m - 1] = float("nan")
+    _, flag = ops.act_epilogue(ab, ac, lb, lc, logits, 8762, scale, shift)
+    assert int(flag) == 1
 
 
 @pytest.mark.parametrize("m,n,k,accumulate", [(300, 256, 192, False), (1000, 8768, 2048, False), (64, 65536, 256, True), (8192, 2048, 2048, False)])

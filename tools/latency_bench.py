@@ -40,6 +40,22 @@ for mode in ("eager", "graph"):
     dt = (time.perf_counter() - t0) / a.steps
     print(f"{mode:6s}: {dt*1e3:.3f} ms / step  ({1/dt:.0f} steps/s)   buttons[0..5] = {[int(x['buttons']) for x in acts[:6]]}")
 
+if getattr(pol, "_step_graph", None) and "graph" in pol._step_graph:      # the GPU side alone: back-to-back replays, no host glue
+    gph = pol._step_graph["graph"]
+    for _ in range(10):
+        gph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        gph.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    print(f"replay: {dt*1e3:.3f} ms / graph replay (no act() glue: input copies, output clones, python)")
+    import cProfile, pstats, io
+    pr = cProfile.Profile(); pr.enable(); run(200); pr.disable()
+    sio = io.StringIO(); pstats.Stats(pr, stream=sio).sort_stats("cumulative").print_stats(18)
+    print("\n".join(l[:150] for l in sio.getvalue().splitlines()[:40]))
+
 from vpt_amd import ops
 pol.disable_step_graph()
 ops.TIMER.enabled = True; ops.TIMER.reset()

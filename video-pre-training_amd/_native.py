@@ -60,6 +60,8 @@ SIGNATURES = {
     "vpt_grads_nonfinite_multi": [_P, _I, _L, _P, _P],
     "vpt_layernorm_linear_forward": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "vpt_masked_attention_step": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vpt_masked_attention_step_inplace": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vpt_act_epilogue": [_P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _I, _P],
     "vpt_clip_frames": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _P],
 }
 

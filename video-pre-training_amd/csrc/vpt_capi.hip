@@ -248,7 +248,22 @@ int vpt_masked_attention_step(const float* qkvr, const float* kmem, const float*
   VptAttnArgs a;
   a.qkvr = qkvr; a.kmem = kmem; a.vmem = vmem; a.memvalid = nullptr; a.b_nd = b_nd; a.out = (vpt_op16*)out;
   a.B = B; a.t = 1; a.heads = heads; a.hid = hid; a.ld = ld; a.maxlen = maxlen; a.causal = 1;
-  CHECK_LAUNCH(vpt_attn_step_launch(&a, state_mask, first, mask_out, kout, vout, (hipStream_t)stream), "vpt_masked_attention_step");
+  CHECK_LAUNCH(vpt_attn_step_launch(&a, state_mask, first, mask_out, kout, vout, nullptr, (hipStream_t)stream), "vpt_masked_attention_step");
+}
+
+int vpt_masked_attention_step_inplace(const float* qkvr, float* kmem, float* vmem, uint8_t* state_mask, const uint8_t* first,
+                                      const float* b_nd, void* out, int* done_counter, int B, int heads, int hid, int ld, int maxlen, void* stream) {
+  if (!done_counter) return fail(-1, "vpt_masked_attention_step_inplace: done_counter ([B] ints, zero before the first launch) is required");
+  VptAttnArgs a;
+  a.qkvr = qkvr; a.kmem = kmem; a.vmem = vmem; a.memvalid = nullptr; a.b_nd = b_nd; a.out = (vpt_op16*)out;
+  a.B = B; a.t = 1; a.heads = heads; a.hid = hid; a.ld = ld; a.maxlen = maxlen; a.causal = 1;
+  CHECK_LAUNCH(vpt_attn_step_launch(&a, state_mask, first, state_mask, kmem, vmem, done_counter, (hipStream_t)stream), "vpt_masked_attention_step_inplace");
+}
+
+int vpt_act_epilogue(const int64_t* action_buttons, const int64_t* action_camera, const float* logp_buttons, const float* logp_camera,
+                     const float* logits, int ld, int value_col, float scale, float shift, int64_t* keep, uint8_t* nan_flag, int B, void* stream) {
+  CHECK_LAUNCH(vpt_act_epilogue_launch(action_buttons, action_camera, logp_buttons, logp_camera, logits, ld, value_col, scale, shift, keep, nan_flag, B,
+                                       (hipStream_t)stream), "vpt_act_epilogue");
 }
 
 int vpt_kv_memory_update(const float* qkvr, const float* kmem, const float* vmem, float* kout, float* vout,

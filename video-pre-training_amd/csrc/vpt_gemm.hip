@@ -47,8 +47,11 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
   for (int m = 0; m < 8; ++m) aoff[m] = (unsigned)min(arow + 32 * m, a.M - 1 - m0) * (unsigned)a.lda * 2u + apart * 16u;
 #define A_LOAD(m_, s_) (*(const u32x4*)(abase + (size_t)(s_) * 128 + aoff[m_]))
   unsigned char* ast = smem + arow * GA_RS + apart * 16;
-  const vpt_op16* wbase = a.wpk + (size_t)nt * (a.K >> 5) * 4096 + tid * 8;
-  unsigned char* bst = smem + GA_BYTES + (tid >> 2) * GB_RS + (tid & 3) * 16;
+  // B staging: a ds_write_b128 is served in groups of 8 consecutive lanes with banks taken modulo 32, and two 64-byte rows
+  // one pitch (80 B) apart overlap in four banks -- the lanes of a group take rows R and R + 4 instead (320 B = 16 banks apart)
+  const int brow = ((tid >> 5) << 3) + ((tid >> 3) & 3) + ((tid >> 2) & 1) * 4;
+  const vpt_op16* wbase = a.wpk + (size_t)nt * (a.K >> 5) * 4096 + (brow * 4 + (tid & 3)) * 8;
+  unsigned char* bst = smem + GA_BYTES + brow * GB_RS + (tid & 3) * 16;
 
   u32x4 areg[8], breg[4];
 #pragma unroll

@@ -319,7 +319,9 @@ int vpt_ln_bwd_launch(const VptLnBwdArgs* a, hipStream_t s);
 int vpt_gate_cast_launch(const VptGateCastArgs* a, hipStream_t s);
 int vpt_colsum_launch(const VptColsumArgs* a, hipStream_t s);
 int vpt_clip_launch(const VptClipArgs* a, hipStream_t s);
-int vpt_attn_step_launch(const VptAttnArgs* a, const uint8_t* state_mask, const uint8_t* first, uint8_t* mask_out, float* kout, float* vout, hipStream_t s);
+int vpt_attn_step_launch(const VptAttnArgs* a, const uint8_t* state_mask, const uint8_t* first, uint8_t* mask_out, float* kout, float* vout, int* done, hipStream_t s);
+int vpt_act_epilogue_launch(const int64_t* act_b, const int64_t* act_c, const float* lp_b, const float* lp_c, const float* logits, int ld, int vcol,
+                            float scale, float shift, int64_t* keep, uint8_t* nan_flag, int B, hipStream_t s);
 int vpt_attn_bwd_launch(const VptAttnBwdArgs* a, hipStream_t s);
 int vpt_conv3x3_launch(const VptConv3x3Args* a, hipStream_t s);
 int vpt_conv_first_launch(const VptConvFirstArgs* a, hipStream_t s);

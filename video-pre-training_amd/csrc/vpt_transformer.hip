@@ -239,8 +239,11 @@ extern "C" int vpt_attn_launch(const VptAttnArgs* a, hipStream_t stream) {
 //   thread (key, half of d_head): 16 float4 of its K row -> dot with q, pair-sum by shuffle -> logit (+ rel-pos bias, visibility);
 //   block softmax; thread (d, half of the keys): 64 V values (coalesced over d) x probabilities -> output.
 // Every row is loaded into registers before a barrier and stored after it, and a workgroup owns its head's 128 columns of the
-// memory: kout / vout MAY ALIAS kmem / vmem (the captured acting graph updates its state in place).  mask_out must NOT alias
-// state_mask: every head's workgroup reads the old mask, head 0's writes the new one, and workgroups are not ordered.
+// memory: kout / vout MAY ALIAS kmem / vmem (the captured acting graph updates its state in place).  Without `done` mask_out must
+// NOT alias state_mask: every head's workgroup reads the old mask, head 0's writes the new one, and workgroups are not ordered.
+// With `done` ([B] ints, zero before the first launch) the mask may be updated in place too: every workgroup counts itself in
+// after its mask bytes are in registers, and the one that arrives LAST writes the new mask and resets the counter -- the captured
+// acting graph then needs no mask copies (four memcpy nodes per step).
 // Same formulas as vpt_attn_kernel (scale 1 / d_head, bias sum_n R[n] b_nd[n][off], invisible rows excluded, all-invisible -> 0);
 // the sums run on the vector ALU in a different order than the matrix cores', so results agree to fp32 rounding, not bit for bit.
 struct VptAttnStepExtra {
@@ -249,10 +252,12 @@ struct VptAttnStepExtra {
   uint8_t* mask_out;           // [B][maxlen]: next step's state_mask
   float* kout;                 // [B][maxlen][hid]
   float* vout;
+  int* done;                   // optional [B]: arrival counter of the sequence's workgroups (in-place mask update)
 };
 
 __global__ __launch_bounds__(256) void vpt_attn_step_kernel(VptAttnArgs a, VptAttnStepExtra x) {
   __shared__ float sc_[128], red_[8], part_[128];
+  __shared__ int last_;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int b = blockIdx.x / a.heads, h = blockIdx.x - b * a.heads;
   const int maxlen = a.maxlen, hid = a.hid;
@@ -306,7 +311,13 @@ __global__ __launch_bounds__(256) void vpt_attn_step_kernel(VptAttnArgs a, VptAt
     float* ko = x.kout + ((size_t)b * maxlen + kk) * hid + h * ATT_DH + half * 64;
 #pragma unroll
     for (int i = 0; i < 16; ++i) *(f32x4*)(ko + 4 * i) = kv[i];   // memory row kk of the next step = row kk + 1 of [memory ; new]
-    if (h == 0 && half == 0) x.mask_out[(size_t)b * maxlen + kk] = vis ? 1 : 0;   // = cat(state_mask[1:] & ~first, [True])
+    if (!x.done && h == 0 && half == 0) x.mask_out[(size_t)b * maxlen + kk] = vis ? 1 : 0;   // = cat(state_mask[1:] & ~first, [True])
+  }
+  if (x.done && tid == 0) {     // this workgroup's mask reads are complete (they fed the barrier above): count in
+    __threadfence();
+    const int arrived = atomicAdd(x.done + b, 1);
+    last_ = (arrived == a.heads - 1);
+    if (last_) x.done[b] = 0;   // the next launch starts from zero again (kernel boundary orders it)
   }
   m = fmaxf(fmaxf(red_[0], red_[1]), fmaxf(red_[2], red_[3]));
   const float e = (s > -1.0e38f) ? expf(s - m) : 0.f;
@@ -316,6 +327,7 @@ __global__ __launch_bounds__(256) void vpt_attn_step_kernel(VptAttnArgs a, VptAt
   __syncthreads();
   const float tot = (red_[4] + red_[5]) + (red_[6] + red_[7]);
   const float inv = (tot > 0.f) ? 1.0f / tot : 0.f;
+  if (x.done && last_ && live && half == 0) x.mask_out[(size_t)b * maxlen + kk] = vis ? 1 : 0;   // every workgroup of b has read the old mask
   // ---- out = P V: thread = (d, half of the keys); all 64 values in registers before the barrier, shifted stores after it ----
   {
     const int d = tid & 127, kh = tid >> 7;
@@ -337,11 +349,11 @@ __global__ __launch_bounds__(256) void vpt_attn_step_kernel(VptAttnArgs a, VptAt
 }
 
 extern "C" int vpt_attn_step_launch(const VptAttnArgs* a, const uint8_t* state_mask, const uint8_t* first, uint8_t* mask_out, float* kout, float* vout,
-                                    hipStream_t stream) {
+                                    int* done, hipStream_t stream) {
   if (a->hid != a->heads * ATT_DH || a->t != 1 || !a->causal || a->maxlen < 1 || a->maxlen > 128) return -1;
-  if (!kout || !vout || !state_mask || !first || !mask_out || mask_out == state_mask) return -1;
+  if (!kout || !vout || !state_mask || !first || !mask_out || (mask_out == state_mask && !done)) return -1;
   VptAttnStepExtra x;
-  x.state_mask = state_mask; x.first = first; x.mask_out = mask_out; x.kout = kout; x.vout = vout;
+  x.state_mask = state_mask; x.first = first; x.mask_out = mask_out; x.kout = kout; x.vout = vout; x.done = done;
   hipLaunchKernelGGL(vpt_attn_step_kernel, dim3((unsigned)(a->B * a->heads)), dim3(256), 0, stream, *a, x);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
@@ -458,5 +470,35 @@ extern "C" int vpt_logsoftmax_launch(const VptLogSoftmaxArgs* a, hipStream_t str
   if (a->M <= 0 || a->n <= 0) return -1;
   if (a->M < 64 && a->n > 1024) hipLaunchKernelGGL((vpt_logsoftmax_kernel<16>), dim3(a->M), dim3(1024), 0, stream, *a);
   else hipLaunchKernelGGL((vpt_logsoftmax_kernel<4>), dim3(a->M), dim3(256), 0, stream, *a);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tail of MinecraftAgentPolicy.act on the acting path (lib/policy.py:307-327), one launch instead of eight ATen kernels inside the
+// captured step: log_prob = sum of the heads' action log-probs, vpred de-normalised (lib/normalize_ewma.py:27-31: v * std + mean),
+// the NaN assertion as a flag, everything the caller keeps packed into ONE buffer (a single clone per step):
+//   keep[b] = { buttons action, camera action, (float bits) log_prob | 0, (float bits) vpred de-normalised | raw vpred << 32 }
+__global__ void vpt_act_epilogue_kernel(const int64_t* act_b, const int64_t* act_c, const float* lp_b, const float* lp_c, const float* logits, int ld,
+                                        int vcol, float scale, float shift, int64_t* keep, uint8_t* nan_flag, int B) {
+  const int b = threadIdx.x;
+  bool bad = false;
+  if (b < B) {
+    const float lp = lp_b[b] + lp_c[b];
+    const float v = logits[(size_t)b * ld + vcol];
+    const float vd = fmaf(v, scale, shift);
+    bad = lp != lp;
+    keep[4 * b + 0] = act_b[b];
+    keep[4 * b + 1] = act_c[b];
+    keep[4 * b + 2] = (int64_t)(uint64_t)__builtin_bit_cast(uint32_t, lp);
+    keep[4 * b + 3] = (int64_t)((uint64_t)__builtin_bit_cast(uint32_t, vd) | ((uint64_t)__builtin_bit_cast(uint32_t, v) << 32));
+  }
+  const unsigned long long any = __ballot(bad);
+  if (threadIdx.x == 0) *nan_flag = any ? 1 : 0;
+}
+
+extern "C" int vpt_act_epilogue_launch(const int64_t* act_b, const int64_t* act_c, const float* lp_b, const float* lp_c, const float* logits, int ld,
+                                       int vcol, float scale, float shift, int64_t* keep, uint8_t* nan_flag, int B, hipStream_t stream) {
+  if (B <= 0 || B > 64 || !keep || !nan_flag) return -1;
+  hipLaunchKernelGGL(vpt_act_epilogue_kernel, dim3(1), dim3(64), 0, stream, act_b, act_c, lp_b, lp_c, logits, ld, vcol, scale, shift, keep, nan_flag, B);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

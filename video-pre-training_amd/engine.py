@@ -82,12 +82,13 @@ def resolve_precision(precision: Optional[str]) -> str:
     return p
 
 
-def action_heads(logits, heads, bsz, t, temperature, mask=None, sample=None):
+def action_heads(logits, heads, bsz, t, temperature, mask=None, sample=None, keep_head_logps=False):
     """DictActionHead.forward (+ sample / logprob) over the fused head logits.  heads: (name, first column, groups, classes);
-    a head's logits are [M, groups * classes] -> log-probs [B, T, groups, classes].  Returns the dict entries to merge."""
+    a head's logits are [M, groups * classes] -> log-probs [B, T, groups, classes].  Returns the dict entries to merge.
+    keep_head_logps: leave the heads' action log-probs un-summed in out["_head_logps"] (the acting step's epilogue kernel adds them)."""
     if sample not in (None, "deterministic", "stochastic"):
         raise ValueError(f"sample must be None, 'deterministic' or 'stochastic', got {sample!r}")
-    out, actions, logp = {}, {}, None
+    out, actions, logp, head_lps = {}, {}, None, {}
     for name, col0, groups, n in heads:
         z = logits if groups == 1 else logits[:, col0:col0 + groups * n].reshape(-1, n)
         c0 = col0 if groups == 1 else 0
@@ -102,11 +103,24 @@ def action_heads(logits, heads, bsz, t, temperature, mask=None, sample=None):
             lp, ac, alp = ops.log_softmax_cols(z, c0, n, temperature, mask=mk, noise=noise, want_action=True)
             actions[name] = ac.view(bsz, t, groups)
             alp = alp.view(bsz, t) if groups == 1 else alp.view(bsz, t, groups).sum(-1)     # (no reduction kernel for the usual single group)
-            logp = alp if logp is None else logp + alp
+            head_lps[name] = alp
+            if not keep_head_logps:
+                logp = alp if logp is None else logp + alp
         out[name] = lp.view(bsz, t, groups, n)
     if sample is not None:
-        out["action"], out["action_log_prob"] = actions, logp
+        out["action"] = actions
+        if keep_head_logps:
+            out["_head_logps"] = head_lps
+        else:
+            out["action_log_prob"] = logp
     return out
+
+
+def unpack_act_tail(keep, bsz):
+    """The caller-visible entries of the acting step as views of the packed record (T = 1)."""
+    ab, ac, lp, vd, v = ops.unpack_act_keep(keep)
+    return dict(action={"buttons": ab.reshape(bsz, 1, 1), "camera": ac.reshape(bsz, 1, 1)}, action_log_prob=lp.reshape(bsz, 1),
+                vpred_denorm=vd.reshape(bsz, 1), vpred=v.reshape(bsz, 1, 1))
 
 
 class PolicyEngine:
@@ -126,6 +140,7 @@ class PolicyEngine:
         self.cnn_chunk = int(os.environ.get("VPT_CNN_CHUNK", cnn_chunk))
         self.cnn_streams = int(os.environ.get("VPT_CNN_STREAMS", cnn_streams))
         self._streams = []
+        self._attn_done = None      # arrival counters of the in-place acting step (ops.masked_attention_step)
         self.w: Dict[str, torch.Tensor] = {}
         self.packed = False
 
@@ -269,11 +284,14 @@ class PolicyEngine:
 
     @torch.no_grad()
     def forward(self, img_u8: torch.Tensor, first: torch.Tensor, state_in: List, mask: Optional[dict] = None,
-                sample: Optional[str] = None, inplace_state: bool = False):
+                sample: Optional[str] = None, inplace_state: bool = False, act_tail: Optional[tuple] = None):
         """mask: optional {"buttons" / "camera": bool [B,T,1,n]} availability masks (obs["mask"], lib/policy.py:257-266).
         sample: None, "deterministic" or "stochastic" -- CategoricalActionHead.sample + logprob fused into the head kernel
         (lib/action_head.py:176-207); adds out["action"] (int64 [B,T,1] per head) and out["action_log_prob"] ([B,T]).
-        inplace_state (T = 1 only): state_out IS state_in, updated in place (the captured acting graph's static state)."""
+        inplace_state (T = 1 only): state_out IS state_in, masks included, updated in place (the captured acting graph's static state).
+        act_tail = (scale, shift) of the value normaliser (T = 1, sample set): the tail of MinecraftAgentPolicy.act in one launch --
+        adds out["_keep"] (ops.act_epilogue's packed record), out["nan_flag"], out["vpred_denorm"]; action / action_log_prob / vpred are
+        views of the record."""
         if not self.packed:
             raise RuntimeError("PolicyEngine.pack(state_dict) must be called before forward")
         cfg, w = self.cfg, self.w
@@ -302,9 +320,16 @@ class PolicyEngine:
             if step:
                 if inplace_state and not (kmem.is_contiguous() and vmem.is_contiguous()):
                     raise ValueError("inplace_state needs contiguous state tensors (a .contiguous() copy would receive the update instead of the state)")
+                done = None
+                if inplace_state:       # the mask too: the last workgroup to arrive writes it (ops.masked_attention_step)
+                    if not state_mask.is_contiguous():
+                        raise ValueError("inplace_state needs contiguous state masks")
+                    if self._attn_done is None or self._attn_done.device != x.device:
+                        self._attn_done = torch.zeros(64, dtype=torch.int32, device=x.device)
+                    done = self._attn_done
                 att, kout, vout, m8 = ops.masked_attention_step(qkvr, kmem.contiguous(), vmem.contiguous(), state_mask.reshape(bsz, maxlen).contiguous(), first8,
-                                                               w[p + "b_nd"], bsz, heads, hid, dtype=self.dtype, inplace=inplace_state)
-                new_mask = m8.view(torch.bool).view(bsz, 1, maxlen)
+                                                               w[p + "b_nd"], bsz, heads, hid, dtype=self.dtype, inplace=inplace_state, done=done)
+                new_mask = state_mask if inplace_state else m8.view(torch.bool).view(bsz, 1, maxlen)
             else:
                 memvalid = (state_mask & not_first).reshape(bsz, maxlen).to(torch.uint8).contiguous()
                 att = ops.masked_attention(qkvr, kmem.contiguous(), vmem.contiguous(), memvalid, w[p + "b_nd"], bsz, t, heads, hid, dtype=self.dtype)
@@ -322,9 +347,17 @@ class PolicyEngine:
         latent, logits, _ = self._ln_linear(y, w["final.g"], w["final.b"], w["heads.w"], nb + nc + 1, bias=w["heads.b"], ln_out_f32=True)
         temp = cfg["temperature"]
         out = dict(latent=latent.view(bsz, t, hid), state_out=state_out)
-        heads_out = action_heads(logits, (("buttons", 0, 1, nb), ("camera", nb, 1, nc)), bsz, t, temp, mask, sample)
+        tail = act_tail is not None and sample is not None and t == 1
+        heads_out = action_heads(logits, (("buttons", 0, 1, nb), ("camera", nb, 1, nc)), bsz, t, temp, mask, sample, keep_head_logps=tail)
         out.update(heads_out)
-        out["vpred"] = logits[:, nb + nc:nb + nc + 1].reshape(bsz, t, 1).clone()
+        if tail:
+            lps = out.pop("_head_logps")
+            keep, flag = ops.act_epilogue(out["action"]["buttons"].view(-1), out["action"]["camera"].view(-1), lps["buttons"].reshape(-1),
+                                          lps["camera"].reshape(-1), logits, nb + nc, act_tail[0], act_tail[1])
+            out["_keep"], out["nan_flag"] = keep, flag
+            out.update(unpack_act_tail(keep, bsz))
+        else:
+            out["vpred"] = logits[:, nb + nc:nb + nc + 1].reshape(bsz, t, 1).clone()
         return out
 
 

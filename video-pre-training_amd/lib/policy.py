@@ -233,6 +233,7 @@ class MinecraftAgentPolicy(nn.Module):
         self._engine = PolicyEngine(self._cfg, n_buttons=action_space["buttons"].eltype.n,
                                     n_camera=action_space["camera"].eltype.n, precision=precision)
         self._packed_key = None
+        self._param_cache = None
         self._step_graph = None
         self._grad_engines = {}
 
@@ -252,16 +253,31 @@ class MinecraftAgentPolicy(nn.Module):
         return self
 
     # ---- engine plumbing --------------------------------------------------------------------
+    def _apply(self, fn, *args, **kwargs):      # .to() / .cuda() / .half(): parameters may be re-created
+        self._param_cache = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):  # assign=True replaces the Parameter objects
+        self._param_cache = None
+        return super().load_state_dict(*args, **kwargs)
+
+    def _params(self):
+        """(name, parameter) list, cached: named_parameters() walks the module tree (~0.1 ms, paid per acting step otherwise).
+        Parameters are created in __init__ and only ever updated in place or moved by .to() (same Parameter objects)."""
+        if self._param_cache is None:
+            self._param_cache = list(self.named_parameters())
+        return self._param_cache
+
     def _device(self):
-        return next(self.parameters()).device
+        return self._params()[0][1].device
 
     def _ensure_packed(self):
-        params = dict(self.named_parameters())
-        key = (str(self._device()),) + tuple((p.data_ptr(), p._version) for p in params.values())
+        named = self._params()
+        key = (named[0][1].device,) + tuple((p.data_ptr(), p._version) for _, p in named)
         if key != self._packed_key:
             if self._device().type != "cuda":
                 raise RuntimeError("MinecraftAgentPolicy (HIP) needs its parameters on the GPU: call .to('cuda')")
-            self._engine.pack(params)
+            self._engine.pack(dict(named))
             self._packed_key = key
             if self._step_graph is not None:      # the graph holds the old packed weights' addresses: re-capture lazily
                 self._step_graph = dict(batch=self._step_graph["batch"])
@@ -299,14 +315,10 @@ class MinecraftAgentPolicy(nn.Module):
             # arg-max + its log-prob ride in the graph; the recurrent state is updated in place (no copies back into the static buffers)
             from .. import ops
             inplace = cfg["maxlen"] <= ops.ATTENTION_STEP_MAXLEN     # the fused step kernel's limit; longer memories go through copies (below)
-            out = eng.forward(sg["img"], sg["first"], sg["state"], sample="deterministic", inplace_state=inplace)
-            # act()'s glue rides in the graph too: the value de-normalisation (one fused multiply-add) and the NaN check of the
-            # action log-prob (lib/policy.py:320-321 asserts it every step) as a flag the host reads with the action
-            out["vpred_denorm"] = torch.add(torch.full_like(out["vpred"][:, 0], shift), out["vpred"][:, 0], alpha=scale)
-            out["nan_flag"] = torch.isnan(out["action_log_prob"]).any()
-            # everything the caller keeps beyond the next replay, packed: two small tensors to clone per step instead of four
-            out["_keep_i"] = torch.cat([out["action"][k].reshape(b, 1) for k in ("buttons", "camera")], 1)                # int64 [B, 2]
-            out["_keep_f"] = torch.cat([out["action_log_prob"].reshape(b, 1), out["vpred_denorm"].reshape(b, 1)], 1)      # fp32 [B, 2]
+            # act()'s glue rides in the graph too, as ONE launch (ops.act_epilogue): the heads' log-probs summed, the value de-normalised,
+            # the NaN check of the action log-prob (lib/policy.py:320-321 asserts it every step) as a flag the host reads with the
+            # action, and everything the caller keeps beyond the next replay packed into one record: a single clone per step
+            out = eng.forward(sg["img"], sg["first"], sg["state"], sample="deterministic", inplace_state=inplace, act_tail=(scale, shift))
             for (m_in, (k_in, v_in)), (m_out, (k_out, v_out)) in zip(sg["state"], out["state_out"]):
                 if m_out.data_ptr() != m_in.data_ptr():
                     m_in.copy_(m_out)
@@ -332,12 +344,9 @@ class MinecraftAgentPolicy(nn.Module):
         sg["graph"].replay()
         out = dict(sg["out"])
         out["state_out"] = sg["state"]
-        if "action" in out:      # handed to the caller: must survive the next replay (the other outputs are consumed at once)
-            ki, kf = out["_keep_i"].clone(), out["_keep_f"].clone()
-            bsz = ki.shape[0]
-            out["action"] = {"buttons": ki[:, 0].reshape(bsz, 1, 1), "camera": ki[:, 1].reshape(bsz, 1, 1)}
-            out["action_log_prob"] = kf[:, 0].reshape(out["action_log_prob"].shape)
-            out["vpred_denorm"] = kf[:, 1].reshape(bsz, 1)
+        if "_keep" in out:       # handed to the caller: must survive the next replay (the other outputs are consumed at once)
+            from ..engine import unpack_act_tail
+            out.update(unpack_act_tail(out["_keep"].clone(), sg["batch"]))
         return out
 
     def initial_state(self, batch_size: int):

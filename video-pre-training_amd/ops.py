@@ -344,12 +344,12 @@ def kv_memory_update(qkvr, kmem, vmem, batch, t, hid):
 ATTENTION_STEP_MAXLEN = 128
 
 
-def masked_attention_step(qkvr, kmem, vmem, state_mask, first, b_nd, batch, heads, hid, dtype=torch.bfloat16, inplace=False):
+def masked_attention_step(qkvr, kmem, vmem, state_mask, first, b_nd, batch, heads, hid, dtype=torch.bfloat16, inplace=False, done=None):
     """Acting step (t = 1): masked_attention(), kv_memory_update() and the state-mask bookkeeping in one launch.
     state_mask bool/uint8 [batch, maxlen], first bool/uint8 [batch] -> (out 16-bit [batch, hid], kout, vout, new mask uint8 [batch, maxlen]).
     inplace: kout / vout ARE kmem / vmem (updated in place: the captured acting graph's static state; a workgroup owns its head's
-    columns and holds the rows in registers across a barrier).  The mask is ALWAYS a new tensor: every head's workgroup reads the old
-    mask while one of them writes the new one, and workgroups of one launch are not ordered."""
+    columns and holds the rows in registers across a barrier).  The mask is a new tensor unless `done` (int32 [>= batch], zero; the
+    kernel leaves it zero) is given with inplace: then the workgroup that arrives last writes it over state_mask."""
     _chk(qkvr, torch.float32, "qkvr"); _chk(kmem, torch.float32, "kmem"); _chk(vmem, torch.float32, "vmem"); _chk(b_nd, torch.float32, "b_nd")
     if state_mask.dtype == torch.bool:
         state_mask = state_mask.view(torch.uint8)
@@ -362,11 +362,42 @@ def masked_attention_step(qkvr, kmem, vmem, state_mask, first, b_nd, batch, head
                          f"(got {qkvr.shape[0]} rows for batch {batch}, maxlen {maxlen}, mask {tuple(state_mask.shape)})")
     dt, fmt = _fmt(dtype=dtype)
     out = torch.empty(batch, hid, dtype=dt, device=qkvr.device)
+    meta = dict(flops=4.0 * batch * maxlen * hid, bytes=16.0 * batch * maxlen * hid)
+    if done is not None:
+        if not inplace:
+            raise ValueError("masked_attention_step: `done` is the in-place variant's counter")
+        if done.dtype != torch.int32 or done.numel() < batch or not done.is_contiguous():
+            raise ValueError("masked_attention_step: done must be a contiguous int32 tensor of at least `batch` zeros")
+        _call("vpt_masked_attention_step_inplace", meta, ptr(qkvr), ptr(kmem), ptr(vmem), ptr(state_mask), ptr(first), ptr(b_nd), ptr(out), ptr(done),
+              batch, heads, hid, qkvr.shape[1], maxlen, _stream(), fmt=fmt, label="vpt_masked_attention_step")
+        return out, kmem, vmem, state_mask
     mout = torch.empty_like(state_mask)
     kout, vout = (kmem, vmem) if inplace else (torch.empty_like(kmem), torch.empty_like(vmem))
-    _call("vpt_masked_attention_step", dict(flops=4.0 * batch * maxlen * hid, bytes=16.0 * batch * maxlen * hid), ptr(qkvr), ptr(kmem), ptr(vmem), ptr(state_mask), ptr(first),
+    _call("vpt_masked_attention_step", meta, ptr(qkvr), ptr(kmem), ptr(vmem), ptr(state_mask), ptr(first),
           ptr(b_nd), ptr(out), ptr(kout), ptr(vout), ptr(mout), batch, heads, hid, qkvr.shape[1], maxlen, _stream(), fmt=fmt)
     return out, kout, vout, mout
+
+
+def act_epilogue(action_buttons, action_camera, logp_buttons, logp_camera, logits, value_col, scale, shift):
+    """Tail of MinecraftAgentPolicy.act on the acting path in one launch (include/vpt_hip.h: vpt_act_epilogue) ->
+    (keep int64 [M, 4], nan_flag uint8 [1]); see unpack_act_keep()."""
+    _chk(action_buttons, torch.int64, "action_buttons"); _chk(action_camera, torch.int64, "action_camera")
+    _chk(logp_buttons, torch.float32, "logp_buttons"); _chk(logp_camera, torch.float32, "logp_camera"); _chk(logits, torch.float32, "logits")
+    m = logits.shape[0]
+    if m > 64 or action_buttons.numel() != m or action_camera.numel() != m or logp_buttons.numel() != m or logp_camera.numel() != m:
+        raise ValueError("act_epilogue: one action / log-prob per row of logits, at most 64 rows")
+    keep = torch.empty(m, 4, dtype=torch.int64, device=logits.device)
+    flag = torch.empty(1, dtype=torch.uint8, device=logits.device)
+    _call("vpt_act_epilogue", dict(bytes=64.0 * m), ptr(action_buttons), ptr(action_camera), ptr(logp_buttons), ptr(logp_camera), ptr(logits),
+          logits.shape[1], int(value_col), ctypes.c_float(scale), ctypes.c_float(shift), ptr(keep), ptr(flag), m, _stream())
+    return keep, flag
+
+
+def unpack_act_keep(keep):
+    """Views (no kernels) of act_epilogue's packed record: (buttons int64 [M], camera int64 [M], log_prob fp32 [M], vpred de-normalised
+    fp32 [M], raw vpred fp32 [M])."""
+    kf = keep.view(torch.float32)       # [M, 8]
+    return keep[:, 0], keep[:, 1], kf[:, 4], kf[:, 6], kf[:, 7]
 
 
 def log_softmax_cols(logits, col0, n, temperature, mask=None, noise=None, want_action=False):
