@@ -70,17 +70,18 @@ def test_conv3x3(frames, h, w, cin, cout, use_res, tiling):
     assert torch.allclose(st_out.cpu(), st_ref, rtol=5e-3, atol=1.0), (st_out.cpu(), st_ref)
 
 
-@pytest.mark.parametrize("frames,cout", [(2, 128), (1, 64), (1, 192)])
-def test_conv_first_pool(frames, cout):
+@pytest.mark.parametrize("frames,cout,h,w", [(2, 128, 128, 128), (1, 64, 128, 128), (1, 192, 128, 128), (5, 64, 32, 80), (3, 128, 48, 16)])
+def test_conv_first_pool(frames, cout, h, w):
+    """(non-square frames: the persistent workgroups count tile coordinates up -- tile column, tile row, frame -- instead of decoding them)"""
     g = torch.Generator().manual_seed(2)
     W = torch.randn(cout, 3, 3, 3, generator=g) * 0.3
     b = 0.1 * torch.randn(cout, generator=g)
-    img = torch.randint(0, 256, (frames, 128, 128, 3), generator=g, dtype=torch.uint8)
+    img = torch.randint(0, 256, (frames, h, w, 3), generator=g, dtype=torch.uint8)
     ref = F.max_pool2d(torch.relu(F.conv2d(img.permute(0, 3, 1, 2).float() / 255.0, W, b, padding=1)), 3, 2, 1)
     st = torch.zeros(frames, 2, dtype=torch.float64, device=DEV)
     y = ops.conv_first(img.to(DEV), packing.pack_conv_first(W.to(DEV), b.to(DEV)), cout, stats_out=st)
     torch.cuda.synchronize()
-    out = packing.blocked_to_nchw(y.cpu(), cout, 64, 64)
+    out = packing.blocked_to_nchw(y.cpu(), cout, h // 2, w // 2)
     err = _relerr(out, ref)
     assert err < 1.5e-2, f"conv_first rel err {err}"
     assert torch.allclose(st.cpu(), _stats_of(out), rtol=1e-4, atol=1e-2)

@@ -362,13 +362,13 @@ def test_conv_layer_param_grads():
     assert eW < 6e-2 and eg < 1e-1 and eb < 1e-1
 
 
-@pytest.mark.parametrize("frames,cout", [(2, 128), (1, 64), (12, 128)])   # 12 frames = 768 tiles: every persistent workgroup sweeps several
-def test_conv_first_backward(frames, cout):
+@pytest.mark.parametrize("frames,cout,h,w", [(2, 128, 128, 128), (1, 64, 128, 128), (12, 128, 128, 128), (7, 64, 32, 80)])   # 12 frames = 768 tiles: every persistent workgroup sweeps several
+def test_conv_first_backward(frames, cout, h, w):
     g = torch.Generator().manual_seed(16)
     W = (torch.randn(cout, 3, 3, 3, generator=g) * 0.3).requires_grad_(True)
     b = (0.1 * torch.randn(cout, generator=g)).requires_grad_(True)
-    img = torch.randint(0, 256, (frames, 128, 128, 3), generator=g, dtype=torch.uint8)
-    dP = torch.randn(frames, cout, 64, 64, generator=g).to(torch.bfloat16).float()
+    img = torch.randint(0, 256, (frames, h, w, 3), generator=g, dtype=torch.uint8)
+    dP = torch.randn(frames, cout, h // 2, w // 2, generator=g).to(torch.bfloat16).float()
     Wb = ((W.detach() / 255.0).to(torch.bfloat16).float() * 255.0).requires_grad_(True)  # the kernel rounds W / 255 to bf16; compare like for like
     y = torch.relu(torch.nn.functional.conv2d(img.permute(0, 3, 1, 2).float() / 255.0, Wb, b, padding=1))
     y = y + (y.detach().to(torch.bfloat16).float() - y.detach())  # the kernel pools bf16-rounded values (straight-through here)

@@ -303,28 +303,28 @@ class MinecraftAgentPolicy(nn.Module):
                         (torch.zeros(b, cfg["maxlen"], cfg["hidsize"], dtype=torch.float32, device=dev),
                          torch.zeros(b, cfg["maxlen"], cfg["hidsize"], dtype=torch.float32, device=dev)))
                        for _ in range(cfg["n_layers"])]
+        from .. import ops
+        inplace = cfg["maxlen"] <= ops.ATTENTION_STEP_MAXLEN     # the fused step kernel's limit; longer memories go through copies (below)
+        scale, shift = self.value_head.normalizer.affine()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):           # warm-up outside capture (lazy kernel attributes, allocator pools)
-            for _ in range(2):
-                eng.forward(sg["img"], sg["first"], sg["state"], sample="deterministic")
+        with torch.cuda.stream(side):           # warm-up outside capture, with the captured call's exact arguments (lazy kernel loading, allocator
+            for _ in range(2):                  # pools, the engine's arrival counters); the state it advances is zeroed again below
+                eng.forward(sg["img"], sg["first"], sg["state"], sample="deterministic", inplace_state=inplace, act_tail=(scale, shift))
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        scale, shift = self.value_head.normalizer.affine()
         with torch.cuda.graph(graph):
-            # arg-max + its log-prob ride in the graph; the recurrent state is updated in place (no copies back into the static buffers)
-            from .. import ops
-            inplace = cfg["maxlen"] <= ops.ATTENTION_STEP_MAXLEN     # the fused step kernel's limit; longer memories go through copies (below)
-            # act()'s glue rides in the graph too, as ONE launch (ops.act_epilogue): the heads' log-probs summed, the value de-normalised,
-            # the NaN check of the action log-prob (lib/policy.py:320-321 asserts it every step) as a flag the host reads with the
-            # action, and everything the caller keeps beyond the next replay packed into one record: a single clone per step
+            # arg-max + its log-prob ride in the graph; the recurrent state -- K, V and masks -- is updated in place (no copies back into
+            # the static buffers).  act()'s glue rides in the graph too, as ONE launch (ops.act_epilogue): the heads' log-probs summed, the
+            # value de-normalised, the NaN check of the action log-prob (lib/policy.py:320-321 asserts it every step) as a flag the host
+            # reads with the action, and everything the caller keeps beyond the next replay packed into one record: a single clone per step
             out = eng.forward(sg["img"], sg["first"], sg["state"], sample="deterministic", inplace_state=inplace, act_tail=(scale, shift))
             for (m_in, (k_in, v_in)), (m_out, (k_out, v_out)) in zip(sg["state"], out["state_out"]):
                 if m_out.data_ptr() != m_in.data_ptr():
                     m_in.copy_(m_out)
                 if k_out.data_ptr() != k_in.data_ptr():
                     k_in.copy_(k_out); v_in.copy_(v_out)
-        for m_in, (k_in, v_in) in sg["state"]:    # the warm-up / capture runs advanced nothing: start from a clean state
+        for m_in, (k_in, v_in) in sg["state"]:    # the warm-up runs advanced the static state: start from a clean one
             m_in.zero_(); k_in.zero_(); v_in.zero_()
         sg["graph"], sg["out"] = graph, out
 
