@@ -139,6 +139,9 @@ class PolicyEngine:
         self.n_buttons, self.n_camera = n_buttons, n_camera
         self.cnn_chunk = int(os.environ.get("VPT_CNN_CHUNK", cnn_chunk))
         self.cnn_streams = int(os.environ.get("VPT_CNN_STREAMS", cnn_streams))
+        # frames per conv + pool sub-chunk of stacks 1.. (0: whole chunk).  Measured (profiles/r03_experiments.md section 12): 64 / 128 / 256 frames
+        # all give +1.2 % on the forward step (the conv launches themselves run 1.8 % faster at 128 / 256); the pool kernel's own time does not move
+        self.pool_subchunk = int(os.environ.get("VPT_POOL_SUBCHUNK", 256))
         self._streams = []
         self._attn_done = None      # arrival counters of the in-place acting step (ops.masked_attention_step)
         self.w: Dict[str, torch.Tensor] = {}
@@ -224,9 +227,20 @@ class PolicyEngine:
                 pooled = ops.conv_first(img, w[p + "firstconv"], c, stats_out=s_pool)
             else:
                 wpk, sa, sg = w[p + "firstconv"]
-                pre = ops.conv3x3(x, wpk, sa, sg, s_x, c, tiling=tiling)
-                pooled = ops.maxpool(pre, stats_out=s_pool)
-                del pre
+                sub = self.pool_subchunk
+                if sub and f > sub:
+                    # conv + pool over sub-chunks of frames: the pre-pool tensor of a sub-chunk (2 MB per frame in stack 1) is pooled while it is
+                    # still in the 256 MB Infinity Cache instead of after the whole chunk's 2 GB have gone through HBM
+                    pooled = torch.empty(f, c // 32, x.shape[2] // 2, x.shape[3] // 2, 32, dtype=x.dtype, device=x.device)
+                    for i in range(0, f, sub):
+                        j = min(i + sub, f)
+                        pre = ops.conv3x3(x[i:j], wpk, sa, sg, s_x[i:j], c, tiling=tiling)
+                        ops.maxpool(pre, stats_out=s_pool[i:j], out=pooled[i:j])
+                        del pre
+                else:
+                    pre = ops.conv3x3(x, wpk, sa, sg, s_x, c, tiling=tiling)
+                    pooled = ops.maxpool(pre, stats_out=s_pool)
+                    del pre
             s_x = nxt()
             x = ops.frame_affine(pooled, w[p + "n.g"], w[p + "n.b"], s_pool, stats_out=s_x, out=pooled)
             for b in range(2):

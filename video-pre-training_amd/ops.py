@@ -194,12 +194,15 @@ def conv3x3(x, wpk, edge_sa, edge_sg, stats_in, cout, res=None, stats_out=None, 
     return out
 
 
-def maxpool(x, stats_out=None, want_argmax=False):
-    """-> pooled, or (pooled, argmax uint8) with want_argmax (training: vpt_conv_backward_prepare routes through it)."""
-    _chk(x, OP16, "x"); _chk(stats_out, torch.float64, "stats_out")
+def maxpool(x, stats_out=None, want_argmax=False, out=None):
+    """-> pooled, or (pooled, argmax uint8) with want_argmax (training: vpt_conv_backward_prepare routes through it).
+    out: pooled tensor to fill (e.g. a slice of a larger batch's)."""
+    _chk(x, OP16, "x"); _chk(stats_out, torch.float64, "stats_out"); _chk(out, OP16, "out")
     f, cb, h, w, _ = x.shape
-    dt, fmt = _fmt(x)
-    y = torch.empty(f, cb, h // 2, w // 2, 32, dtype=dt, device=x.device)
+    dt, fmt = _fmt(x, out)
+    if out is not None and (tuple(out.shape) != (f, cb, h // 2, w // 2, 32) or not out.is_contiguous()):
+        raise ValueError("maxpool: out must be a contiguous [F, C/32, H/2, W/2, 32] tensor")
+    y = out if out is not None else torch.empty(f, cb, h // 2, w // 2, 32, dtype=dt, device=x.device)
     am = torch.empty(f, cb, h // 2, w // 2, 32, dtype=torch.uint8, device=x.device) if want_argmax else None
     _call("vpt_maxpool_forward", dict(bytes=2.0 * f * cb * 32 * h * w * 1.25), ptr(x), ptr(y), ptr(stats_out), ptr(am), f, cb * 32, h, w, _stream(), fmt=fmt)
     return (y, am) if want_argmax else y
