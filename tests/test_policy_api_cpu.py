@@ -49,3 +49,16 @@ def test_action_head_algebra():
     ref = lp["buttons"].max(-1).values.sum(-1) + lp["camera"].max(-1).values.sum(-1)
     assert torch.allclose(logp, ref)
     assert torch.allclose(head.kl_divergence(lp, lp), torch.zeros(2, 3, 1), atol=1e-6)
+
+
+def test_idm_engine_has_every_attribute_the_shared_cnn_code_reads():
+    """IDMEngine borrows PolicyEngine's CNN walk (`_cnn_chunk`): every `self.<attribute>` that code reads must exist on an IDMEngine
+    (a missing one only shows on the GPU, in the first IDM forward)."""
+    import inspect, re
+    from vpt_amd import configs, engine
+    from vpt_amd.lib.policy import InverseActionPolicy
+    pol = InverseActionPolicy(minecraft_action_space(), pi_head_kwargs=dict(temperature=2.0), idm_net_kwargs=configs.idm_kwargs_for("tiny"))
+    src = inspect.getsource(engine.PolicyEngine._cnn_chunk)
+    attrs = set(re.findall(r"self\.([A-Za-z_][A-Za-z_0-9]*)", src))
+    missing = [a for a in sorted(attrs) if not hasattr(pol._engine, a)]
+    assert not missing, f"IDMEngine lacks {missing}"

@@ -388,6 +388,7 @@ class IDMEngine(PolicyEngine):
         self.button_shape, self.camera_shape = tuple(button_shape), tuple(camera_shape)  # (20, 2), (2, 11)
         self.cnn_chunk = cnn_chunk
         self.cnn_streams = 1
+        self.pool_subchunk = 0      # (PolicyEngine._cnn_chunk's option; the IDM's chunks are one 128-frame window)
         self._streams = []
         self.w = {}
         self.packed = False
