@@ -181,17 +181,21 @@ def _roofline(ops, pol, step, state, args, B, T, mode):
         ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
         # HBM traffic cannot be counted live (PMC needs rocprofv3): the committed PMC measurement of this same workload
         # (separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 per the gfx950 correction), per launch, labelled as such
-        traffic, tsrc = None, None
+        traffic, tsrc, talg = None, None, 173.9e9 / c["calls"]
         for tp in TRAFFIC_FILES.get(mode, ()):
             tpath = os.path.join(ROOT, "profiles", tp)
             if args.model == "2x" and B * T == 8192 and os.path.exists(tpath):
-                try:
-                    traffic, tsrc = round(json.load(open(tpath))["hbm_bytes_per_launch"]), f"committed PMC (profiles/{tp}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, tools/profile_round.sh), not measured by this run"
+                try:      # per-step totals of the committed measurement over THIS run's launch count (sub-chunking changes the count, not the bytes)
+                    tj = json.load(open(tpath))
+                    per_step = tj.get("hbm_bytes_per_step", tj["hbm_bytes_per_launch"] * 112.0)
+                    alg_step = tj.get("algorithmic_bytes_per_step", 173.9e9)
+                    traffic, talg = round(per_step / c["calls"]), alg_step / c["calls"]
+                    tsrc = f"committed PMC (profiles/{tp}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, tools/profile_round.sh: {per_step / 1e9:.1f} GB per step / {c['calls']} launches), not measured by this run"
                     break
                 except Exception:
                     traffic = None
         roof = dict(bound="mfma", kernel="vpt_conv3x3_kernel", achieved=round(ach, 1), peak=2500.0, unit="TFLOP/s",
-                    frac=round(ach / 2500.0, 4), traffic=traffic, traffic_unit="HBM bytes per launch (algorithmic 1.55e9)", traffic_source=tsrc,
+                    frac=round(ach / 2500.0, 4), traffic=traffic, traffic_unit=f"HBM bytes per launch (algorithmic {talg:.3g})", traffic_source=tsrc,
                     launches=c["calls"], avg_launch_ms=round(c["ms"] / c["calls"], 4), share_of_step_time=round(c["ms"] / total_ms, 3),
                     flop_accounting="direct-convolution FLOPs (2 x H x W x Cout x 9 x Cin per frame and layer) / summed HIP-event durations of the launches")
     return roof, kernels

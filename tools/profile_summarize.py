@@ -106,10 +106,19 @@ for sub, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     launches = n
 if len(tot) == 2 and launches:
     hbm = (tot["FETCH_SIZE"] * 2.0 + tot["WRITE_SIZE"]) * 1024.0
-    alg_per_launch = 173.9e9 / 112.0     # 21.2 MB / frame x 8192 frames over the 112 conv launches of one step
-    t = dict(fetch_size_kb_sum=tot["FETCH_SIZE"], write_size_kb_sum=tot["WRITE_SIZE"], launches=launches, hbm_bytes_total_fetch_x2_plus_write=hbm,
-             hbm_bytes_per_launch=hbm / launches, algorithmic_bytes_per_launch=alg_per_launch, ratio_measured_over_algorithmic=hbm / launches / alg_per_launch,
-             note="forward passes of the bench workload (2x, 64x128 frames: 112 launches of vpt_conv3x3_kernel per pass), `rocprofv3 --kernel-trace --pmc "
+    # launches per forward pass from the bench line of the profiled run itself (112 with whole-chunk launches, 160 with the conv + pool
+    # sub-chunks of stacks 1 / 2, engine.pool_subchunk); the run makes two passes (the timed step and the instrumented one)
+    per_pass = 112.0
+    try:
+        per_pass = float(json.loads(open(os.path.join(SRC, "pmc_fetch.json")).read().strip().splitlines()[-1])["roofline"]["launches"])
+    except Exception:
+        pass
+    passes = launches / per_pass
+    alg_per_step = 173.9e9               # 21.2 MB / frame x 8192 frames
+    t = dict(fetch_size_kb_sum=tot["FETCH_SIZE"], write_size_kb_sum=tot["WRITE_SIZE"], launches=launches, launches_per_step=per_pass,
+             hbm_bytes_total_fetch_x2_plus_write=hbm, hbm_bytes_per_step=hbm / passes, algorithmic_bytes_per_step=alg_per_step,
+             hbm_bytes_per_launch=hbm / launches, algorithmic_bytes_per_launch=alg_per_step / per_pass, ratio_measured_over_algorithmic=hbm / passes / alg_per_step,
+             note="forward pass(es) of the bench workload (2x, 64x128 frames), `rocprofv3 --kernel-trace --pmc "
                   "FETCH_SIZE` / `--pmc WRITE_SIZE` in separate passes; FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B); KB units x1024")
     json.dump(t, open(os.path.join(DST, f"{TAG}_bench_conv3x3_traffic.json"), "w"), indent=1)
     print(f"traffic: {hbm / launches / 1e9:.3f} GB per launch over {launches} launches (x{t['ratio_measured_over_algorithmic']:.3f} of algorithmic)")
