@@ -62,3 +62,17 @@ def test_idm_engine_has_every_attribute_the_shared_cnn_code_reads():
     attrs = set(re.findall(r"self\.([A-Za-z_][A-Za-z_0-9]*)", src))
     missing = [a for a in sorted(attrs) if not hasattr(pol._engine, a)]
     assert not missing, f"IDMEngine lacks {missing}"
+
+
+def test_act_keep_record_views():
+    """ops.unpack_act_keep: the acting step's packed int64 record decodes through views only (no kernels) -- layout of vpt_act_epilogue."""
+    import struct
+    from vpt_amd import ops
+    f2i = lambda x: struct.unpack("<I", struct.pack("<f", x))[0]
+    rows = [(5957, 60, -3.25, 1.5, -0.75), (0, 120, -0.001, -2.0, 8.0)]
+    s64 = lambda u: u - (1 << 64) if u >= (1 << 63) else u          # the record is int64: a set sign bit of the upper float wraps
+    keep = torch.tensor([[b, c, f2i(lp), s64(f2i(vd) | (f2i(v) << 32))] for b, c, lp, vd, v in rows], dtype=torch.int64)
+    ab, ac, lp, vd, v = ops.unpack_act_keep(keep)
+    assert ab.tolist() == [5957, 0] and ac.tolist() == [60, 120]
+    assert torch.equal(lp, torch.tensor([-3.25, -0.001])) and torch.equal(vd, torch.tensor([1.5, -2.0])) and torch.equal(v, torch.tensor([-0.75, 8.0]))
+    assert lp.data_ptr() - keep.data_ptr() == 16 and vd.data_ptr() - keep.data_ptr() == 24      # views of the record, no copies

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_tn_kernel(VptGemmTnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;
   const int hi = lane >> 5, l31 = lane & 31;
-  const int t1 = (a.N1 + 255) >> 8, t2 = (a.N2 + 127) >> 7;
+  const int t2 = (a.N2 + 127) >> 7;
   int L = xcd_remap(blockIdx.x, gridDim.x);
   const int j2 = L % t2; L /= t2;
   const int j1 = L;
