@@ -27,6 +27,13 @@ extern "C" {
 
 /* Library / build identification: returns "vpt_hip <version> gfx950". */
 const char* vpt_version(void);
+/* Binary-interface number of THIS header (VPT_HIP_ABI).  It is raised whenever an existing entry point changes its argument
+ * list or a symbol is renamed or removed (adding entry points does not raise it); a caller compares it with the VPT_HIP_ABI it
+ * was built against before the first call -- _native.py does -- instead of finding out through a mis-typed argument.
+ * History: 3 = round 3 (vpt_adam_step_multi + skip_flag, vpt_heads_logprob_backward + grad_scale, vpt_gate_cast renamed);
+ * 4 = round 4 (vpt_conv3x3_forward_tiled rejects tiling 0; vpt_action_head_forward takes a counter-based noise source). */
+#define VPT_HIP_ABI 4
+int vpt_abi_version(void);
 /* "bf16" (libvpt_hip.so, the default) or "fp16" (libvpt_hip_f16.so: the same sources built with -DVPT_OPERAND_F16): the format
  * of every 16-bit buffer this library reads or writes -- activations, packed weights, MFMA operands.  Same ABI, same
  * MFMA rate; the fp16 build is the parity mode (8x finer operand rounding; lib/policy.py: precision="fp16"). */
@@ -96,11 +103,11 @@ int vpt_conv3d_t5_forward(const uint8_t* img, const void* wfrag, const float* bi
 int vpt_conv3x3_forward(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg,
                         const double* stats_in, const void* res, void* y, double* stats_out,
                         int frames, int H, int W, int Cin, int Cout, void* stream);
-/* The same call with the workgroup tiling chosen by the caller instead of by the grid size: 1 = the throughput kernel (16x16
- * pixels x 128 output channels per workgroup: batches of frames, what bench.py measures), 2 = the latency kernel (x 32 output
- * channels: 4x the workgroups, a quarter of the serial MFMA chain each -- the acting path of agent.py:190-206, where one frame
- * would otherwise occupy 2-32 of the 256 CUs), 0 = throughput unless that grid has fewer workgroups than the chip has CUs.
- * Same layouts, same arithmetic, same K order. */
+/* The same call with the workgroup tiling named by the caller: 1 = the throughput kernel (16x16 pixels x 128 output channels per
+ * workgroup: batches of frames, what bench.py measures and what vpt_conv3x3_forward always runs), 2 = the latency kernel (x 32
+ * output channels: 4x the workgroups, a quarter of the serial MFMA chain each -- the acting path of agent.py:190-206, where one
+ * frame would otherwise occupy 2-32 of the 256 CUs).  Any other value is an error: the tiling is never derived from the grid size
+ * (a frame's result must not depend on how many frames share a launch).  Same layouts, same arithmetic, same K order. */
 int vpt_conv3x3_forward_tiled(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg,
                               const double* stats_in, const void* res, void* y, double* stats_out,
                               int frames, int H, int W, int Cin, int Cout, int tiling, void* stream);
@@ -187,9 +194,11 @@ int vpt_masked_attention_step_inplace(const float* qkvr, float* kmem, float* vme
  * (lib/action_head.py:227-237 sums the heads), value de-normalisation v * scale + shift (lib/normalize_ewma.py:27-31 with
  * scale = sqrt(var + eps), shift = mean), the NaN assertion of lib/policy.py:320-321 as a byte flag, and one packed record per
  * environment:  keep[b][4] (int64) = { buttons action, camera action, float bits of log_prob, float bits of the de-normalised value
- * (low half) | float bits of the raw value-head output (high half) }.  value_col: column of the value head in logits[B][ld]. */
+ * (low half) | float bits of the raw value-head output (high half) }.  value_col: column of the value head in logits[B][ld].
+ * rng_state (optional, device uint64 {seed, step}): step += 1 -- the stochastic heads of this acting step have drawn (vpt_action_head_forward). */
 int vpt_act_epilogue(const int64_t* action_buttons, const int64_t* action_camera, const float* logp_buttons, const float* logp_camera,
-                     const float* logits, int ld, int value_col, float scale, float shift, int64_t* keep, uint8_t* nan_flag, int B, void* stream);
+                     const float* logits, int ld, int value_col, float scale, float shift, int64_t* keep, uint8_t* nan_flag, uint64_t* rng_state,
+                     int B, void* stream);
 
 /* CategoricalActionHead.forward tail (lib/action_head.py:170-174): out[M][n] = log_softmax(logits[:, col0:col0+n] / T). */
 int vpt_log_softmax_forward(const float* logits, float* out, int M, int ld, int col0, int n, float temperature,
@@ -200,11 +209,18 @@ int vpt_log_softmax_forward(const float* logits, float* out, int M, int ld, int 
  *          (shaped_out[~mask] = LOG0, lib/action_head.py:170-171; obs["mask"] of lib/policy.py:257-266);
  *   action [M] int64, optional: CategoricalActionHead.sample -- arg-max of the log-probs (deterministic), or of
  *          log-probs - log(-log u) with u = noise[M][n] uniform in [0,1] (Gumbel-max, u == 1 -> 0.999 as the reference);
- *          the FIRST maximum, as torch.argmax.  The caller owns the random numbers (the reference draws them from torch's
- *          generator, lib/action_head.py:200);
+ *          the FIRST maximum, as torch.argmax.  The random numbers are the caller's (noise; the reference draws them from torch's
+ *          generator, lib/action_head.py:200) OR generated inside the kernel from rng_state = device uint64 {seed, step} and
+ *          rng_stream (Philox4x32-10: key = seed, counter = (element / 4, row, step, stream << 24), u = (word >> 8) * 2^-24 --
+ *          what a captured acting step needs: a fresh draw per replay with no host generator in the loop).  The kernel does not
+ *          advance `step`: vpt_act_epilogue does, once per acting step (or the host between calls).  noise and rng_state are
+ *          mutually exclusive; both null = deterministic;
  *   action_logp [M] fp32, optional: log-prob of that action (CategoricalActionHead.logprob, lib/action_head.py:176-184). */
-int vpt_action_head_forward(const float* logits, const uint8_t* mask, const float* noise, float* out, int64_t* action,
-                            float* action_logp, int M, int ld, int col0, int n, float temperature, void* stream);
+int vpt_action_head_forward(const float* logits, const uint8_t* mask, const float* noise, const uint64_t* rng_state, uint32_t rng_stream,
+                            float* out, int64_t* action, float* action_logp, int M, int ld, int col0, int n, float temperature, void* stream);
+/* out[M][n] = exactly the uniforms vpt_action_head_forward generates for (rng_state, rng_stream) -- to inspect or replay a draw through
+ * the `noise` argument (th.rand_like(logits), lib/action_head.py:200).  rng_state is not advanced. */
+int vpt_uniform_noise(const uint64_t* rng_state, uint32_t rng_stream, float* out, int M, int n, void* stream);
 
 /* Fused Adam update of one flat fp32 bucket: th.optim.Adam(lr, weight_decay).step() as configured by
  * behavioural_cloning.py:63-67,122 (L2 weight decay folded into the gradient, bias-corrected moments).

@@ -30,10 +30,13 @@ BOUNDS = {
 # points (oracle/vpt_oracle_bf16.py, 1x model, 12 frames) puts a number on it per operand format:
 #   bf16: mean rel-L2 over all tensors 0.31 (trunk 0.23, CNN 0.43), worst tensor cosine 0.48 (a stack-0 GroupNorm gain)
 #   fp16: mean rel-L2 0.094 (trunk 0.069, CNN 0.13), worst tensor cosine 0.979
-# cos_min: every tensor; cos_mean: mean over tensors; l2_mean: mean relative L2 over tensors (where a test computes it).
+# cos_min: every tensor, tests at T >= 8 frames per sequence (the config-sized ones and the autograd-boundary test); cos_min_small:
+# every tensor in the 12-frame 1x test the emulator figures above come from -- there bf16's worst tensor is a matter of which
+# handful of gates flip (emulator 0.48, GPU 0.76 on the round-3 boxes), so the bound sits below the emulator's own worst case;
+# cos_mean: mean over tensors; l2_mean: mean relative L2 over tensors (where a test computes it).
 GRAD_BOUNDS = {
-    "fp16": dict(cos_min=0.90, cos_mean=0.985, l2_mean=0.15),
-    "bf16": dict(cos_min=0.70, cos_mean=0.90, l2_mean=0.40),
+    "fp16": dict(cos_min=0.90, cos_min_small=0.90, cos_mean=0.985, l2_mean=0.15),
+    "bf16": dict(cos_min=0.70, cos_min_small=0.40, cos_mean=0.90, l2_mean=0.40),
 }
 
 

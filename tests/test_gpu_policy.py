@@ -194,6 +194,7 @@ def test_step_graph_matches_eager(pol_1x):
         torch.cuda.synchronize()
         return outs, [(m.clone(), (k.clone(), v.clone())) for m, (k, v) in st]
 
+    pol.disable_step_graph()                    # (act() would capture the step by itself from the third call on)
     eager, st_e = rollout()
     pol.enable_step_graph(1)
     try:
@@ -228,6 +229,7 @@ def test_step_graph_matches_eager(pol_1x):
         assert not torch.allclose(after[-1][2], eager[-1][2], atol=1e-3)
     finally:
         pol.disable_step_graph()
+        pol.auto_step_graph(True)
         with torch.no_grad():
             pol.pi_head.buttons.linear_layer.bias[:200].sub_(2.0)
 

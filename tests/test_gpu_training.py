@@ -189,7 +189,7 @@ def test_bc_gradients_vs_oracle(trainer_1x, train_cnn):
           f"cosine to the fp32 oracle: mean {mean_cos:.4f}, worst {min(cos_ref.values()):.3f}")
     assert mean_gpu < 1.15 * mean_em + 0.02, (mean_gpu, mean_em)
     GB = P.GRAD_BOUNDS[mode]                       # absolute, per format (not relative to our own emulator)
-    assert mean_gpu < GB["l2_mean"] and mean_cos > GB["cos_mean"] and min(cos_ref.values()) > (GB["cos_min"] if mode == "fp16" else 0.4), \
+    assert mean_gpu < GB["l2_mean"] and mean_cos > GB["cos_mean"] and min(cos_ref.values()) > GB["cos_min_small"], \
         (mean_gpu, mean_cos, min(cos_ref.values()))
     bad = {k: v for k, v in l2_em.items() if v > (0.75 if "cnn" in k else 0.4)}
     assert not bad, bad
@@ -668,3 +668,41 @@ def test_fp16_loss_scale_overflow_skips_the_step_on_the_device():
     assert tr.skipped_steps == 1 and tr.step_count == 4 and losses[-1] < losses[0] - 0.1
     moved = sum(int(not torch.equal(v.detach(), before[k])) for k, v in pol.named_parameters() if k in tr.m)
     assert moved == len(tr.m)
+
+
+def test_fp16_autograd_boundary_overflow_returns_no_gradients():
+    """The reference's own loop (loss.backward() + th.optim.Adam, behavioural_cloning.py:117-122) over precision="fp16": a half overflow
+    inside the 16-bit gradient buffers must never reach param.grad.  With the lift forced far beyond IEEE half's range the backward
+    warns, leaves every .grad None (an optimizer then skips the parameters) and halves the lift; at the normal lift the same call
+    yields finite gradients."""
+    pk = O.policy_kwargs_for("1x")
+    cfg = O.config_from_policy_kwargs(pk, dict(temperature=2.0))
+    sd = O.synthetic_state_dict(cfg, seed=0)
+    pol = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0), precision="fp16")
+    pol.load_state_dict(sd, strict=False)
+    pol = pol.to(DEV)
+    g = torch.Generator().manual_seed(62)
+    img = torch.randint(0, 256, (2, 128, 128, 3), generator=g, dtype=torch.uint8).to(DEV)
+    first = torch.zeros(2, dtype=torch.bool, device=DEV)
+    tgt = {"buttons": torch.randint(0, 8641, (2, 1), generator=g).to(DEV), "camera": torch.randint(0, 121, (2, 1), generator=g).to(DEV)}
+
+    def backward_once():
+        pol.zero_grad(set_to_none=True)
+        pd, _, _ = pol.get_output_for_observation({"img": img}, pol.initial_state(2), first)
+        loss = -pol.get_logprob_of_action(pd, tgt).mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss)
+
+    backward_once()                                          # creates the gradient engine
+    eng = next(iter(pol._grad_engines.values()))
+    assert eng.autograd_overflows == 0 and all(torch.isfinite(p.grad).all() for p in pol.parameters() if p.grad is not None)
+    eng.autograd_lift = 2.0 ** 40
+    with pytest.warns(RuntimeWarning, match="overflowed"):
+        backward_once()
+    assert eng.autograd_overflows == 1 and eng.autograd_lift == 2.0 ** 39
+    assert all(p.grad is None for p in pol.parameters())
+    eng.autograd_lift = 256.0
+    backward_once()
+    grads = [p.grad for p in pol.parameters() if p.grad is not None]
+    assert len(grads) >= 129 and all(torch.isfinite(g_).all() for g_ in grads)

@@ -40,6 +40,19 @@ def test_version_and_error_strings(lib):
     assert isinstance(lib.vpt_last_error(), bytes)
 
 
+def test_abi_number_matches_header_and_binding(lib, monkeypatch):
+    """vpt_abi_version() == VPT_HIP_ABI of the header == the number _native.py was written against; a library that reports another
+    number (a stale build: argument lists differ) is refused at load time, before any call."""
+    from vpt_amd import _native
+    hdr = open(os.path.join(ROOT, "include", "vpt_hip.h")).read()
+    abi_hdr = int(re.search(r"#define\s+VPT_HIP_ABI\s+(\d+)", hdr).group(1))
+    assert lib.vpt_abi_version() == abi_hdr == _native.ABI_VERSION
+    monkeypatch.setattr(_native, "_libs", {})
+    monkeypatch.setattr(_native, "ABI_VERSION", abi_hdr + 1)
+    with pytest.raises(_native.NativeLibraryError, match="C-ABI version"):
+        _native.load("bf16")
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     import vpt_amd  # noqa: F401
     from vpt_amd import _native

@@ -11,6 +11,8 @@ _LIB_PATH = os.environ.get("VPT_HIP_LIB") or os.path.join(_HERE, "libvpt_hip.so"
 _LIB_PATHS = {"bf16": _LIB_PATH, "fp16": os.path.join(_HERE, "libvpt_hip_f16.so")}
 _libs = {}
 
+ABI_VERSION = 4      # VPT_HIP_ABI of the include/vpt_hip.h this signature table was written against
+
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
@@ -37,7 +39,8 @@ SIGNATURES = {
     "vpt_masked_attention_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "vpt_kv_memory_update": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_log_softmax_forward": [_P, _P, _I, _I, _I, _I, _F, _P],
-    "vpt_action_head_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "vpt_action_head_forward": [_P, _P, _P, _P, ctypes.c_uint32, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "vpt_uniform_noise": [_P, ctypes.c_uint32, _P, _I, _I, _P],
     "vpt_conv_backward_prepare": [_P] * 14 + [_I, _I, _I, _I, _I, _P],
     "vpt_conv3x3_dgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_conv_first_backward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -61,7 +64,7 @@ SIGNATURES = {
     "vpt_layernorm_linear_forward": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "vpt_masked_attention_step": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_masked_attention_step_inplace": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "vpt_act_epilogue": [_P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _I, _P],
+    "vpt_act_epilogue": [_P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P, _I, _P],
     "vpt_clip_frames": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _P],
 }
 
@@ -86,6 +89,13 @@ def load(fmt: str = "bf16"):
         raise NativeLibraryError(
             f"{path} is missing: run `python __graft_entry__.py` (build()) first; there is no CPU fallback")
     lib = ctypes.CDLL(path)
+    try:
+        lib.vpt_abi_version.restype = ctypes.c_int
+        abi = int(lib.vpt_abi_version())
+    except AttributeError:
+        abi = None
+    if abi != ABI_VERSION:      # a stale .so would take a stream handle for a flag pointer, etc.: refuse before the first call
+        raise NativeLibraryError(f"{path} has C-ABI version {abi}, this package binds version {ABI_VERSION}: rebuild it (`python __graft_entry__.py`)")
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes

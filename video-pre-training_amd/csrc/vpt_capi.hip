@@ -15,7 +15,8 @@ static int fail(int code, const char* what) {
 
 extern "C" {
 
-const char* vpt_version(void) { return "vpt_hip 0.2 gfx950"; }
+const char* vpt_version(void) { return "vpt_hip 0.4 gfx950"; }
+int vpt_abi_version(void) { return VPT_HIP_ABI; }
 const char* vpt_operand_format(void) { return VPT_OPERAND_NAME; }
 const char* vpt_last_error(void) { return g_err; }
 
@@ -84,14 +85,14 @@ int vpt_conv3d_t5_forward(const uint8_t* img, const void* wfrag, const float* bi
 int vpt_conv3x3_forward(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg,
                         const double* stats_in, const void* res, void* y, double* stats_out,
                         int frames, int H, int W, int Cin, int Cout, void* stream) {
-  return vpt_conv3x3_forward_tiled(x, wpk, edge_sa, edge_sg, stats_in, res, y, stats_out, frames, H, W, Cin, Cout, 0, stream);
+  return vpt_conv3x3_forward_tiled(x, wpk, edge_sa, edge_sg, stats_in, res, y, stats_out, frames, H, W, Cin, Cout, 1, stream);
 }
 
 int vpt_conv3x3_forward_tiled(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg,
                               const double* stats_in, const void* res, void* y, double* stats_out,
                               int frames, int H, int W, int Cin, int Cout, int tiling, void* stream) {
   if (!stats_in) return fail(-1, "vpt_conv3x3_forward: stats_in is required");
-  if (tiling < 0 || tiling > 2) return fail(-1, "vpt_conv3x3_forward_tiled: tiling must be 0 (auto), 1 (throughput) or 2 (latency)");
+  if (tiling != 1 && tiling != 2) return fail(-1, "vpt_conv3x3_forward_tiled: tiling must be 1 (throughput) or 2 (latency)");
   VptConv3x3Args a;
   a.tiling = tiling;
   a.x = (const vpt_op16*)x; a.wpk = (const vpt_op16*)wpk; a.edge_sa = edge_sa; a.edge_sg = edge_sg;
@@ -261,9 +262,14 @@ int vpt_masked_attention_step_inplace(const float* qkvr, float* kmem, float* vme
 }
 
 int vpt_act_epilogue(const int64_t* action_buttons, const int64_t* action_camera, const float* logp_buttons, const float* logp_camera,
-                     const float* logits, int ld, int value_col, float scale, float shift, int64_t* keep, uint8_t* nan_flag, int B, void* stream) {
-  CHECK_LAUNCH(vpt_act_epilogue_launch(action_buttons, action_camera, logp_buttons, logp_camera, logits, ld, value_col, scale, shift, keep, nan_flag, B,
-                                       (hipStream_t)stream), "vpt_act_epilogue");
+                     const float* logits, int ld, int value_col, float scale, float shift, int64_t* keep, uint8_t* nan_flag, uint64_t* rng_state,
+                     int B, void* stream) {
+  CHECK_LAUNCH(vpt_act_epilogue_launch(action_buttons, action_camera, logp_buttons, logp_camera, logits, ld, value_col, scale, shift, keep, nan_flag,
+                                       rng_state, B, (hipStream_t)stream), "vpt_act_epilogue");
+}
+
+int vpt_uniform_noise(const uint64_t* rng_state, uint32_t rng_stream, float* out, int M, int n, void* stream) {
+  CHECK_LAUNCH(vpt_uniform_noise_launch(rng_state, rng_stream, out, M, n, (hipStream_t)stream), "vpt_uniform_noise");
 }
 
 int vpt_kv_memory_update(const float* qkvr, const float* kmem, const float* vmem, float* kout, float* vout,
@@ -278,16 +284,17 @@ int vpt_log_softmax_forward(const float* logits, float* out, int M, int ld, int 
                             void* stream) {
   VptLogSoftmaxArgs a;
   a.logits = logits; a.out = out; a.M = M; a.ld = ld; a.col0 = col0; a.n = n; a.temperature = temperature;
-  a.mask = nullptr; a.noise = nullptr; a.action = nullptr; a.action_logp = nullptr;
+  a.mask = nullptr; a.noise = nullptr; a.action = nullptr; a.action_logp = nullptr; a.rng_state = nullptr; a.rng_stream = 0;
   CHECK_LAUNCH(vpt_logsoftmax_launch(&a, (hipStream_t)stream), "vpt_log_softmax_forward");
 }
 
-int vpt_action_head_forward(const float* logits, const uint8_t* mask, const float* noise, float* out, int64_t* action,
-                            float* action_logp, int M, int ld, int col0, int n, float temperature, void* stream) {
+int vpt_action_head_forward(const float* logits, const uint8_t* mask, const float* noise, const uint64_t* rng_state, uint32_t rng_stream,
+                            float* out, int64_t* action, float* action_logp, int M, int ld, int col0, int n, float temperature, void* stream) {
   if (action_logp && !action) return fail(-1, "vpt_action_head_forward: action_logp needs action");
+  if (noise && rng_state) return fail(-1, "vpt_action_head_forward: give the uniforms (noise) or the generator state (rng_state), not both");
   VptLogSoftmaxArgs a;
   a.logits = logits; a.out = out; a.M = M; a.ld = ld; a.col0 = col0; a.n = n; a.temperature = temperature;
-  a.mask = mask; a.noise = noise; a.action = (long*)action; a.action_logp = action_logp;
+  a.mask = mask; a.noise = noise; a.action = (long*)action; a.action_logp = action_logp; a.rng_state = rng_state; a.rng_stream = rng_stream;
   CHECK_LAUNCH(vpt_logsoftmax_launch(&a, (hipStream_t)stream), "vpt_action_head_forward");
 }
 

@@ -122,6 +122,28 @@ __device__ __forceinline__ void block_stats_atomic(float s_sum, float s_sq, doub
   }
 }
 
+// ---- counter-based random numbers (Philox4x32-10, Salmon et al. SC'11: the generator torch's CUDA / HIP backend uses too) ------------
+// CategoricalActionHead.sample draws u = th.rand_like(logits) from torch's generator (lib/action_head.py:200); inside a captured
+// acting step the draw has to be a pure function of device-resident state, so the head kernel generates its uniforms itself:
+// key = the 64-bit seed, counter = (element / 4, row, step lo, step hi ^ stream << 24), word element % 4 of the block, top 24 bits
+// -> u in [0, 1) exactly as torch.rand's float32 path (x >> 8) * 2^-24.  `step` is a device counter the caller advances once per
+// acting step (vpt_act_epilogue); `stream` separates the heads.  oracle/philox.py restates it for the tests (bit-exact).
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float vpt_philox_uniform(uint64_t seed, uint64_t step, uint32_t stream, uint32_t row, uint32_t elem) {
+  uint32_t o[4];
+  philox4x32_10(elem >> 2, row, (uint32_t)step, (uint32_t)(step >> 32) ^ (stream << 24), (uint32_t)seed, (uint32_t)(seed >> 32), o);
+  return (float)(o[elem & 3] >> 8) * (1.0f / 16777216.0f);
+}
+
 // streaming accesses of the HBM-bound kernels (touched once per pass; nothing on the chip can hold a 1 GB chunk)
 #ifndef VPT_STREAM_PLAIN   // nontemporal by default: measured -2 ms on conv_bwd_prep, -0.5 ms on the affine backward per BC step
 #define VPT_LD_STREAM(p) __builtin_nontemporal_load(p)

@@ -37,9 +37,6 @@
 // Profiling switches (VPT_CONV_ABLATE = 1: skip the epilogue, 2: skip the main loop; VPT_CONV_EXTRA_LDS: dynamic LDS to force one
 // workgroup per CU) exist ONLY in builds made with -DVPT_CONV_PROFILE (tools/build_variant.sh): the shipped library reads no
 // environment variable and its kernel carries no ablation branch -- a stray variable cannot change results.
-#ifndef VPT_CONV_SMALL_GRID
-#define VPT_CONV_SMALL_GRID 256   // throughput-kernel grids below this (less than one workgroup per CU) take vpt_conv3x3_small_kernel
-#endif
 #ifdef VPT_CONV_PROFILE
 #define CONV_ABLATE (a.ablate)
 #else
@@ -769,8 +766,10 @@ extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream
   if (grid > 0x7fffffffL) return -2;
   const int mode = a->bwd ? (a->res ? 3 : 2) : (a->res ? 1 : 0);
   if (a->bwd && (!a->xin || !a->coef)) return -1;   // dgrad always carries the GroupNorm-statistics terms (c0 + c1 * xin)
-  // fewer workgroups than CUs (a handful of frames: the acting path): the latency tiling, 32 output channels per workgroup
-  if (!a->bwd && !a->trace && (a->tiling == 2 || (a->tiling == 0 && grid < VPT_CONV_SMALL_GRID))) {
+  // the latency tiling (32 output channels per workgroup) is the CALLER's choice, never the grid size's: a frame's result must not
+  // depend on how many frames share the launch (the two tilings sum a tile's statistics in different orders)
+  if (!a->bwd && a->tiling != 1 && a->tiling != 2) return -1;
+  if (!a->bwd && !a->trace && a->tiling == 2) {
     const long sgrid = (long)a->frames * (a->H >> 4) * (a->W >> 4) * (a->Cout >> 5);
     if (a->res) hipLaunchKernelGGL((vpt_conv3x3_small_kernel<true>), dim3((unsigned)sgrid), dim3(512), 0, stream, *a);
     else hipLaunchKernelGGL((vpt_conv3x3_small_kernel<false>), dim3((unsigned)sgrid), dim3(512), 0, stream, *a);

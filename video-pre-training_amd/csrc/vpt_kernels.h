@@ -21,7 +21,7 @@ struct VptConv3x3Args {
   double* stats_out;       // optional [F][2], accumulated (caller zeroes)
   int frames, H, W, Cin, Cout, CoutPad, NT;
   double inv_count_in;     // 1 / (Cin*H*W)
-  int tiling;              // forward only: 0 = by grid size, 1 = throughput kernel (16x16 px x 128 couts), 2 = latency kernel (x 32 couts)
+  int tiling;              // forward only: 1 = throughput kernel (16x16 px x 128 couts), 2 = latency kernel (x 32 couts)
   int ablate;              // profiling only (env VPT_CONV_ABLATE)
   long long* trace;        // profiling only: per-workgroup phase timestamps (vpt_conv3x3_set_trace)
   // dgrad mode (bwd != 0): no GroupNorm fold, no ReLU; out = conv + res + coef[f][0] + coef[f][1] * xin
@@ -137,6 +137,8 @@ struct VptLogSoftmaxArgs {
   float temperature;
   const uint8_t* mask;     // optional [M][n]: 0 = action not available -> its scaled logit is LOG0 = -100 (lib/action_head.py:170-171)
   const float* noise;      // optional [M][n] uniforms in [0, 1]: Gumbel-max sampling (lib/action_head.py:198-207); null = argmax
+  const uint64_t* rng_state;  // optional device {seed, step}: the uniforms are generated in the kernel instead (Philox4x32-10 keyed by the seed,
+  uint32_t rng_stream;        //   counter = (element / 4, row, step, stream): vpt_philox_uniform in vpt_common.h); rng_stream tells one head's draw from another's
   long* action;            // optional [M]: sampled / arg-max index (first maximum)
   float* action_logp;      // optional [M]: out[row][action[row]]
 };
@@ -321,7 +323,8 @@ int vpt_colsum_launch(const VptColsumArgs* a, hipStream_t s);
 int vpt_clip_launch(const VptClipArgs* a, hipStream_t s);
 int vpt_attn_step_launch(const VptAttnArgs* a, const uint8_t* state_mask, const uint8_t* first, uint8_t* mask_out, float* kout, float* vout, int* done, hipStream_t s);
 int vpt_act_epilogue_launch(const int64_t* act_b, const int64_t* act_c, const float* lp_b, const float* lp_c, const float* logits, int ld, int vcol,
-                            float scale, float shift, int64_t* keep, uint8_t* nan_flag, int B, hipStream_t s);
+                            float scale, float shift, int64_t* keep, uint8_t* nan_flag, uint64_t* rng_state, int B, hipStream_t s);
+int vpt_uniform_noise_launch(const uint64_t* rng_state, uint32_t rng_stream, float* out, int M, int n, hipStream_t s);
 int vpt_attn_bwd_launch(const VptAttnBwdArgs* a, hipStream_t s);
 int vpt_conv3x3_launch(const VptConv3x3Args* a, hipStream_t s);
 int vpt_conv_first_launch(const VptConvFirstArgs* a, hipStream_t s);

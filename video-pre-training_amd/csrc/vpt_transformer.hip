@@ -431,7 +431,12 @@ __global__ __launch_bounds__(64 * NW) void vpt_logsoftmax_kernel(VptLogSoftmaxAr
   float* o = a.out + (size_t)row * a.n;
   // CategoricalActionHead.sample (lib/action_head.py:195-207) on the way out: argmax of the log-probs, or of
   // log-probs - log(-log u) (Gumbel-max; u == 1 -> 0.999 as the reference guards); FIRST maximum, as torch.argmax.
+  // The uniforms are the caller's (a.noise) or generated here from device-resident state (a.rng_state: seed + step counter,
+  // vpt_philox_uniform) -- the form a captured acting step needs: no buffer, no host-side generator, a new draw per replay.
   const float* u = a.noise ? a.noise + (size_t)row * a.n : nullptr;
+  const bool gen = !u && a.rng_state != nullptr;
+  uint64_t seed = 0, rstep = 0;
+  if (gen) { seed = a.rng_state[0]; rstep = a.rng_state[1]; }
   float best = -3.0e38f;
   int besti = 0x7fffffff;
   auto emit = [&](int i, float sc_) __attribute__((always_inline)) {
@@ -439,7 +444,11 @@ __global__ __launch_bounds__(64 * NW) void vpt_logsoftmax_kernel(VptLogSoftmaxAr
     o[i] = lp;
     if (a.action) {
       float sc = lp;
-      if (u) { float ui = u[i]; if (ui == 1.0f) ui = 0.999f; sc = lp - logf(-logf(ui)); }
+      if (u || gen) {
+        float ui = u ? u[i] : vpt_philox_uniform(seed, rstep, a.rng_stream, (uint32_t)row, (uint32_t)i);
+        if (ui == 1.0f) ui = 0.999f;
+        sc = lp - logf(-logf(ui));
+      }
       if (sc > best) { best = sc; besti = i; }     // ascending i per thread: keeps the first maximum
     }
   };
@@ -479,7 +488,7 @@ extern "C" int vpt_logsoftmax_launch(const VptLogSoftmaxArgs* a, hipStream_t str
 // the NaN assertion as a flag, everything the caller keeps packed into ONE buffer (a single clone per step):
 //   keep[b] = { buttons action, camera action, (float bits) log_prob | 0, (float bits) vpred de-normalised | raw vpred << 32 }
 __global__ void vpt_act_epilogue_kernel(const int64_t* act_b, const int64_t* act_c, const float* lp_b, const float* lp_c, const float* logits, int ld,
-                                        int vcol, float scale, float shift, int64_t* keep, uint8_t* nan_flag, int B) {
+                                        int vcol, float scale, float shift, int64_t* keep, uint8_t* nan_flag, uint64_t* rng_state, int B) {
   const int b = threadIdx.x;
   bool bad = false;
   if (b < B) {
@@ -493,12 +502,34 @@ __global__ void vpt_act_epilogue_kernel(const int64_t* act_b, const int64_t* act
     keep[4 * b + 3] = (int64_t)((uint64_t)__builtin_bit_cast(uint32_t, vd) | ((uint64_t)__builtin_bit_cast(uint32_t, v) << 32));
   }
   const unsigned long long any = __ballot(bad);
-  if (threadIdx.x == 0) *nan_flag = any ? 1 : 0;
+  if (threadIdx.x == 0) {
+    *nan_flag = any ? 1 : 0;
+    if (rng_state) rng_state[1] += 1;    // the step's draws are done (both head launches precede this one in stream order): next step, next counter
+  }
+}
+
+// The uniforms vpt_logsoftmax_kernel generates for (rng_state, rng_stream), written out [M][n] -- for callers that want to see / replay a
+// draw (the tests feed them back through the `noise` argument: the two paths must pick the same actions).  Does NOT advance the state.
+__global__ __launch_bounds__(256) void vpt_uniform_noise_kernel(const uint64_t* rng_state, uint32_t rng_stream, float* out, int M, int n) {
+  const uint64_t seed = rng_state[0], rstep = rng_state[1];
+  const long total = (long)M * n;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int row = (int)(idx / n), i = (int)(idx - (long)row * n);
+    out[idx] = vpt_philox_uniform(seed, rstep, rng_stream, (uint32_t)row, (uint32_t)i);
+  }
+}
+
+extern "C" int vpt_uniform_noise_launch(const uint64_t* rng_state, uint32_t rng_stream, float* out, int M, int n, hipStream_t stream) {
+  if (!rng_state || !out || M <= 0 || n <= 0) return -1;
+  const long total = (long)M * n;
+  const unsigned grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(vpt_uniform_noise_kernel, dim3(grid), dim3(256), 0, stream, rng_state, rng_stream, out, M, n);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 extern "C" int vpt_act_epilogue_launch(const int64_t* act_b, const int64_t* act_c, const float* lp_b, const float* lp_c, const float* logits, int ld,
-                                       int vcol, float scale, float shift, int64_t* keep, uint8_t* nan_flag, int B, hipStream_t stream) {
+                                       int vcol, float scale, float shift, int64_t* keep, uint8_t* nan_flag, uint64_t* rng_state, int B, hipStream_t stream) {
   if (B <= 0 || B > 64 || !keep || !nan_flag) return -1;
-  hipLaunchKernelGGL(vpt_act_epilogue_kernel, dim3(1), dim3(64), 0, stream, act_b, act_c, lp_b, lp_c, logits, ld, vcol, scale, shift, keep, nan_flag, B);
+  hipLaunchKernelGGL(vpt_act_epilogue_kernel, dim3(1), dim3(64), 0, stream, act_b, act_c, lp_b, lp_c, logits, ld, vcol, scale, shift, keep, nan_flag, rng_state, B);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -82,12 +82,19 @@ def resolve_precision(precision: Optional[str]) -> str:
     return p
 
 
-def action_heads(logits, heads, bsz, t, temperature, mask=None, sample=None, keep_head_logps=False):
+RNG_STREAM = {"buttons": 0, "camera": 1}     # which draw of a step a head takes from the in-kernel generator (ops.log_softmax_cols: rng)
+
+
+def action_heads(logits, heads, bsz, t, temperature, mask=None, sample=None, keep_head_logps=False, rng_state=None):
     """DictActionHead.forward (+ sample / logprob) over the fused head logits.  heads: (name, first column, groups, classes);
     a head's logits are [M, groups * classes] -> log-probs [B, T, groups, classes].  Returns the dict entries to merge.
-    keep_head_logps: leave the heads' action log-probs un-summed in out["_head_logps"] (the acting step's epilogue kernel adds them)."""
+    keep_head_logps: leave the heads' action log-probs un-summed in out["_head_logps"] (the acting step's epilogue kernel adds them).
+    sample="stochastic" draws the uniforms of CategoricalActionHead.sample (th.rand_like, lib/action_head.py:200) INSIDE the head
+    kernel from `rng_state` (ops.new_rng_state: device {seed, step}); the caller advances the step once all heads have drawn."""
     if sample not in (None, "deterministic", "stochastic"):
         raise ValueError(f"sample must be None, 'deterministic' or 'stochastic', got {sample!r}")
+    if sample == "stochastic" and rng_state is None:
+        raise ValueError("action_heads: stochastic sampling needs the generator state (ops.new_rng_state)")
     out, actions, logp, head_lps = {}, {}, None, {}
     for name, col0, groups, n in heads:
         z = logits if groups == 1 else logits[:, col0:col0 + groups * n].reshape(-1, n)
@@ -99,8 +106,8 @@ def action_heads(logits, heads, bsz, t, temperature, mask=None, sample=None, kee
         if sample is None:
             lp = ops.log_softmax_cols(z, c0, n, temperature, mask=mk)
         else:
-            noise = torch.rand(rows, n, dtype=torch.float32, device=z.device) if sample == "stochastic" else None
-            lp, ac, alp = ops.log_softmax_cols(z, c0, n, temperature, mask=mk, noise=noise, want_action=True)
+            rng = (rng_state, RNG_STREAM[name]) if sample == "stochastic" else None
+            lp, ac, alp = ops.log_softmax_cols(z, c0, n, temperature, mask=mk, want_action=True, rng=rng)
             actions[name] = ac.view(bsz, t, groups)
             alp = alp.view(bsz, t) if groups == 1 else alp.view(bsz, t, groups).sum(-1)     # (no reduction kernel for the usual single group)
             head_lps[name] = alp
@@ -144,8 +151,23 @@ class PolicyEngine:
         self.pool_subchunk = int(os.environ.get("VPT_POOL_SUBCHUNK", 256))
         self._streams = []
         self._attn_done = None      # arrival counters of the in-place acting step (ops.masked_attention_step)
+        self._rng_state = None      # in-kernel sampler state {seed, step} (ops.new_rng_state), created on first stochastic use
         self.w: Dict[str, torch.Tensor] = {}
         self.packed = False
+
+    def rng_state(self, device):
+        """The device-resident {seed, step} the stochastic heads draw from.  One per engine: a captured acting step holds its address."""
+        if self._rng_state is None or self._rng_state.device != device:
+            self._rng_state = ops.new_rng_state(device, seed=getattr(self, "_pending_seed", None))
+            self._pending_seed = None
+        return self._rng_state
+
+    def seed(self, seed: int):
+        """Re-seed the sampler in place (the captured graph keeps reading the same buffer) and restart its step counter."""
+        if self._rng_state is not None:
+            self._rng_state.copy_(torch.tensor([int(seed), 0], dtype=torch.int64))
+        else:
+            self._pending_seed = int(seed)
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -276,8 +298,8 @@ class PolicyEngine:
         n_streams = min(self.cnn_streams, n_chunks)
         main = torch.cuda.current_stream()
         if n_streams > 1:
-            if len(self._streams) < n_streams:
-                self._streams = [torch.cuda.Stream() for _ in range(n_streams)]
+            while len(self._streams) < n_streams:      # created once, appended to, never replaced
+                self._streams.append(torch.cuda.Stream())
             for st in self._streams[:n_streams]:
                 st.wait_stream(main)
         for ci, i in enumerate(range(0, n, self.cnn_chunk)):
@@ -362,16 +384,19 @@ class PolicyEngine:
         temp = cfg["temperature"]
         out = dict(latent=latent.view(bsz, t, hid), state_out=state_out)
         tail = act_tail is not None and sample is not None and t == 1
-        heads_out = action_heads(logits, (("buttons", 0, 1, nb), ("camera", nb, 1, nc)), bsz, t, temp, mask, sample, keep_head_logps=tail)
+        rng = self.rng_state(x.device) if sample == "stochastic" else None
+        heads_out = action_heads(logits, (("buttons", 0, 1, nb), ("camera", nb, 1, nc)), bsz, t, temp, mask, sample, keep_head_logps=tail, rng_state=rng)
         out.update(heads_out)
         if tail:
             lps = out.pop("_head_logps")
             keep, flag = ops.act_epilogue(out["action"]["buttons"].view(-1), out["action"]["camera"].view(-1), lps["buttons"].reshape(-1),
-                                          lps["camera"].reshape(-1), logits, nb + nc, act_tail[0], act_tail[1])
+                                          lps["camera"].reshape(-1), logits, nb + nc, act_tail[0], act_tail[1], rng_state=rng)   # (advances rng's step)
             out["_keep"], out["nan_flag"] = keep, flag
             out.update(unpack_act_tail(keep, bsz))
         else:
             out["vpred"] = logits[:, nb + nc:nb + nc + 1].reshape(bsz, t, 1).clone()
+            if rng is not None:
+                rng[1:].add_(1)         # both heads have drawn: next call, next counter
         return out
 
 
@@ -390,6 +415,7 @@ class IDMEngine(PolicyEngine):
         self.cnn_streams = 1
         self.pool_subchunk = 0      # (PolicyEngine._cnn_chunk's option; the IDM's chunks are one 128-frame window)
         self._streams = []
+        self._rng_state = None
         self.w = {}
         self.packed = False
 
@@ -477,15 +503,18 @@ class IDMEngine(PolicyEngine):
         out = {}
         temp = cfg["temperature"]
         logp = None
+        rng = self.rng_state(x.device) if sample == "stochastic" else None
         for h, shape in (("buttons", self.button_shape), ("camera", self.camera_shape)):
             n_groups, n = shape
             z, _ = ops.linear(lb, w[h + ".w"], n_groups * n, bias=w[h + ".b"])
-            r = action_heads(z, ((h, 0, n_groups, n),), bsz, t, temp, mask, sample)
+            r = action_heads(z, ((h, 0, n_groups, n),), bsz, t, temp, mask, sample, rng_state=rng)
             out[h] = r[h]
             if sample is not None:
                 out.setdefault("action", {})[h] = r["action"][h]
                 logp = r["action_log_prob"] if logp is None else logp + r["action_log_prob"]
         if sample is not None:
             out["action_log_prob"] = logp
+        if rng is not None:
+            rng[1:].add_(1)
         out["latent"] = latent.view(bsz, t, hid)
         return out

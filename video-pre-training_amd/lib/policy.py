@@ -205,12 +205,25 @@ class _PolicyForwardFn(torch.autograd.Function):
             if eng.scaled:
                 # fp16 operands: the 16-bit gradient buffers need the incoming gradients lifted into IEEE half's range (a mean
                 # over M frames arrives as 1 / M per element).  Power of two, so un-scaling the fp32 results below is exact.
+                # `autograd_lift` (256 to start with) is where the largest incoming element is placed; an overflow halves it.
                 gmax = max([float(x.abs().max()) for x in (gb, gc, gv) if x is not None and x.numel()] or [0.0])
                 if gmax > 0.0 and math.isfinite(gmax):
-                    scale = 2.0 ** math.floor(math.log2(256.0 / gmax))
+                    scale = 2.0 ** math.floor(math.log2(eng.autograd_lift / gmax))
             dz = ops.heads_logprob_backward(S["lp_b"], S["lp_c"], gb, gc, gv, S["ldz"], eng.engine.cfg["temperature"],
                                             mask_buttons=S["mask"]["buttons"], mask_camera=S["mask"]["camera"], dtype=eng.dtype, grad_scale=scale)
             g = eng.backward_from(S, dz, value_grads=gv is not None)
+            if eng.scaled:
+                # GradScaler semantics at the autograd boundary: the caller's optimizer (th.optim.Adam in the reference's loop,
+                # behavioural_cloning.py:117-122) must never see the inf / nan a half overflow in dz / dacc / dx16 leaves behind.
+                # On overflow this backward contributes NO gradient (every input gradient None: an optimizer skips parameters
+                # whose .grad is None, an accumulation loop simply misses this sample), warns, and the next backward lifts less.
+                if int(ops.grads_nonfinite(list(g.values())).item()):
+                    import warnings
+                    eng.autograd_lift = max(1.0, eng.autograd_lift * 0.5)
+                    eng.autograd_overflows += 1
+                    warnings.warn(f"fp16 backward overflowed (gradient lift 2^{math.log2(scale):.0f}): this backward returns no gradients; "
+                                  f"the next one lifts to {eng.autograd_lift:g}", RuntimeWarning)
+                    return (None,) * (7 + len(ctx.names))
             if scale != 1.0:
                 for t_ in g.values():
                     t_.mul_(1.0 / scale)
@@ -219,9 +232,9 @@ class _PolicyForwardFn(torch.autograd.Function):
 
 
 class MinecraftAgentPolicy(nn.Module):
-    """`precision` (not a reference argument; also env VPT_PRECISION or set_precision()): "bf16" -- the default and the
-    benchmarked mode -- or "fp16", the parity mode: the same kernels with IEEE-half MFMA operands, same speed, 8x finer
-    operand rounding (engine.PolicyEngine)."""
+    """`precision` (not a reference argument; also env VPT_PRECISION or set_precision()): "fp16" -- the default: the parity
+    mode, IEEE-half MFMA operands -- or "bf16", the north star's "MFMA bf16 tiles" and bench.py's headline: the same kernels,
+    same speed, 8x coarser operand rounding (engine.PolicyEngine / engine.resolve_precision)."""
 
     def __init__(self, action_space, policy_kwargs, pi_head_kwargs, precision: Optional[str] = None):
         super().__init__()
@@ -235,6 +248,8 @@ class MinecraftAgentPolicy(nn.Module):
         self._packed_key = None
         self._param_cache = None
         self._step_graph = None
+        import os
+        self._auto_graph = dict(enabled=os.environ.get("VPT_STEP_GRAPH", "1") != "0", batch=None, count=0)
         self._grad_engines = {}
 
     @property
@@ -249,7 +264,7 @@ class MinecraftAgentPolicy(nn.Module):
                                         precision=precision)
             self._packed_key = None
             if self._step_graph is not None:
-                self._step_graph = dict(batch=self._step_graph["batch"])
+                self._step_graph = dict(batch=self._step_graph["batch"])      # (static buffers and graphs are rebuilt lazily)
         return self
 
     # ---- engine plumbing --------------------------------------------------------------------
@@ -283,57 +298,105 @@ class MinecraftAgentPolicy(nn.Module):
                 self._step_graph = dict(batch=self._step_graph["batch"])
 
     # ---- T = 1 acting path: one hipGraph replay per environment step ---------------------------
+    # The reference's entry point is MineRLAgent.get_action -> policy.act(agent_input, first, hidden_state, stochastic=True)
+    # (agent.py:190-206): one frame, one environment, every 50 ms.  act() therefore captures that step into a hipGraph BY ITSELF
+    # once it has seen the same (B, T = 1) shape twice in a row -- run_agent.py needs no extra call -- with the stochastic sampling
+    # inside the graph (the heads draw their uniforms in the kernel from a device-resident {seed, step}, engine.rng_state).
+    AUTO_GRAPH_AFTER = 2     # consecutive same-shape act() calls that run eagerly before the step is captured
+
     def enable_step_graph(self, batch_size: int = 1):
-        """Capture the T = 1 forward for `batch_size` environments into a hipGraph (the ~90 kernel launches of one
-        agent step, agent.py:190-206, become one graph launch).  The recurrent state lives in static buffers
-        that the graph updates in place: the `state_out` returned by a graphed step ALIASES them and is
-        overwritten by the next step (the acting loop only ever keeps the latest state).  Any other state_in
-        (initial_state, a restored snapshot) is copied in.  Other (B, T) shapes keep using eager launches."""
+        """Capture the T = 1 forward for `batch_size` environments into a hipGraph at the next such call (the ~50 kernel launches of
+        one agent step, agent.py:190-206, become one graph launch; one graph per sampling mode, captured on first use).  act() does
+        this on its own after AUTO_GRAPH_AFTER same-shape calls; forward() / v() only after this explicit call.  The recurrent state
+        lives in static buffers that the graph updates in place: the `state_out` returned by a graphed step ALIASES them and is
+        overwritten by the next step (the acting loop only ever keeps the latest state, agent.py:201-205; clone it to keep a
+        snapshot).  Any other state_in (initial_state, a restored snapshot) is copied in.  Other (B, T) shapes keep using eager
+        launches."""
         self._step_graph = dict(batch=int(batch_size))
+        self._auto_graph = dict(enabled=self._auto_graph["enabled"], batch=None, count=0)
 
     def disable_step_graph(self):
+        """Back to eager launches, and no automatic capture either (env VPT_STEP_GRAPH=0 does the same for a whole process;
+        auto_step_graph(True) turns the automatic capture back on)."""
         self._step_graph = None
+        self._auto_graph = dict(enabled=False, batch=None, count=0)
 
-    def _capture_step_graph(self):
-        sg, eng, dev = self._step_graph, self._engine, self._device()
-        b, cfg = sg["batch"], self._cfg
-        sg["img"] = torch.zeros(b, 1, *cfg["img_shape"], dtype=torch.uint8, device=dev)
-        sg["first"] = torch.zeros(b, 1, dtype=torch.bool, device=dev)
-        sg["state"] = [(torch.zeros(b, 1, cfg["maxlen"], dtype=torch.bool, device=dev),
-                        (torch.zeros(b, cfg["maxlen"], cfg["hidsize"], dtype=torch.float32, device=dev),
-                         torch.zeros(b, cfg["maxlen"], cfg["hidsize"], dtype=torch.float32, device=dev)))
-                       for _ in range(cfg["n_layers"])]
+    def auto_step_graph(self, enabled: bool = True):
+        """Switch act()'s automatic capture of the acting step on / off without touching a graph that is already in use."""
+        self._auto_graph = dict(enabled=bool(enabled), batch=None, count=0)
+
+    def seed_sampler(self, seed: int):
+        """Re-seed the in-kernel generator behind act(stochastic=True) / predict(deterministic=False) (default: a seed drawn from
+        torch's generator when first needed, so torch.manual_seed() already makes runs repeatable)."""
+        self._engine.seed(seed)
+
+    def _auto_graph_tick(self, batch: int):
+        """act() saw an eligible (B, T = 1) call while no graph is enabled: count it; the call after AUTO_GRAPH_AFTER of them in a
+        row with the same B turns the graph on."""
+        from .. import ops
+        ag = self._auto_graph
+        if not ag["enabled"] or batch > ops.LN_LINEAR_MAX_ROWS:      # the acting path proper: a handful of environments
+            return
+        if ag["batch"] == batch:
+            ag["count"] += 1
+        else:
+            ag["batch"], ag["count"] = batch, 1
+        if ag["count"] > self.AUTO_GRAPH_AFTER:
+            self._step_graph = dict(batch=batch)
+
+    def _static_step_buffers(self):
+        sg, dev, cfg = self._step_graph, self._device(), self._cfg
+        if "img" not in sg:
+            b = sg["batch"]
+            sg["img"] = torch.zeros(b, 1, *cfg["img_shape"], dtype=torch.uint8, device=dev)
+            sg["first"] = torch.zeros(b, 1, dtype=torch.bool, device=dev)
+            sg["state"] = [(torch.zeros(b, 1, cfg["maxlen"], dtype=torch.bool, device=dev),
+                            (torch.zeros(b, cfg["maxlen"], cfg["hidsize"], dtype=torch.float32, device=dev),
+                             torch.zeros(b, cfg["maxlen"], cfg["hidsize"], dtype=torch.float32, device=dev)))
+                           for _ in range(cfg["n_layers"])]
+            sg["graphs"] = {}
+        return sg
+
+    def _capture_step_graph(self, mode: str):
+        """mode: "deterministic" or "stochastic" -- the head kernel's sampling rule is part of the captured launch arguments, so each
+        mode is its own graph over the SAME static inputs and recurrent state."""
+        sg, eng, cfg = self._static_step_buffers(), self._engine, self._cfg
         from .. import ops
         inplace = cfg["maxlen"] <= ops.ATTENTION_STEP_MAXLEN     # the fused step kernel's limit; longer memories go through copies (below)
         scale, shift = self.value_head.normalizer.affine()
+        # the static state may hold a LIVE episode (the other mode's graph, or the eager steps before an automatic capture, copied in by
+        # _graphed_forward): the warm-up and the capture itself execute nothing / must change nothing the caller can see
+        snap = [(m.clone(), (k.clone(), v.clone())) for m, (k, v) in sg["state"]]
+        rng = eng.rng_state(self._device())
+        rng_snap = rng.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):           # warm-up outside capture, with the captured call's exact arguments (lazy kernel loading, allocator
-            for _ in range(2):                  # pools, the engine's arrival counters); the state it advances is zeroed again below
-                eng.forward(sg["img"], sg["first"], sg["state"], sample="deterministic", inplace_state=inplace, act_tail=(scale, shift))
+            for _ in range(2):                  # pools, the engine's arrival counters); what it advances is restored below
+                eng.forward(sg["img"], sg["first"], sg["state"], sample=mode, inplace_state=inplace, act_tail=(scale, shift))
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            # arg-max + its log-prob ride in the graph; the recurrent state -- K, V and masks -- is updated in place (no copies back into
-            # the static buffers).  act()'s glue rides in the graph too, as ONE launch (ops.act_epilogue): the heads' log-probs summed, the
-            # value de-normalised, the NaN check of the action log-prob (lib/policy.py:320-321 asserts it every step) as a flag the host
-            # reads with the action, and everything the caller keeps beyond the next replay packed into one record: a single clone per step
-            out = eng.forward(sg["img"], sg["first"], sg["state"], sample="deterministic", inplace_state=inplace, act_tail=(scale, shift))
+            # sampling (arg-max, or Gumbel-max on uniforms the head kernel draws from the device-resident {seed, step}) + its log-prob ride
+            # in the graph; the recurrent state -- K, V and masks -- is updated in place (no copies back into the static buffers).  act()'s
+            # glue rides in the graph too, as ONE launch (ops.act_epilogue): the heads' log-probs summed, the value de-normalised, the NaN
+            # check of the action log-prob (lib/policy.py:320-321 asserts it every step) as a flag the host reads with the action, the
+            # sampler's step counter advanced, and everything the caller keeps beyond the next replay packed into one record: a single
+            # clone per step
+            out = eng.forward(sg["img"], sg["first"], sg["state"], sample=mode, inplace_state=inplace, act_tail=(scale, shift))
             for (m_in, (k_in, v_in)), (m_out, (k_out, v_out)) in zip(sg["state"], out["state_out"]):
                 if m_out.data_ptr() != m_in.data_ptr():
                     m_in.copy_(m_out)
                 if k_out.data_ptr() != k_in.data_ptr():
                     k_in.copy_(k_out); v_in.copy_(v_out)
-        for m_in, (k_in, v_in) in sg["state"]:    # the warm-up runs advanced the static state: start from a clean one
-            m_in.zero_(); k_in.zero_(); v_in.zero_()
-        sg["graph"], sg["out"] = graph, out
+        for (m_in, (k_in, v_in)), (m_s, (k_s, v_s)) in zip(sg["state"], snap):    # the warm-up runs advanced the static state and the sampler
+            m_in.copy_(m_s); k_in.copy_(k_s); v_in.copy_(v_s)
+        rng.copy_(rng_snap)
+        sg["graphs"][mode] = (graph, out)
 
-    def _graphed_forward(self, img, first, state_in):
-        sg = self._step_graph
-        if "graph" not in sg:
-            self._capture_step_graph()
-        sg["img"].copy_(img)
-        sg["first"].copy_(first)
+    def _graphed_forward(self, img, first, state_in, mode: str):
+        sg = self._static_step_buffers()
+        # the caller's state first (a capture below must see -- and preserve -- the live episode)
         for (m_s, (k_s, v_s)), (m, (k, v)) in zip(sg["state"], state_in):
             if k.data_ptr() != k_s.data_ptr():   # not the aliased state of the previous graphed step
                 k_s.copy_(k); v_s.copy_(v)
@@ -341,8 +404,13 @@ class MinecraftAgentPolicy(nn.Module):
                     m_s.zero_()
                 else:
                     m_s.copy_(m)
-        sg["graph"].replay()
-        out = dict(sg["out"])
+        if mode not in sg["graphs"]:
+            self._capture_step_graph(mode)
+        sg["img"].copy_(img)
+        sg["first"].copy_(first)
+        graph, gout = sg["graphs"][mode]
+        graph.replay()
+        out = dict(gout)
         out["state_out"] = sg["state"]
         if "_keep" in out:       # handed to the caller: must survive the next replay (the other outputs are consumed at once)
             from ..engine import unpack_act_tail
@@ -360,8 +428,9 @@ class MinecraftAgentPolicy(nn.Module):
         (pd, vpred, _), state_out, _ = self._run(obs, first, state_in, sample=None)
         return (pd, vpred, None), state_out
 
-    def _run(self, obs, first, state_in, sample=None):
-        """forward() plus, on request, the fused CategoricalActionHead.sample / logprob of the head kernel (act())."""
+    def _run(self, obs, first, state_in, sample=None, auto_graph=False):
+        """forward() plus, on request, the fused CategoricalActionHead.sample / logprob of the head kernel (act()).
+        auto_graph: the caller is act() -- eligible calls count towards the automatic capture of the acting step."""
         if isinstance(obs, dict):
             obs = obs.copy()
             mask = obs.pop("mask", None)        # {"buttons"/"camera": bool [B,T,1,n]}: False -> LOG0 (lib/action_head.py:170-171)
@@ -378,11 +447,15 @@ class MinecraftAgentPolicy(nn.Module):
             # fp16 scales the incoming gradients into half's range inside the node, _PolicyForwardFn.backward)
             pd_v, state_out = self._forward_differentiable(img, first, state_in, mask)
             return pd_v, state_out, {}
+        graphable = mask is None and img.shape[1] == 1
+        if auto_graph and sample is not None and self._step_graph is None and graphable:
+            self._auto_graph_tick(img.shape[0])
         sg = self._step_graph
-        if sg is not None and mask is None and img.shape[0] == sg["batch"] and img.shape[1] == 1:
-            out = self._graphed_forward(img, first, state_in)
-            if sample == "stochastic":
-                out = {k: v for k, v in out.items() if k not in ("action", "action_log_prob")}   # the graph holds the arg-max only
+        if sg is not None and graphable and img.shape[0] == sg["batch"]:
+            # (a plain forward() on the graphed shape replays the deterministic graph and ignores its action outputs)
+            out = self._graphed_forward(img, first, state_in, sample or "deterministic")
+            if sample is None:
+                out = {k: v for k, v in out.items() if k not in ("action", "action_log_prob", "vpred_denorm", "nan_flag")}
         else:
             out = self._engine.forward(img, first, state_in, mask=mask, sample=sample)
         pi_logits = {"camera": out["camera"], "buttons": out["buttons"]}
@@ -425,7 +498,7 @@ class MinecraftAgentPolicy(nn.Module):
         obs = tree_map(lambda x: x.unsqueeze(1), obs)
         first = first.unsqueeze(1)
         want = None if taken_action is not None else ("stochastic" if stochastic else "deterministic")
-        (pd, vpred, _), state_out, extra = self._run(obs, first, state_in, sample=want)
+        (pd, vpred, _), state_out, extra = self._run(obs, first, state_in, sample=want, auto_graph=True)
         if taken_action is None and "action" in extra:
             # CategoricalActionHead.sample / logprob (lib/action_head.py:176-207) came out of the head kernel
             ac = {k: extra["action"][k] for k in pd}

@@ -168,14 +168,14 @@ def conv_first(img_u8, wfrag, cout, stats_out=None):
     return y
 
 
-CONV_TILING = {"auto": 0, "throughput": 1, "latency": 2}
+CONV_TILING = {"throughput": 1, "latency": 2}
 
 
 def conv3x3(x, wpk, edge_sa, edge_sg, stats_in, cout, res=None, stats_out=None, out=None, tiling="throughput"):
     """x blocked bf16 [F,Cin/32,H,W,32] -> blocked bf16 [F,cout/32,H,W,32] (GN fold + ReLU [+res]).
     tiling: "throughput" (default: a frame's result must not depend on how many frames share the launch -- chunking, sharding
     over ranks and the batch size are free choices of the caller; the two tilings sum a tile's statistics in different orders),
-    "latency" (the acting step asks for it explicitly) or "auto" (by grid size) -- vpt_conv3x3_forward_tiled."""
+    or "latency" (the acting step asks for it explicitly) -- vpt_conv3x3_forward_tiled; the library never picks by grid size."""
     _chk(x, OP16, "x"); _chk(wpk, OP16, "wpk"); _chk(edge_sa, torch.float32, "edge_sa")
     _chk(edge_sg, torch.float32, "edge_sg"); _chk(stats_in, torch.float64, "stats_in")
     _chk(res, OP16, "res"); _chk(stats_out, torch.float64, "stats_out")
@@ -184,13 +184,11 @@ def conv3x3(x, wpk, edge_sa, edge_sg, stats_in, cout, res=None, stats_out=None, 
     if out is None:
         out = torch.empty(f, cout // 32, h, w, 32, dtype=dt, device=x.device)
     meta = dict(flops=2.0 * f * h * w * cout * 9 * cb * 32, bytes=2.0 * f * h * w * (cb * 32 + cout * (2 if res is not None else 1)))
-    if tiling == "auto":
-        _call("vpt_conv3x3_forward", meta, ptr(x), ptr(wpk), ptr(edge_sa), ptr(edge_sg), ptr(stats_in), ptr(res),
-              ptr(out), ptr(stats_out), f, h, w, cb * 32, cout, _stream(), fmt=fmt)
-    else:
-        _call("vpt_conv3x3_forward_tiled", meta, ptr(x), ptr(wpk), ptr(edge_sa), ptr(edge_sg), ptr(stats_in), ptr(res),
-              ptr(out), ptr(stats_out), f, h, w, cb * 32, cout, CONV_TILING[tiling], _stream(), fmt=fmt,
-              label="vpt_conv3x3_forward" if tiling == "throughput" else "vpt_conv3x3_forward_latency")
+    if tiling not in CONV_TILING:
+        raise ValueError(f"conv3x3: tiling must be one of {sorted(CONV_TILING)}, got {tiling!r}")
+    _call("vpt_conv3x3_forward_tiled", meta, ptr(x), ptr(wpk), ptr(edge_sa), ptr(edge_sg), ptr(stats_in), ptr(res),
+          ptr(out), ptr(stats_out), f, h, w, cb * 32, cout, CONV_TILING[tiling], _stream(), fmt=fmt,
+          label="vpt_conv3x3_forward" if tiling == "throughput" else "vpt_conv3x3_forward_latency")
     return out
 
 
@@ -381,9 +379,32 @@ def masked_attention_step(qkvr, kmem, vmem, state_mask, first, b_nd, batch, head
     return out, kout, vout, mout
 
 
-def act_epilogue(action_buttons, action_camera, logp_buttons, logp_camera, logits, value_col, scale, shift):
+def new_rng_state(device, seed=None):
+    """Device-resident state of the in-kernel generator: int64 [2] = {seed, step}.  The seed comes from torch's default CPU generator
+    unless given, so torch.manual_seed() makes a run's sampled actions reproducible, as it does for the reference's th.rand_like."""
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    return torch.tensor([int(seed), 0], dtype=torch.int64, device=device)
+
+
+def _chk_rng(rng_state):
+    if rng_state is not None and (rng_state.dtype != torch.int64 or rng_state.numel() != 2 or not rng_state.is_cuda or not rng_state.is_contiguous()):
+        raise ValueError("rng_state must be a contiguous int64 [2] GPU tensor {seed, step} (ops.new_rng_state)")
+
+
+def uniform_noise(rng_state, rng_stream, m, n):
+    """fp32 [m, n]: exactly the uniforms log_softmax_cols(..., rng=(rng_state, rng_stream)) draws (vpt_uniform_noise); state not advanced."""
+    _chk_rng(rng_state)
+    out = torch.empty(m, n, dtype=torch.float32, device=rng_state.device)
+    _call("vpt_uniform_noise", dict(bytes=4.0 * m * n), ptr(rng_state), ctypes.c_uint32(rng_stream), ptr(out), m, n, _stream())
+    return out
+
+
+def act_epilogue(action_buttons, action_camera, logp_buttons, logp_camera, logits, value_col, scale, shift, rng_state=None):
     """Tail of MinecraftAgentPolicy.act on the acting path in one launch (include/vpt_hip.h: vpt_act_epilogue) ->
-    (keep int64 [M, 4], nan_flag uint8 [1]); see unpack_act_keep()."""
+    (keep int64 [M, 4], nan_flag uint8 [1]); see unpack_act_keep().  rng_state: the generator state whose step counter this launch
+    advances (the stochastic heads of the step drew from it)."""
+    _chk_rng(rng_state)
     _chk(action_buttons, torch.int64, "action_buttons"); _chk(action_camera, torch.int64, "action_camera")
     _chk(logp_buttons, torch.float32, "logp_buttons"); _chk(logp_camera, torch.float32, "logp_camera"); _chk(logits, torch.float32, "logits")
     m = logits.shape[0]
@@ -392,7 +413,7 @@ def act_epilogue(action_buttons, action_camera, logp_buttons, logp_camera, logit
     keep = torch.empty(m, 4, dtype=torch.int64, device=logits.device)
     flag = torch.empty(1, dtype=torch.uint8, device=logits.device)
     _call("vpt_act_epilogue", dict(bytes=64.0 * m), ptr(action_buttons), ptr(action_camera), ptr(logp_buttons), ptr(logp_camera), ptr(logits),
-          logits.shape[1], int(value_col), ctypes.c_float(scale), ctypes.c_float(shift), ptr(keep), ptr(flag), m, _stream())
+          logits.shape[1], int(value_col), ctypes.c_float(scale), ctypes.c_float(shift), ptr(keep), ptr(flag), ptr(rng_state), m, _stream())
     return keep, flag
 
 
@@ -403,11 +424,16 @@ def unpack_act_keep(keep):
     return keep[:, 0], keep[:, 1], kf[:, 4], kf[:, 6], kf[:, 7]
 
 
-def log_softmax_cols(logits, col0, n, temperature, mask=None, noise=None, want_action=False):
+def log_softmax_cols(logits, col0, n, temperature, mask=None, noise=None, want_action=False, rng=None):
     """log_softmax(logits[:, col0:col0+n] / T) -> fp32 [M, n]; mask uint8 [M, n] (0 -> LOG0).  want_action: also
-    CategoricalActionHead.sample + logprob in the same kernel -> (lp, action int64 [M], action_logp fp32 [M]); noise fp32
-    [M, n] uniforms = stochastic (Gumbel-max), None = deterministic arg-max."""
+    CategoricalActionHead.sample + logprob in the same kernel -> (lp, action int64 [M], action_logp fp32 [M]).  Stochastic
+    (Gumbel-max) when uniforms are given -- noise fp32 [M, n], or rng = (rng_state, stream id): drawn inside the kernel from the
+    device-resident generator state (new_rng_state; the caller advances its step) --, deterministic arg-max otherwise."""
     _chk(logits, torch.float32, "logits"); _chk(mask, torch.uint8, "mask"); _chk(noise, torch.float32, "noise")
+    rng_state, rng_stream = rng if rng is not None else (None, 0)
+    _chk_rng(rng_state)
+    if noise is not None and rng_state is not None:
+        raise ValueError("log_softmax_cols: give noise or rng, not both")
     m = logits.shape[0]
     out = torch.empty(m, n, dtype=torch.float32, device=logits.device)
     if mask is None and not want_action:
@@ -416,8 +442,8 @@ def log_softmax_cols(logits, col0, n, temperature, mask=None, noise=None, want_a
         return out
     action = torch.empty(m, dtype=torch.int64, device=logits.device) if want_action else None
     alp = torch.empty(m, dtype=torch.float32, device=logits.device) if want_action else None
-    _call("vpt_action_head_forward", dict(bytes=8.0 * m * n), ptr(logits), ptr(mask), ptr(noise), ptr(out), ptr(action), ptr(alp),
-          m, logits.shape[1], col0, n, ctypes.c_float(temperature), _stream())
+    _call("vpt_action_head_forward", dict(bytes=8.0 * m * n), ptr(logits), ptr(mask), ptr(noise), ptr(rng_state), ctypes.c_uint32(rng_stream),
+          ptr(out), ptr(action), ptr(alp), m, logits.shape[1], col0, n, ctypes.c_float(temperature), _stream())
     return (out, action, alp) if want_action else out
 
 
@@ -460,6 +486,23 @@ def adam_step_multi_(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1=0.9, 
           ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps), ctypes.c_float(weight_decay),
           ctypes.c_float(grad_scale), ptr(found_inf), _stream())
     return table   # keep alive until the launch has been enqueued (the caller may drop it afterwards: stream-ordered free)
+
+
+def grads_nonfinite(grads):
+    """int32 [1] device flag: 1 if any element of the fp32 tensors in `grads` is inf / nan (vpt_grads_nonfinite_multi, one launch; what
+    torch.cuda.amp.GradScaler.unscale_ computes).  No host synchronisation here: the caller reads the flag when it needs it."""
+    import numpy as np
+    grads = [g for g in grads if g is not None and g.numel()]
+    flag = torch.zeros(1, dtype=torch.int32, device=grads[0].device)
+    rec = np.zeros(len(grads), dtype=[("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<u8"), ("fb", "<i8")])
+    blk = 0
+    for i, g in enumerate(grads):
+        _chk(g, torch.float32, "grad")
+        rec[i] = (0, g.data_ptr(), 0, 0, g.numel(), blk)
+        blk += (g.numel() + 1023) // 1024
+    table = torch.from_numpy(rec.view(np.uint8)).to(grads[0].device, non_blocking=False)
+    _call("vpt_grads_nonfinite_multi", dict(bytes=4.0 * sum(g.numel() for g in grads)), ptr(table), len(grads), blk, ptr(flag), _stream())
+    return flag
 
 
 # ---- backward (behavioural-cloning step) ---------------------------------------------------------------

@@ -83,13 +83,20 @@ class BCTrainer:
         self.scaled = self.engine.precision == "fp16"
         self.loss_scale = float(loss_scale) if loss_scale is not None else (256.0 if self.scaled else 1.0)
         self.scale_growth_interval, self._clean_steps, self.skipped_steps = int(scale_growth_interval), 0, 0
+        # the autograd boundary's counterpart of loss_scale (lib/policy.py:_PolicyForwardFn.backward): where the largest incoming
+        # gradient element is lifted to before it enters the 16-bit buffers; halved on every overflow it detects
+        self.autograd_lift, self.autograd_overflows = 256.0, 0
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.step_count = 0
         # Frame chunks of the CNN (forward-saving AND backward) alternate over this many HIP streams, chunk ci always on stream
         # ci % n: one chunk's HBM-bound passes (conv_backward_prepare, the affine backward, pool) and launch tails overlap the
         # other chunks' MFMA-bound convolutions, as in the inference engine.  Each stream accumulates its weight-gradient pieces in
-        # its own buffers (summed in a fixed order at the end: deterministic); a chunk's saved activations are allocated, used and
-        # released on ONE stream, so the caching allocator's per-stream pools need no cross-stream bookkeeping.
+        # its own buffers, merged in stream order at the end (the merge order is fixed; WITHIN a buffer the wgrad / first-conv kernels
+        # add their per-workgroup pieces with fp32 atomics in arrival order, so the last bits of the stack-0 gradients vary from run to
+        # run -- 1e-7 relative in bf16, up to 1e-4 on heavily cancelling fp16 sums, tests/test_gpu_training.py); a chunk's saved
+        # activations are allocated, used and released on ONE stream, so the caching allocator's per-stream pools need no cross-stream
+        # bookkeeping.  The streams are created ONCE per trainer and only ever appended to (never replaced): the activations a
+        # forward_saving() left for a later backward stay tied to the stream object that produced them.
         self.cnn_streams = int(os.environ.get("VPT_BC_STREAMS", self.engine.cnn_streams))
         self._streams: List[torch.cuda.Stream] = []
         self.params: Dict[str, torch.nn.Parameter] = dict(policy.named_parameters())
@@ -139,6 +146,10 @@ class BCTrainer:
         left multiplied by 1 / grad_unscale(global_frames) -- the optimiser launch folds that factor in, no extra pass.
         on_trunk_grads(g): called once the gradients of everything behind the CNN (88 % of the parameters) are final and
         before the CNN's backward starts -- the data-parallel step starts their all-reduce there."""
+        if on_trunk_grads is not None and unscaled and self.scaled:
+            # the callback (an asynchronous all-reduce in the data-parallel step) would see loss-SCALED gradients that this function then
+            # multiplies in place while the collective may still be reading them
+            raise ValueError("loss_and_grads: on_trunk_grads needs unscaled=False in the fp16 (loss-scaled) mode; apply grad_unscale() after the exchange")
         S = self.forward_saving(img_u8, first, state_in)
         m = S["m"]
         ab = act_buttons.reshape(m).to(torch.int64).contiguous()
@@ -350,8 +361,8 @@ class BCTrainer:
         n = min(self.cnn_streams, n_chunks)
         if n <= 1:
             return [], main
-        if len(self._streams) < n:
-            self._streams = [torch.cuda.Stream() for _ in range(n)]
+        while len(self._streams) < n:        # append only: chunk ci of an earlier forward_saving() must find ITS stream at index ci % n again
+            self._streams.append(torch.cuda.Stream())
         for st in self._streams[:n]:
             st.wait_stream(main)
         return self._streams[:n], main
