@@ -171,7 +171,12 @@ def _roofline(ops, pol, step, state, args, B, T, mode):
     summ = ops.TIMER.summary()
     ops.TIMER.enabled = False
     pol._engine.cnn_streams = streams_saved
-    c = summ.get("vpt_conv3x3_forward")
+    # every launch of the roofline kernel vpt_conv3x3_kernel: its plain / residual modes ("vpt_conv3x3_forward") AND its pool-fused mode
+    # ("vpt_conv3x3_pool_forward": the stacks' firstconv with the max-pool in the epilogue; the seam kernel behind it is a different kernel)
+    c = None
+    for lab in ("vpt_conv3x3_forward", "vpt_conv3x3_pool_forward"):
+        if lab in summ:
+            c = dict(summ[lab]) if c is None else {k: c[k] + summ[lab][k] for k in c}
     total_ms = sum(v["ms"] for v in summ.values())
     kernels = {k: dict(ms=round(v["ms"], 3), calls=v["calls"],
                        tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] and v["ms"] else None)
@@ -197,6 +202,8 @@ def _roofline(ops, pol, step, state, args, B, T, mode):
         roof = dict(bound="mfma", kernel="vpt_conv3x3_kernel", achieved=round(ach, 1), peak=2500.0, unit="TFLOP/s",
                     frac=round(ach / 2500.0, 4), traffic=traffic, traffic_unit=f"HBM bytes per launch (algorithmic {talg:.3g})", traffic_source=tsrc,
                     launches=c["calls"], avg_launch_ms=round(c["ms"] / c["calls"], 4), share_of_step_time=round(c["ms"] / total_ms, 3),
+                    by_mode={lab: dict(ms=round(summ[lab]["ms"], 3), calls=summ[lab]["calls"], tflops=round(summ[lab]["flops"] / (summ[lab]["ms"] * 1e-3) / 1e12, 1))
+                             for lab in ("vpt_conv3x3_forward", "vpt_conv3x3_pool_forward") if lab in summ and summ[lab]["ms"] > 0},
                     flop_accounting="direct-convolution FLOPs (2 x H x W x Cout x 9 x Cin per frame and layer) / summed HIP-event durations of the launches")
     return roof, kernels
 

@@ -84,8 +84,10 @@ int vpt_pack_linear(const float* weight, void* wpk, int N, int K, int transposed
 /* Stack-0 firstconv + ingest + ReLU + max-pool.
  * Replaces ImgPreprocessing.forward (lib/policy.py:39-45), the permute at lib/impala_cnn.py:190,
  * CnnDownStack.firstconv of stack 0 (lib/impala_cnn.py:86-97,115) and F.max_pool2d (lib/impala_cnn.py:117).
- * img: uint8 [frames][H][W][3]; wfrag: bf16 [NT][4][2][64][8]; y: blocked [frames][Cout/32][H/2][W/2][32]. */
-int vpt_conv_first_forward(const uint8_t* img, const void* wfrag, void* y, double* stats_out,
+ * img: uint8 [frames][H][W][3]; wfrag: bf16 [NT][4][2][64][8]; y: blocked [frames][Cout/32][H/2][W/2][32].
+ * out_gain (optional, [Cout]): y is stored multiplied by it per channel -- the gain of the stack's GroupNorm `n` when that norm is
+ * folded into the first block (vpt_nfold_coef); stats_out always holds the statistics of the UNscaled pooled tensor. */
+int vpt_conv_first_forward(const uint8_t* img, const void* wfrag, void* y, double* stats_out, const float* out_gain,
                            int frames, int H, int W, int Cout, void* stream);
 
 /* IDM temporal conv + ingest + bias + ReLU.
@@ -111,6 +113,39 @@ int vpt_conv3x3_forward(const void* x, const void* wpk, const float* edge_sa, co
 int vpt_conv3x3_forward_tiled(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg,
                               const double* stats_in, const void* res, void* y, double* stats_out,
                               int frames, int H, int W, int Cin, int Cout, int tiling, void* stream);
+
+/* The same layer FUSED with the max-pool that follows it in CnnDownStack.forward (lib/impala_cnn.py:114-117: x = firstconv(x);
+ * x = F.max_pool2d(x, 3, 2, 1)) -- stacks 1.., inference: pooled [frames][Cout/32][H/2][W/2][32] and its frame statistics come out, the
+ * pre-pool tensor never reaches HBM.  Two launches inside: the convolution pools every 16 x 16 output tile through LDS and writes the
+ * tile's last row / column to seam_scratch (vpt_conv3x3_pool_seam_elems(frames, H, W, Cout) 16-bit elements, caller-owned); a small
+ * second kernel completes the pooled pixels whose 3 x 3 window crosses a tile border.  Bit-identical to vpt_conv3x3_forward followed by
+ * vpt_maxpool_forward (the statistics to the order of their fp32 / fp64 additions).  No residual, throughput tiling only.
+ * phases: 3 = both launches (the normal call); 1 = the convolution only, 2 = the seam kernel only (a caller that times them apart).
+ * out_gain: as for vpt_conv_first_forward (the pooled tensor stored times GroupNorm `n`'s gain; statistics of the unscaled values). */
+int64_t vpt_conv3x3_pool_seam_elems(int frames, int H, int W, int Cout);
+int vpt_conv3x3_pool_forward(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg, const double* stats_in,
+                             void* pooled, void* seam_scratch, double* stats_out, const float* out_gain, int frames, int H, int W, int Cin,
+                             int Cout, int phases, void* stream);
+
+/* ---- GroupNorm `n` of a stack folded into its first residual block (CnnDownStack.forward, lib/impala_cnn.py:118-121: x = self.n(x);
+ * for block in self.blocks: x = block(x)) -- inference.  The producer of the pooled tensor P stores Q = n.weight[c] * P (out_gain above);
+ * x = n(P) = r_P Q + b[c] is never written:
+ *   vpt_channel_stats: chs[f][c] = (sum_p Q, sum_p Q^2) over the HW pixels of a frame, fp64, ACCUMULATED (caller zeroes);
+ *   vpt_nfold_coef:    from tot[f] = the frame statistics of P (the producer's stats_out), chs, n.weight / n.bias and four edge tables of
+ *                      block 0's conv0 -- its own edge_sa / edge_sg plus tb / tg = the edge_sg sums with every input channel weighted by
+ *                      n.bias / n.weight -- the per-frame epilogue table kk_frame [frames][9][ceil(Cout/128)*128], the accumulator scale
+ *                      rs_frame [frames] (conv0) and res_scale [frames], res_bias [frames][C] (conv1's residual x = res_scale * Q + res_bias);
+ *   vpt_conv3x3_forward_folded: vpt_conv3x3_forward with either of the two substitutions: (kk_frame, rs_frame) replace edge_sa and the
+ *                      statistics of x (conv0 on Q; edge_sg must still point at a table of the right size, stats_in may be null);
+ *                      (res_scale, res_bias) turn the residual into res_scale[f] * res + res_bias[f][c] (conv1, res = Q).
+ * Saves the read and the write of every pooled tensor that vpt_frame_affine_forward costs. */
+int vpt_channel_stats(const void* x, double* chs, int frames, int C, int HW, void* stream);
+int vpt_nfold_coef(const double* tot, const double* chs, const float* gain, const float* bias, const float* sa, const float* sg,
+                   const float* tb, const float* tg, float* kk_frame, float* rs_frame, float* res_scale, float* res_bias,
+                   int frames, int C, int HW, int Cout, void* stream);
+int vpt_conv3x3_forward_folded(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg, const double* stats_in,
+                               const float* kk_frame, const float* rs_frame, const void* res, const float* res_scale, const float* res_bias,
+                               void* y, double* stats_out, int frames, int H, int W, int Cin, int Cout, void* stream);
 
 /* F.max_pool2d(x, 3, 2, 1) on a post-ReLU blocked tensor (lib/impala_cnn.py:117, stacks 1..2).  argmax (optional, for
  * training): uint8, shaped like y, the window position kh*3+kw of the first maximum (15 when the window is all zero). */

@@ -378,6 +378,55 @@ def peak_heads(sd: Dict[str, torch.Tensor], seed: int = 0) -> Dict[str, torch.Te
     return out
 
 
+def scene_frames(b: int, t: int, n_scenes: int, generator, noise: int = 10):
+    """uint8 [b, t, 128, 128, 3] frames drawn from `n_scenes` low-frequency base images (+-noise per pixel), and the scene index of every
+    frame [b, t]: WHICH scene a frame shows is a property of the input that the network's latent carries linearly (fit_scene_heads)."""
+    low = torch.randint(0, 256, (n_scenes, 3, 4, 4), generator=generator).float()
+    base = torch.nn.functional.interpolate(low, size=(128, 128), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    ids = torch.randint(0, n_scenes, (b, t), generator=generator)
+    nz = torch.randint(-noise, noise + 1, (b, t, 128, 128, 3), generator=generator).float()
+    return (base[ids] + nz).clamp(0, 255).to(torch.uint8).contiguous(), ids
+
+
+def fit_scene_heads(sd: Dict[str, torch.Tensor], latent: torch.Tensor, scene: torch.Tensor, temperature: float, n_live: int = 16,
+                    margin_nat: float = 4.0, ridge: float = 1e-2, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """The "competitive" head family: INPUT-DRIVEN decisions with margins above 16-bit noise.  Per policy head, `n_live` classes stay in
+    play (every other class: zero weights, scaled logit -12 nat, i.e. never chosen and free of input-dependent error); the first
+    n_scenes of them are a linear read-out of the scene the current frame shows, fitted by ridge regression on the ORACLE's latents of
+    the very frames the test runs (target: margin_nat above the other live classes after the temperature), the remaining live classes
+    are random directions of the same norm (they compete, rarely win).  The arg-max therefore changes with the input -- one action per
+    scene -- and nothing in the bias decides it: all live classes share bias terms that only centre the read-out.
+    latent [N, hid] (oracle, fp32), scene [N] int64.  Returns a new dict; only pi_head tensors differ from `sd`."""
+    g = torch.Generator().manual_seed(2000 + seed)
+    z = latent.double()
+    mu = z.mean(0)
+    zc = z - mu
+    n_sc = int(scene.max()) + 1
+    alpha = margin_nat * temperature
+    y = torch.nn.functional.one_hot(scene, n_sc).double() * alpha - alpha / n_sc
+    gram = zc @ zc.t()
+    coef = torch.linalg.solve(gram + ridge * gram.diagonal().mean() * torch.eye(gram.shape[0], dtype=torch.float64), y)
+    w_sc = (zc.t() @ coef).t()                                           # [n_sc, hid]
+    out = dict(sd)
+    for head in ("buttons", "camera"):
+        wk, bk = f"pi_head.{head}.linear_layer.weight", f"pi_head.{head}.linear_layer.bias"
+        n = sd[bk].numel()
+        live = torch.randperm(n, generator=g)[:max(n_live, n_sc)]
+        w = torch.zeros(n, z.shape[1], dtype=torch.float64)
+        b = torch.full((n,), -12.0 * temperature, dtype=torch.float64)
+        perm = torch.randperm(n_sc, generator=g)                         # the two heads map scenes to classes differently
+        w[live[:n_sc]] = w_sc[perm]
+        b[live[:n_sc]] = -(w_sc[perm] @ mu)
+        extra = live[n_sc:]
+        if extra.numel():
+            r = torch.randn(extra.numel(), z.shape[1], generator=g, dtype=torch.float64)
+            r = r / r.norm(dim=1, keepdim=True) * w_sc.norm(dim=1).mean()
+            w[extra] = r
+            b[extra] = -(r @ mu) - 0.25 * alpha
+        out[wk], out[bk] = w.float().contiguous(), b.float().contiguous()
+    return out
+
+
 def synthetic_state_dict(cfg: dict, seed: int = 0, heads: str = "uniform") -> Dict[str, torch.Tensor]:
     """Seeded weights with the reference's shapes and roughly its init scales, but with *every* 1-D
     parameter randomised (default init leaves gains 1 / biases 0, hiding affine bugs -- SURVEY.md §7).

@@ -70,6 +70,58 @@ def test_conv3x3(frames, h, w, cin, cout, use_res, tiling):
     assert torch.allclose(st_out.cpu(), st_ref, rtol=5e-3, atol=1.0), (st_out.cpu(), st_ref)
 
 
+@pytest.mark.parametrize("frames,h,w,cin,cout", [
+    (3, 64, 64, 128, 256),     # 2x stack-1 firstconv: 4 x 4 tiles, two channel tiles
+    (2, 32, 32, 256, 256),     # 2x stack-2 firstconv: 2 x 2 tiles
+    (2, 64, 64, 64, 128),      # 1x stack-1 firstconv
+    (5, 16, 16, 64, 96),       # one tile per frame: no seams at all; Cout / 32 odd (a wave with one valid channel block)
+    (2, 48, 16, 32, 160),      # tiles in one direction only (row seams, no column seams), a channel tile with a single valid block
+    (3, 16, 80, 96, 64),       # column seams only
+    (1, 128, 128, 128, 128),   # the IDM's stack-0 firstconv shape: 8 x 8 tiles
+])
+@pytest.mark.parametrize("fmt", ["bf16", "fp16"])
+def test_conv3x3_pool_fused(frames, h, w, cin, cout, fmt):
+    """firstconv + ReLU + max_pool2d(3, 2, 1) in one pass (vpt_conv3x3_pool_forward: LDS-pooled tiles + the seam kernel) == the
+    two-kernel path vpt_conv3x3_forward -> vpt_maxpool_forward BIT FOR BIT (same MFMA order, same rounding point, the maximum is
+    exact), its statistics to the order of their fp64 additions; and close to CnnDownStack's first two lines in fp32
+    (lib/impala_cnn.py:114-117) like every conv test."""
+    dt = torch.bfloat16 if fmt == "bf16" else torch.float16
+    g = torch.Generator().manual_seed(17)
+    W = torch.randn(cout, cin, 3, 3, generator=g) * (1.6 / (cin * 9) ** 0.5)
+    gain = 1 + 0.2 * torch.randn(cin, generator=g)
+    bias = 0.1 * torch.randn(cin, generator=g)
+    x = (torch.relu(torch.randn(frames, cin, h, w, generator=g)) + 0.2 * torch.randn(frames, cin, h, w, generator=g)).to(dt)
+    wpk, sa, sg = ops.pack_conv3x3(W.to(DEV), gain.to(DEV), bias.to(DEV), dtype=dt)
+    xb = packing.nchw_to_blocked(x.float(), dtype=dt).to(DEV)
+    st_in = _stats_of(x.float()).to(DEV)
+    pre = ops.conv3x3(xb, wpk, sa, sg, st_in, cout)
+    st_a = torch.zeros(frames, 2, dtype=torch.float64, device=DEV)
+    want = ops.maxpool(pre, stats_out=st_a)
+    st_b = torch.zeros(frames, 2, dtype=torch.float64, device=DEV)
+    got = ops.conv3x3_pool(xb, wpk, sa, sg, st_in, cout, stats_out=st_b)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape == (frames, cout // 32, h // 2, w // 2, 32)
+    neq = (got.view(torch.int16) != want.view(torch.int16))
+    assert not bool(neq.any()), f"{int(neq.sum())} of {neq.numel()} pooled values differ; first at {neq.nonzero()[0].tolist()}"
+    assert torch.allclose(st_a, st_b, rtol=1e-6, atol=1e-3), (st_a, st_b)     # fp32 partial sums in a different order, fp64 across tiles
+    ref = F.max_pool2d(O._norm_conv_relu({"norm.weight": gain, "norm.bias": bias, "layer.weight": W}, "", x.float()), 3, 2, 1)
+    assert _relerr(packing.blocked_to_nchw(got.cpu(), cout, h // 2, w // 2), ref) < 2e-2
+    # out_gain: the pooled tensor stored times a per-channel gain (GroupNorm `n` folded), statistics still those of the unscaled tensor
+    gain = (1 + 0.3 * torch.randn(cout, generator=g)).to(DEV)
+    gain[1] = -0.5
+    st_c = torch.zeros(frames, 2, dtype=torch.float64, device=DEV)
+    scaled = ops.conv3x3_pool(xb, wpk, sa, sg, st_in, cout, stats_out=st_c, out_gain=gain)
+    torch.cuda.synchronize()
+    want_scaled = (want.float() * gain.view(1, cout // 32, 1, 1, 32)).to(dt)
+    assert torch.equal(scaled.view(torch.int16), want_scaled.view(torch.int16))
+    assert torch.allclose(st_c, st_b, rtol=1e-9, atol=1e-6)
+    # into a slice of a larger batch's tensor (the engine's sub-chunk use)
+    big = torch.zeros(frames + 2, cout // 32, h // 2, w // 2, 32, dtype=dt, device=DEV)
+    ops.conv3x3_pool(xb, wpk, sa, sg, st_in, cout, out=big[1:1 + frames])
+    torch.cuda.synchronize()
+    assert torch.equal(big[1:1 + frames].view(torch.int16), want.view(torch.int16)) and not bool(big[0].any()) and not bool(big[-1].any())
+
+
 @pytest.mark.parametrize("frames,cout,h,w", [(2, 128, 128, 128), (1, 64, 128, 128), (1, 192, 128, 128), (5, 64, 32, 80), (3, 128, 48, 16)])
 def test_conv_first_pool(frames, cout, h, w):
     """(non-square frames: the persistent workgroups count tile coordinates up -- tile column, tile row, frame -- instead of decoding them)"""
@@ -85,6 +137,12 @@ def test_conv_first_pool(frames, cout, h, w):
     err = _relerr(out, ref)
     assert err < 1.5e-2, f"conv_first rel err {err}"
     assert torch.allclose(st.cpu(), _stats_of(out), rtol=1e-4, atol=1e-2)
+    gain = (1 + 0.3 * torch.randn(cout, generator=g)).to(DEV)       # out_gain: stored times a per-channel gain, statistics of the unscaled tensor
+    st2 = torch.zeros(frames, 2, dtype=torch.float64, device=DEV)
+    y2 = ops.conv_first(img.to(DEV), packing.pack_conv_first(W.to(DEV), b.to(DEV)), cout, stats_out=st2, out_gain=gain)
+    torch.cuda.synchronize()
+    assert torch.equal(y2.view(torch.int16), (y.float() * gain.view(1, cout // 32, 1, 1, 32)).to(torch.bfloat16).view(torch.int16))
+    assert torch.allclose(st2, st, rtol=1e-9, atol=1e-6)
 
 
 def test_maxpool_and_affine():
@@ -483,3 +541,70 @@ def test_device_pack_first_convs_and_permutes_bit_exact(dtype):
     assert lib.vpt_workspace_bytes(1, 8, 0, 0, 64, 128) == 4 * lib.vpt_conv3x3_wgrad_scratch_floats(8, 64, 128)
     assert lib.vpt_workspace_bytes(2, 8, 0, 0, 0, 128) == 4 * 8 * (9 * 128 + 4)
     assert lib.vpt_workspace_bytes(3, 16, 1024, 256, 0, 0) == 4 * 16 * 1024 * 256 and lib.vpt_workspace_bytes(99, 1, 1, 1, 1, 1) == -1
+
+
+@pytest.mark.parametrize("frames,c,h,w", [(3, 128, 64, 64), (2, 256, 32, 32), (5, 64, 16, 16), (2, 96, 32, 48)])
+@pytest.mark.parametrize("fmt", ["bf16", "fp16"])
+def test_group_norm_n_folded_into_block0(frames, c, h, w, fmt):
+    """CnnDownStack.forward after the pool (lib/impala_cnn.py:118-121): x = n(P); x = x + conv1(conv0(x)) -- with the GroupNorm `n`
+    FOLDED (vpt_channel_stats + vpt_nfold_coef + vpt_conv3x3_forward_folded on Q = n.weight * P: no affine pass, x never written) against
+    (1) the fp32 composition of the reference's layers and (2) the unfolded HIP path (vpt_frame_affine_forward -> conv -> conv + res)."""
+    dt = torch.bfloat16 if fmt == "bf16" else torch.float16
+    g = torch.Generator().manual_seed(23)
+    P_ = torch.relu(torch.randn(frames, c, h, w, generator=g) * 1.3 + 0.4).to(dt)            # a pooled post-ReLU tensor
+    gn, bn = 1 + 0.2 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    gn[3] = -0.7                                                                             # a negative gain must work too
+    conv = []
+    for _ in range(2):
+        conv.append({"layer.weight": torch.randn(c, c, 3, 3, generator=g) * (1.6 / (c * 9) ** 0.5),
+                     "norm.weight": 1 + 0.2 * torch.randn(c, generator=g), "norm.bias": 0.1 * torch.randn(c, generator=g)})
+    x_ref = O.group_norm_1(P_.float(), gn, bn)
+    ref = x_ref + O._norm_conv_relu(conv[1], "", O._norm_conv_relu(conv[0], "", x_ref))
+    dev = lambda t_: t_.to(DEV)
+    pk = [ops.pack_conv3x3(dev(cv["layer.weight"]), dev(cv["norm.weight"]), dev(cv["norm.bias"]), dtype=dt) for cv in conv]
+    Pb = packing.nchw_to_blocked(P_.float(), dtype=dt).to(DEV)
+    tot = _stats_of(P_.float()).to(DEV)
+    # ---- unfolded HIP path
+    s_x = torch.zeros(frames, 2, dtype=torch.float64, device=DEV)
+    xb = ops.frame_affine(Pb, dev(gn), dev(bn), tot, stats_out=s_x)
+    s_y = torch.zeros(frames, 2, dtype=torch.float64, device=DEV)
+    yb = ops.conv3x3(xb, *pk[0], s_x, c, stats_out=s_y)
+    s_o = torch.zeros(frames, 2, dtype=torch.float64, device=DEV)
+    unfolded = ops.conv3x3(yb, *pk[1], s_y, c, res=xb, stats_out=s_o)
+    # ---- folded: Q = gain * P as the producer would store it
+    Qb = packing.nchw_to_blocked((P_.float() * gn.view(1, -1, 1, 1)).to(dt).float(), dtype=dt).to(DEV)
+    chs = ops.channel_stats(Qb)
+    q = packing.blocked_to_nchw(Qb.cpu(), c, h, w).double()
+    want_chs = torch.stack([q.sum((2, 3)), (q * q).sum((2, 3))], -1)
+    assert torch.allclose(chs.cpu(), want_chs, rtol=1e-6, atol=1e-4)
+    wp = (conv[0]["layer.weight"] * conv[0]["norm.weight"].view(1, -1, 1, 1)).to(dt).double()
+    m = packing.edge_tap_matrix("cpu", torch.float64)
+    pad = (c + 127) // 128 * 128
+    tabs = []
+    for v in (bn, gn):
+        tap = (wp * v.double().view(1, -1, 1, 1)).sum(1).view(c, 9)
+        t_ = torch.zeros(9, pad)
+        t_[:, :c] = (m @ tap.t()).float()
+        tabs.append(t_.contiguous().to(DEV))
+    kk, rs, rsc, rb = ops.nfold_coef(tot, chs, dev(gn), dev(bn), pk[0][1], pk[0][2], tabs[0], tabs[1], h * w, c)
+    s_y2 = torch.zeros(frames, 2, dtype=torch.float64, device=DEV)
+    y2 = ops.conv3x3_folded(Qb, pk[0][0], pk[0][1], pk[0][2], None, c, kk_frame=kk, rs_frame=rs, stats_out=s_y2)
+    s_o2 = torch.zeros(frames, 2, dtype=torch.float64, device=DEV)
+    folded = ops.conv3x3_folded(y2, *pk[1], s_y2, c, res=Qb, res_scale=rsc, res_bias=rb, stats_out=s_o2)
+    torch.cuda.synchronize()
+    # the scalars against their definitions
+    n_tot = c * h * w
+    mu_p = tot[:, 0].cpu() / n_tot
+    r_p = torch.rsqrt(tot[:, 1].cpu() / n_tot - mu_p * mu_p + 1e-5)
+    assert torch.allclose(rsc.cpu().double(), r_p, rtol=1e-5)
+    xq = r_p.view(-1, 1, 1, 1) * q + (bn.double().view(1, -1, 1, 1) - (r_p * mu_p).view(-1, 1, 1, 1) * gn.double().view(1, -1, 1, 1))
+    assert torch.allclose(rb.cpu().double(), bn.double().view(1, -1) - (r_p * mu_p).view(-1, 1) * gn.double().view(1, -1), rtol=1e-5, atol=1e-6)
+    r_x = torch.rsqrt(xq.reshape(frames, -1).var(1, unbiased=False) + 1e-5)
+    assert torch.allclose(rs.cpu().double(), r_x * r_p, rtol=1e-4), (rs.cpu(), r_x * r_p)
+    out_f = packing.blocked_to_nchw(folded.cpu(), c, h, w)
+    out_u = packing.blocked_to_nchw(unfolded.cpu(), c, h, w)
+    e_ref, e_unf, e_u_ref = _relerr(out_f, ref), _relerr(out_f, out_u), _relerr(out_u, ref)
+    print(f"NFOLD[{fmt}] {frames}x{c}x{h}x{w}: folded vs fp32 reference {e_ref:.2e} (unfolded path {e_u_ref:.2e}); folded vs unfolded {e_unf:.2e}")
+    assert e_ref < 2e-2 and e_ref < 1.5 * e_u_ref + 2e-3, (e_ref, e_u_ref)
+    assert torch.allclose(s_o2.cpu(), _stats_of(out_f.float()), rtol=5e-3, atol=1.0)
+    assert torch.allclose(s_y2.cpu(), s_y.cpu(), rtol=2e-2)

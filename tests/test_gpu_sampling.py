@@ -95,11 +95,11 @@ def test_act_stochastic_is_captured_automatically_and_matches_the_eager_draws(mo
     pol.disable_step_graph()
     eager = rollout()
     assert pol._step_graph is None
-    assert int(pol._engine.rng_state(torch.device(DEV))[1]) == n            # one step of the counter per act()
+    assert int(pol._engine._rng_state[1]) == n            # one step of the counter per act()
     pol.auto_step_graph(True)
     auto = rollout()                                                      # calls 1-2 eager, 3.. replay the captured stochastic step
     assert pol._step_graph is not None and "stochastic" in pol._step_graph["graphs"] and "deterministic" not in pol._step_graph["graphs"]
-    assert int(pol._engine.rng_state(torch.device(DEV))[1]) == n
+    assert int(pol._engine._rng_state[1]) == n
     again = rollout()                                                     # every step a replay; a new episode's state copied in
     same = sum(e[:2] == a[:2] == b[:2] for e, a, b in zip(eager, auto, again))
     print(f"SAMPLING[{mode}]: act(stochastic=True), auto-captured graph vs eager on the same seed: {same}/{n} identical action pairs; "

@@ -51,4 +51,26 @@ for name, hw, cin, cout, use_res in shapes:
     ms, best = times[2], times[0]
     flops = 2.0 * f * hw * hw * cout * 9 * cin
     tag = " ".join(f"{k[9:].lower()}={v}" for k, v in os.environ.items() if k.startswith("VPT_CONV_"))
+    if name.endswith(".first") and os.environ.get("VPT_BENCH_POOL", "1") == "1":
+        # the stack's firstconv -> max-pool pair: two kernels (the pre-pool tensor through HBM) vs the pool-fused convolution + seam kernel
+        stp = torch.zeros(f, 2, dtype=torch.float64, device=dev)
+        pooled = torch.empty(f, cout // 32, hw // 2, hw // 2, 32, dtype=DT, device=dev)
+
+        def pair():
+            ops.conv3x3(x, wpk, sa, sg, st_in, cout, out=out)
+            ops.maxpool(out, stats_out=stp, out=pooled)
+
+        def fused():
+            ops.conv3x3_pool(x, wpk, sa, sg, st_in, cout, stats_out=stp, out=pooled)
+
+        for label, fn in (("conv+pool", pair), ("fused", fused), ("conv+pool", pair), ("fused", fused)):
+            fn(); torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            t = a.elapsed_time(b) / reps
+            print(f"[{os.environ.get('VPT_PRECISION', 'bf16')}] {name:9s} {label:9s}: {t:7.3f} ms per layer incl. pool ({flops / t / 1e9:7.1f} TF/s conv-equivalent)")
     print(f"[{os.environ.get('VPT_PRECISION', 'bf16')}] {name:9s} frames={f:5d} {hw}x{hw} {cin}->{cout}: median {ms:7.3f} ms {flops / ms / 1e9:7.1f} TF/s | best {flops / best / 1e9:7.1f} TF/s  {tag}")

@@ -21,7 +21,7 @@ _D = ctypes.c_double
 
 # name -> argtypes, exactly as declared in include/vpt_hip.h
 SIGNATURES = {
-    "vpt_conv_first_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vpt_conv_first_forward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_conv3d_t5_forward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_pack_conv3x3": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
     "vpt_pack_linear": [_P, _P, _I, _I, _I, _I, _I, _P],
@@ -30,6 +30,10 @@ SIGNATURES = {
     "vpt_chw_to_blocked": [_P, _P, ctypes.c_int64, _I, _I, _I, _P],
     "vpt_conv3x3_forward": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_conv3x3_forward_tiled": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vpt_conv3x3_pool_forward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vpt_conv3x3_forward_folded": [_P] * 12 + [_I, _I, _I, _I, _I, _P],
+    "vpt_channel_stats": [_P, _P, _I, _I, _I, _P],
+    "vpt_nfold_coef": [_P] * 12 + [_I, _I, _I, _I, _P],
     "vpt_maxpool_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_frame_affine_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_linear_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
@@ -104,6 +108,7 @@ def load(fmt: str = "bf16"):
     lib.vpt_operand_format.restype = ctypes.c_char_p
     lib.vpt_conv3x3_wgrad_scratch_floats.restype = ctypes.c_long
     lib.vpt_workspace_bytes.argtypes, lib.vpt_workspace_bytes.restype = [_I] * 6, ctypes.c_int64
+    lib.vpt_conv3x3_pool_seam_elems.argtypes, lib.vpt_conv3x3_pool_seam_elems.restype = [_I] * 4, ctypes.c_int64
     for q, at in (("vpt_conv3x3_packed_elems", [_I, _I]), ("vpt_conv3x3_table_floats", [_I]), ("vpt_linear_packed_elems", [_I, _I]),
                   ("vpt_conv_first_packed_elems", [_I]), ("vpt_conv3d_t5_packed_elems", [_I])):
         getattr(lib, q).argtypes, getattr(lib, q).restype = at, ctypes.c_long

@@ -66,10 +66,10 @@ int64_t vpt_workspace_bytes(int op, int frames, int H, int W, int Cin, int Cout)
   }
 }
 
-int vpt_conv_first_forward(const uint8_t* img, const void* wfrag, void* y, double* stats_out,
+int vpt_conv_first_forward(const uint8_t* img, const void* wfrag, void* y, double* stats_out, const float* out_gain,
                            int frames, int H, int W, int Cout, void* stream) {
   VptConvFirstArgs a;
-  a.img = img; a.wfrag = (const vpt_op16*)wfrag; a.y = (vpt_op16*)y; a.stats_out = stats_out;
+  a.img = img; a.wfrag = (const vpt_op16*)wfrag; a.y = (vpt_op16*)y; a.stats_out = stats_out; a.out_gain = out_gain;
   a.frames = frames; a.H = H; a.W = W; a.Cout = Cout; a.NT = (Cout + 127) / 128;
   CHECK_LAUNCH(vpt_conv_first_launch(&a, (hipStream_t)stream), "vpt_conv_first_forward");
 }
@@ -100,8 +100,76 @@ int vpt_conv3x3_forward_tiled(const void* x, const void* wpk, const float* edge_
   a.frames = frames; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.NT = (Cout + 127) / 128; a.CoutPad = a.NT * 128;
   a.inv_count_in = 1.0 / ((double)Cin * H * W);
-  a.bwd = 0; a.xin = nullptr; a.coef = nullptr;
+  a.bwd = 0; a.xin = nullptr; a.coef = nullptr; a.pool = 0; a.seam_r = nullptr; a.seam_c = nullptr; a.out_gain = nullptr;
+  a.kk_frame = a.rs_frame = a.res_scale = a.res_bias = nullptr;
   CHECK_LAUNCH(vpt_conv3x3_launch(&a, (hipStream_t)stream), "vpt_conv3x3_forward");
+}
+
+int vpt_conv3x3_forward_folded(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg, const double* stats_in,
+                               const float* kk_frame, const float* rs_frame, const void* res, const float* res_scale, const float* res_bias,
+                               void* y, double* stats_out, int frames, int H, int W, int Cin, int Cout, void* stream) {
+  if ((kk_frame == nullptr) != (rs_frame == nullptr)) return fail(-1, "vpt_conv3x3_forward_folded: kk_frame and rs_frame go together");
+  if (!kk_frame && !stats_in) return fail(-1, "vpt_conv3x3_forward_folded: stats_in is required unless kk_frame replaces it");
+  if (res_bias && (!res || !res_scale)) return fail(-1, "vpt_conv3x3_forward_folded: res_bias needs res and res_scale");
+  if (!edge_sg || (!kk_frame && !edge_sa)) return fail(-1, "vpt_conv3x3_forward_folded: edge tables missing");
+  VptConv3x3Args a;
+  a.tiling = 1;
+  a.x = (const vpt_op16*)x; a.wpk = (const vpt_op16*)wpk; a.edge_sa = edge_sa; a.edge_sg = edge_sg;
+  a.stats_in = stats_in; a.res = (const vpt_op16*)res; a.y = (vpt_op16*)y; a.stats_out = stats_out;
+  a.frames = frames; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.NT = (Cout + 127) / 128; a.CoutPad = a.NT * 128;
+  a.inv_count_in = 1.0 / ((double)Cin * H * W);
+  a.bwd = 0; a.xin = nullptr; a.coef = nullptr; a.pool = 0; a.seam_r = nullptr; a.seam_c = nullptr; a.out_gain = nullptr;
+  a.kk_frame = kk_frame; a.rs_frame = rs_frame; a.res_scale = res_bias ? res_scale : nullptr; a.res_bias = res_bias;
+  CHECK_LAUNCH(vpt_conv3x3_launch(&a, (hipStream_t)stream), "vpt_conv3x3_forward_folded");
+}
+
+int vpt_channel_stats(const void* x, double* chs, int frames, int C, int HW, void* stream) {
+  if (!x || !chs || (C & 31)) return fail(-1, "vpt_channel_stats: null pointer or C not a multiple of 32");
+  VptChannelStatsArgs a;
+  a.x = (const vpt_op16*)x; a.chs = chs; a.frames = frames; a.CB = C / 32; a.HW = HW; a.split = 1;
+  CHECK_LAUNCH(vpt_channel_stats_launch(&a, (hipStream_t)stream), "vpt_channel_stats");
+}
+
+int vpt_nfold_coef(const double* tot, const double* chs, const float* gain, const float* bias, const float* sa, const float* sg,
+                   const float* tb, const float* tg, float* kk_frame, float* rs_frame, float* res_scale, float* res_bias,
+                   int frames, int C, int HW, int Cout, void* stream) {
+  if (!tot || !chs || !gain || !bias || !sa || !sg || !tb || !tg || !kk_frame || !rs_frame || !res_scale || !res_bias)
+    return fail(-1, "vpt_nfold_coef: null pointer");
+  VptNfoldCoefArgs a;
+  a.tot = tot; a.chs = chs; a.gain = gain; a.bias = bias; a.sa = sa; a.sg = sg; a.tb = tb; a.tg = tg;
+  a.kk_frame = kk_frame; a.rs_frame = rs_frame; a.res_scale = res_scale; a.res_bias = res_bias;
+  a.frames = frames; a.C = C; a.HW = HW; a.CoutPad = ((Cout + 127) / 128) * 128;
+  CHECK_LAUNCH(vpt_nfold_coef_launch(&a, (hipStream_t)stream), "vpt_nfold_coef");
+}
+
+int64_t vpt_conv3x3_pool_seam_elems(int frames, int H, int W, int Cout) { return (int64_t)frames * Cout * ((int64_t)(H / 16) * W + (int64_t)(W / 16) * H); }
+
+int vpt_conv3x3_pool_forward(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg, const double* stats_in,
+                             void* pooled, void* seam_scratch, double* stats_out, const float* out_gain, int frames, int H, int W, int Cin, int Cout,
+                             int phases, void* stream) {
+  if (!stats_in || !pooled || !seam_scratch) return fail(-1, "vpt_conv3x3_pool_forward: stats_in, pooled and seam_scratch are required");
+  if (phases < 1 || phases > 3) return fail(-1, "vpt_conv3x3_pool_forward: phases = 1 (tiles), 2 (seams) or 3 (both)");
+  if ((H & 15) || (W & 15) || (Cout & 31)) return fail(-1, "vpt_conv3x3_pool_forward: H, W multiples of 16, Cout of 32");
+  VptConv3x3Args a;
+  a.tiling = 1;
+  a.x = (const vpt_op16*)x; a.wpk = (const vpt_op16*)wpk; a.edge_sa = edge_sa; a.edge_sg = edge_sg;
+  a.stats_in = stats_in; a.res = nullptr; a.y = (vpt_op16*)pooled; a.stats_out = stats_out;
+  a.frames = frames; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.NT = (Cout + 127) / 128; a.CoutPad = a.NT * 128;
+  a.inv_count_in = 1.0 / ((double)Cin * H * W);
+  a.bwd = 0; a.xin = nullptr; a.coef = nullptr; a.pool = 1; a.out_gain = out_gain;
+  a.kk_frame = a.rs_frame = a.res_scale = a.res_bias = nullptr;
+  a.seam_r = (vpt_op16*)seam_scratch;
+  a.seam_c = a.seam_r + (size_t)frames * Cout * (H / 16) * W;
+  if (phases & 1) {
+    int rc = vpt_conv3x3_launch(&a, (hipStream_t)stream);
+    if (rc != 0) return fail(rc, "vpt_conv3x3_pool_forward (convolution)");
+  }
+  if (!(phases & 2)) return 0;
+  VptPoolSeamArgs p;
+  p.y = a.y; p.seam_r = a.seam_r; p.seam_c = a.seam_c; p.stats_out = stats_out; p.gain = out_gain; p.frames = frames; p.CB = Cout / 32; p.H = H; p.W = W;
+  CHECK_LAUNCH(vpt_pool_seam_launch(&p, (hipStream_t)stream), "vpt_conv3x3_pool_forward (seams)");
 }
 
 int vpt_conv3x3_dgrad(const void* dacc, const void* wpk_t, const void* skip, const void* xin, const float* coef, void* dx,
@@ -111,7 +179,8 @@ int vpt_conv3x3_dgrad(const void* dacc, const void* wpk_t, const void* skip, con
   a.stats_in = nullptr; a.res = (const vpt_op16*)skip; a.y = (vpt_op16*)dx; a.stats_out = nullptr;
   a.frames = frames; a.H = H; a.W = W; a.Cin = Cout; a.Cout = Cin;   // roles swap in the transposed convolution
   a.NT = (Cin + 127) / 128; a.CoutPad = a.NT * 128; a.inv_count_in = 1.0;
-  a.bwd = 1; a.xin = (const vpt_op16*)xin; a.coef = coef; a.tiling = 1;
+  a.bwd = 1; a.xin = (const vpt_op16*)xin; a.coef = coef; a.tiling = 1; a.pool = 0; a.seam_r = nullptr; a.seam_c = nullptr; a.out_gain = nullptr;
+  a.kk_frame = a.rs_frame = a.res_scale = a.res_bias = nullptr;
   CHECK_LAUNCH(vpt_conv3x3_launch(&a, (hipStream_t)stream), "vpt_conv3x3_dgrad");
 }
 

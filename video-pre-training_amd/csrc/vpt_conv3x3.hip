@@ -48,7 +48,10 @@
 #define B_BYTES (3 * 128 * 64)          // 24576 per buffer (unpadded, swizzled)
 #define KK_OFF (A_BYTES + 2 * B_BYTES)  // 75072
 #define KK_BYTES (9 * 128 * 4)          // 4608
-#define SMEM_BYTES (KK_OFF + KK_BYTES + 32)  // 79712 (+32: block stats reduction)
+#define BT_OFF (KK_OFF + KK_BYTES + 32)  // 79712: per-channel residual bias of mode 5 (128 floats), after the block statistics' 32 bytes
+#define SMEM_BYTES (BT_OFF + 512)       // 80224: two workgroups per CU = 160448 of 163840 bytes
+#define PT_RS 272                       // pixel pitch of the 16 x 16 x 128-channel output tile of the pool-fused mode (256 + 16 bytes)
+static_assert(256 * PT_RS <= KK_OFF, "the pooled mode's output tile must fit below the epilogue table");
 
 // MFMA M-subtile row i (0..31) -> pixel (row 0/1, col 0..15) of a 2x16 patch.  Rows are swapped for columns
 // 4..11 so that each 16-lane ds_read_b128 group {0-3,12-15,20-27} / {4-11,16-19,28-31} stays in one image row.
@@ -61,10 +64,17 @@ __device__ __forceinline__ int sub_row(int i) { return ((i >> 4) ^ (i >> 2) ^ (i
 // TRACE (tools/conv_trace.py): phase timestamps.  Compile time because s_memrealtime is a scalar-memory operation: one of them
 // in flight makes lgkmcnt out of order and every LDS wait of the epilogue degenerates to lgkmcnt(0).
 // MODE (compile time, so the epilogue carries no runtime branches): 0 forward, 1 forward + residual,
-// 2 dgrad (+ c0 + c1 * xin), 3 dgrad + skip connection.
+// 2 dgrad (+ c0 + c1 * xin), 3 dgrad + skip connection, 4 forward + the stack's 3x3 / stride-2 max-pool (CnnDownStack.forward,
+// lib/impala_cnn.py:114-117: firstconv -> max_pool2d): the 16 x 16 output tile goes to LDS instead of HBM, its 8 x 8 pooled pixels are
+// written -- complete where the 3 x 3 window lies inside the tile, the in-tile part of the maximum on the tile's first pooled row /
+// column otherwise -- together with the tile's last row and column (the "seams"); vpt_pool_seam_kernel finishes the seam pixels.
+// The pre-pool tensor (2 MB per frame in stack 1: written and read back by vpt_pool_kernel before) never reaches HBM.
 template <bool TRACE, int MODE>
 __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
-  constexpr bool BWD = MODE >= 2, HAS_RES = (MODE == 1 || MODE == 3), USE_X = MODE >= 2;
+  // 5 forward + residual through a per-frame affine:  out = relu(...) + res_scale[f] * res + res_bias[f][channel]  -- the block that
+  // follows a stack's GroupNorm `n` reads the pooled tensor itself (already multiplied by n's gain) instead of a normalised copy
+  // (lib/impala_cnn.py:118-121 with the `n` pass folded away).
+  constexpr bool BWD = (MODE == 2 || MODE == 3), HAS_RES = (MODE == 1 || MODE == 3 || MODE == 5), USE_X = BWD, POOL = MODE == 4, RES_AFF = MODE == 5;
   constexpr bool DEFER_STORES = MODE != 3;   // mode 3 holds skip + xin pieces as well: no registers left for the packed results
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -132,8 +142,14 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
 #pragma unroll
   for (int m = 0; m < 6; ++m) areg[m] = *(const u32x4*)((const char*)xplane + a_gbyte[m]);
   float mean = 0.f, rstd = 1.f, c0f = 0.f, c1f = 0.f;
+  const float* esa = a.edge_sa;
   if (!BWD) {
-    frame_mean_rstd(a.stats_in, f, a.inv_count_in, mean, rstd);
+    if (a.kk_frame) {   // the epilogue table of THIS frame was prepared by vpt_nfold_coef_kernel (the input is a pooled tensor whose GroupNorm `n`
+      rstd = a.rs_frame[f];                               // is folded into this layer): out = relu(rs * acc + kk_frame[f][e][o])
+      esa = a.kk_frame + (size_t)f * 9 * a.CoutPad;
+    } else {
+      frame_mean_rstd(a.stats_in, f, a.inv_count_in, mean, rstd);
+    }
   } else if (a.coef) {
     c0f = a.coef[2 * f];
     c1f = a.coef[2 * f + 1];
@@ -145,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     for (int k = 0; k < 5; ++k) {  // 9*128 = 4.5 * 256 entries: all ten loads in flight together
       const int idx = tid + 256 * k;
       const int o = (idx >> 7) * a.CoutPad + nt * 128 + (idx & 127);
-      ksa[k] = (idx < 9 * 128 && !BWD) ? a.edge_sa[o] : 0.f;
+      ksa[k] = (idx < 9 * 128 && !BWD) ? esa[o] : 0.f;
       ksg[k] = (idx < 9 * 128 && !BWD) ? a.edge_sg[o] : 0.f;
     }
 #pragma unroll
@@ -153,6 +169,11 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
       const int idx = tid + 256 * k;
       if (idx < 9 * 128) kk[idx] = ksa[k] - rstd * mean * ksg[k];
     }
+  }
+  float res_s = 1.f;
+  if (RES_AFF) {
+    res_s = a.res_scale[f];
+    if (tid < 128) ((float*)(smem + BT_OFF))[tid] = (nt * 128 + tid < a.Cout) ? a.res_bias[(size_t)f * a.Cout + nt * 128 + tid] : 0.f;
   }
 #define WRITE_HALO()                                                                                      \
   _Pragma("unroll") for (int m_ = 0; m_ < 6; ++m_)                                                        \
@@ -197,11 +218,26 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   size_t cbase[2];                                  // element offset of channel block n2 of this frame
 #pragma unroll
   for (int n2 = 0; n2 < 2; ++n2) cbase[n2] = (size_t)(f * CB_out + (nvalid[n2] ? cb0 + n2 : 0)) * HW * 32;
-  u32x4 rq[4][2][2];                                // residual [subtile m][n2][instruction j of the pair]
 #define EPI_LD(ptr_, m_, n2_, p_) (*(const u32x4*)((const char*)((ptr_) + cbase[n2_]) + (svoff[p_] + (unsigned)(m_) * gm_b)))
+#ifndef VPT_RES_NATIVE
+#define VPT_RES_NATIVE 1   // 1: the residual arrives in the accumulators' own layout (8-byte loads: a lane's 4 channels of a group), no lane exchanges;
+#endif                     // 0: whole 128-byte lines per 16-byte load + v_permlane16/32_swap (round 2-3; the output stores still go that way)
+#if VPT_RES_NATIVE
+  // Round 4 (profiles/r04_experiments.md): the residual path cost 16 % of a K = 1152 tile beyond its loads -- 128 of its 256 vector
+  // instructions were lane exchanges (43 cycles of latency each, half the issue rate of a plain instruction: tools/ubench/permlane.hip) in
+  // front of every add.  An 8-byte load per (subtile, channel block, group) puts the lane's own 4 channels where the add needs them.
+  u32x2 rq[4][2][4];                                // residual [subtile m][n2][group g]
+  const unsigned nvoff = (unsigned)(((ty0 + wm * 8 + sub_row(l31)) * a.W + tx0 + (l31 & 15)) * 32 + 4 * hi) * 2u;
+#define EPI_LDN(ptr_, m_, n2_, g_) (*(const u32x2*)((const char*)((ptr_) + cbase[n2_]) + (nvoff + (unsigned)(m_) * gm_b + 16u * (unsigned)(g_))))
+#define LOAD_RES(m_)                                                                                      \
+  _Pragma("unroll") for (int n2_ = 0; n2_ < 2; ++n2_)                                                     \
+    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) rq[m_][n2_][g_] = EPI_LDN(a.res, m_, n2_, g_)
+#else
+  u32x4 rq[4][2][2];                                // residual [subtile m][n2][instruction j of the pair]
 #define LOAD_RES(m_)                                                                                      \
   _Pragma("unroll") for (int n2_ = 0; n2_ < 2; ++n2_)                                                     \
     _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) rq[m_][n2_][p_] = EPI_LD(a.res, m_, n2_, p_)
+#endif
 
   // ---- main loop ----------------------------------------------------------------------------------------------------
   // One K step = one kernel row (3 taps) of one 32-channel block = 6 groups (tap dx, 16-channel half ks) of 8 MFMAs per
@@ -256,7 +292,11 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp_ + (m_) * 2048),    \
                                    (__attribute__((address_space(3))) void*)(bd_ + (m_) * 4096), 16, 0, 0); } while (0)
 #define XA(m_) do { if (VPT_CONV_HALO_ABLATE != 2) areg[m_] = *(const u32x4*)((const char*)xplane + (cbo_ + a_gbyte[m_])); } while (0)
+#if VPT_RES_NATIVE
+#define XR(m_, n2_, p_) do { rq[m_][n2_][2 * (p_)] = EPI_LDN(resp, m_, n2_, 2 * (p_)); rq[m_][n2_][2 * (p_) + 1] = EPI_LDN(resp, m_, n2_, 2 * (p_) + 1); } while (0)
+#else
 #define XR(m_, n2_, p_) rq[m_][n2_][p_] = EPI_LD(resp, m_, n2_, p_)
+#endif
 #define NOP_() ((void)0)
 #define WAIT_BARRIER(n_late_)                                                                             \
   do {                                                                                                    \
@@ -297,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     } else if ((PRE_R) && HAS_RES) { /* compile-time: without a residual the loads would be dead code and the count wrong */ \
       GROUP(1, dy_, 4, boff_, do { XR(0, 0, 0); XR(0, 0, 1); } while (0), do { XR(0, 1, 0); XR(0, 1, 1); } while (0)); \
       GROUP(0, dy_, 5, boff_, do { XR(1, 0, 0); XR(1, 0, 1); } while (0), do { XR(1, 1, 0); XR(1, 1, 1); } while (0)); \
-      WAIT_BARRIER(8);                                                                                    \
+      if (VPT_RES_NATIVE) WAIT_BARRIER(16); else WAIT_BARRIER(8);   /* (two 8-byte loads per XR in the native layout) */ \
     } else {                                                                                              \
       GROUP(1, dy_, 4, boff_, NOP_(), NOP_());                                                            \
       GROUP(0, dy_, 5, boff_, NOP_(), NOP_());                                                            \
@@ -433,7 +473,14 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     (e_).x = s0_[0]; (o_).x = s0_[1]; (e_).y = s1_[0]; (o_).y = s1_[1];                                   \
   } while (0)
   const f32x2 zero2 = {0.f, 0.f};
-  const f32x2 rstd2 = {rstd, rstd}, c0f2 = {c0f, c0f}, c1f2 = {c1f, c1f};
+  const f32x2 rstd2 = {rstd, rstd}, c0f2 = {c0f, c0f}, c1f2 = {c1f, c1f}, ress2 = {res_s, res_s};
+  f32x4 bq[2][4];             // mode 5: the residual's per-channel bias of this lane's 32 channels (independent of the subtile)
+  if (RES_AFF) {
+#pragma unroll
+    for (int n2_ = 0; n2_ < NV; ++n2_)
+#pragma unroll
+      for (int g_ = 0; g_ < 4; ++g_) bq[n2_][g_] = *(const f32x4*)((const float*)(smem + BT_OFF) + wn * 64 + n2_ * 32 + 8 * g_ + 4 * hi);
+  }
 
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
@@ -452,13 +499,19 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     const auto sw_ = __builtin_amdgcn_permlane16_swap((src_)[0][j_], (src_)[1][j_], false, false);        \
     (dst_)[0][j_] = sw_[0]; (dst_)[1][j_] = sw_[1];                                                       \
   }
+#if !VPT_RES_NATIVE
       if (HAS_RES) ROWS_TO_PIECES(rq[(VPT_EPI_ABLATE & 2) ? (m & 1) : m][n2], rp);
+#endif
       if (use_x) ROWS_TO_PIECES(xq[m & 1][n2], xp);
 #undef ROWS_TO_PIECES
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         u32x2 r2[2] = {{0u, 0u}, {0u, 0u}}, x2[2] = {{0u, 0u}, {0u, 0u}}, pk[2];
+#if VPT_RES_NATIVE
+        if (HAS_RES) { r2[0] = rq[(VPT_EPI_ABLATE & 2) ? (m & 1) : m][n2][2 * p]; r2[1] = rq[(VPT_EPI_ABLATE & 2) ? (m & 1) : m][n2][2 * p + 1]; }
+#else
         if (HAS_RES) UNSWAP(rp[p], r2[0], r2[1]);
+#endif
         if (use_x) UNSWAP(xp[p], x2[0], x2[1]);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -476,8 +529,15 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
           }
           if (HAS_RES) {
             const f32x2 r01 = {op16_lo_to_f32(r2[q].x), op16_hi_to_f32(r2[q].x)}, r23 = {op16_lo_to_f32(r2[q].y), op16_hi_to_f32(r2[q].y)};
-            v01 += r01;
-            v23 += r23;
+            if (RES_AFF) {
+              const f32x4 b4 = bq[n2][g];
+              const f32x2 b01 = {b4.x, b4.y}, b23 = {b4.z, b4.w};
+              v01 = ress2 * r01 + (v01 + b01);
+              v23 = ress2 * r23 + (v23 + b23);
+            } else {
+              v01 += r01;
+              v23 += r23;
+            }
           }
           if (!BWD) {   // frame statistics of the output (the next layer's GroupNorm); dgrad has no consumer for them
             s_sum2 += v01 + v23;
@@ -522,8 +582,104 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
         if (!(VPT_EPI_ABLATE & 1) || s_sum2.x == 12345.678f) *(u32x4*)((char*)(a.y + cbase[n2]) + (svoff[p] + (unsigned)m * gm_b)) = outv[m][n2][p];
     }
   };
+  if constexpr (POOL) {
+    // ---- phase 1: GroupNorm fold + ReLU, rounded to 16 bits, into the LDS tile [16 x 16 pixels][128 channels] (pixel pitch PT_RS: the
+    // 16 extra bytes spread a column of pixels over the banks).  The tile reuses the halo / weight buffers: every wave must be past
+    // its last fragment read first.  A lane holds 4 consecutive channels of one pixel per accumulator group: one ds_write_b64 each.
+    __syncthreads();
+    {
+      const float* kk = (const float*)(smem + KK_OFF);
+      const f32x2 zero2 = {0.f, 0.f};
+      const f32x2 rstd2 = {rstd, rstd};
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int py = wm * 8 + 2 * m + sub_row(l31), px = l31 & 15;
+        const int y = ty0 + py, x = tx0 + px;
+        const int ey = (y == 0) ? 0 : ((y == a.H - 1) ? 2 : 1);
+        const int ex = (x == 0) ? 0 : ((x == a.W - 1) ? 2 : 1);
+        const float* ke = kk + (ey * 3 + ex) * 128 + wn * 64 + 4 * hi;
+        unsigned char* dst = smem + (py * 16 + px) * PT_RS + (wn * 64 + 4 * hi) * 2;
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+          if (!nvalid[n2]) continue;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 k4 = *(const f32x4*)(ke + n2 * 32 + 8 * g);
+            const f32x2 k01 = {k4.x, k4.y}, k23 = {k4.z, k4.w};
+            f32x2 v01 = {acc[m][n2][4 * g + 0], acc[m][n2][4 * g + 1]}, v23 = {acc[m][n2][4 * g + 2], acc[m][n2][4 * g + 3]};
+            v01 = __builtin_elementwise_max(rstd2 * v01 + k01, zero2);
+            v23 = __builtin_elementwise_max(rstd2 * v23 + k23, zero2);
+            const u32x2 pk = {pack_op16x2(v01.x, v01.y), pack_op16x2(v23.x, v23.y)};
+            *(u32x2*)(dst + (n2 * 32 + 8 * g) * 2) = pk;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: pooled pixel (j, i) of the tile = max over conv rows 2j-1 .. 2j+1, columns 2i-1 .. 2i+1 that lie INSIDE the tile (j = 0
+    // / i = 0 miss the row / column above / left of the tile: image border -> the pool's padding, nothing is missing; otherwise the seam
+    // kernel adds it).  Packed signed 16-bit max from 0 on the raw bit patterns (post-ReLU values are >= +0; a -0.0 stays below 0).
+    // item = (pooled pixel, channel octet): the 16 lanes of a ds_read_b128 group read the 256 contiguous bytes of one pixel.
+    typedef short i16x8 __attribute__((ext_vector_type(8)));
+    const int PH = a.H >> 1, PW = a.W >> 1;
+    const bool top_open = ty0 > 0, left_open = tx0 > 0;      // the tile's first pooled row / column is incomplete
+    float p_sum = 0.f, p_sq = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int item = tid + 256 * it;
+      const int oct = item & 15, pi = (item >> 4) & 7, pj = item >> 7;
+      const int cg = nt * 128 + oct * 8;
+      const unsigned char* src = smem + oct * 16;
+      i16x8 mx = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int r = 2 * pj + dy;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int c = 2 * pi + dx;
+          const i16x8 v = *(const i16x8*)(src + (max(r, 0) * 16 + max(c, 0)) * PT_RS);     // (clamped: the duplicate does not change a maximum)
+          mx = __builtin_elementwise_max(mx, v);
+        }
+      }
+      if (cg < a.Cout) {
+        u32x4 mv = __builtin_bit_cast(u32x4, mx);
+        const size_t off = ((size_t)(f * CB_out + (cg >> 5)) * PH * PW + (size_t)(((ty0 >> 1) + pj) * PW + (tx0 >> 1) + pi)) * 32 + (cg & 31);
+        const bool complete = (pj > 0 || !top_open) && (pi > 0 || !left_open);
+        if (complete) {      // the seam kernel accounts for the others once they are final
+          float vals[8];
+          unpack8(mv, vals);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { p_sum += vals[k]; p_sq = fmaf(vals[k], vals[k], p_sq); }
+          if (a.out_gain) {  // GroupNorm `n`'s gain folded into the stored tensor (a thread's items share the channel octet: 8 cached loads)
+            const f32x4 g0 = *(const f32x4*)(a.out_gain + cg), g1 = *(const f32x4*)(a.out_gain + cg + 4);
+            vals[0] *= g0.x; vals[1] *= g0.y; vals[2] *= g0.z; vals[3] *= g0.w; vals[4] *= g1.x; vals[5] *= g1.y; vals[6] *= g1.z; vals[7] *= g1.w;
+            mv = pack8(vals);
+          }
+        }
+        *(u32x4*)(a.y + off) = mv;
+      }
+    }
+    // ---- seams: the tile's last row (-> the pooled row below) and last column (-> the pooled column to the right), one 16-byte piece per
+    // thread each: seam_r [f][C/32][H/16][W][32], seam_c [f][C/32][W/16][H][32] (whole image rows / columns, so the corner pixel needs no case)
+    {
+      const int oct = tid & 15, q = tid >> 4;     // q = position along the seam
+      const int cg = nt * 128 + oct * 8;
+      if (cg < a.Cout) {
+        if (ty0 + 16 < a.H) {
+          const u32x4 v = *(const u32x4*)(smem + (15 * 16 + q) * PT_RS + oct * 16);
+          *(u32x4*)(a.seam_r + ((size_t)((f * CB_out + (cg >> 5)) * tilesY + ty) * a.W + tx0 + q) * 32 + (cg & 31)) = v;
+        }
+        if (tx0 + 16 < a.W) {
+          const u32x4 v = *(const u32x4*)(smem + (q * 16 + 15) * PT_RS + oct * 16);
+          *(u32x4*)(a.seam_c + ((size_t)((f * CB_out + (cg >> 5)) * tilesX + tx) * a.H + ty0 + q) * 32 + (cg & 31)) = v;
+        }
+      }
+    }
+    s_sum2.x = p_sum; s_sum2.y = 0.f; s_sq2.x = p_sq; s_sq2.y = 0.f;
+  } else {
   if (nvalid[1]) epilogue(std::integral_constant<int, 2>{});
   else if (nvalid[0]) epilogue(std::integral_constant<int, 1>{});
+  }
   float s_sum = s_sum2.x + s_sum2.y, s_sq = s_sq2.x + s_sq2.y;
   if (!BWD && a.stats_out) {
     float* red = (float*)(smem + KK_OFF + KK_BYTES);
@@ -764,8 +920,11 @@ extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream
   if ((a->H & 15) || (a->W & 15) || (a->Cin & 31) || (a->Cout & 31) || a->frames <= 0) return -1;
   const long grid = (long)a->frames * (a->H >> 4) * (a->W >> 4) * a->NT;
   if (grid > 0x7fffffffL) return -2;
-  const int mode = a->bwd ? (a->res ? 3 : 2) : (a->res ? 1 : 0);
+  const int mode = a->bwd ? (a->res ? 3 : 2) : (a->pool ? 4 : (a->res ? (a->res_bias ? 5 : 1) : 0));
+  if ((a->res_bias != nullptr) != (a->res_scale != nullptr) || (a->res_bias && (a->bwd || !a->res))) return -1;
+  if ((a->kk_frame != nullptr) != (a->rs_frame != nullptr) || (a->kk_frame && a->bwd)) return -1;
   if (a->bwd && (!a->xin || !a->coef)) return -1;   // dgrad always carries the GroupNorm-statistics terms (c0 + c1 * xin)
+  if (a->pool && (a->bwd || a->res || a->tiling != 1 || a->trace || !a->seam_r || !a->seam_c)) return -1;
   // the latency tiling (32 output channels per workgroup) is the CALLER's choice, never the grid size's: a frame's result must not
   // depend on how many frames share the launch (the two tilings sum a tile's statistics in different orders)
   if (!a->bwd && a->tiling != 1 && a->tiling != 2) return -1;
@@ -776,8 +935,86 @@ extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream
     return hipGetLastError() == hipSuccess ? 0 : -3;
   }
 #define LAUNCH_(T_, M_) hipLaunchKernelGGL((vpt_conv3x3_kernel<T_, M_>), dim3((unsigned)grid), dim3(256), extra_lds, stream, *a)
+  if (a->trace && mode > 3) return -1;
   if (a->trace) { if (mode == 0) LAUNCH_(true, 0); else if (mode == 1) LAUNCH_(true, 1); else if (mode == 2) LAUNCH_(true, 2); else LAUNCH_(true, 3); }
-  else { if (mode == 0) LAUNCH_(false, 0); else if (mode == 1) LAUNCH_(false, 1); else if (mode == 2) LAUNCH_(false, 2); else LAUNCH_(false, 3); }
+  else { if (mode == 0) LAUNCH_(false, 0); else if (mode == 1) LAUNCH_(false, 1); else if (mode == 2) LAUNCH_(false, 2); else if (mode == 3) LAUNCH_(false, 3); else if (mode == 4) LAUNCH_(false, 4); else LAUNCH_(false, 5); }
 #undef LAUNCH_
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Seam pass of the pool-fused convolution (mode 4 above): the pooled pixels on a tile's first pooled row / column got the in-tile part of
+// their 3 x 3 window only.  Pooled pixel (J, I), J % 8 == 0, J > 0: conv row 2J - 1 is row 15 of the tile row above = seam_r[J / 8 - 1],
+// columns 2I - 1 .. 2I + 1 (whole image rows: the corner needs no case); I % 8 == 0, I > 0: conv column 2I - 1 = seam_c[I / 8 - 1], rows
+// 2J - 1 .. 2J + 1.  A pixel on both kinds of seam is handled once, by its row item.  Adds these pixels' share of the frame statistics.
+// Work per frame: ((H/16 - 1) * W/2 + (W/16 - 1) * (H/2 - (H/16 - 1))) pixels x C/8 sixteen-byte items -- 18 % of the pooled tensor at
+// 64 x 64, instead of the whole pre-pool tensor written and read back.
+__global__ __launch_bounds__(256) void vpt_pool_seam_kernel(VptPoolSeamArgs a) {
+  typedef short i16x8 __attribute__((ext_vector_type(8)));
+  const int PH = a.H >> 1, PW = a.W >> 1, TY = a.H >> 4, TX = a.W >> 4;
+  const int n_row = (TY - 1) * PW;                   // pixels on row seams
+  const int col_len = PH - (TY - 1);                 // pixels of one column seam that are not on a row seam
+  const int n_pix = n_row + (TX - 1) * col_len;
+  const int per_frame = n_pix * a.CB * 4;            // 16-byte items
+  const int blocks_per_frame = (per_frame + 255) / 256;
+  const int f = blockIdx.x / blocks_per_frame;
+  const int item = (blockIdx.x - f * blocks_per_frame) * 256 + threadIdx.x;
+  float s_sum = 0.f, s_sq = 0.f;
+  if (item < per_frame) {
+    const int oct = item & 3;
+    int r = item >> 2;
+    const int pix = r % n_pix;
+    const int cb = r / n_pix;
+    int J, I;
+    if (pix < n_row) { J = (pix / PW + 1) * 8; I = pix % PW; }
+    else {
+      const int q = pix - n_row, t = q / col_len, k = q - t * col_len;   // k-th pooled row that is not a multiple of 8 (row 0 counts: it is not a seam)
+      I = (t + 1) * 8;
+      J = (k == 0) ? 0 : (k - 1) / 7 * 8 + (k - 1) % 7 + 1;
+    }
+    const size_t plane = (size_t)(f * a.CB + cb);
+    vpt_op16* yp = a.y + (plane * PH * PW + (size_t)(J * PW + I)) * 32 + oct * 8;
+    i16x8 m = *(const i16x8*)yp;
+    if ((J & 7) == 0 && J > 0) {
+      const vpt_op16* sr = a.seam_r + ((plane * TY + (J >> 3) - 1) * a.W) * 32 + oct * 8;
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int x = 2 * I + dx;
+        if (x >= 0) m = __builtin_elementwise_max(m, *(const i16x8*)(sr + (size_t)x * 32));
+      }
+    }
+    if ((I & 7) == 0 && I > 0) {
+      const vpt_op16* sc = a.seam_c + ((plane * TX + (I >> 3) - 1) * a.H) * 32 + oct * 8;
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int y = 2 * J + dy;
+        if (y >= 0) m = __builtin_elementwise_max(m, *(const i16x8*)(sc + (size_t)y * 32));
+      }
+    }
+    float vals[8];
+    unpack8(__builtin_bit_cast(u32x4, m), vals);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s_sum += vals[k]; s_sq = fmaf(vals[k], vals[k], s_sq); }
+    if (a.gain) {
+      const float* gp = a.gain + cb * 32 + oct * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) vals[k] *= gp[k];
+      *(u32x4*)yp = pack8(vals);
+    } else {
+      *(i16x8*)yp = m;
+    }
+  }
+  if (a.stats_out) block_stats_atomic(s_sum, s_sq, a.stats_out, f);
+}
+
+extern "C" int vpt_pool_seam_launch(const VptPoolSeamArgs* a, hipStream_t stream) {
+  if ((a->H & 15) || (a->W & 15) || a->frames <= 0 || a->CB <= 0) return -1;
+  const int PH = a->H >> 1, PW = a->W >> 1, TY = a->H >> 4, TX = a->W >> 4;
+  const int n_pix = (TY - 1) * PW + (TX - 1) * (PH - (TY - 1));
+  if (n_pix == 0) return 0;                          // a single tile per frame: every window is inside it
+  const int per_frame = n_pix * a->CB * 4;
+  const long grid = (long)a->frames * ((per_frame + 255) / 256);
+  if (grid > 0x7fffffffL) return -2;
+  hipLaunchKernelGGL(vpt_pool_seam_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

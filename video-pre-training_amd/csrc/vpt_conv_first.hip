@@ -113,12 +113,19 @@ __global__ __launch_bounds__(CF_THREADS, 4) void vpt_conv_first_kernel(VptConvFi
         m = __builtin_elementwise_max(m, v);
       }
     if (cg < a.Cout) {
-      const u32x4 mv = __builtin_bit_cast(u32x4, m);
+      u32x4 mv = __builtin_bit_cast(u32x4, m);
       const uint32_t ones = CF_ONE_BITS | (CF_ONE_BITS << 16);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {     // packed pairs: one dot2 per two values for the sum, one for the sum of squares (products of 16-bit operands are exact in fp32)
         s_sum = dot2_op16(mv[k], ones, s_sum);
         s_sq = dot2_op16(mv[k], mv[k], s_sq);
+      }
+      if (a.out_gain) {   // GroupNorm `n`'s gain folded into the stored tensor (the statistics above are those of the unscaled values)
+        const f32x4 g0 = *(const f32x4*)(a.out_gain + cg), g1 = *(const f32x4*)(a.out_gain + cg + 4);
+        float vals[8];
+        unpack8(mv, vals);
+        vals[0] *= g0.x; vals[1] *= g0.y; vals[2] *= g0.z; vals[3] *= g0.w; vals[4] *= g1.x; vals[5] *= g1.y; vals[6] *= g1.z; vals[7] *= g1.w;
+        mv = pack8(vals);
       }
       const size_t off = ((size_t)(f * CB_out + (cg >> 5)) * PH * PW + (size_t)((py0 + pyl) * PW + px0 + pxl)) * 32 + (cg & 31);
       *(u32x4*)(a.y + off) = mv;

@@ -156,3 +156,111 @@ extern "C" int vpt_affine_launch(const VptAffineArgs* a, hipStream_t stream) {
   else hipLaunchKernelGGL(vpt_affine_kernel<false>, dim3((unsigned)grid), dim3(256), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// GroupNorm `n` of a stack WITHOUT a pass of its own (lib/impala_cnn.py:118-121: x = self.n(x); x = block(x)).
+// The producer stores Q = gain_n[c] * P (P: the pooled tensor).  With (mu_P, r_P) the frame statistics of P and kappa = r_P mu_P:
+//     x[c] = n(P)[c] = r_P Q[c] + b[c],   b[c] = bias_n[c] - kappa gain_n[c]
+// is never written.  Block 0's conv0 = GroupNorm(x) -> conv folds into a convolution of Q with its ordinary packed weights W':
+//     out = relu( r_x r_P conv(W', Q)  +  SA[e][o] + r_x TB[e][o] - r_x kappa TG[e][o] - r_x mu_x SG[e][o] )
+// (SA, SG: the layer's own edge tables; TB / TG: the same sums of W' weighted by bias_n / gain_n) and conv1 takes its residual as
+// r_P Q + b[c].  (mu_x, r_x) -- the statistics of x over the frame -- follow from the PER-CHANNEL sums of Q:
+//     sum x = sum_c (r_P S1[c] + HW b[c]),   sum x^2 = sum_c (r_P^2 S2[c] + 2 r_P b[c] S1[c] + HW b[c]^2).
+// vpt_channel_stats_kernel reads Q once for S1 / S2 (fp32 within a workgroup, fp64 across: independent of how the batch is cut);
+// vpt_nfold_coef_kernel turns them into the per-frame epilogue table kk_frame and the scalars.  What is saved: the affine pass's read AND
+// write of every pooled tensor (3.25 MB per frame of the 2x model).
+__global__ __launch_bounds__(256) void vpt_channel_stats_kernel(VptChannelStatsArgs a) {
+  __shared__ float red[4][4][16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int L = blockIdx.x;
+  const int sp = L % a.split; L /= a.split;
+  const int cb = L % a.CB;
+  const int f = L / a.CB;
+  const int per = (a.HW + a.split - 1) / a.split;
+  const int p0 = sp * per, p1 = min(p0 + per, a.HW);
+  const int oct = tid & 3;
+  const vpt_op16* base = a.x + ((size_t)(f * a.CB + cb) * a.HW) * 32 + oct * 8;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+  for (int p = p0 + (tid >> 2); p < p1; p += 256) {       // four 16-byte loads in flight per thread
+    u32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (p + 64 * j < p1) ? VPT_LD_STREAM((const u32x4*)(base + (size_t)(p + 64 * j) * 32)) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float vals[8];
+      unpack8(v[j], vals);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { s1[k] += vals[k]; s2[k] = fmaf(vals[k], vals[k], s2[k]); }
+    }
+  }
+  // lanes with the same octet: lane & 3; reduce over the other 4 lane bits, then over the 4 waves
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+#pragma unroll
+    for (int off = 4; off < 64; off <<= 1) { s1[k] += __shfl_xor(s1[k], off, 64); s2[k] += __shfl_xor(s2[k], off, 64); }
+  }
+  if (lane < 4) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { red[w][lane][k] = s1[k]; red[w][lane][8 + k] = s2[k]; }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int o = tid >> 4, k = tid & 15;          // octet, value (0..7 sums, 8..15 sums of squares)
+    const float t = (red[0][o][k] + red[1][o][k]) + (red[2][o][k] + red[3][o][k]);
+    atomicAdd(a.chs + ((size_t)f * a.CB * 32 + cb * 32 + o * 8 + (k & 7)) * 2 + (k >> 3), (double)t);
+  }
+}
+
+extern "C" int vpt_channel_stats_launch(const VptChannelStatsArgs* a_in, hipStream_t stream) {
+  VptChannelStatsArgs a = *a_in;
+  if (a.frames <= 0 || a.CB <= 0 || a.HW <= 0) return -1;
+  a.split = (a.HW + 1023) / 1024;                  // <= 1024 pixels (64 KB) per workgroup
+  const long grid = (long)a.frames * a.CB * a.split;
+  if (grid > 0x7fffffffL) return -2;
+  hipLaunchKernelGGL(vpt_channel_stats_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+__global__ __launch_bounds__(256) void vpt_nfold_coef_kernel(VptNfoldCoefArgs a) {
+  __shared__ double redd[2][4];
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const double n_tot = (double)a.C * a.HW;
+  const double mu_p = a.tot[2 * f] / n_tot;
+  double var_p = a.tot[2 * f + 1] / n_tot - mu_p * mu_p;
+  if (var_p < 0.0) var_p = 0.0;
+  const double r_p = (double)rsqrtf((float)var_p + VPT_NORM_EPS);      // (the same fp32 rsqrt as frame_mean_rstd: the affine kernel's r_P)
+  const double kappa = r_p * (double)(float)mu_p;
+  double sx = 0.0, sxx = 0.0;
+  for (int c = tid; c < a.C; c += 256) {
+    const double q1 = a.chs[((size_t)f * a.C + c) * 2], q2 = a.chs[((size_t)f * a.C + c) * 2 + 1];
+    const double b = (double)a.bias[c] - kappa * (double)a.gain[c];
+    a.res_bias[(size_t)f * a.C + c] = (float)b;
+    sx += r_p * q1 + (double)a.HW * b;
+    sxx += r_p * r_p * q2 + 2.0 * r_p * b * q1 + (double)a.HW * b * b;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { sx += __shfl_xor(sx, off, 64); sxx += __shfl_xor(sxx, off, 64); }
+  if (lane == 0) { redd[0][w] = sx; redd[1][w] = sxx; }
+  __syncthreads();
+  sx = (redd[0][0] + redd[0][1]) + (redd[0][2] + redd[0][3]);
+  sxx = (redd[1][0] + redd[1][1]) + (redd[1][2] + redd[1][3]);
+  const double mu_x = sx / n_tot;
+  double var_x = sxx / n_tot - mu_x * mu_x;
+  if (var_x < 0.0) var_x = 0.0;
+  const float r_x = rsqrtf((float)var_x + VPT_NORM_EPS);
+  if (tid == 0) {
+    a.rs_frame[f] = r_x * (float)r_p;
+    a.res_scale[f] = (float)r_p;
+  }
+  const float c_b = r_x, c_g = -r_x * (float)kappa, c_s = -r_x * (float)mu_x;
+  float* kk = a.kk_frame + (size_t)f * 9 * a.CoutPad;
+  for (int i = tid; i < 9 * a.CoutPad; i += 256) kk[i] = a.sa[i] + c_b * a.tb[i] + c_g * a.tg[i] + c_s * a.sg[i];
+}
+
+extern "C" int vpt_nfold_coef_launch(const VptNfoldCoefArgs* a, hipStream_t stream) {
+  if (a->frames <= 0 || a->C <= 0 || a->HW <= 0 || a->CoutPad <= 0) return -1;
+  hipLaunchKernelGGL(vpt_nfold_coef_kernel, dim3((unsigned)a->frames), dim3(256), 0, stream, *a);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}

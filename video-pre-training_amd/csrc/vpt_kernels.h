@@ -24,10 +24,55 @@ struct VptConv3x3Args {
   int tiling;              // forward only: 1 = throughput kernel (16x16 px x 128 couts), 2 = latency kernel (x 32 couts)
   int ablate;              // profiling only (env VPT_CONV_ABLATE)
   long long* trace;        // profiling only: per-workgroup phase timestamps (vpt_conv3x3_set_trace)
+  // GroupNorm `n` of the stack folded into its first block (forward, optional): kk_frame [F][9][CoutPad] = this frame's whole epilogue table and
+  // rs_frame [F] = its accumulator scale (replace edge_sa / the statistics of x: vpt_nfold_coef_kernel); res_scale [F] + res_bias [F][Cout]:
+  // the residual enters as res_scale[f] * res + res_bias[f][channel]
+  const float* kk_frame;
+  const float* rs_frame;
+  const float* res_scale;
+  const float* res_bias;
+  // pool-fused forward (pool != 0, no residual): y is the POOLED output [F][Cout/32][H/2][W/2][32]; the tiles' last rows / columns go to
+  // seam_r [F][Cout/32][H/16][W][32] / seam_c [F][Cout/32][W/16][H][32]; stats_out receives the pooled pixels that are complete in-tile
+  int pool;
+  vpt_op16* seam_r;
+  vpt_op16* seam_c;
+  const float* out_gain;   // pool mode, optional [Cout]: the pooled pixels that are complete in-tile are stored multiplied by it (GroupNorm `n`'s gain,
+                           // folded: the seam kernel does the same for the others); the statistics are those of the unscaled values
   // dgrad mode (bwd != 0): no GroupNorm fold, no ReLU; out = conv + res + coef[f][0] + coef[f][1] * xin
   int bwd;
   const vpt_op16* xin;     // the forward layer's input x (same shape as this call's output)
   const float* coef;       // [F][2]
+};
+
+struct VptChannelStatsArgs {   // per-frame, per-channel sums of a blocked tensor: chs[f][c] = (sum_p x, sum_p x^2), accumulated in fp64
+  const vpt_op16* x;       // [F][CB][HW][32]
+  double* chs;             // [F][CB*32][2]  (caller zeroes)
+  int frames, CB, HW, split;   // split: workgroups per (frame, channel block), set by the launcher
+};
+
+struct VptNfoldCoefArgs {      // GroupNorm `n` of a stack folded into its first block: per-frame coefficients
+  const double* tot;       // [F][2] sum / sum of squares of the pooled tensor P (all channels)
+  const double* chs;       // [F][C][2] per-channel sums of Q = gain_n * P
+  const float* gain;       // [C] n.weight
+  const float* bias;       // [C] n.bias
+  const float* sa;         // [9][CoutPad] edge tables of block 0's conv0: SA, SG (vpt_pack_conv3x3) and TB / TG = its rounded weights summed
+  const float* sg;         //   against n.bias / n.weight instead of ones
+  const float* tb;
+  const float* tg;
+  float* kk_frame;         // [F][9][CoutPad]  out: conv0's epilogue table of the frame
+  float* rs_frame;         // [F]              out: conv0's accumulator scale r_x * r_P
+  float* res_scale;        // [F]              out: conv1's residual = res_scale * Q + res_bias[c]
+  float* res_bias;         // [F][C]
+  int frames, C, HW, CoutPad;
+};
+
+struct VptPoolSeamArgs {    // finishes the pooled pixels whose 3x3 window crosses a tile border of the pool-fused convolution
+  vpt_op16* y;             // pooled [F][CB][H/2][W/2][32]: the seam pixels hold the in-tile part of their maximum
+  const vpt_op16* seam_r;  // [F][CB][H/16][W][32]  row 15 of every tile row
+  const vpt_op16* seam_c;  // [F][CB][W/16][H][32]  column 15 of every tile column
+  double* stats_out;       // [F][2] accumulated: the seam pixels' share of the pooled frame's statistics
+  const float* gain;       // optional [CB*32]: the finished pixels are stored multiplied by it (statistics: of the unscaled values)
+  int frames, CB, H, W;    // H, W: the PRE-pool size
 };
 
 struct VptPackConvArgs {
@@ -45,6 +90,7 @@ struct VptConvFirstArgs {
   const vpt_op16* wfrag;   // [NT][4][2][64][8]  MFMA A-operand fragments (bias folded in k=27,28)
   vpt_op16* y;             // pooled output [F][Cout/32][H/2][W/2][32]
   double* stats_out;       // [F][2]
+  const float* out_gain;   // optional [Cout]: the pooled output is stored multiplied by it (statistics: of the unscaled values)
   int frames, H, W, Cout, NT;
 };
 
@@ -327,6 +373,9 @@ int vpt_act_epilogue_launch(const int64_t* act_b, const int64_t* act_c, const fl
 int vpt_uniform_noise_launch(const uint64_t* rng_state, uint32_t rng_stream, float* out, int M, int n, hipStream_t s);
 int vpt_attn_bwd_launch(const VptAttnBwdArgs* a, hipStream_t s);
 int vpt_conv3x3_launch(const VptConv3x3Args* a, hipStream_t s);
+int vpt_pool_seam_launch(const VptPoolSeamArgs* a, hipStream_t s);
+int vpt_channel_stats_launch(const VptChannelStatsArgs* a, hipStream_t s);
+int vpt_nfold_coef_launch(const VptNfoldCoefArgs* a, hipStream_t s);
 int vpt_conv_first_launch(const VptConvFirstArgs* a, hipStream_t s);
 int vpt_conv3d_launch(const VptConv3dArgs* a, hipStream_t s);
 int vpt_pool_launch(const VptPoolArgs* a, hipStream_t s);

@@ -149,6 +149,12 @@ class PolicyEngine:
         # frames per conv + pool sub-chunk of stacks 1.. (0: whole chunk).  Measured (profiles/r03_experiments.md section 12): 64 / 128 / 256 frames
         # all give +1.2 % on the forward step (the conv launches themselves run 1.8 % faster at 128 / 256); the pool kernel's own time does not move
         self.pool_subchunk = int(os.environ.get("VPT_POOL_SUBCHUNK", 256))
+        # stacks 1..: firstconv and the max-pool behind it as one pass (ops.conv3x3_pool); 0 = the two-kernel path above (A/B, and what the
+        # latency tiling of the acting step always takes)
+        self.fuse_pool = os.environ.get("VPT_FUSE_POOL", "1") != "0"
+        self.fuse_pool_sub = int(os.environ.get("VPT_FUSE_POOL_SUB", 0))      # frames per pool-fused launch (0: the whole chunk)
+        # each stack's GroupNorm `n` folded into its first block (no affine pass; needs fuse_pool): 0 = the vpt_affine_kernel pass
+        self.fold_n = os.environ.get("VPT_FOLD_N", "1") != "0"
         self._streams = []
         self._attn_done = None      # arrival counters of the in-place acting step (ops.masked_attention_step)
         self._rng_state = None      # in-kernel sampler state {seed, step} (ops.new_rng_state), created on first stochastic use
@@ -157,7 +163,8 @@ class PolicyEngine:
 
     def rng_state(self, device):
         """The device-resident {seed, step} the stochastic heads draw from.  One per engine: a captured acting step holds its address."""
-        if self._rng_state is None or self._rng_state.device != device:
+        cur = self._rng_state
+        if cur is None or cur.device.type != device.type or (device.index is not None and cur.device.index != device.index):
             self._rng_state = ops.new_rng_state(device, seed=getattr(self, "_pending_seed", None))
             self._pending_seed = None
         return self._rng_state
@@ -224,6 +231,30 @@ class PolicyEngine:
         w["heads.w"], w["heads.b"] = ops.pack_linear(wh, dtype=self.dtype), bh.contiguous()
         self.w = w
         self.packed = True
+        # sources of the n-fold tables (computed on first use after a pack: inference only, nothing on the BC step's path)
+        self._fold_src = {s: (sd[f"net.img_process.cnn.stacks.{s}.blocks.0.conv0.layer.weight"], sd[f"net.img_process.cnn.stacks.{s}.blocks.0.conv0.norm.weight"])
+                          for s in range(len(cfg["chans"]))}
+        self._fold_tab = {}
+
+    def _nfold_tables(self, s: int):
+        """TB / TG of stack s: the edge-class sums of block 0's conv0 weights W' = op16(W * gain_conv0) with every input channel weighted by
+        n.bias / n.weight (edge_sg is the same sum with weight 1) -- fp32 [9, CoutPad], vpt_nfold_coef's `tb` / `tg`."""
+        if s not in self._fold_tab:
+            wt, g0 = self._fold_src[s]
+            p = f"net.img_process.cnn.stacks.{s}."
+            gam, bet = self.w[p + "n.g"], self.w[p + "n.b"]
+            cout = wt.shape[0]
+            wp = (wt.detach().float() * g0.detach().float().view(1, -1, 1, 1)).to(self.dtype).double()        # the packed (rounded) weights
+            m = packing.edge_tap_matrix(wp.device, torch.float64)                                            # [9 classes, 9 taps]
+            pad = (cout + 127) // 128 * 128
+            tabs = []
+            for v in (bet, gam):
+                tap = (wp * v.double().view(1, -1, 1, 1)).sum(1).view(cout, 9)                                # [Cout, 9]
+                t = torch.zeros(9, pad, dtype=torch.float32, device=wp.device)
+                t[:, :cout] = (m.unsqueeze(1) * tap.unsqueeze(0)).sum(-1).float()                             # (an index-sum, not a GEMM)
+                tabs.append(t.contiguous())
+            self._fold_tab[s] = tuple(tabs)
+        return self._fold_tab[s]
 
     # ------------------------------------------------------------------------------------------
     def _cnn_chunk(self, img: torch.Tensor, x0=None, s_x0=None, tiling: str = "throughput") -> torch.Tensor:
@@ -242,30 +273,61 @@ class PolicyEngine:
             return st[si - 1]
 
         x, s_x = x0, s_x0
+        fold = self.fold_n and self.fuse_pool and tiling == "throughput"
         for s, c in enumerate(cfg["chans"]):
             p = f"net.img_process.cnn.stacks.{s}."
             s_pool = nxt()
+            gn = w[p + "n.g"] if fold else None      # folded: the producer stores Q = n.weight * P (statistics: those of P)
             if s == 0 and x0 is None:
-                pooled = ops.conv_first(img, w[p + "firstconv"], c, stats_out=s_pool)
+                pooled = ops.conv_first(img, w[p + "firstconv"], c, stats_out=s_pool, out_gain=gn)
             else:
                 wpk, sa, sg = w[p + "firstconv"]
-                sub = self.pool_subchunk
-                if sub and f > sub:
-                    # conv + pool over sub-chunks of frames: the pre-pool tensor of a sub-chunk (2 MB per frame in stack 1) is pooled while it is
-                    # still in the 256 MB Infinity Cache instead of after the whole chunk's 2 GB have gone through HBM
-                    pooled = torch.empty(f, c // 32, x.shape[2] // 2, x.shape[3] // 2, 32, dtype=x.dtype, device=x.device)
-                    for i in range(0, f, sub):
-                        j = min(i + sub, f)
-                        pre = ops.conv3x3(x[i:j], wpk, sa, sg, s_x[i:j], c, tiling=tiling)
-                        ops.maxpool(pre, stats_out=s_pool[i:j], out=pooled[i:j])
-                        del pre
+                if self.fuse_pool and tiling == "throughput":
+                    # firstconv + ReLU + max-pool in ONE pass: the 16 x 16 output tiles are pooled in LDS, a seam kernel completes the windows
+                    # that cross tile borders; the pre-pool tensor (2 MB per frame in stack 1) is never written (ops.conv3x3_pool)
+                    fsub = self.fuse_pool_sub
+                    if fsub and f > fsub:
+                        pooled = torch.empty(f, c // 32, x.shape[2] // 2, x.shape[3] // 2, 32, dtype=x.dtype, device=x.device)
+                        for i in range(0, f, fsub):
+                            j = min(i + fsub, f)
+                            ops.conv3x3_pool(x[i:j], wpk, sa, sg, s_x[i:j], c, stats_out=s_pool[i:j], out=pooled[i:j], out_gain=gn)
+                    else:
+                        pooled = ops.conv3x3_pool(x, wpk, sa, sg, s_x, c, stats_out=s_pool, out_gain=gn)
                 else:
-                    pre = ops.conv3x3(x, wpk, sa, sg, s_x, c, tiling=tiling)
-                    pooled = ops.maxpool(pre, stats_out=s_pool)
-                    del pre
-            s_x = nxt()
-            x = ops.frame_affine(pooled, w[p + "n.g"], w[p + "n.b"], s_pool, stats_out=s_x, out=pooled)
-            for b in range(2):
+                    sub = self.pool_subchunk
+                    if sub and f > sub:
+                        # conv + pool over sub-chunks of frames: the pre-pool tensor of a sub-chunk (2 MB per frame in stack 1) is pooled while it
+                        # is still in the 256 MB Infinity Cache instead of after the whole chunk's 2 GB have gone through HBM
+                        pooled = torch.empty(f, c // 32, x.shape[2] // 2, x.shape[3] // 2, 32, dtype=x.dtype, device=x.device)
+                        for i in range(0, f, sub):
+                            j = min(i + sub, f)
+                            pre = ops.conv3x3(x[i:j], wpk, sa, sg, s_x[i:j], c, tiling=tiling)
+                            ops.maxpool(pre, stats_out=s_pool[i:j], out=pooled[i:j])
+                            del pre
+                    else:
+                        pre = ops.conv3x3(x, wpk, sa, sg, s_x, c, tiling=tiling)
+                        pooled = ops.maxpool(pre, stats_out=s_pool)
+                        del pre
+            if fold:
+                # GroupNorm `n` without a pass of its own: x = n(P) is never written.  Block 0's conv0 convolves Q with its
+                # ordinary weights and a per-frame epilogue table, conv1 takes its residual as res_scale * Q + res_bias[c].
+                hw = pooled.shape[2] * pooled.shape[3]
+                chs = ops.channel_stats(pooled)
+                wpk, sa, sg = w[f"{p}blocks.0.conv0"]
+                tb, tg = self._nfold_tables(s)
+                kk, rs, rsc, rb = ops.nfold_coef(s_pool, chs, w[p + "n.g"], w[p + "n.b"], sa, sg, tb, tg, hw, c)
+                s_y = nxt()
+                y = ops.conv3x3_folded(pooled, wpk, sa, sg, None, c, kk_frame=kk, rs_frame=rs, stats_out=s_y)
+                wpk, sa, sg = w[f"{p}blocks.0.conv1"]
+                s_x = nxt()
+                x = ops.conv3x3_folded(y, wpk, sa, sg, s_y, c, res=pooled, res_scale=rsc, res_bias=rb, stats_out=s_x)
+                del y, pooled, chs, kk
+                first_block = 1
+            else:
+                s_x = nxt()
+                x = ops.frame_affine(pooled, w[p + "n.g"], w[p + "n.b"], s_pool, stats_out=s_x, out=pooled)
+                first_block = 0
+            for b in range(first_block, 2):
                 wpk, sa, sg = w[f"{p}blocks.{b}.conv0"]
                 s_y = nxt()
                 y = ops.conv3x3(x, wpk, sa, sg, s_x, c, stats_out=s_y, tiling=tiling)
@@ -414,6 +476,9 @@ class IDMEngine(PolicyEngine):
         self.cnn_chunk = cnn_chunk
         self.cnn_streams = 1
         self.pool_subchunk = 0      # (PolicyEngine._cnn_chunk's option; the IDM's chunks are one 128-frame window)
+        self.fuse_pool = os.environ.get("VPT_FUSE_POOL", "1") != "0"
+        self.fuse_pool_sub = 0
+        self.fold_n = os.environ.get("VPT_FOLD_N", "1") != "0"
         self._streams = []
         self._rng_state = None
         self.w = {}
@@ -461,6 +526,9 @@ class IDMEngine(PolicyEngine):
             w[h + ".b"] = f32(sd[f"pi_head.{h}.linear_layer.bias"])
         self.w = w
         self.packed = True
+        self._fold_src = {s: (sd[f"net.img_process.cnn.stacks.{s}.blocks.0.conv0.layer.weight"], sd[f"net.img_process.cnn.stacks.{s}.blocks.0.conv0.norm.weight"])
+                          for s in range(len(cfg["chans"]))}
+        self._fold_tab = {}
 
     @torch.no_grad()
     def forward(self, img_u8: torch.Tensor, mask: Optional[dict] = None, sample: Optional[str] = None):

@@ -428,9 +428,11 @@ class MinecraftAgentPolicy(nn.Module):
         (pd, vpred, _), state_out, _ = self._run(obs, first, state_in, sample=None)
         return (pd, vpred, None), state_out
 
-    def _run(self, obs, first, state_in, sample=None, auto_graph=False):
+    def _run(self, obs, first, state_in, sample=None, auto_graph=False, keep_pd=True):
         """forward() plus, on request, the fused CategoricalActionHead.sample / logprob of the head kernel (act()).
-        auto_graph: the caller is act() -- eligible calls count towards the automatic capture of the acting step."""
+        auto_graph: the caller is act() -- eligible calls count towards the automatic capture of the acting step.
+        keep_pd=False: the caller drops the log-prob tensors at once (act() without return_pd) -- a graphed step then hands out its
+        static output buffers instead of copies (everything else a graphed step returns, the recurrent state excepted, is a copy)."""
         if isinstance(obs, dict):
             obs = obs.copy()
             mask = obs.pop("mask", None)        # {"buttons"/"camera": bool [B,T,1,n]}: False -> LOG0 (lib/action_head.py:170-171)
@@ -456,6 +458,8 @@ class MinecraftAgentPolicy(nn.Module):
             out = self._graphed_forward(img, first, state_in, sample or "deterministic")
             if sample is None:
                 out = {k: v for k, v in out.items() if k not in ("action", "action_log_prob", "vpred_denorm", "nan_flag")}
+            if keep_pd:      # the next replay overwrites the graph's output buffers: what the caller may keep is copied
+                out["camera"], out["buttons"] = out["camera"].clone(), out["buttons"].clone()
         else:
             out = self._engine.forward(img, first, state_in, mask=mask, sample=sample)
         pi_logits = {"camera": out["camera"], "buttons": out["buttons"]}
@@ -498,7 +502,7 @@ class MinecraftAgentPolicy(nn.Module):
         obs = tree_map(lambda x: x.unsqueeze(1), obs)
         first = first.unsqueeze(1)
         want = None if taken_action is not None else ("stochastic" if stochastic else "deterministic")
-        (pd, vpred, _), state_out, extra = self._run(obs, first, state_in, sample=want, auto_graph=True)
+        (pd, vpred, _), state_out, extra = self._run(obs, first, state_in, sample=want, auto_graph=True, keep_pd=return_pd or taken_action is not None)
         if taken_action is None and "action" in extra:
             # CategoricalActionHead.sample / logprob (lib/action_head.py:176-207) came out of the head kernel
             ac = {k: extra["action"][k] for k in pd}

@@ -158,13 +158,14 @@ def chw_to_blocked(x, c, h, w):
     return out
 
 
-def conv_first(img_u8, wfrag, cout, stats_out=None):
-    """img_u8 [F,H,W,3] uint8 -> pooled blocked bf16 [F, cout/32, H/2, W/2, 32]."""
-    _chk(img_u8, torch.uint8, "img"); _chk(wfrag, OP16, "wfrag"); _chk(stats_out, torch.float64, "stats_out")
+def conv_first(img_u8, wfrag, cout, stats_out=None, out_gain=None):
+    """img_u8 [F,H,W,3] uint8 -> pooled blocked bf16 [F, cout/32, H/2, W/2, 32].  out_gain fp32 [cout]: stored times it per channel
+    (GroupNorm `n`'s gain when the norm is folded into the first block); stats_out are the statistics of the unscaled tensor."""
+    _chk(img_u8, torch.uint8, "img"); _chk(wfrag, OP16, "wfrag"); _chk(stats_out, torch.float64, "stats_out"); _chk(out_gain, torch.float32, "out_gain")
     f, h, w, _ = img_u8.shape
     dt, fmt = _fmt(wfrag)
     y = torch.empty(f, cout // 32, h // 2, w // 2, 32, dtype=dt, device=img_u8.device)
-    _call("vpt_conv_first_forward", dict(flops=2.0 * f * h * w * cout * 27, bytes=f * (h * w * 3 + h * w * cout // 2)), ptr(img_u8), ptr(wfrag), ptr(y), ptr(stats_out), f, h, w, cout, _stream(), fmt=fmt)
+    _call("vpt_conv_first_forward", dict(flops=2.0 * f * h * w * cout * 27, bytes=f * (h * w * 3 + h * w * cout // 2)), ptr(img_u8), ptr(wfrag), ptr(y), ptr(stats_out), ptr(out_gain), f, h, w, cout, _stream(), fmt=fmt)
     return y
 
 
@@ -190,6 +191,73 @@ def conv3x3(x, wpk, edge_sa, edge_sg, stats_in, cout, res=None, stats_out=None, 
           ptr(out), ptr(stats_out), f, h, w, cb * 32, cout, CONV_TILING[tiling], _stream(), fmt=fmt,
           label="vpt_conv3x3_forward" if tiling == "throughput" else "vpt_conv3x3_forward_latency")
     return out
+
+
+def conv3x3_pool(x, wpk, edge_sa, edge_sg, stats_in, cout, stats_out=None, out=None, out_gain=None):
+    """GN fold + conv3x3 + ReLU + max_pool2d(3, 2, 1) in one pass (vpt_conv3x3_pool_forward): x blocked [F,Cin/32,H,W,32] -> pooled
+    [F,cout/32,H/2,W/2,32] (+ its frame statistics into stats_out) -- what conv3x3() followed by maxpool() returns, bit for bit, without
+    the pre-pool tensor's round trip through HBM.  Inference path of the stacks' firstconv (the BC step keeps the pre-pool tensor)."""
+    _chk(x, OP16, "x"); _chk(wpk, OP16, "wpk"); _chk(edge_sa, torch.float32, "edge_sa"); _chk(edge_sg, torch.float32, "edge_sg")
+    _chk(stats_in, torch.float64, "stats_in"); _chk(stats_out, torch.float64, "stats_out"); _chk(out, OP16, "out"); _chk(out_gain, torch.float32, "out_gain")
+    f, cb, h, w, _ = x.shape
+    dt, fmt = _fmt(x, wpk, out)
+    if out is not None and (tuple(out.shape) != (f, cout // 32, h // 2, w // 2, 32) or not out.is_contiguous()):
+        raise ValueError("conv3x3_pool: out must be a contiguous [F, cout/32, H/2, W/2, 32] tensor")
+    y = out if out is not None else torch.empty(f, cout // 32, h // 2, w // 2, 32, dtype=dt, device=x.device)
+    seam = torch.empty(_native.load(fmt).vpt_conv3x3_pool_seam_elems(f, h, w, cout), dtype=dt, device=x.device)
+    meta = dict(flops=2.0 * f * h * w * cout * 9 * cb * 32, bytes=2.0 * f * h * w * (cb * 32 + cout * 0.25))
+    args = (ptr(x), ptr(wpk), ptr(edge_sa), ptr(edge_sg), ptr(stats_in), ptr(y), ptr(seam), ptr(stats_out), ptr(out_gain), f, h, w, cb * 32, cout)
+    if TIMER.enabled:    # the two launches timed apart: the convolution is the roofline kernel (vpt_conv3x3_kernel, pool-fused mode: same FLOPs)
+        _call("vpt_conv3x3_pool_forward", meta, *args, 1, _stream(), fmt=fmt, label="vpt_conv3x3_pool_forward")
+        _call("vpt_conv3x3_pool_forward", dict(bytes=2.0 * y.numel() * 0.4), *args, 2, _stream(), fmt=fmt, label="vpt_pool_seam")
+    else:
+        _call("vpt_conv3x3_pool_forward", meta, *args, 3, _stream(), fmt=fmt)
+    return y
+
+
+def conv3x3_folded(x, wpk, edge_sa, edge_sg, stats_in, cout, kk_frame=None, rs_frame=None, res=None, res_scale=None, res_bias=None, stats_out=None):
+    """conv3x3() with the GroupNorm `n` of the stack folded in (vpt_conv3x3_forward_folded): (kk_frame [F,9,CoutPad], rs_frame [F]) from
+    nfold_coef() replace edge_sa and the statistics of x (conv0 on the gain-scaled pooled tensor Q); (res_scale [F], res_bias [F,cout])
+    make the residual res_scale * res + res_bias (conv1 with res = Q)."""
+    _chk(x, OP16, "x"); _chk(wpk, OP16, "wpk"); _chk(edge_sa, torch.float32, "edge_sa"); _chk(edge_sg, torch.float32, "edge_sg")
+    _chk(stats_in, torch.float64, "stats_in"); _chk(kk_frame, torch.float32, "kk_frame"); _chk(rs_frame, torch.float32, "rs_frame")
+    _chk(res, OP16, "res"); _chk(res_scale, torch.float32, "res_scale"); _chk(res_bias, torch.float32, "res_bias"); _chk(stats_out, torch.float64, "stats_out")
+    f, cb, h, w, _ = x.shape
+    dt, fmt = _fmt(x, wpk, res)
+    if kk_frame is not None and tuple(kk_frame.shape) != (f, 9, edge_sg.shape[1]):
+        raise ValueError(f"conv3x3_folded: kk_frame must be [F, 9, {edge_sg.shape[1]}], got {tuple(kk_frame.shape)}")
+    if res_bias is not None and tuple(res_bias.shape) != (f, cout):
+        raise ValueError(f"conv3x3_folded: res_bias must be [F, {cout}], got {tuple(res_bias.shape)}")
+    out = torch.empty(f, cout // 32, h, w, 32, dtype=dt, device=x.device)
+    meta = dict(flops=2.0 * f * h * w * cout * 9 * cb * 32, bytes=2.0 * f * h * w * (cb * 32 + cout * (2 if res is not None else 1)))
+    _call("vpt_conv3x3_forward_folded", meta, ptr(x), ptr(wpk), ptr(edge_sa), ptr(edge_sg), ptr(stats_in), ptr(kk_frame), ptr(rs_frame), ptr(res),
+          ptr(res_scale), ptr(res_bias), ptr(out), ptr(stats_out), f, h, w, cb * 32, cout, _stream(), fmt=fmt, label="vpt_conv3x3_forward")
+    return out
+
+
+def channel_stats(x, out=None):
+    """Blocked [F,C/32,H,W,32] -> fp64 [F, C, 2] per-frame, per-channel (sum, sum of squares) (vpt_channel_stats)."""
+    _chk(x, OP16, "x"); _chk(out, torch.float64, "out")
+    f, cb, h, w, _ = x.shape
+    chs = out if out is not None else torch.zeros(f, cb * 32, 2, dtype=torch.float64, device=x.device)
+    _call("vpt_channel_stats", dict(bytes=2.0 * x.numel()), ptr(x), ptr(chs), f, cb * 32, h * w, _stream(), fmt=_fmt(x)[1])
+    return chs
+
+
+def nfold_coef(tot, chs, gain, bias, sa, sg, tb, tg, hw, cout):
+    """Per-frame coefficients of the folded GroupNorm `n` (vpt_nfold_coef) -> (kk_frame [F,9,CoutPad], rs_frame [F], res_scale [F], res_bias [F,C])."""
+    _chk(tot, torch.float64, "tot"); _chk(chs, torch.float64, "chs")
+    for t_, nme in ((gain, "gain"), (bias, "bias"), (sa, "sa"), (sg, "sg"), (tb, "tb"), (tg, "tg")):
+        _chk(t_, torch.float32, nme)
+    f, c, _ = chs.shape
+    dev = chs.device
+    kk = torch.empty(f, 9, sa.shape[1], dtype=torch.float32, device=dev)
+    rs = torch.empty(f, dtype=torch.float32, device=dev)
+    rsc = torch.empty(f, dtype=torch.float32, device=dev)
+    rb = torch.empty(f, c, dtype=torch.float32, device=dev)
+    _call("vpt_nfold_coef", dict(bytes=4.0 * kk.numel()), ptr(tot), ptr(chs), ptr(gain), ptr(bias), ptr(sa), ptr(sg), ptr(tb), ptr(tg),
+          ptr(kk), ptr(rs), ptr(rsc), ptr(rb), f, c, int(hw), int(cout), _stream())
+    return kk, rs, rsc, rb
 
 
 def maxpool(x, stats_out=None, want_argmax=False, out=None):

@@ -622,7 +622,10 @@ class BCTrainer:
 # ---------------------------------------------------------------------------------------------------------
 def _tap_sum(tab: torch.Tensor, cout: int) -> torch.Tensor:
     """[9 edge classes, >= cout] -> [cout, 3, 3]: for every tap, the sum over the edge classes in which it is inside the image."""
-    return (tab[:, :cout].t() @ packing.edge_tap_matrix(tab.device, tab.dtype)).view(cout, 3, 3)
+    # an index-sum, not a matrix product: `tab.t() @ M` dispatched to a Tensile / hipBLASLt GEMM (84 of them per BC step in the round-3
+    # PMC survey) -- there is no vendor BLAS on the measured path
+    m = packing.edge_tap_matrix(tab.device, tab.dtype)                      # [9 classes, 9 taps] of 0 / 1
+    return (tab[:, :cout].t().unsqueeze(2) * m.unsqueeze(0)).sum(dim=1).view(cout, 3, 3)
 
 
 def conv_param_grads(dw_raw: torch.Tensor, d_sa: torch.Tensor, d_sg: torch.Tensor, weight: torch.Tensor,
