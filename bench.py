@@ -100,12 +100,61 @@ def cpu_baseline(model: str):
             st = O.initial_state(cfg, 1)
             med, n = _median_time(lambda: O.policy_forward(sd, cfg, img, first, st), 12.0)
             rates[name] = (t / med, n)
+    bc = None
+    if kind == "reference":
+        try:
+            bc = _cpu_bc_step(RefPolicy, space, O, model, cores)
+        except Exception as e:
+            bc = dict(error=f"{type(e).__name__}: {e}")
     what = "the unmodified reference MinecraftAgentPolicy.forward (oracle/_ref/vpt_reference.zip)" if kind == "reference" else "oracle/vpt_oracle.py (fp32 port)"
     out = dict(value=round(rates[model][0], 2), unit="frames/s", cores=cores, kind=kind,
                sample=f"{what}, fp32, {model} model, B=1 T={t} synthetic frames, median of {rates[model][1]} after 1 warm-up, torch.set_num_threads({cores})")
     if "1x" in rates and model != "1x":
         out["config1_1x_frames_per_s"] = round(rates["1x"][0], 2)     # BASELINE.json configs[0]: 1x, B=1, T=16 on CPU
+    if bc is not None:
+        out["bc_step"] = bc
     return out
+
+
+def _cpu_bc_step(RefPolicy, space, O, model, cores):
+    """The BC half of the metric on the host: the reference's OWN training loop (behavioural_cloning.py:86-122) -- BATCH_SIZE = 8
+    samples, each one frame (B = 1, T = 1) through get_output_for_observation -> get_logprob_of_action -> (-log_prob / 8).backward()
+    with the hidden state carried detached, then th.optim.Adam(lr 1.81e-4, weight_decay 0.039428).step() -- on the unmodified
+    reference policy, fp32, `cores` threads.  One warm-up step, then 2 timed steps (bounded: ~10-20 s for the 2x model)."""
+    import numpy as np
+    import torch as th
+    from lib.tree_util import tree_map
+    cfg = O.config_from_policy_kwargs(O.policy_kwargs_for(model), dict(temperature=2.0))
+    policy = RefPolicy(space, O.policy_kwargs_for(model), dict(temperature=2.0))
+    policy.load_state_dict(O.synthetic_state_dict(cfg, seed=0), strict=False)
+    optimizer = th.optim.Adam(policy.parameters(), lr=0.000181, weight_decay=0.039428)
+    g = th.Generator().manual_seed(2)
+    n = 8
+    frames = th.randint(0, 256, (n, 1, 128, 128, 3), generator=g, dtype=th.uint8)
+    ab, ac = th.randint(0, 8641, (n, 1, 1), generator=g), th.randint(0, 121, (n, 1, 1), generator=g)
+    dummy_first = th.from_numpy(np.array((False,)))
+    state = policy.initial_state(1)
+
+    def one_step(state):
+        for i in range(n):
+            pi_distribution, _, new_state = policy.get_output_for_observation({"img": frames[i]}, state, dummy_first)
+            log_prob = policy.get_logprob_of_action(pi_distribution, {"buttons": ab[i], "camera": ac[i]})
+            state = tree_map(lambda x: x.detach(), new_state)
+            (-log_prob / n).backward()
+        optimizer.step()
+        optimizer.zero_grad()
+        return state
+
+    state = one_step(state)
+    times = []
+    for _ in range(2):
+        t0 = time.time()
+        state = one_step(state)
+        times.append(time.time() - t0)
+    sec = min(times)
+    return dict(s_per_step=round(sec, 3), frames_per_step=n, s_per_frame=round(sec / n, 4), frames_per_s=round(n / sec, 2), cores=cores, kind="reference",
+                sample=f"the reference's own BC loop (behavioural_cloning.py:86-122: 8 x (B=1, T=1) forward + backward, state carried, then Adam), {model} model, "
+                       f"fp32, best of 2 steps after 1 warm-up, torch.set_num_threads({cores})")
 
 
 def parity_block(model: str, dev):
@@ -262,6 +311,102 @@ def _bc_leg(pol, args, img, first, g, dev, world, distributed, barrier, dist, mo
     return bc
 
 
+def configs_block(dev):
+    """The other 1-GPU configurations of BASELINE.json, timed by this run (bounded: ~15 s of GPU time):
+       idm_4x_t128    -- configs[2]: the 4x inverse-dynamics model on one 128-frame window (non-causal attention, lib/policy.py:374-403),
+                         ms per window and frames/s, + action parity against the oracle on a 16-frame window of the same model;
+       bc_3x_b32_t256 -- configs[4]'s model and per-GPU shape: a 3x BC step (forward + backward + Adam) at B = 32, T = 256 on two consecutive
+                         chunks with the detached KV memory carried (behavioural_cloning.py:86-123 generalised), ms per step, peak memory."""
+    from vpt_amd import configs
+    from vpt_amd.lib.policy import InverseActionPolicy, MinecraftAgentPolicy
+    from vpt_amd.lib.types import idm_action_space, minecraft_action_space
+    from vpt_amd.training import BCTrainer
+    out = {}
+    # ---- config 3
+    try:
+        kw = configs.idm_kwargs_for("4x")
+        pol = InverseActionPolicy(idm_action_space(), pi_head_kwargs=dict(temperature=2.0), idm_net_kwargs=kw, precision="bf16")
+        configs.randomize_(pol, 0)
+        pol = pol.to(dev)
+        g = torch.Generator().manual_seed(1)
+        img = torch.randint(0, 256, (1, 128, 128, 128, 3), generator=g, dtype=torch.uint8).to(dev)
+        rec = {}
+        for mode in ("bf16", "fp16"):
+            pol.set_precision(mode)
+            with torch.no_grad():
+                for _ in range(2):
+                    pol.predict({"img": img}, first=None, state_in=pol.initial_state(1), deterministic=True)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    pol.predict({"img": img}, first=None, state_in=pol.initial_state(1), deterministic=True)
+                torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 5
+            rec[mode] = dict(ms_per_window=round(1e3 * dt, 3), frames_per_s=round(128 / dt, 1))
+        try:       # parity on a bounded sample: 16-frame window, synthetic oracle weights, predicted actions vs the oracle's arg-max
+            from oracle import vpt_oracle as O
+            from tests import parity as P
+            torch.set_num_threads(_host_threads(32))
+            cfg = O.idm_config_from_kwargs(O.idm_kwargs_for("4x"), dict(temperature=2.0))
+            sd = O.idm_synthetic_state_dict(cfg, seed=0)
+            pol.load_state_dict(sd, strict=False)
+            im16 = torch.randint(0, 256, (1, 16, 128, 128, 3), generator=torch.Generator().manual_seed(22), dtype=torch.uint8)
+            ref = O.idm_forward(sd, cfg, im16)
+            for mode in ("bf16", "fp16"):
+                pol.set_precision(mode)
+                with torch.no_grad():
+                    ac, _, res = pol.predict({"img": im16.to(dev)}, first=None, state_in=pol.initial_state(1), deterministic=True)
+                torch.cuda.synchronize()
+                hm = {h: P.head_metrics(res["pd"][h].cpu(), ref[h]) for h in ("buttons", "camera")}
+                rec[mode]["parity"] = dict(sample="4x IDM, T=16 window, vs oracle/vpt_oracle.py:idm_forward",
+                                           logprob_rel_l2=round(max(v["lp_l2"] for v in hm.values()), 6), max_abs_err=round(max(v["max_abs_err"] for v in hm.values()), 5),
+                                           action_agreement=round(min(v["argmax_agree"] for v in hm.values()), 4),
+                                           mismatches_outside_noise_band=sum(v["argmax_safe_mismatch"] for v in hm.values()))
+        except Exception as e:
+            rec["parity_error"] = f"{type(e).__name__}: {e}"
+        rec["workload"] = "4x_idm forward, B=1, seq=128 (BASELINE.json configs[2]), random-init weights, frames resident in HBM"
+        out["idm_4x_t128"] = rec
+        del pol, img
+    except Exception as e:
+        out["idm_4x_t128"] = dict(error=f"{type(e).__name__}: {e}")
+    torch.cuda.empty_cache()
+    # ---- config 5's model at its per-GPU shape
+    try:
+        torch.cuda.reset_peak_memory_stats()
+        pol = MinecraftAgentPolicy(minecraft_action_space(), configs.policy_kwargs_for("3x"), dict(temperature=2.0), precision="bf16")
+        configs.randomize_(pol, 0)
+        pol = pol.to(dev)
+        B, T = 32, 256
+        g = torch.Generator().manual_seed(5)
+        imgs = [torch.randint(0, 256, (B, T, 128, 128, 3), generator=g, dtype=torch.uint8).to(dev) for _ in range(2)]
+        first = torch.zeros(B, T, dtype=torch.bool, device=dev)
+        ab = torch.randint(0, pol._engine.n_buttons, (B, T), generator=g).to(dev)
+        ac = torch.randint(0, pol._engine.n_camera, (B, T), generator=g).to(dev)
+        tr = BCTrainer(pol, train_cnn=True)
+        st = pol.initial_state(B)
+        losses = []
+        l, st = tr.step(imgs[0], first, st, ab, ac)          # warm-up (chunk 0)
+        losses.append(l)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for c in (1, 0, 1):                                  # three timed steps, every one on the memory the previous chunk left
+            l, st = tr.step(imgs[c], first, st, ab, ac)
+            losses.append(l)
+        torch.cuda.synchronize()
+        sec = (time.perf_counter() - t0) / 3
+        out["bc_3x_b32_t256"] = dict(ms_per_step=round(1e3 * sec, 1), frames_per_s=round(B * T / sec, 1), steps=3, warmup=1, batch=B, seq_len=T,
+                                     kv_carry="consecutive T=256 chunks, detached KV memory carried between steps", precision="bf16",
+                                     tflops=round(3 * FLOP_PER_FRAME["3x"] * B * T / sec / 1e12, 1),
+                                     frac_of_mfma_peak=round(3 * FLOP_PER_FRAME["3x"] * B * T / sec / MFMA_BF16_PEAK, 4),
+                                     peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1), loss_first=round(losses[0], 4), loss_last=round(losses[-1], 4),
+                                     workload="foundation-model-3x BC step (forward + backward + Adam), B=32 seq=256 per GPU (BASELINE.json configs[4], single GPU: no all-reduce)")
+        del tr, pol, imgs
+    except Exception as e:
+        out["bc_3x_b32_t256"] = dict(error=f"{type(e).__name__}: {e}")
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -414,6 +559,12 @@ def main():
                 line["parity"] = parity_block(args.model, dev)
             except Exception as e:
                 line["parity"] = dict(error=f"{type(e).__name__}: {e}")
+            del pol, img
+            torch.cuda.empty_cache()
+            try:
+                line["configs"] = configs_block(dev)
+            except Exception as e:
+                line["configs"] = dict(error=f"{type(e).__name__}: {e}")
             line["cpu_baseline"] = cpu_baseline(args.model)
         print(json.dumps(line))
     if distributed:

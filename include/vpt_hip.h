@@ -86,8 +86,10 @@ int vpt_pack_linear(const float* weight, void* wpk, int N, int K, int transposed
  * CnnDownStack.firstconv of stack 0 (lib/impala_cnn.py:86-97,115) and F.max_pool2d (lib/impala_cnn.py:117).
  * img: uint8 [frames][H][W][3]; wfrag: bf16 [NT][4][2][64][8]; y: blocked [frames][Cout/32][H/2][W/2][32].
  * out_gain (optional, [Cout]): y is stored multiplied by it per channel -- the gain of the stack's GroupNorm `n` when that norm is
- * folded into the first block (vpt_nfold_coef); stats_out always holds the statistics of the UNscaled pooled tensor. */
-int vpt_conv_first_forward(const uint8_t* img, const void* wfrag, void* y, double* stats_out, const float* out_gain,
+ * folded into the first block (vpt_nfold_coef); stats_out always holds the statistics of the UNscaled pooled tensor.
+ * chs_out (optional, [frames][Cout][2] fp64, ACCUMULATED, Cout <= 128): per-channel (sum, sum of squares) of y as stored -- what
+ * vpt_channel_stats would compute in a pass of its own; here the sums run in registers across the tiles of a frame. */
+int vpt_conv_first_forward(const uint8_t* img, const void* wfrag, void* y, double* stats_out, const float* out_gain, double* chs_out,
                            int frames, int H, int W, int Cout, void* stream);
 
 /* IDM temporal conv + ingest + bias + ReLU.
@@ -121,11 +123,12 @@ int vpt_conv3x3_forward_tiled(const void* x, const void* wpk, const float* edge_
  * second kernel completes the pooled pixels whose 3 x 3 window crosses a tile border.  Bit-identical to vpt_conv3x3_forward followed by
  * vpt_maxpool_forward (the statistics to the order of their fp32 / fp64 additions).  No residual, throughput tiling only.
  * phases: 3 = both launches (the normal call); 1 = the convolution only, 2 = the seam kernel only (a caller that times them apart).
- * out_gain: as for vpt_conv_first_forward (the pooled tensor stored times GroupNorm `n`'s gain; statistics of the unscaled values). */
+ * out_gain, chs_out: as for vpt_conv_first_forward (the pooled tensor stored times GroupNorm `n`'s gain, statistics of the unscaled
+ * values; per-channel sums of the stored tensor, accumulated by both launches). */
 int64_t vpt_conv3x3_pool_seam_elems(int frames, int H, int W, int Cout);
 int vpt_conv3x3_pool_forward(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg, const double* stats_in,
-                             void* pooled, void* seam_scratch, double* stats_out, const float* out_gain, int frames, int H, int W, int Cin,
-                             int Cout, int phases, void* stream);
+                             void* pooled, void* seam_scratch, double* stats_out, const float* out_gain, double* chs_out, int frames, int H,
+                             int W, int Cin, int Cout, int phases, void* stream);
 
 /* ---- GroupNorm `n` of a stack folded into its first residual block (CnnDownStack.forward, lib/impala_cnn.py:118-121: x = self.n(x);
  * for block in self.blocks: x = block(x)) -- inference.  The producer of the pooled tensor P stores Q = n.weight[c] * P (out_gain above);

@@ -40,6 +40,18 @@ def _worker(rank, world, port, out):
     assert n >= 2
     for t, b in zip(mine_g, base):
         assert torch.allclose(t, b * (sum(range(1, world + 1)) / world), atol=1e-6)
+    # the persistent flat arena of the data-parallel BC step: adopt (one copy in), in-place all-reduce of contiguous slices, views out
+    names, shapes = ["w0", "b0", "w1", "unused"], [torch.Size([300, 7]), torch.Size([7]), torch.Size([1000]), torch.Size([3])]
+    arena = D.GradArena(names, shapes, "cpu", bucket_bytes=4096)
+    assert len(arena.buckets) >= 2 and arena.buckets[0][0] == 0 and arena.buckets[-1][1] == arena.flat.numel()
+    for step in range(2):                      # the arena is reused step after step
+        gs = {"w0": torch.ones(300, 7) * (rank + 1 + step), "b0": torch.arange(7.0) * (rank + 1), "w1": base[0].clone() * (rank + 1)}
+        arena.adopt(gs)
+        assert gs["w1"].data_ptr() == arena.view("w1").data_ptr() and float(gs["unused"].abs().sum()) == 0.0
+        D.bucketed_all_reduce_finish(arena.all_reduce_start())
+        tot = sum(range(1, world + 1))
+        assert torch.allclose(gs["w1"], base[0] * tot, atol=1e-5) and torch.allclose(gs["b0"], torch.arange(7.0) * tot)
+        assert torch.allclose(gs["w0"], torch.full((300, 7), float(tot + world * step)))
     out[rank] = True
     dist.destroy_process_group()
 

@@ -115,6 +115,12 @@ def test_conv3x3_pool_fused(frames, h, w, cin, cout, fmt):
     want_scaled = (want.float() * gain.view(1, cout // 32, 1, 1, 32)).to(dt)
     assert torch.equal(scaled.view(torch.int16), want_scaled.view(torch.int16))
     assert torch.allclose(st_c, st_b, rtol=1e-9, atol=1e-6)
+    # chs_out: the per-channel sums of the stored tensor from the two launches themselves == a pass over the result
+    chs = torch.zeros(frames, cout, 2, dtype=torch.float64, device=DEV)
+    scaled2 = ops.conv3x3_pool(xb, wpk, sa, sg, st_in, cout, out_gain=gain, chs_out=chs)
+    torch.cuda.synchronize()
+    assert torch.equal(scaled2.view(torch.int16), want_scaled.view(torch.int16))
+    assert torch.allclose(chs, ops.channel_stats(scaled2), rtol=1e-6, atol=1e-4), (chs - ops.channel_stats(scaled2)).abs().max()
     # into a slice of a larger batch's tensor (the engine's sub-chunk use)
     big = torch.zeros(frames + 2, cout // 32, h // 2, w // 2, 32, dtype=dt, device=DEV)
     ops.conv3x3_pool(xb, wpk, sa, sg, st_in, cout, out=big[1:1 + frames])
@@ -143,6 +149,12 @@ def test_conv_first_pool(frames, cout, h, w):
     torch.cuda.synchronize()
     assert torch.equal(y2.view(torch.int16), (y.float() * gain.view(1, cout // 32, 1, 1, 32)).to(torch.bfloat16).view(torch.int16))
     assert torch.allclose(st2, st, rtol=1e-9, atol=1e-6)
+    if cout <= 128:        # chs_out: per-channel sums of the stored tensor, accumulated in registers across a frame's tiles
+        chs = torch.zeros(frames, cout, 2, dtype=torch.float64, device=DEV)
+        y3 = ops.conv_first(img.to(DEV), packing.pack_conv_first(W.to(DEV), b.to(DEV)), cout, out_gain=gain, chs_out=chs)
+        torch.cuda.synchronize()
+        assert torch.equal(y3.view(torch.int16), y2.view(torch.int16))
+        assert torch.allclose(chs, ops.channel_stats(y3), rtol=1e-6, atol=1e-4), (chs - ops.channel_stats(y3)).abs().max()
 
 
 def test_maxpool_and_affine():

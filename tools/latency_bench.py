@@ -19,29 +19,74 @@ frames = torch.randint(0, 256, (a.steps, 1, 128, 128, 3), generator=g, dtype=tor
 first = torch.zeros(1, dtype=torch.bool, device="cuda")
 
 
-def run(n):
+def run(n, stochastic=False):
     st = pol.initial_state(1)
     acts = []
     for i in range(n):
-        ac, st, _ = pol.act({"img": frames[i]}, first, st, stochastic=False)
+        ac, st, _ = pol.act({"img": frames[i % frames.shape[0]]}, first, st, stochastic=stochastic)
         acts.append(ac)
     torch.cuda.synchronize()
     return acts
 
 
-for mode in ("eager", "graph"):
+for mode, stoch in (("eager", False), ("eager", True), ("graph", False), ("graph", True)):
     if mode == "graph":
-        if not hasattr(pol, "enable_step_graph"):
-            break
-        pol.enable_step_graph()
-    run(10)
+        pol.auto_step_graph(True)       # what act() does by itself: the step is captured from the third same-shape call on
+    else:
+        pol.disable_step_graph()
+    run(10, stoch)
     t0 = time.perf_counter()
-    acts = run(a.steps)
+    acts = run(a.steps, stoch)
     dt = (time.perf_counter() - t0) / a.steps
-    print(f"{mode:6s}: {dt*1e3:.3f} ms / step  ({1/dt:.0f} steps/s)   buttons[0..5] = {[int(x['buttons']) for x in acts[:6]]}")
+    print(f"{mode:6s} {'stochastic   ' if stoch else 'deterministic'}: {dt*1e3:.3f} ms / step  ({1/dt:.0f} steps/s)   buttons[0..5] = {[int(x['buttons']) for x in acts[:6]]}")
 
-if getattr(pol, "_step_graph", None) and "graph" in pol._step_graph:      # the GPU side alone: back-to-back replays, no host glue
-    gph = pol._step_graph["graph"]
+# ---- the reference's own wrapper, unmodified: MineRLAgent.get_action on a 640x360 observation (agent.py:190-206: resize, H2D copy,
+# policy.act(..., stochastic=True), action mapping on the host) over the HIP policy -- what run_agent.py's loop pays per step
+try:
+    from tests import ref_env
+    R = ref_env.reference()
+    if R is not None:
+        import numpy as np
+        ag_mod = R.agent
+        ref_class = ag_mod.MinecraftAgentPolicy
+        from vpt_amd.lib import policy as hip_policy
+        ag_mod.MinecraftAgentPolicy = hip_policy.MinecraftAgentPolicy           # the one-line swap of INTEGRATION.md
+        try:
+            agent = ag_mod.MineRLAgent(ref_env.FakeEnv(ag_mod), device="cuda", policy_kwargs=pk, pi_head_kwargs=dict(temperature=2.0))
+        finally:
+            ag_mod.MinecraftAgentPolicy = ref_class
+        agent.policy.load_state_dict(pol.state_dict(), strict=False)
+        agent.policy.set_precision(pol.precision)
+        rng = np.random.default_rng(0)
+        obs = [{"pov": rng.integers(0, 256, (360, 640, 3), dtype=np.uint8)} for _ in range(16)]
+        for variant in ("auto graph (default)", "eager (VPT_STEP_GRAPH=0)"):
+            if variant.startswith("eager"):
+                agent.policy.disable_step_graph()
+            agent.reset()
+            for i in range(12):
+                agent.get_action(obs[i % 16])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(a.steps):
+                act = agent.get_action(obs[i % 16])
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / a.steps
+            print(f"wrapper: unmodified MineRLAgent.get_action (stochastic=True), {variant}: {dt*1e3:.3f} ms / step  ({1/dt:.0f} steps/s)")
+        # where the wrapper's time goes besides policy.act: its own host code
+        agent.policy.auto_step_graph(True)
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            agent._env_obs_to_agent(obs[i % 16])
+        torch.cuda.synchronize()
+        print(f"wrapper: _env_obs_to_agent alone (resize stub + from_numpy + H2D): {(time.perf_counter() - t0) / a.steps * 1e3:.3f} ms / step")
+except Exception as e:
+    print("wrapper measurement unavailable:", type(e).__name__, e)
+
+pol.auto_step_graph(True)
+run(10, True)
+sg = getattr(pol, "_step_graph", None)
+if sg and "graphs" in sg and "stochastic" in sg["graphs"]:      # the GPU side alone: back-to-back replays, no host glue
+    gph = sg["graphs"]["stochastic"][0]
     for _ in range(10):
         gph.replay()
     torch.cuda.synchronize()
@@ -52,7 +97,7 @@ if getattr(pol, "_step_graph", None) and "graph" in pol._step_graph:      # the 
     dt = (time.perf_counter() - t0) / a.steps
     print(f"replay: {dt*1e3:.3f} ms / graph replay (no act() glue: input copies, output clones, python)")
     import cProfile, pstats, io
-    pr = cProfile.Profile(); pr.enable(); run(200); pr.disable()
+    pr = cProfile.Profile(); pr.enable(); run(200, True); pr.disable()
     sio = io.StringIO(); pstats.Stats(pr, stream=sio).sort_stats("cumulative").print_stats(18)
     print("\n".join(l[:150] for l in sio.getvalue().splitlines()[:40]))
 

@@ -21,7 +21,7 @@ _D = ctypes.c_double
 
 # name -> argtypes, exactly as declared in include/vpt_hip.h
 SIGNATURES = {
-    "vpt_conv_first_forward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vpt_conv_first_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_conv3d_t5_forward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_pack_conv3x3": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
     "vpt_pack_linear": [_P, _P, _I, _I, _I, _I, _I, _P],
@@ -30,7 +30,7 @@ SIGNATURES = {
     "vpt_chw_to_blocked": [_P, _P, ctypes.c_int64, _I, _I, _I, _P],
     "vpt_conv3x3_forward": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_conv3x3_forward_tiled": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "vpt_conv3x3_pool_forward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vpt_conv3x3_pool_forward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vpt_conv3x3_forward_folded": [_P] * 12 + [_I, _I, _I, _I, _I, _P],
     "vpt_channel_stats": [_P, _P, _I, _I, _I, _P],
     "vpt_nfold_coef": [_P] * 12 + [_I, _I, _I, _I, _P],

@@ -66,10 +66,11 @@ int64_t vpt_workspace_bytes(int op, int frames, int H, int W, int Cin, int Cout)
   }
 }
 
-int vpt_conv_first_forward(const uint8_t* img, const void* wfrag, void* y, double* stats_out, const float* out_gain,
+int vpt_conv_first_forward(const uint8_t* img, const void* wfrag, void* y, double* stats_out, const float* out_gain, double* chs_out,
                            int frames, int H, int W, int Cout, void* stream) {
+  if (chs_out && Cout > 128) return fail(-1, "vpt_conv_first_forward: chs_out needs Cout <= 128 (use vpt_channel_stats)");
   VptConvFirstArgs a;
-  a.img = img; a.wfrag = (const vpt_op16*)wfrag; a.y = (vpt_op16*)y; a.stats_out = stats_out; a.out_gain = out_gain;
+  a.img = img; a.wfrag = (const vpt_op16*)wfrag; a.y = (vpt_op16*)y; a.stats_out = stats_out; a.out_gain = out_gain; a.chs_out = chs_out;
   a.frames = frames; a.H = H; a.W = W; a.Cout = Cout; a.NT = (Cout + 127) / 128;
   CHECK_LAUNCH(vpt_conv_first_launch(&a, (hipStream_t)stream), "vpt_conv_first_forward");
 }
@@ -100,7 +101,7 @@ int vpt_conv3x3_forward_tiled(const void* x, const void* wpk, const float* edge_
   a.frames = frames; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.NT = (Cout + 127) / 128; a.CoutPad = a.NT * 128;
   a.inv_count_in = 1.0 / ((double)Cin * H * W);
-  a.bwd = 0; a.xin = nullptr; a.coef = nullptr; a.pool = 0; a.seam_r = nullptr; a.seam_c = nullptr; a.out_gain = nullptr;
+  a.bwd = 0; a.xin = nullptr; a.coef = nullptr; a.pool = 0; a.seam_r = nullptr; a.seam_c = nullptr; a.out_gain = nullptr; a.chs_out = nullptr;
   a.kk_frame = a.rs_frame = a.res_scale = a.res_bias = nullptr;
   CHECK_LAUNCH(vpt_conv3x3_launch(&a, (hipStream_t)stream), "vpt_conv3x3_forward");
 }
@@ -119,7 +120,7 @@ int vpt_conv3x3_forward_folded(const void* x, const void* wpk, const float* edge
   a.frames = frames; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.NT = (Cout + 127) / 128; a.CoutPad = a.NT * 128;
   a.inv_count_in = 1.0 / ((double)Cin * H * W);
-  a.bwd = 0; a.xin = nullptr; a.coef = nullptr; a.pool = 0; a.seam_r = nullptr; a.seam_c = nullptr; a.out_gain = nullptr;
+  a.bwd = 0; a.xin = nullptr; a.coef = nullptr; a.pool = 0; a.seam_r = nullptr; a.seam_c = nullptr; a.out_gain = nullptr; a.chs_out = nullptr;
   a.kk_frame = kk_frame; a.rs_frame = rs_frame; a.res_scale = res_bias ? res_scale : nullptr; a.res_bias = res_bias;
   CHECK_LAUNCH(vpt_conv3x3_launch(&a, (hipStream_t)stream), "vpt_conv3x3_forward_folded");
 }
@@ -146,8 +147,8 @@ int vpt_nfold_coef(const double* tot, const double* chs, const float* gain, cons
 int64_t vpt_conv3x3_pool_seam_elems(int frames, int H, int W, int Cout) { return (int64_t)frames * Cout * ((int64_t)(H / 16) * W + (int64_t)(W / 16) * H); }
 
 int vpt_conv3x3_pool_forward(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg, const double* stats_in,
-                             void* pooled, void* seam_scratch, double* stats_out, const float* out_gain, int frames, int H, int W, int Cin, int Cout,
-                             int phases, void* stream) {
+                             void* pooled, void* seam_scratch, double* stats_out, const float* out_gain, double* chs_out, int frames, int H, int W,
+                             int Cin, int Cout, int phases, void* stream) {
   if (!stats_in || !pooled || !seam_scratch) return fail(-1, "vpt_conv3x3_pool_forward: stats_in, pooled and seam_scratch are required");
   if (phases < 1 || phases > 3) return fail(-1, "vpt_conv3x3_pool_forward: phases = 1 (tiles), 2 (seams) or 3 (both)");
   if ((H & 15) || (W & 15) || (Cout & 31)) return fail(-1, "vpt_conv3x3_pool_forward: H, W multiples of 16, Cout of 32");
@@ -158,7 +159,7 @@ int vpt_conv3x3_pool_forward(const void* x, const void* wpk, const float* edge_s
   a.frames = frames; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.NT = (Cout + 127) / 128; a.CoutPad = a.NT * 128;
   a.inv_count_in = 1.0 / ((double)Cin * H * W);
-  a.bwd = 0; a.xin = nullptr; a.coef = nullptr; a.pool = 1; a.out_gain = out_gain;
+  a.bwd = 0; a.xin = nullptr; a.coef = nullptr; a.pool = 1; a.out_gain = out_gain; a.chs_out = chs_out;
   a.kk_frame = a.rs_frame = a.res_scale = a.res_bias = nullptr;
   a.seam_r = (vpt_op16*)seam_scratch;
   a.seam_c = a.seam_r + (size_t)frames * Cout * (H / 16) * W;
@@ -168,7 +169,7 @@ int vpt_conv3x3_pool_forward(const void* x, const void* wpk, const float* edge_s
   }
   if (!(phases & 2)) return 0;
   VptPoolSeamArgs p;
-  p.y = a.y; p.seam_r = a.seam_r; p.seam_c = a.seam_c; p.stats_out = stats_out; p.gain = out_gain; p.frames = frames; p.CB = Cout / 32; p.H = H; p.W = W;
+  p.y = a.y; p.seam_r = a.seam_r; p.seam_c = a.seam_c; p.stats_out = stats_out; p.gain = out_gain; p.chs_out = chs_out; p.frames = frames; p.CB = Cout / 32; p.H = H; p.W = W;
   CHECK_LAUNCH(vpt_pool_seam_launch(&p, (hipStream_t)stream), "vpt_conv3x3_pool_forward (seams)");
 }
 
@@ -179,7 +180,7 @@ int vpt_conv3x3_dgrad(const void* dacc, const void* wpk_t, const void* skip, con
   a.stats_in = nullptr; a.res = (const vpt_op16*)skip; a.y = (vpt_op16*)dx; a.stats_out = nullptr;
   a.frames = frames; a.H = H; a.W = W; a.Cin = Cout; a.Cout = Cin;   // roles swap in the transposed convolution
   a.NT = (Cin + 127) / 128; a.CoutPad = a.NT * 128; a.inv_count_in = 1.0;
-  a.bwd = 1; a.xin = (const vpt_op16*)xin; a.coef = coef; a.tiling = 1; a.pool = 0; a.seam_r = nullptr; a.seam_c = nullptr; a.out_gain = nullptr;
+  a.bwd = 1; a.xin = (const vpt_op16*)xin; a.coef = coef; a.tiling = 1; a.pool = 0; a.seam_r = nullptr; a.seam_c = nullptr; a.out_gain = nullptr; a.chs_out = nullptr;
   a.kk_frame = a.rs_frame = a.res_scale = a.res_bias = nullptr;
   CHECK_LAUNCH(vpt_conv3x3_launch(&a, (hipStream_t)stream), "vpt_conv3x3_dgrad");
 }

@@ -624,6 +624,9 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     const int PH = a.H >> 1, PW = a.W >> 1;
     const bool top_open = ty0 > 0, left_open = tx0 > 0;      // the tile's first pooled row / column is incomplete
     float p_sum = 0.f, p_sq = 0.f;
+    float c1[8], c2[8];      // per-channel sums of the STORED (scaled, rounded) complete pixels: a thread's four items share the octet tid & 15
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { c1[k] = 0.f; c2[k] = 0.f; }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int item = tid + 256 * it;
@@ -655,6 +658,12 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
             vals[0] *= g0.x; vals[1] *= g0.y; vals[2] *= g0.z; vals[3] *= g0.w; vals[4] *= g1.x; vals[5] *= g1.y; vals[6] *= g1.z; vals[7] *= g1.w;
             mv = pack8(vals);
           }
+          if (a.chs_out) {
+            float q[8];
+            unpack8(mv, q);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { c1[k] += q[k]; c2[k] = fmaf(q[k], q[k], c2[k]); }
+          }
         }
         *(u32x4*)(a.y + off) = mv;
       }
@@ -676,6 +685,27 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
       }
     }
     s_sum2.x = p_sum; s_sum2.y = 0.f; s_sq2.x = p_sq; s_sq2.y = 0.f;
+    if (a.chs_out) {
+      // threads tid = octet + 16 q share an octet: lanes octet + 16 {0..3} of each wave (two exchanges), then the four waves through the
+      // epilogue-table area of the LDS (dead since phase 1), then one fp64 atomic per (channel, moment): 256 per tile
+      float* scr = (float*)(smem + KK_OFF);          // [4 waves][16 octets][16]
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        c1[k] += __shfl_xor(c1[k], 16, 64); c1[k] += __shfl_xor(c1[k], 32, 64);
+        c2[k] += __shfl_xor(c2[k], 16, 64); c2[k] += __shfl_xor(c2[k], 32, 64);
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { scr[(w * 16 + lane) * 16 + k] = c1[k]; scr[(w * 16 + lane) * 16 + 8 + k] = c2[k]; }
+      }
+      __syncthreads();
+      {
+        const int o = tid >> 4, k = tid & 15;
+        const float t = (scr[(0 * 16 + o) * 16 + k] + scr[(1 * 16 + o) * 16 + k]) + (scr[(2 * 16 + o) * 16 + k] + scr[(3 * 16 + o) * 16 + k]);
+        const int ch = nt * 128 + o * 8 + (k & 7);
+        if (ch < a.Cout) atomicAdd(a.chs_out + ((size_t)f * a.Cout + ch) * 2 + (k >> 3), (double)t);
+      }
+    }
   } else {
   if (nvalid[1]) epilogue(std::integral_constant<int, 2>{});
   else if (nvalid[0]) epilogue(std::integral_constant<int, 1>{});
@@ -950,21 +980,23 @@ extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream
 // Work per frame: ((H/16 - 1) * W/2 + (W/16 - 1) * (H/2 - (H/16 - 1))) pixels x C/8 sixteen-byte items -- 18 % of the pooled tensor at
 // 64 x 64, instead of the whole pre-pool tensor written and read back.
 __global__ __launch_bounds__(256) void vpt_pool_seam_kernel(VptPoolSeamArgs a) {
+  // one workgroup per (frame, 32-channel block): thread = (seam pixel slot tid >> 2, channel octet tid & 3), a slot walks the seam pixels in steps of 64
   typedef short i16x8 __attribute__((ext_vector_type(8)));
+  __shared__ float red[4][4][18];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int PH = a.H >> 1, PW = a.W >> 1, TY = a.H >> 4, TX = a.W >> 4;
   const int n_row = (TY - 1) * PW;                   // pixels on row seams
   const int col_len = PH - (TY - 1);                 // pixels of one column seam that are not on a row seam
   const int n_pix = n_row + (TX - 1) * col_len;
-  const int per_frame = n_pix * a.CB * 4;            // 16-byte items
-  const int blocks_per_frame = (per_frame + 255) / 256;
-  const int f = blockIdx.x / blocks_per_frame;
-  const int item = (blockIdx.x - f * blocks_per_frame) * 256 + threadIdx.x;
-  float s_sum = 0.f, s_sq = 0.f;
-  if (item < per_frame) {
-    const int oct = item & 3;
-    int r = item >> 2;
-    const int pix = r % n_pix;
-    const int cb = r / n_pix;
+  const int cb = blockIdx.x % a.CB, f = blockIdx.x / a.CB;
+  const int oct = tid & 3;
+  const size_t plane = (size_t)(f * a.CB + cb);
+  float s_sum = 0.f, s_sq = 0.f;                     // statistics of the UNscaled finished pixels (the frame statistics of P)
+  float c1[8], c2[8];                                // per-channel sums of the STORED pixels
+  float gv[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { c1[k] = 0.f; c2[k] = 0.f; gv[k] = a.gain ? a.gain[cb * 32 + oct * 8 + k] : 1.f; }
+  for (int pix = tid >> 2; pix < n_pix; pix += 64) {
     int J, I;
     if (pix < n_row) { J = (pix / PW + 1) * 8; I = pix % PW; }
     else {
@@ -972,7 +1004,6 @@ __global__ __launch_bounds__(256) void vpt_pool_seam_kernel(VptPoolSeamArgs a) {
       I = (t + 1) * 8;
       J = (k == 0) ? 0 : (k - 1) / 7 * 8 + (k - 1) % 7 + 1;
     }
-    const size_t plane = (size_t)(f * a.CB + cb);
     vpt_op16* yp = a.y + (plane * PH * PW + (size_t)(J * PW + I)) * 32 + oct * 8;
     i16x8 m = *(const i16x8*)yp;
     if ((J & 7) == 0 && J > 0) {
@@ -992,19 +1023,45 @@ __global__ __launch_bounds__(256) void vpt_pool_seam_kernel(VptPoolSeamArgs a) {
       }
     }
     float vals[8];
-    unpack8(__builtin_bit_cast(u32x4, m), vals);
+    u32x4 mv = __builtin_bit_cast(u32x4, m);
+    unpack8(mv, vals);
 #pragma unroll
     for (int k = 0; k < 8; ++k) { s_sum += vals[k]; s_sq = fmaf(vals[k], vals[k], s_sq); }
     if (a.gain) {
-      const float* gp = a.gain + cb * 32 + oct * 8;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) vals[k] *= gp[k];
-      *(u32x4*)yp = pack8(vals);
-    } else {
-      *(i16x8*)yp = m;
+      for (int k = 0; k < 8; ++k) vals[k] *= gv[k];
+      mv = pack8(vals);
+      unpack8(mv, vals);
     }
+    *(u32x4*)yp = mv;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { c1[k] += vals[k]; c2[k] = fmaf(vals[k], vals[k], c2[k]); }
   }
-  if (a.stats_out) block_stats_atomic(s_sum, s_sq, a.stats_out, f);
+  // reduce: lanes with the same octet (lane & 3), then the four waves
+#pragma unroll
+  for (int off = 4; off < 64; off <<= 1) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { c1[k] += __shfl_xor(c1[k], off, 64); c2[k] += __shfl_xor(c2[k], off, 64); }
+    s_sum += __shfl_xor(s_sum, off, 64); s_sq += __shfl_xor(s_sq, off, 64);
+  }
+  if (lane < 4) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { red[w][lane][k] = c1[k]; red[w][lane][8 + k] = c2[k]; }
+    red[w][lane][16] = s_sum; red[w][lane][17] = s_sq;
+  }
+  __syncthreads();
+  if (tid < 64 && a.chs_out) {
+    const int o = tid >> 4, k = tid & 15;
+    const float t = (red[0][o][k] + red[1][o][k]) + (red[2][o][k] + red[3][o][k]);
+    atomicAdd(a.chs_out + ((size_t)f * a.CB * 32 + cb * 32 + o * 8 + (k & 7)) * 2 + (k >> 3), (double)t);
+  }
+  if (tid >= 64 && tid < 66 && a.stats_out) {        // the frame totals: four octets x four waves
+    const int k = 16 + (tid - 64);
+    float t = 0.f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) t += (red[0][o][k] + red[1][o][k]) + (red[2][o][k] + red[3][o][k]);
+    atomicAdd(a.stats_out + 2 * f + (tid - 64), (double)t);
+  }
 }
 
 extern "C" int vpt_pool_seam_launch(const VptPoolSeamArgs* a, hipStream_t stream) {
@@ -1012,8 +1069,7 @@ extern "C" int vpt_pool_seam_launch(const VptPoolSeamArgs* a, hipStream_t stream
   const int PH = a->H >> 1, PW = a->W >> 1, TY = a->H >> 4, TX = a->W >> 4;
   const int n_pix = (TY - 1) * PW + (TX - 1) * (PH - (TY - 1));
   if (n_pix == 0) return 0;                          // a single tile per frame: every window is inside it
-  const int per_frame = n_pix * a->CB * 4;
-  const long grid = (long)a->frames * ((per_frame + 255) / 256);
+  const long grid = (long)a->frames * a->CB;
   if (grid > 0x7fffffffL) return -2;
   hipLaunchKernelGGL(vpt_pool_seam_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -3;

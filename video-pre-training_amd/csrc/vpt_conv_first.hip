@@ -25,6 +25,10 @@ typedef short i16x8 __attribute__((ext_vector_type(8)));
 // barriers per tile with nothing else to run.
 #define CF_THREADS 512
 
+// CHS: also accumulate the per-channel sums of the stored tensor (a.chs_out, NT = 1).  The pooling items are then mapped so that BOTH items
+// of a thread have the same channel octet (tid & 15): 16 running sums per thread instead of 32 -- the kernel must stay within 128 registers
+// (four waves per SIMD) -- and the 16 lanes of a ds_read_b128 group read the 256 contiguous bytes of one conv pixel.
+template <bool CHS>
 __global__ __launch_bounds__(CF_THREADS, 4) void vpt_conv_first_kernel(VptConvFirstArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[CF_SMEM_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -61,6 +65,36 @@ __global__ __launch_bounds__(CF_THREADS, 4) void vpt_conv_first_kernel(VptConvFi
   // depend on how the tile list happens to be cut into workgroup ranges, i.e. on the batch size)
   int nt_loaded = -1, stat_f = -1;
   double d_sum = 0.0, d_sq = 0.0;
+  // Per-channel sums of the STORED tensor (a.chs_out: the GroupNorm-`n` fold needs sum_p Q and sum_p Q^2 per channel and frame).  A thread's
+  // pooling items keep their channel octet from tile to tile, so the sums run in registers over all tiles of a frame this workgroup owns
+  // and are combined across threads (4 lanes x 8 waves per octet) only when the frame changes -- once per ~64 tiles -- through the then
+  // idle conv-tile area of the LDS, ending in one fp64 atomic per (channel, moment).
+  float c1[8], c2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { c1[k] = 0.f; c2[k] = 0.f; }
+  auto flush_channel_sums = [&](int fr) {      // uniform; the caller guarantees the conv tile is idle and follows up with a barrier
+    float* scr = (float*)smem;                 // [8 waves][16 octets][16]
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      c1[k] += __shfl_xor(c1[k], 16, 64); c1[k] += __shfl_xor(c1[k], 32, 64);
+      c2[k] += __shfl_xor(c2[k], 16, 64); c2[k] += __shfl_xor(c2[k], 32, 64);
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { scr[((tid >> 6) * 16 + lane) * 16 + k] = c1[k]; scr[((tid >> 6) * 16 + lane) * 16 + 8 + k] = c2[k]; }
+    }
+    __syncthreads();
+    if (tid < 256) {
+      const int o = tid >> 4, k = tid & 15;            // channel octet, value (0..7 sums, 8..15 sums of squares)
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += scr[(w * 16 + o) * 16 + k];
+      const int ch = o * 8 + (k & 7);
+      if (ch < a.Cout) atomicAdd(a.chs_out + ((size_t)fr * a.Cout + ch) * 2 + (k >> 3), (double)t);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { c1[k] = 0.f; c2[k] = 0.f; }
+  };
   op16x8 wfr[4][2];
   // Two barriers per tile: [records(t) staged, counter 0] -> fetch(t + 1) into registers, conv slices -> barrier -> stage
   // records(t + 1) (the slices were their last readers), reset the counter, pool the conv tile -> barrier.
@@ -101,7 +135,9 @@ __global__ __launch_bounds__(CF_THREADS, 4) void vpt_conv_first_kernel(VptConvFi
     // A ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} (+32): the four lane quads of a
     // group take pooled columns 0, 2, 4, 6 or 1, 3, 5, 7 -- neighbouring pooled pixels are 2 * CT_RS = 8 banks apart and a quad
     // covers 16, so consecutive columns collide two by two (576 conflict cycles per tile, profiles/r03_experiments.md section 8)
-    const int oct4 = item & 3, pxl = (0x76452310u >> (4 * ((item >> 2) & 7))) & 7, pyl = (item >> 5) & 7, cbl = item >> 8;
+    int oct4, pxl, pyl, cbl;
+    if (CHS) { oct4 = item & 3; cbl = (item >> 2) & 3; pxl = (item >> 4) & 7; pyl = item >> 7; }     // octet (cbl, oct4) = tid & 15 for both items
+    else { oct4 = item & 3; pxl = (0x76452310u >> (4 * ((item >> 2) & 7))) & 7; pyl = (item >> 5) & 7; cbl = item >> 8; }
     const int cg = nt * 128 + cbl * 32 + oct4 * 8;
     const unsigned char* src = smem + ((2 * pyl) * 17 + 2 * pxl) * CT_RS + (cbl * 32 + oct4 * 8) * 2;
     i16x8 m = {0, 0, 0, 0, 0, 0, 0, 0};    // = ReLU: positive bf16 patterns order like signed 16-bit integers, negative ones stay below 0
@@ -127,6 +163,12 @@ __global__ __launch_bounds__(CF_THREADS, 4) void vpt_conv_first_kernel(VptConvFi
         vals[0] *= g0.x; vals[1] *= g0.y; vals[2] *= g0.z; vals[3] *= g0.w; vals[4] *= g1.x; vals[5] *= g1.y; vals[6] *= g1.z; vals[7] *= g1.w;
         mv = pack8(vals);
       }
+      if (CHS) {          // per-channel sums of what is STORED (rounded to 16 bits, scaled)
+        float q[8];
+        unpack8(mv, q);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { c1[k] += q[k]; c2[k] = fmaf(q[k], q[k], c2[k]); }
+      }
       const size_t off = ((size_t)(f * CB_out + (cg >> 5)) * PH * PW + (size_t)((py0 + pyl) * PW + px0 + pxl)) * 32 + (cg & 31);
       *(u32x4*)(a.y + off) = mv;
     }
@@ -136,6 +178,10 @@ __global__ __launch_bounds__(CF_THREADS, 4) void vpt_conv_first_kernel(VptConvFi
       d_sq += (double)wave_sum(s_sq);
     }
     __syncthreads();   // all pooling reads of the conv tile done before the next tile overwrites it
+    if (CHS && (nf != f || tile + 1 >= t_end)) {     // last tile of this frame in the workgroup's range: hand the per-channel sums over
+      flush_channel_sums(f);
+      __syncthreads();
+    }
   }
   if (a.stats_out && stat_f >= 0 && lane == 0) {
     atomicAdd(a.stats_out + 2 * stat_f, d_sum);
@@ -154,7 +200,9 @@ extern "C" int vpt_conv_first_launch(const VptConvFirstArgs* a, hipStream_t stre
   }
   long grid = (long)a->frames * (a->H >> 4) * (a->W >> 4) * a->NT;
   if ((long)a->frames * a->H * a->W * 3 > 0x7fffffffL) return -2;   // 32-bit pixel offsets inside a launch
+  if (a->chs_out && a->NT != 1) return -1;                          // running per-channel sums: one channel tile (Cout <= 128); else vpt_channel_stats
   if (grid > 2L * num_cu) grid = 2L * num_cu;
-  hipLaunchKernelGGL(vpt_conv_first_kernel, dim3((unsigned)grid), dim3(CF_THREADS), 0, stream, *a);
+  if (a->chs_out) hipLaunchKernelGGL(vpt_conv_first_kernel<true>, dim3((unsigned)grid), dim3(CF_THREADS), 0, stream, *a);
+  else hipLaunchKernelGGL(vpt_conv_first_kernel<false>, dim3((unsigned)grid), dim3(CF_THREADS), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -36,6 +36,7 @@ struct VptConv3x3Args {
   int pool;
   vpt_op16* seam_r;
   vpt_op16* seam_c;
+  double* chs_out;         // pool mode, optional [F][Cout][2], accumulated: per-channel (sum, sum of squares) of the stored complete pixels
   const float* out_gain;   // pool mode, optional [Cout]: the pooled pixels that are complete in-tile are stored multiplied by it (GroupNorm `n`'s gain,
                            // folded: the seam kernel does the same for the others); the statistics are those of the unscaled values
   // dgrad mode (bwd != 0): no GroupNorm fold, no ReLU; out = conv + res + coef[f][0] + coef[f][1] * xin
@@ -72,6 +73,7 @@ struct VptPoolSeamArgs {    // finishes the pooled pixels whose 3x3 window cross
   const vpt_op16* seam_c;  // [F][CB][W/16][H][32]  column 15 of every tile column
   double* stats_out;       // [F][2] accumulated: the seam pixels' share of the pooled frame's statistics
   const float* gain;       // optional [CB*32]: the finished pixels are stored multiplied by it (statistics: of the unscaled values)
+  double* chs_out;         // optional [F][CB*32][2], accumulated: per-channel (sum, sum of squares) of the finished pixels as stored
   int frames, CB, H, W;    // H, W: the PRE-pool size
 };
 
@@ -91,6 +93,7 @@ struct VptConvFirstArgs {
   vpt_op16* y;             // pooled output [F][Cout/32][H/2][W/2][32]
   double* stats_out;       // [F][2]
   const float* out_gain;   // optional [Cout]: the pooled output is stored multiplied by it (statistics: of the unscaled values)
+  double* chs_out;         // optional [F][Cout][2], accumulated: per-channel (sum, sum of squares) of the stored output (Cout <= 128)
   int frames, H, W, Cout, NT;
 };
 

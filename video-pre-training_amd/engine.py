@@ -155,6 +155,7 @@ class PolicyEngine:
         self.fuse_pool_sub = int(os.environ.get("VPT_FUSE_POOL_SUB", 0))      # frames per pool-fused launch (0: the whole chunk)
         # each stack's GroupNorm `n` folded into its first block (no affine pass; needs fuse_pool): 0 = the vpt_affine_kernel pass
         self.fold_n = os.environ.get("VPT_FOLD_N", "1") != "0"
+        self.fold_stats_in_producer = os.environ.get("VPT_FOLD_STATS", "1") != "0"     # 0: per-channel sums by a pass of their own (A/B)
         self._streams = []
         self._attn_done = None      # arrival counters of the in-place acting step (ops.masked_attention_step)
         self._rng_state = None      # in-kernel sampler state {seed, step} (ops.new_rng_state), created on first stochastic use
@@ -278,8 +279,12 @@ class PolicyEngine:
             p = f"net.img_process.cnn.stacks.{s}."
             s_pool = nxt()
             gn = w[p + "n.g"] if fold else None      # folded: the producer stores Q = n.weight * P (statistics: those of P)
+            # ... and the per-channel sums of Q the fold needs (a pass of their own only where the producer cannot: vpt_channel_stats)
+            chs = torch.zeros(f, c, 2, dtype=torch.float64, device=dev) if fold and self.fold_stats_in_producer else None
             if s == 0 and x0 is None:
-                pooled = ops.conv_first(img, w[p + "firstconv"], c, stats_out=s_pool, out_gain=gn)
+                if c > 128:
+                    chs = None
+                pooled = ops.conv_first(img, w[p + "firstconv"], c, stats_out=s_pool, out_gain=gn, chs_out=chs)
             else:
                 wpk, sa, sg = w[p + "firstconv"]
                 if self.fuse_pool and tiling == "throughput":
@@ -290,9 +295,10 @@ class PolicyEngine:
                         pooled = torch.empty(f, c // 32, x.shape[2] // 2, x.shape[3] // 2, 32, dtype=x.dtype, device=x.device)
                         for i in range(0, f, fsub):
                             j = min(i + fsub, f)
-                            ops.conv3x3_pool(x[i:j], wpk, sa, sg, s_x[i:j], c, stats_out=s_pool[i:j], out=pooled[i:j], out_gain=gn)
+                            ops.conv3x3_pool(x[i:j], wpk, sa, sg, s_x[i:j], c, stats_out=s_pool[i:j], out=pooled[i:j], out_gain=gn,
+                                             chs_out=chs[i:j] if chs is not None else None)
                     else:
-                        pooled = ops.conv3x3_pool(x, wpk, sa, sg, s_x, c, stats_out=s_pool, out_gain=gn)
+                        pooled = ops.conv3x3_pool(x, wpk, sa, sg, s_x, c, stats_out=s_pool, out_gain=gn, chs_out=chs)
                 else:
                     sub = self.pool_subchunk
                     if sub and f > sub:
@@ -312,7 +318,8 @@ class PolicyEngine:
                 # GroupNorm `n` without a pass of its own: x = n(P) is never written.  Block 0's conv0 convolves Q with its
                 # ordinary weights and a per-frame epilogue table, conv1 takes its residual as res_scale * Q + res_bias[c].
                 hw = pooled.shape[2] * pooled.shape[3]
-                chs = ops.channel_stats(pooled)
+                if chs is None:
+                    chs = ops.channel_stats(pooled)
                 wpk, sa, sg = w[f"{p}blocks.0.conv0"]
                 tb, tg = self._nfold_tables(s)
                 kk, rs, rsc, rb = ops.nfold_coef(s_pool, chs, w[p + "n.g"], w[p + "n.b"], sa, sg, tb, tg, hw, c)
@@ -479,6 +486,7 @@ class IDMEngine(PolicyEngine):
         self.fuse_pool = os.environ.get("VPT_FUSE_POOL", "1") != "0"
         self.fuse_pool_sub = 0
         self.fold_n = os.environ.get("VPT_FOLD_N", "1") != "0"
+        self.fold_stats_in_producer = os.environ.get("VPT_FOLD_STATS", "1") != "0"
         self._streams = []
         self._rng_state = None
         self.w = {}

@@ -158,14 +158,16 @@ def chw_to_blocked(x, c, h, w):
     return out
 
 
-def conv_first(img_u8, wfrag, cout, stats_out=None, out_gain=None):
+def conv_first(img_u8, wfrag, cout, stats_out=None, out_gain=None, chs_out=None):
     """img_u8 [F,H,W,3] uint8 -> pooled blocked bf16 [F, cout/32, H/2, W/2, 32].  out_gain fp32 [cout]: stored times it per channel
-    (GroupNorm `n`'s gain when the norm is folded into the first block); stats_out are the statistics of the unscaled tensor."""
+    (GroupNorm `n`'s gain when the norm is folded into the first block); stats_out are the statistics of the unscaled tensor.
+    chs_out fp64 [F, cout, 2] (zeroed; cout <= 128): receives the per-channel sums of the stored tensor (what channel_stats() computes)."""
     _chk(img_u8, torch.uint8, "img"); _chk(wfrag, OP16, "wfrag"); _chk(stats_out, torch.float64, "stats_out"); _chk(out_gain, torch.float32, "out_gain")
+    _chk(chs_out, torch.float64, "chs_out")
     f, h, w, _ = img_u8.shape
     dt, fmt = _fmt(wfrag)
     y = torch.empty(f, cout // 32, h // 2, w // 2, 32, dtype=dt, device=img_u8.device)
-    _call("vpt_conv_first_forward", dict(flops=2.0 * f * h * w * cout * 27, bytes=f * (h * w * 3 + h * w * cout // 2)), ptr(img_u8), ptr(wfrag), ptr(y), ptr(stats_out), ptr(out_gain), f, h, w, cout, _stream(), fmt=fmt)
+    _call("vpt_conv_first_forward", dict(flops=2.0 * f * h * w * cout * 27, bytes=f * (h * w * 3 + h * w * cout // 2)), ptr(img_u8), ptr(wfrag), ptr(y), ptr(stats_out), ptr(out_gain), ptr(chs_out), f, h, w, cout, _stream(), fmt=fmt)
     return y
 
 
@@ -193,12 +195,12 @@ def conv3x3(x, wpk, edge_sa, edge_sg, stats_in, cout, res=None, stats_out=None, 
     return out
 
 
-def conv3x3_pool(x, wpk, edge_sa, edge_sg, stats_in, cout, stats_out=None, out=None, out_gain=None):
+def conv3x3_pool(x, wpk, edge_sa, edge_sg, stats_in, cout, stats_out=None, out=None, out_gain=None, chs_out=None):
     """GN fold + conv3x3 + ReLU + max_pool2d(3, 2, 1) in one pass (vpt_conv3x3_pool_forward): x blocked [F,Cin/32,H,W,32] -> pooled
     [F,cout/32,H/2,W/2,32] (+ its frame statistics into stats_out) -- what conv3x3() followed by maxpool() returns, bit for bit, without
     the pre-pool tensor's round trip through HBM.  Inference path of the stacks' firstconv (the BC step keeps the pre-pool tensor)."""
     _chk(x, OP16, "x"); _chk(wpk, OP16, "wpk"); _chk(edge_sa, torch.float32, "edge_sa"); _chk(edge_sg, torch.float32, "edge_sg")
-    _chk(stats_in, torch.float64, "stats_in"); _chk(stats_out, torch.float64, "stats_out"); _chk(out, OP16, "out"); _chk(out_gain, torch.float32, "out_gain")
+    _chk(stats_in, torch.float64, "stats_in"); _chk(stats_out, torch.float64, "stats_out"); _chk(out, OP16, "out"); _chk(out_gain, torch.float32, "out_gain"); _chk(chs_out, torch.float64, "chs_out")
     f, cb, h, w, _ = x.shape
     dt, fmt = _fmt(x, wpk, out)
     if out is not None and (tuple(out.shape) != (f, cout // 32, h // 2, w // 2, 32) or not out.is_contiguous()):
@@ -206,7 +208,7 @@ def conv3x3_pool(x, wpk, edge_sa, edge_sg, stats_in, cout, stats_out=None, out=N
     y = out if out is not None else torch.empty(f, cout // 32, h // 2, w // 2, 32, dtype=dt, device=x.device)
     seam = torch.empty(_native.load(fmt).vpt_conv3x3_pool_seam_elems(f, h, w, cout), dtype=dt, device=x.device)
     meta = dict(flops=2.0 * f * h * w * cout * 9 * cb * 32, bytes=2.0 * f * h * w * (cb * 32 + cout * 0.25))
-    args = (ptr(x), ptr(wpk), ptr(edge_sa), ptr(edge_sg), ptr(stats_in), ptr(y), ptr(seam), ptr(stats_out), ptr(out_gain), f, h, w, cb * 32, cout)
+    args = (ptr(x), ptr(wpk), ptr(edge_sa), ptr(edge_sg), ptr(stats_in), ptr(y), ptr(seam), ptr(stats_out), ptr(out_gain), ptr(chs_out), f, h, w, cb * 32, cout)
     if TIMER.enabled:    # the two launches timed apart: the convolution is the roofline kernel (vpt_conv3x3_kernel, pool-fused mode: same FLOPs)
         _call("vpt_conv3x3_pool_forward", meta, *args, 1, _stream(), fmt=fmt, label="vpt_conv3x3_pool_forward")
         _call("vpt_conv3x3_pool_forward", dict(bytes=2.0 * y.numel() * 0.4), *args, 2, _stream(), fmt=fmt, label="vpt_pool_seam")

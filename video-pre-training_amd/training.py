@@ -562,26 +562,30 @@ class BCTrainer:
         early = [n for n in self.trainable if not n.startswith("net.img_process.cnn.")]   # final before the CNN backward
         late = [n for n in self.trainable if n.startswith("net.img_process.cnn.")]
         pending, state = [], dict(early_sent=False)
+        # the gradients live in two flat fp32 arenas that persist across steps (distributed.GradArena): each tensor is copied in once when it
+        # is final, the collectives run in place on 64 MB slices of the arena, the optimiser reads the views -- no cat, no copy back
+        if getattr(self, "_arenas", None) is None:
+            self._arenas = tuple(D.GradArena(ns, [self.params[n].shape for n in ns], dev) for ns in (early, late))
+        arena_early, arena_late = self._arenas
 
         def start_trunk_exchange(g):
-            for n in early:
-                g[n] = g[n].contiguous()
-            pending.extend(D.bucketed_all_reduce_start([g[n] for n in early]))
+            arena_early.adopt(g)
+            pending.extend(arena_early.all_reduce_start())
             state["early_sent"] = True
 
         err, loss, grads, state_out = None, None, None, None
         try:
             loss, grads, state_out = self.loss_and_grads(img_u8, first, state_in, act_buttons, act_camera,
                                                          global_frames=m_global, on_trunk_grads=start_trunk_exchange, unscaled=False)
-            for n in late:
-                grads[n] = grads[n].contiguous()
-            pending.extend(D.bucketed_all_reduce_start([grads[n] for n in late]))
+            arena_late.adopt(grads)
+            pending.extend(arena_late.all_reduce_start())
         except Exception as e:          # e.g. out of memory on this rank: still take part in every collective (with zeros of
             err = e                     # the same shapes) so that the other ranks are not left blocked, then fail everywhere
-            zeros = lambda names: [torch.zeros_like(self.params[n], dtype=torch.float32) for n in names]
             if not state["early_sent"]:
-                pending.extend(D.bucketed_all_reduce_start(zeros(early)))
-            pending.extend(D.bucketed_all_reduce_start(zeros(late)))
+                arena_early.flat.zero_()
+                pending.extend(arena_early.all_reduce_start())
+            arena_late.flat.zero_()
+            pending.extend(arena_late.all_reduce_start())
         D.bucketed_all_reduce_finish(pending)
         tail = torch.tensor([0.0 if err is not None else float(loss) * m_local, 0.0 if err is not None else 1.0], device=dev)
         dist.all_reduce(tail)           # (sum over ranks of loss x local frames, number of healthy ranks)
