@@ -225,6 +225,46 @@ def test_linear(m, n, k, bias, relu, res, splitk):
         assert _relerr(o16.cpu().float(), ref) < 1e-2
 
 
+@pytest.mark.parametrize("bias,relu,res,mask,out_f32,out_bf16", [
+    (True, False, False, False, True, False),     # qkvr / heads
+    (True, False, True, False, True, False),      # proj / mlp1
+    (False, True, False, False, False, True),     # mlp0
+    (False, True, False, False, True, False),     # img linear / lastlayer (inference)
+    (False, True, False, False, True, True),      # ... (training forward keeps both)
+    (False, False, False, False, True, False),    # dgrad -> fp32
+    (False, False, False, False, False, True),    # dense dgrad -> 16-bit
+    (False, False, True, False, True, False),     # dgrad + skip
+    (False, False, False, True, False, True),     # dgrad through a ReLU gate -> 16-bit
+    (True, True, True, True, True, True),         # no dedicated instantiation: the generic epilogue
+])
+@pytest.mark.parametrize("m,n,k", [(300, 2048, 512), (777, 6304, 256), (256, 8764, 128)])
+def test_linear_epilogue_variants(bias, relu, res, mask, out_f32, out_bf16, m, n, k):
+    """Every compile-time epilogue of vpt_gemm_kernel (16-byte stores from the swapped-operand accumulator layout) and the generic one,
+    on ragged M (rows beyond M are never written), an N with a partial last 128-tile and an N that is only a multiple of 4."""
+    g = torch.Generator().manual_seed(40)
+    A = torch.randn(m, k, generator=g).to(torch.bfloat16)
+    W = torch.randn(n, k, generator=g) / k ** 0.5
+    b = torch.randn(n, generator=g) if bias else None
+    r = torch.randn(m, n, generator=g) if res else None
+    mk = (torch.randn(m, n, generator=g)).to(torch.bfloat16) if mask else None
+    ref = A.float() @ W.to(torch.bfloat16).float().t()
+    if bias:
+        ref = ref + b
+    if relu:
+        ref = torch.relu(ref)
+    if mask:
+        ref = torch.where(mk.float() > 0, ref, torch.zeros_like(ref))
+    if res:
+        ref = ref + r
+    o32, o16 = ops.linear(A.to(DEV), packing.pack_linear(W.to(DEV)), n, bias=b.to(DEV) if bias else None, res=r.to(DEV) if res else None,
+                          relu=relu, mask=mk.to(DEV) if mask else None, out_f32=out_f32, out_bf16=out_bf16)
+    torch.cuda.synchronize()
+    if out_f32:
+        assert tuple(o32.shape) == (m, n) and _relerr(o32.cpu(), ref) < 2e-3, _relerr(o32.cpu(), ref)
+    if out_bf16:
+        assert tuple(o16.shape) == (m, n) and _relerr(o16.cpu().float(), ref) < 1e-2
+
+
 @pytest.mark.parametrize("m,d,relu_in", [(5, 256, True), (130, 2048, False), (7, 3072, False)])
 def test_layernorm(m, d, relu_in):
     g = torch.Generator().manual_seed(5)

@@ -59,19 +59,21 @@ try:
         agent.policy.set_precision(pol.precision)
         rng = np.random.default_rng(0)
         obs = [{"pov": rng.integers(0, 256, (360, 640, 3), dtype=np.uint8)} for _ in range(16)]
+        obs128 = [{"pov": rng.integers(0, 256, (128, 128, 3), dtype=np.uint8)} for _ in range(16)]   # already at AGENT_RESOLUTION: cv2.resize is the identity
         for variant in ("auto graph (default)", "eager (VPT_STEP_GRAPH=0)"):
             if variant.startswith("eager"):
                 agent.policy.disable_step_graph()
-            agent.reset()
-            for i in range(12):
-                agent.get_action(obs[i % 16])
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(a.steps):
-                act = agent.get_action(obs[i % 16])
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / a.steps
-            print(f"wrapper: unmodified MineRLAgent.get_action (stochastic=True), {variant}: {dt*1e3:.3f} ms / step  ({1/dt:.0f} steps/s)")
+            for what, ob in (("640x360 obs (the image's cv2 STUB resizes in numpy: test infrastructure, ~2 ms)", obs), ("128x128 obs (no resize: policy + the wrapper's own host code)", obs128)):
+                agent.reset()
+                for i in range(12):
+                    agent.get_action(ob[i % 16])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(a.steps):
+                    act = agent.get_action(ob[i % 16])
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / a.steps
+                print(f"wrapper: unmodified MineRLAgent.get_action (stochastic=True), {variant}, {what}: {dt*1e3:.3f} ms / step  ({1/dt:.0f} steps/s)")
         # where the wrapper's time goes besides policy.act: its own host code
         agent.policy.auto_step_graph(True)
         t0 = time.perf_counter()

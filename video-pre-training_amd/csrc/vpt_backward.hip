@@ -243,7 +243,10 @@ extern "C" int vpt_colsum_launch(const VptColsumArgs* a, hipStream_t stream) {
 #define AB_D_OFF (AB_P_OFF + ATT_QT * ATT_SS)             // dP, then dS  [32][ATT_SS]
 #define AB_R_OFF (AB_D_OFF + ATT_QT * ATT_SS)
 #define AB_B_OFF (AB_R_OFF + ATT_QT * 10)
-#define AB_PT_OFF ((AB_B_OFF + 10 * 129 + 3) & ~3)        // partial tiles of key tile 4: [wave][16][64]
+#define AB_BP 133                                         // pitch of a b_nd row in LDS: odd, so that ten lanes reading one offset of ten DIFFERENT rows (the
+                                                          // dR loop) hit ten banks -- at pitch maxlen = 128 they all hit one (47 % of this kernel's LDS cycles
+                                                          // were bank conflicts in the round-3 PMC survey)
+#define AB_PT_OFF ((AB_B_OFF + 10 * AB_BP + 3) & ~3)      // partial tiles of key tile 4: [wave][16][64]
 #define AB_FLOATS (AB_PT_OFF + 4 * 16 * 64)
 
 // Round 2: every contraction runs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) with its operands taken straight from global
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void vpt_attn_bwd_kernel(VptAttnBwdArgs a) 
     const int r = idx / 10, n = idx - r * 10;
     Rs[idx] = (q0 + r < t) ? a.qkvr[(tok0 + q0 + r) * a.ld + 3 * hid + h * 10 + n] : 0.f;
   }
-  for (int idx = tid; idx < 10 * maxlen; idx += 256) Bs[idx] = a.b_nd[idx];
+  for (int idx = tid; idx < 10 * maxlen; idx += 256) { const int n = idx / maxlen; Bs[n * AB_BP + (idx - n * maxlen)] = a.b_nd[idx]; }
   __syncthreads();
 
   // row j of [memory ; chunk] -> its K (which = 1) / V (which = 2) row of this head, or null beyond the chunk
@@ -284,8 +287,13 @@ __global__ __launch_bounds__(256, 2) void vpt_attn_bwd_kernel(VptAttnBwdArgs a) 
     if (j - maxlen < t) return a.qkvr + (tok0 + j - maxlen) * a.ld + which * hid + h * ATT_DH;
     return nullptr;
   };
-  auto q_row = [&](int qi) -> const float* { return (q0 + qi < t) ? a.qkvr + (tok0 + q0 + qi) * a.ld + h * ATT_DH : nullptr; };
-  auto do_row = [&](int qi) -> const float* { return (q0 + qi < t) ? a.dout + (tok0 + q0 + qi) * hid + h * ATT_DH : nullptr; };
+  // query-indexed rows as (wave-uniform base pointer, 32-bit element offset or -1): one scalar register per row instead of a 64-bit pointer
+  // (the pointer-returning form kept 8 pointers x several unrolled iterations alive: 163 spilled SGPRs)
+  const float* qbase = a.qkvr + (tok0 + q0) * a.ld + h * ATT_DH;
+  const float* dobase = a.dout + (tok0 + q0) * hid + h * ATT_DH;
+  const int nq_valid = t - q0;                            // queries q0 + qi with qi < nq_valid exist
+  auto q_row = [&](int qi) -> const float* { return (qi < nq_valid) ? qbase + qi * a.ld : nullptr; };
+  auto do_row = [&](int qi) -> const float* { return (qi < nq_valid) ? dobase + qi * hid : nullptr; };
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   const uint8_t* memv = a.memvalid + (size_t)b * maxlen;
 
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void vpt_attn_bwd_kernel(VptAttnBwdArgs a) 
     if (vis) {
       float rb = 0.f;
 #pragma unroll
-      for (int n = 0; n < 10; ++n) rb = fmaf(Rs[qi * 10 + n], Bs[n * maxlen + off], rb);
+      for (int n = 0; n < 10; ++n) rb = fmaf(Rs[qi * 10 + n], Bs[n * AB_BP + off], rb);
       sc = dot * inv_dh + rb;
     }
     Ps[qi * ATT_SS + kk] = sc;
@@ -378,9 +386,11 @@ __global__ __launch_bounds__(256, 2) void vpt_attn_bwd_kernel(VptAttnBwdArgs a) 
   __syncthreads();
 
   const int dcol = w * 32 + l31;        // wave w owns d_head slice 32 w .. 32 w + 31 from here on
+  const float* kmem_h = a.kmem + (size_t)b * maxlen * hid + h * ATT_DH;        // K rows of the memory / of the chunk, this head
+  const float* kchunk_h = a.qkvr + tok0 * a.ld + hid + h * ATT_DH;
   // dV-like contraction: out[key][d] = scale * sum_query X[query][key] Y[query][d]; accumulated into the K / V columns of the
   // chunk's keys (memory keys are detached state: no gradient)
-  auto dv_like = [&](const float* X, auto yrow, int which, float scale) __attribute__((always_inline)) {
+  auto dv_like = [&](const float* X, const float* ybase, int ystride, int which, float scale) __attribute__((always_inline)) {
     f32x16 acc[5];
 #pragma unroll
     for (int kt = 0; kt < 5; ++kt)
@@ -391,10 +401,8 @@ __global__ __launch_bounds__(256, 2) void vpt_attn_bwd_kernel(VptAttnBwdArgs a) 
       float y[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float* r0 = yrow(8 * g + e);          // wave-uniform rows: scalar address arithmetic
-        const float* r1 = yrow(8 * g + 4 + e);
-        const float* rr = hi ? r1 : r0;
-        y[e] = rr ? rr[dcol] : 0.f;
+        const int qi = 8 * g + 4 * hi + e;          // this lane's query row of the k step
+        y[e] = (qi < nq_valid) ? ybase[qi * ystride + dcol] : 0.f;
       }
 #pragma unroll
       for (int kt = 0; kt < 5; ++kt) {
@@ -412,13 +420,15 @@ __global__ __launch_bounds__(256, 2) void vpt_attn_bwd_kernel(VptAttnBwdArgs a) 
     for (int kt = 0; kt < 5; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int jr = jr0 + kt * 32 + (r & 3) + 8 * (r >> 2);
-        if (jr >= 0 && jr < t) atomicAdd(colbase + (jr * a.ld + dcol), acc[kt][r] * scale);
+        int jr = jr0 + kt * 32 + (r & 3) + 8 * (r >> 2);
+        asm volatile("" : "+v"(jr));     // keep the validity test next to its atomic: hoisted and shared between the two calls, the 80 lane masks
+                                         // were 160 scalar registers, all spilled
+        if ((unsigned)jr < (unsigned)t) atomicAdd(colbase + (jr * a.ld + dcol), acc[kt][r] * scale);
       }
   };
   // ---- 4. dV += P^T dO ;  5. dK += dS^T Q / d_h ----
-  dv_like(Ps, do_row, 2, 1.0f);
-  dv_like(Ds, q_row, 1, inv_dh);
+  dv_like(Ps, dobase, hid, 2, 1.0f);
+  dv_like(Ds, qbase, a.ld, 1, inv_dh);
   // ---- 6. dQ = dS K / d_h (PV-like) ----
   {
     f32x16 o;
@@ -430,10 +440,9 @@ __global__ __launch_bounds__(256, 2) void vpt_attn_bwd_kernel(VptAttnBwdArgs a) 
       const f32x4 p4 = *(const f32x4*)(pa + 8 * g);
       float v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float* r0 = kv_row(jbase + 8 * g + e, 1);
-        const float* r1 = kv_row(jbase + 8 * g + 4 + e, 1);
-        const float* rr = hi ? r1 : r0;
+      for (int e = 0; e < 4; ++e) {          // per-LANE row arithmetic (32-bit offsets from two uniform bases), no wave-uniform pointer sets
+        const int j = jbase + 8 * g + 4 * hi + e;
+        const float* rr = (j < maxlen) ? kmem_h + (size_t)j * hid : ((j - maxlen < t) ? kchunk_h + (size_t)(j - maxlen) * a.ld : nullptr);
         v[e] = rr ? rr[dcol] : 0.f;
       }
       o = __builtin_amdgcn_mfma_f32_32x32x2f32(p4.x, v[0], o, 0, 0, 0);
@@ -454,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void vpt_attn_bwd_kernel(VptAttnBwdArgs a) 
     float s = 0.f;
     for (int kk = 0; kk < ATT_NK; ++kk) {
       const int off = maxlen - 1 + r - kk;
-      if (off >= 0 && off < maxlen) s = fmaf(Ds[r * ATT_SS + kk], Bs[n * maxlen + off], s);
+      if (off >= 0 && off < maxlen) s = fmaf(Ds[r * ATT_SS + kk], Bs[n * AB_BP + off], s);
     }
     if (q0 + r < t) a.dqkvr[(tok0 + q0 + r) * a.ld + 3 * hid + h * 10 + n] = s;
   }

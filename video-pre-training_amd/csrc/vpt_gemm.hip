@@ -20,8 +20,21 @@
 #define GB_RS 80
 #define GB_BYTES (2 * 128 * GB_RS)  // 20480
 
+// Epilogue variants are COMPILE-TIME (round 4): one instantiation per combination of stages a call site uses, so the kernel carries only the
+// pointers it needs across the main loop (the single runtime-flag version held all of them: 94 spilled SGPRs, reloaded around every tile) and
+// the epilogue has no branches.  GE_VEC: every row stride and N are multiples of 4 -- the MFMA operands are swapped (weights = A rows,
+// tokens = B columns, as in vpt_conv3x3_kernel) so that a lane holds 4 CONSECUTIVE output columns of one token per accumulator group and
+// every access is 16 bytes (fp32) / 8 bytes (16-bit): 32 store instructions per wave and output instead of 128 four-byte ones.
+// GE_GENERIC keeps the round-3 epilogue (runtime flags, any stride) for everything else.
+enum : unsigned { GE_BIAS = 1, GE_RELU = 2, GE_MASK = 4, GE_RES = 8, GE_OUTF = 16, GE_OUTB = 32, GE_SPLIT = 64, GE_VEC = 128, GE_GENERIC = 0x8000 };
+
+template <unsigned F>
 __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
+  constexpr bool VEC = (F & GE_VEC) != 0 && F != GE_GENERIC;
   __shared__ __attribute__((aligned(16))) unsigned char smem[GA_BYTES + GB_BYTES];
+  // GE_GENERIC: the epilogue's pointers and strides wait in LDS while the main loop runs (held in SGPRs they did not fit: 94 spills)
+  __shared__ VptGemmArgs epi_args;
+  if (F == GE_GENERIC && threadIdx.x == 0) epi_args = a;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;
   const int hi = lane >> 5, l31 = lane & 31;
@@ -85,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
   // per step, plus two bare barriers: 670 TF/s on the trunk GEMMs.
   op16x8 fa[4], fb[2][2];
 #define GSB() __builtin_amdgcn_sched_barrier(0)
-#define GMM(setb_, m_, n_) acc[m_][n_] = VPT_MFMA_32X32X16(fa[m_], fb[setb_][n_], acc[m_][n_], 0, 0, 0)
+#define GMM(setb_, m_, n_) acc[m_][n_] = VEC ? VPT_MFMA_32X32X16(fb[setb_][n_], fa[m_], acc[m_][n_], 0, 0, 0) : VPT_MFMA_32X32X16(fa[m_], fb[setb_][n_], acc[m_][n_], 0, 0, 0)
 #define GFA(kk_, m_) fa[m_] = *(const op16x8*)(aL + (m_) * (32 * GA_RS) + (kk_) * 32)
 #define GFB(setb_, kk_, n_) fb[setb_][n_] = *(const op16x8*)(bL + ((kk_) >> 1) * (128 * GB_RS) + (n_) * (32 * GB_RS) + ((kk_) & 1) * 32)
 #define GLA(m_) areg[m_] = A_LOAD(m_, s + 1)
@@ -142,7 +155,50 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
 #undef GMM
 #undef GSB
 
-  // ---- epilogue (direct from the accumulator layout: lane = column, 16 rows per accumulator) ----
+  if constexpr (VEC) {
+    // ---- vector epilogue: lane = token row (l31 of the 32-row subtile), accumulator group g = output columns 8 g + 4 hi .. + 3 ----
+    const int col0 = nt * 128 + wn * 64 + 4 * hi;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int row = m0 + wm * 128 + m * 32 + l31;
+      const bool rvalid = row < a.M;
+#pragma unroll
+      for (int n2 = 0; n2 < 2; ++n2) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = col0 + n2 * 32 + 8 * g;
+          if (!(rvalid && col < a.N)) continue;        // (N % 4 == 0: a group of four columns is valid or invalid as a whole)
+          f32x4 v = {acc[m][n2][4 * g + 0], acc[m][n2][4 * g + 1], acc[m][n2][4 * g + 2], acc[m][n2][4 * g + 3]};
+          if constexpr ((F & GE_SPLIT) != 0) {
+            *(f32x4*)(a.out_f32 + ((size_t)split * a.M + row) * a.ldc + col) = v;
+            continue;
+          }
+          if constexpr ((F & GE_BIAS) != 0) v += *(const f32x4*)(a.bias + col);
+          if constexpr ((F & GE_RELU) != 0) v = __builtin_elementwise_max(v, (f32x4){0.f, 0.f, 0.f, 0.f});
+          if constexpr ((F & GE_MASK) != 0) {          // ReLU backward: gate by the saved activation
+            const u32x2 mk = *(const u32x2*)(a.mask + (size_t)row * a.ldm + col);
+            if (!(op16_lo_to_f32(mk.x) > 0.f)) v.x = 0.f;
+            if (!(op16_hi_to_f32(mk.x) > 0.f)) v.y = 0.f;
+            if (!(op16_lo_to_f32(mk.y) > 0.f)) v.z = 0.f;
+            if (!(op16_hi_to_f32(mk.y) > 0.f)) v.w = 0.f;
+          }
+          if constexpr ((F & GE_RES) != 0) v += *(const f32x4*)(a.res + (size_t)row * a.ldr + col);
+          if constexpr ((F & GE_OUTF) != 0) *(f32x4*)(a.out_f32 + (size_t)row * a.ldc + col) = v;
+          if constexpr ((F & GE_OUTB) != 0) {
+            const u32x2 pk = {pack_op16x2(v.x, v.y), pack_op16x2(v.z, v.w)};
+            *(u32x2*)(a.out_bf16 + (size_t)row * a.ldcb + col) = pk;
+          }
+        }
+      }
+    }
+    return;
+  }
+  // ---- generic epilogue (direct from the accumulator layout: lane = column, 16 rows per accumulator) ----
+  {
+    const volatile VptGemmArgs* ev = &epi_args;       // (written before the main loop's first barrier)
+    a.bias = ev->bias; a.res = ev->res; a.out_f32 = ev->out_f32; a.out_bf16 = ev->out_bf16; a.mask = ev->mask;
+    a.ldr = ev->ldr; a.ldc = ev->ldc; a.ldcb = ev->ldcb; a.ldm = ev->ldm; a.relu = ev->relu; a.atomic_out = ev->atomic_out;
+  }
   // One accumulator (16 values) at a time, the optional stages as separate uniform-branch loops over 32-bit offsets
   // from a per-tile base: the straightforward per-element chain of pointer tests and 64-bit index products made the
   // compiler spill accumulators and cost ~100 us per tile (an intercept of 0.4 ms on an 8192 x 8192 output).
@@ -156,17 +212,15 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
     for (int m = 0; m < 4; ++m) {
       const int row0 = rbase + m * 32;
       float v[16];
-      bool ok[16];
+      // (the validity test is re-evaluated at every use: sixteen stored lane masks were 32 SGPRs, spilled together with everything else)
+#define OK_(r_) (cvalid && (row0 + ((r_) & 3) + 8 * ((r_) >> 2)) < a.M)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        v[r] = acc[m][n2][r] + bv;
-        ok[r] = cvalid && (row0 + (r & 3) + 8 * (r >> 2)) < a.M;
-      }
+      for (int r = 0; r < 16; ++r) v[r] = acc[m][n2][r] + bv;
       if (a.atomic_out) {   // split-K: this split's partial product goes to its own [M][ldc] slice (deterministic; the caller sums)
         float* o = a.out_f32 + ((size_t)split * a.M + row0) * a.ldc + col;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (ok[r]) o[((r & 3) + 8 * (r >> 2)) * a.ldc] = v[r];
+          if (OK_(r)) o[((r & 3) + 8 * (r >> 2)) * a.ldc] = v[r];
         continue;
       }
       if (a.relu) {
@@ -177,25 +231,25 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
         const vpt_op16* mk = a.mask + (size_t)row0 * a.ldm + col;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (ok[r] && !((float)mk[((r & 3) + 8 * (r >> 2)) * a.ldm] > 0.f)) v[r] = 0.f;
+          if (OK_(r) && !((float)mk[((r & 3) + 8 * (r >> 2)) * a.ldm] > 0.f)) v[r] = 0.f;
       }
       if (a.res) {
         const float* rp = a.res + (size_t)row0 * a.ldr + col;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (ok[r]) v[r] += rp[((r & 3) + 8 * (r >> 2)) * a.ldr];
+          if (OK_(r)) v[r] += rp[((r & 3) + 8 * (r >> 2)) * a.ldr];
       }
       if (a.out_f32) {
         float* o = a.out_f32 + (size_t)row0 * a.ldc + col;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (ok[r]) o[((r & 3) + 8 * (r >> 2)) * a.ldc] = v[r];
+          if (OK_(r)) o[((r & 3) + 8 * (r >> 2)) * a.ldc] = v[r];
       }
       if (a.out_bf16) {
         vpt_op16* o = a.out_bf16 + (size_t)row0 * a.ldcb + col;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (ok[r]) o[((r & 3) + 8 * (r >> 2)) * a.ldcb] = (vpt_op16)v[r];
+          if (OK_(r)) o[((r & 3) + 8 * (r >> 2)) * a.ldcb] = (vpt_op16)v[r];
       }
     }
   }
@@ -353,6 +407,31 @@ extern "C" int vpt_gemm_launch(const VptGemmArgs* a, hipStream_t stream) {
   if (a->splitk > 1 && (!a->atomic_out || a->relu || a->res || a->out_bf16 || a->mask)) return -1;
   const long grid = (long)((a->M + 255) >> 8) * ((a->N + 127) >> 7) * a->splitk;
   if (grid > 0x7fffffffL) return -2;
-  hipLaunchKernelGGL(vpt_gemm_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *a);
+  unsigned f = 0;
+  if (a->atomic_out) f = GE_SPLIT | GE_OUTF;
+  else f = (a->bias ? GE_BIAS : 0u) | (a->relu ? GE_RELU : 0u) | (a->mask ? GE_MASK : 0u) | (a->res ? GE_RES : 0u) | (a->out_f32 ? GE_OUTF : 0u) | (a->out_bf16 ? GE_OUTB : 0u);
+  const bool aligned = !(a->N & 3) && (!a->out_f32 || !(a->ldc & 3)) && (!a->out_bf16 || !(a->ldcb & 3)) && (!a->res || !(a->ldr & 3)) && (!a->mask || !(a->ldm & 3))
+                       && (!a->bias || !((uintptr_t)a->bias & 15)) && (!a->out_f32 || !((uintptr_t)a->out_f32 & 15)) && (!a->res || !((uintptr_t)a->res & 15))
+                       && (!a->out_bf16 || !((uintptr_t)a->out_bf16 & 7)) && (!a->mask || !((uintptr_t)a->mask & 7));
+#define GE_LAUNCH(F_) hipLaunchKernelGGL((vpt_gemm_kernel<(F_)>), dim3((unsigned)grid), dim3(256), 0, stream, *a)
+  bool done = false;
+  if (aligned) {
+    done = true;
+    switch (f) {   // the combinations the engine / trainer use (forward: qkvr / heads, proj / mlp1, mlp0, img linear, lastlayer, dense split-K; dgrad)
+      case GE_BIAS | GE_OUTF: GE_LAUNCH(GE_VEC | GE_BIAS | GE_OUTF); break;
+      case GE_BIAS | GE_RES | GE_OUTF: GE_LAUNCH(GE_VEC | GE_BIAS | GE_RES | GE_OUTF); break;
+      case GE_RELU | GE_OUTB: GE_LAUNCH(GE_VEC | GE_RELU | GE_OUTB); break;
+      case GE_RELU | GE_OUTF: GE_LAUNCH(GE_VEC | GE_RELU | GE_OUTF); break;
+      case GE_RELU | GE_OUTF | GE_OUTB: GE_LAUNCH(GE_VEC | GE_RELU | GE_OUTF | GE_OUTB); break;
+      case GE_OUTF: GE_LAUNCH(GE_VEC | GE_OUTF); break;
+      case GE_OUTB: GE_LAUNCH(GE_VEC | GE_OUTB); break;
+      case GE_RES | GE_OUTF: GE_LAUNCH(GE_VEC | GE_RES | GE_OUTF); break;
+      case GE_MASK | GE_OUTB: GE_LAUNCH(GE_VEC | GE_MASK | GE_OUTB); break;
+      case GE_SPLIT | GE_OUTF: GE_LAUNCH(GE_VEC | GE_SPLIT | GE_OUTF); break;
+      default: done = false;
+    }
+  }
+  if (!done) GE_LAUNCH(GE_GENERIC);
+#undef GE_LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

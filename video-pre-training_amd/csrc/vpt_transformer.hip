@@ -336,14 +336,16 @@ __global__ __launch_bounds__(256) void vpt_attn_step_kernel(VptAttnArgs a, VptAt
 #pragma unroll
     for (int i = 0; i < 64; ++i) v[i] = kv_row(1 + min(k0 + i, maxlen - 1), 2)[d];
     float o = 0.f;
+    int cnt = __builtin_amdgcn_readfirstlane(maxlen - k0);       // rows k0 .. k0 + cnt - 1 of this half exist (wave-uniform)
 #pragma unroll
     for (int i = 0; i < 64; ++i)
-      if (k0 + i < maxlen) o = fmaf(sc_[k0 + i], v[i], o);
+      if (i < cnt) o = fmaf(sc_[k0 + i], v[i], o);
     if (kh == 1) part_[d] = o;
     __syncthreads();
+    asm volatile("" : "+s"(cnt));   // the 64 row tests are re-derived here: shared with the loop above they sat in 64 scalar registers across the barrier (54 spills)
 #pragma unroll
     for (int i = 0; i < 64; ++i)
-      if (k0 + i < maxlen) x.vout[((size_t)b * maxlen + k0 + i) * hid + h * ATT_DH + d] = v[i];
+      if (i < cnt) x.vout[((size_t)b * maxlen + k0 + i) * hid + h * ATT_DH + d] = v[i];
     if (kh == 0) a.out[(size_t)b * hid + h * ATT_DH + d] = (vpt_op16)((o + part_[d]) * inv);
   }
 }
