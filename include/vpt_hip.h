@@ -173,11 +173,25 @@ int vpt_linear_forward(const void* A, const void* wpk, const float* bias, const 
                        float* out_f32, void* out_bf16, int M, int N, int K,
                        int lda, int ldr, int ldc, int ldcb, int relu, int splitk, const void* mask, int ldm,
                        void* stream);
+/* The same with the kernel named by the caller: 1 = the MFMA GEMM whatever M, 2 = the weight-streaming kernel of the acting step (M <= 8
+ * rows), 0 = by M (what vpt_linear_forward does: <= 8 rows stream the weights).  The two kernels sum in different orders; a caller
+ * whose rows must not depend on how many rows share the call (batches of sequences: chunking, sharding) passes 1. */
+int vpt_linear_forward_tiled(const void* A, const void* wpk, const float* bias, const float* res,
+                             float* out_f32, void* out_bf16, int M, int N, int K,
+                             int lda, int ldr, int ldc, int ldcb, int relu, int splitk, const void* mask, int ldm,
+                             int tiling, void* stream);
 
 /* Weight gradient of a linear layer without transposed copies: dw[n][k] (+)= sum_m dy[m][n] * x[m][k]; dy bf16 [M][ldy],
  * x bf16 [M][ldx] (both row-major over the M frames / tokens), dw fp32 [N][ldw]; N, K, ldy, ldx multiples of 8.
  * Replaces autograd's dW = dY^T X for every nn.Linear of the BC step (behavioural_cloning.py:117-119). */
 int vpt_linear_wgrad(const void* dy, const void* x, float* dw, int M, int N, int K, int ldy, int ldx, int ldw, int accumulate, void* stream);
+
+/* ImpalaCNN.dense with its LayerNorm folded into the GEMM (lib/impala_cnn.py:177-194; inference): run vpt_linear_forward with splitk > 1 on the RAW
+ * block output x [M = frames][K = C*16*16] against weights packed from W * gain (per element), then this: out[f][n] = rstd_f * sum_s part[s][f][n]
+ * - rstd_f * mean_f * sg[n] + sb[n], (mean_f, rstd_f) from stats [M][2] of x (count = K), sg[n] = sum_k op16(W gain)[n][k], sb[n] = sum_k W[n][k]
+ * bias[k].  Replaces vpt_frame_affine_forward(per_element = 1) + the split-K sum. */
+int vpt_dense_fold_epilogue(const float* part, int splitk, const double* stats, int count, const float* sg, const float* sb, float* out,
+                            int M, int N, void* stream);
 
 /* Second stage of a split-K linear: out = epilogue(sum_s part[s][M][N]) with the same epilogue options as
  * vpt_linear_forward (part = the [splitk][M][N] buffer a vpt_linear_forward call with splitk > 1 filled). */

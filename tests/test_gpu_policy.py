@@ -151,6 +151,36 @@ def test_first_resets_memory(pol_1x):
     assert torch.equal(pd1["buttons"], pd2["buttons"])
 
 
+def test_a_sequence_result_does_not_depend_on_the_batch_around_it(pol_1x):
+    """A frame's output must not depend on how many frames share its launches: every statistic is fp32 inside a
+    tile / tile group whose extent is fixed and fp64 across them, whatever the batch, the CNN chunk or the stream it lands on.  The same
+    two sequences alone (B = 2), inside a batch of six at other positions, and with the CNN cut into uneven chunks: BIT-identical
+    log-probs and KV memory.  (Covers the pool-fused convolution, its seam kernel and the folded GroupNorm `n` with its in-kernel
+    per-channel sums -- the inference path's newest pieces.)"""
+    pol, cfg, sd = pol_1x
+    t = 5
+    a, other = _inputs(301, 2, t), _inputs(302, 4, t)
+    big = torch.stack([other[0], a[0], other[1], other[2], a[1], other[3]])
+    f2, f6 = torch.zeros(2, t, dtype=torch.bool, device=DEV), torch.zeros(6, t, dtype=torch.bool, device=DEV)
+    (pd_a, v_a, _), st_a = pol({"img": a.to(DEV)}, f2, pol.initial_state(2))
+    (pd_b, v_b, _), st_b = pol({"img": big.to(DEV)}, f6, pol.initial_state(6))
+    eng = pol._engine
+    saved = eng.cnn_chunk
+    try:
+        eng.cnn_chunk = 7                       # 30 frames as 7 + 7 + 7 + 7 + 2 on three streams (chunks of <= 8 frames: still the MFMA kernels)
+        (pd_c, v_c, _), st_c = pol({"img": big.to(DEV)}, f6, pol.initial_state(6))
+    finally:
+        eng.cnn_chunk = saved
+    torch.cuda.synchronize()
+    idx = torch.tensor([1, 4], device=DEV)
+    for pd_x, v_x, st_x in ((pd_b, v_b, st_b), (pd_c, v_c, st_c)):
+        for h in ("buttons", "camera"):
+            assert torch.equal(pd_a[h], pd_x[h][idx]), (h, float((pd_a[h] - pd_x[h][idx]).abs().max()), [float((pd_a[h][:, j] - pd_x[h][idx][:, j]).abs().max()) for j in range(t)])
+        assert torch.equal(v_a, v_x[idx])
+        for (m1, (k1, v1)), (m2, (k2, v2)) in zip(st_a, st_x):
+            assert torch.equal(k1, k2[idx]) and torch.equal(v1, v2[idx])
+
+
 def test_policy_full_chunk_t128(pol_1x):
     """One full training-size chunk (T = 128, B = 2) against the oracle: all four query tiles of the band, the
     memory fully replaced by the chunk, then a T = 1 step on the carried state (the run_agent.py shape)."""

@@ -37,7 +37,9 @@ SIGNATURES = {
     "vpt_maxpool_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_frame_affine_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_linear_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    "vpt_linear_forward_tiled": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "vpt_linear_wgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vpt_dense_fold_epilogue": [_P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
     "vpt_linear_splitk_epilogue": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "vpt_layernorm_forward": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "vpt_masked_attention_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

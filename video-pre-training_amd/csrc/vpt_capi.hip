@@ -259,7 +259,16 @@ int vpt_linear_forward(const void* A, const void* wpk, const float* bias, const 
                        float* out_f32, void* out_bf16, int M, int N, int K,
                        int lda, int ldr, int ldc, int ldcb, int relu, int splitk, const void* mask, int ldm,
                        void* stream) {
+  return vpt_linear_forward_tiled(A, wpk, bias, res, out_f32, out_bf16, M, N, K, lda, ldr, ldc, ldcb, relu, splitk, mask, ldm, 0, stream);
+}
+
+int vpt_linear_forward_tiled(const void* A, const void* wpk, const float* bias, const float* res,
+                             float* out_f32, void* out_bf16, int M, int N, int K,
+                             int lda, int ldr, int ldc, int ldcb, int relu, int splitk, const void* mask, int ldm,
+                             int tiling, void* stream) {
+  if (tiling < 0 || tiling > 2) return fail(-1, "vpt_linear_forward_tiled: tiling must be 0 (by M), 1 (MFMA GEMM) or 2 (weight-streaming, M <= 8)");
   VptGemmArgs a{};
+  a.tiling = tiling;
   a.mask = (const vpt_op16*)mask; a.ldm = ldm;
   a.A = (const vpt_op16*)A; a.wpk = (const vpt_op16*)wpk; a.bias = bias; a.res = res;
   a.out_f32 = out_f32; a.out_bf16 = (vpt_op16*)out_bf16;
@@ -285,6 +294,12 @@ int vpt_linear_wgrad(const void* dy, const void* x, float* dw, int M, int N, int
   a.A = (const vpt_op16*)dy; a.B = (const vpt_op16*)x; a.C = dw; a.M = M; a.N1 = N; a.N2 = K; a.lda = ldy; a.ldb = ldx; a.ldc = ldw;
   a.accumulate = accumulate;
   CHECK_LAUNCH(vpt_gemm_tn_launch(&a, (hipStream_t)stream), "vpt_linear_wgrad");
+}
+
+int vpt_dense_fold_epilogue(const float* part, int splitk, const double* stats, int count, const float* sg, const float* sb, float* out,
+                            int M, int N, void* stream) {
+  if (count <= 0) return fail(-1, "vpt_dense_fold_epilogue: count = elements per frame of the normalised tensor");
+  CHECK_LAUNCH(vpt_dense_fold_epilogue_launch(part, splitk, stats, 1.0 / (double)count, sg, sb, out, M, N, (hipStream_t)stream), "vpt_dense_fold_epilogue");
 }
 
 int vpt_linear_splitk_epilogue(const float* part, int splitk, const float* bias, const float* res, float* out_f32, void* out_bf16,

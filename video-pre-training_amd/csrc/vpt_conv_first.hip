@@ -45,7 +45,13 @@ __global__ __launch_bounds__(CF_THREADS, 4) void vpt_conv_first_kernel(VptConvFi
   };
   // contiguous tile range per workgroup: consecutive tiles belong to the same frame, so the frame statistics are
   // summed in registers and flushed with one atomic pair per (workgroup, frame)
-  const long per = (T + gridDim.x - 1) / gridDim.x;
+  // CHS: the running per-channel sums are fp32 over a GROUP of tiles (a quarter of a 128 x 128 frame's 64) and fp64 across groups; the
+  // workgroup ranges are cut at group boundaries only, so which tiles share an fp32 sum never depends on the number of frames in the
+  // launch -- a frame's statistics, hence its result, must not depend on how the batch is chunked
+  const int tiles_per_frame = tilesY * tilesX * a.NT;
+  const int group = !CHS ? 1 : ((tiles_per_frame & 15) == 0 ? 16 : tiles_per_frame);
+  const long n_groups = (T + group - 1) / group;
+  const long per = ((n_groups + gridDim.x - 1) / gridDim.x) * group;
   const long t_begin = blockIdx.x * per, t_end = min(t_begin + per, T);
   // tile coordinates (frame, tile row, tile column, channel tile) are decoded once and then counted up: the 64-bit
   // divisions of a per-tile decode were ~1000 scalar instructions per tile
@@ -66,9 +72,9 @@ __global__ __launch_bounds__(CF_THREADS, 4) void vpt_conv_first_kernel(VptConvFi
   int nt_loaded = -1, stat_f = -1;
   double d_sum = 0.0, d_sq = 0.0;
   // Per-channel sums of the STORED tensor (a.chs_out: the GroupNorm-`n` fold needs sum_p Q and sum_p Q^2 per channel and frame).  A thread's
-  // pooling items keep their channel octet from tile to tile, so the sums run in registers over all tiles of a frame this workgroup owns
-  // and are combined across threads (4 lanes x 8 waves per octet) only when the frame changes -- once per ~64 tiles -- through the then
-  // idle conv-tile area of the LDS, ending in one fp64 atomic per (channel, moment).
+  // pooling items keep their channel octet from tile to tile, so the sums run in registers over a group of 16 tiles and are combined
+  // across threads (4 lanes x 8 waves per octet) once per group, through the then idle conv-tile area of the LDS, ending in one fp64
+  // atomic per (channel, moment).
   float c1[8], c2[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { c1[k] = 0.f; c2[k] = 0.f; }
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(CF_THREADS, 4) void vpt_conv_first_kernel(VptConvFi
       d_sq += (double)wave_sum(s_sq);
     }
     __syncthreads();   // all pooling reads of the conv tile done before the next tile overwrites it
-    if (CHS && (nf != f || tile + 1 >= t_end)) {     // last tile of this frame in the workgroup's range: hand the per-channel sums over
+    if (CHS && ((tile + 1) % group == 0 || tile + 1 >= t_end)) {     // last tile of a group (groups never straddle frames): hand the per-channel sums over
       flush_channel_sums(f);
       __syncthreads();
     }

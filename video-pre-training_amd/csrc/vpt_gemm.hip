@@ -399,10 +399,37 @@ extern "C" int vpt_splitk_epilogue_launch(const float* part, int splitk, const V
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+// Second stage of the split-K dense layer with ImpalaCNN.dense's LayerNorm(65536) FOLDED in (lib/impala_cnn.py:177-194: LN -> Linear -> the
+// ReLU comes later): the GEMM ran on the raw block output x with weights op16(W * gain), so per frame f
+//     out[f][n] = rstd_f * sum_s part[s][f][n]  -  rstd_f * mean_f * sg[n]  +  sb[n],     sg[n] = sum_k op16(W g)[n][k],  sb[n] = sum_k W[n][k] bias[k]
+// with (mean_f, rstd_f) from the producer's frame statistics -- the per-element affine pass over the 16 x 16 x C tensor disappears.
+// Fixed summation order over the splits: deterministic.
+__global__ __launch_bounds__(256) void vpt_dense_fold_epilogue_kernel(const float* __restrict__ part, int splitk, const double* __restrict__ stats, double inv_count,
+                                                                      const float* __restrict__ sg, const float* __restrict__ sb, float* __restrict__ out, int M, int N) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)M * N;
+  if (i >= total) return;
+  const int row = (int)(i / N), col = (int)(i - (long)row * N);
+  float mean, rstd;
+  frame_mean_rstd(stats, row, inv_count, mean, rstd);
+  float v = 0.f;
+  for (int sp = 0; sp < splitk; ++sp) v += part[(size_t)sp * total + i];
+  out[i] = fmaf(rstd, v, fmaf(-rstd * mean, sg[col], sb[col]));
+}
+
+extern "C" int vpt_dense_fold_epilogue_launch(const float* part, int splitk, const double* stats, double inv_count, const float* sg, const float* sb, float* out,
+                                              int M, int N, hipStream_t stream) {
+  if (M <= 0 || N <= 0 || splitk < 1 || !part || !stats || !sg || !sb || !out) return -1;
+  const long total = (long)M * N;
+  hipLaunchKernelGGL(vpt_dense_fold_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, part, splitk, stats, inv_count, sg, sb, out, M, N);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 extern "C" int vpt_gemv_launch(const VptGemmArgs* a, hipStream_t stream);
 
 extern "C" int vpt_gemm_launch(const VptGemmArgs* a, hipStream_t stream) {
-  if (a->M > 0 && a->M <= 8) return vpt_gemv_launch(a, stream);   // acting path (T = 1): HBM-bound weight stream, vpt_gemv.hip
+  if (a->tiling == 2 && a->M > 8) return -1;
+  if (a->M > 0 && a->M <= 8 && a->tiling != 1) return vpt_gemv_launch(a, stream);   // acting path (T = 1): HBM-bound weight stream, vpt_gemv.hip
   if (a->M <= 0 || a->N <= 0 || (a->K & 63) || a->splitk < 1 || (a->lda & 7)) return -1;
   if (a->splitk > 1 && (!a->atomic_out || a->relu || a->res || a->out_bf16 || a->mask)) return -1;
   const long grid = (long)((a->M + 255) >> 8) * ((a->N + 127) >> 7) * a->splitk;

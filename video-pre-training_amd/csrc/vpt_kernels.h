@@ -134,6 +134,7 @@ struct VptGemmArgs {
   vpt_op16* out_bf16;      // [M][ldcb] or null
   int M, N, K, lda, ldr, ldc, ldcb;
   int relu, splitk, atomic_out;
+  int tiling;              // 0: M <= 8 rows take the weight-streaming kernel (vpt_gemv.hip), more the MFMA GEMM; 1: MFMA GEMM whatever M; 2: weight-streaming (M <= 8)
   const vpt_op16* mask;    // optional [M][ldm]: output is zeroed where mask <= 0 (ReLU backward)
   int ldm;
   // fused LayerNorm prologue (skinny path only, M <= 8, K <= 3072): A = op16(LayerNorm(ln_x)) computed by every workgroup
@@ -358,6 +359,7 @@ int vpt_conv_bwd_prep_launch(const VptConvBwdPrepArgs* a, hipStream_t s);
 int vpt_conv_first_bwd_launch(const VptConvFirstBwdArgs* a, hipStream_t s);
 int vpt_gemm_tn_launch(const VptGemmTnArgs* a, hipStream_t s);
 int vpt_splitk_epilogue_launch(const float* part, int splitk, const VptGemmArgs* a, hipStream_t s);
+int vpt_dense_fold_epilogue_launch(const float* part, int splitk, const double* stats, double inv_count, const float* sg, const float* sb, float* out, int M, int N, hipStream_t s);
 int vpt_camera_codec_launch(int decode, const void* in, void* out, long n, double maxval, double binsize, double mu, int mu_law, hipStream_t s);
 int vpt_action_mapping_launch(int to_factored, const long* a, const long* b, long* oa, long* ob, long n, int n_camera_bins, hipStream_t s);
 int vpt_conv_wgrad_groups(int frames, int Cin, int Cout);

@@ -156,6 +156,7 @@ class PolicyEngine:
         # each stack's GroupNorm `n` folded into its first block (no affine pass; needs fuse_pool): 0 = the vpt_affine_kernel pass
         self.fold_n = os.environ.get("VPT_FOLD_N", "1") != "0"
         self.fold_stats_in_producer = os.environ.get("VPT_FOLD_STATS", "1") != "0"     # 0: per-channel sums by a pass of their own (A/B)
+        self.fold_dense = os.environ.get("VPT_FOLD_DENSE", "1") != "0"                 # dense.norm (LayerNorm 65536) folded into the dense GEMM
         self._streams = []
         self._attn_done = None      # arrival counters of the in-place acting step (ops.masked_attention_step)
         self._rng_state = None      # in-kernel sampler state {seed, step} (ops.new_rng_state), created on first stochastic use
@@ -235,7 +236,24 @@ class PolicyEngine:
         # sources of the n-fold tables (computed on first use after a pack: inference only, nothing on the BC step's path)
         self._fold_src = {s: (sd[f"net.img_process.cnn.stacks.{s}.blocks.0.conv0.layer.weight"], sd[f"net.img_process.cnn.stacks.{s}.blocks.0.conv0.norm.weight"])
                           for s in range(len(cfg["chans"]))}
+        self._dense_src = sd["net.img_process.cnn.dense.layer.weight"]
         self._fold_tab = {}
+
+    def _dense_fold(self):
+        """ImpalaCNN.dense with its LayerNorm(65536) folded into the GEMM (inference): (weights packed from W * gain in blocked order,
+        sg[n] = sum_k op16(W gain)[n][k], sb[n] = sum_k W[n][k] bias[k]).  Built on first use after a pack."""
+        if "dense" not in self._fold_tab:
+            w = self.w
+            c2 = self.cfg["chans"][-1]
+            wt = self._dense_src.detach().float()                                           # [256, C*16*16] in the reference's C,H,W order
+            g, b = w["net.img_process.cnn.dense.g"], w["net.img_process.cnn.dense.b"]       # blocked order
+            wb = ops.chw_to_blocked(wt.contiguous(), c2, 16, 16)                            # [256, K] blocked
+            wg = wb * g.view(1, -1)
+            wgr = wg.to(self.dtype)
+            sg = wgr.double().sum(1).float().contiguous()
+            sb = (wb.double() * b.double().view(1, -1)).sum(1).float().contiguous()
+            self._fold_tab["dense"] = (ops.pack_linear(wg.contiguous(), dtype=self.dtype), sg, sb)
+        return self._fold_tab["dense"]
 
     def _nfold_tables(self, s: int):
         """TB / TG of stack s: the edge-class sums of block 0's conv0 weights W' = op16(W * gain_conv0) with every input channel weighted by
@@ -258,7 +276,22 @@ class PolicyEngine:
         return self._fold_tab[s]
 
     # ------------------------------------------------------------------------------------------
-    def _cnn_chunk(self, img: torch.Tensor, x0=None, s_x0=None, tiling: str = "throughput") -> torch.Tensor:
+    def _cnn_dense(self, img, tiling: str = "throughput", x0=None, s_x0=None) -> torch.Tensor:
+        """ImpalaCNN.forward up to the dense layer's pre-activation output, fp32 [F, 256].  Throughput path: the 65536-wide LayerNorm is folded
+        into the split-K GEMM (_dense_fold + ops.dense_fold_epilogue: no per-element affine pass); otherwise affine pass + GEMM."""
+        w = self.w
+        f = img.shape[0] if x0 is None else x0.shape[0]
+        if self.fold_dense and tiling == "throughput":
+            x, s_x = self._cnn_chunk(img, x0=x0, s_x0=s_x0, tiling=tiling, raw=True)
+            wg, sg, sb = self._dense_fold()
+            flat = x.view(f, -1)
+            part, _ = ops.linear(flat, wg, 256, splitk=DENSE_SPLITK, splitk_raw=True, tiling="throughput")
+            return ops.dense_fold_epilogue(part, s_x, flat.shape[1], sg, sb)
+        xn = self._cnn_chunk(img, x0=x0, s_x0=s_x0, tiling=tiling)
+        d32, _ = ops.linear(xn.view(f, -1), w["net.img_process.cnn.dense.w"], 256, splitk=DENSE_SPLITK, tiling=tiling)
+        return d32
+
+    def _cnn_chunk(self, img: torch.Tensor, x0=None, s_x0=None, tiling: str = "throughput", raw: bool = False) -> torch.Tensor:
         """img uint8 [F,128,128,3] -> blocked bf16 [F, C2/32, 16, 16, 32] normalised for the dense layer,
         i.e. everything of ImpalaCNN.forward up to (and including) dense.norm.  With (x0, s_x0) given (IDM:
         the temporal conv's blocked output and its frame statistics) stack 0 uses the normed conv3x3 path."""
@@ -343,17 +376,22 @@ class PolicyEngine:
                 x = ops.conv3x3(y, wpk, sa, sg, s_y, c, res=x, stats_out=s_n, tiling=tiling)
                 s_x = s_n
                 del y
+        if raw:          # (the caller folds dense.norm into the dense GEMM: _cnn_dense)
+            return x, s_x
         p = "net.img_process.cnn.dense."
         return ops.frame_affine(x, w[p + "g"], w[p + "b"], s_x, per_element=True)
 
-    def _ln_linear(self, x, g, b, wpk, n, bias=None, res=None, relu=False, relu_in=False, ln_out_f32=False, out_f32=True, out_bf16=False):
-        """LayerNorm -> linear.  Acting path (<= 8 rows): ONE launch (the normalisation is a prologue of the weight-streaming kernel,
-        bit-identical); otherwise vpt_layernorm_kernel + the GEMM.  -> (normalised rows fp32 | None, fp32 out | None, 16-bit out | None)."""
-        if x.shape[0] <= ops.LN_LINEAR_MAX_ROWS and x.shape[1] <= ops.LN_LINEAR_MAX_K:
+    def _ln_linear(self, x, g, b, wpk, n, bias=None, res=None, relu=False, relu_in=False, ln_out_f32=False, out_f32=True, out_bf16=False,
+                   tiling="throughput"):
+        """LayerNorm -> linear.  tiling "latency" (the acting step: <= 8 rows): ONE launch (the normalisation is a prologue of the
+        weight-streaming kernel); "throughput": vpt_layernorm_kernel + the MFMA GEMM whatever the row count -- the CALLER's choice, never
+        the row count's, so a row's result does not depend on the batch around it.
+        -> (normalised rows fp32 | None, fp32 out | None, 16-bit out | None)."""
+        if tiling == "latency" and x.shape[0] <= ops.LN_LINEAR_MAX_ROWS and x.shape[1] <= ops.LN_LINEAR_MAX_K:
             return ops.layernorm_linear(x, g, b, wpk, n, bias=bias, res=res, relu=relu, relu_in=relu_in, ln_out_f32=ln_out_f32,
                                         out_f32=out_f32, out_bf16=out_bf16, dtype=self.dtype)
         ln32, ln16 = ops.layernorm(x, g, b, relu_in=relu_in, out_f32=ln_out_f32, dtype=self.dtype)
-        o32, o16 = ops.linear(ln16, wpk, n, bias=bias, res=res, relu=relu, out_f32=out_f32, out_bf16=out_bf16)
+        o32, o16 = ops.linear(ln16, wpk, n, bias=bias, res=res, relu=relu, out_f32=out_f32, out_bf16=out_bf16, tiling=tiling)
         return ln32, o32, o16
 
     def _img_process(self, frames: torch.Tensor, tiling: str = "throughput") -> torch.Tensor:
@@ -374,17 +412,13 @@ class PolicyEngine:
         for ci, i in enumerate(range(0, n, self.cnn_chunk)):
             ctx = torch.cuda.stream(self._streams[ci % n_streams]) if n_streams > 1 else _NullCtx()
             with ctx:
-                xn = self._cnn_chunk(frames[i:i + self.cnn_chunk], tiling=tiling)
-                flat = xn.view(xn.shape[0], -1)
-                d32, _ = ops.linear(flat, w["net.img_process.cnn.dense.w"], 256, splitk=DENSE_SPLITK)
-                outs.append(d32)
-                del xn, flat
+                outs.append(self._cnn_dense(frames[i:i + self.cnn_chunk], tiling=tiling))
         if n_streams > 1:
             for st in self._streams[:n_streams]:
                 main.wait_stream(st)
         d = outs[0] if len(outs) == 1 else torch.cat(outs, 0)
         p = "net.img_process.linear."
-        _, x, _ = self._ln_linear(d, w[p + "g"], w[p + "b"], w[p + "w"], cfg["hidsize"], relu=True, relu_in=True)
+        _, x, _ = self._ln_linear(d, w[p + "g"], w[p + "b"], w[p + "w"], cfg["hidsize"], relu=True, relu_in=True, tiling=tiling)
         return x
 
     @torch.no_grad()
@@ -404,7 +438,8 @@ class PolicyEngine:
         hid, heads, maxlen = cfg["hidsize"], cfg["heads"], cfg["maxlen"]
         frames = img_u8.reshape(bsz * t, *img_u8.shape[2:]).contiguous()
         # the acting step (agent.py:190-206: T = 1, a handful of environments) runs the convolutions on the latency tiling
-        x = self._img_process(frames, tiling="latency" if (t == 1 and bsz <= ops.LN_LINEAR_MAX_ROWS) else "throughput")
+        tiling = "latency" if (t == 1 and bsz <= ops.LN_LINEAR_MAX_ROWS) else "throughput"     # one choice for every kernel of the step
+        x = self._img_process(frames, tiling=tiling)
         if cfg["use_pre_lstm_ln"]:
             x, _ = ops.layernorm(x, w["prelstm.g"], w["prelstm.b"], out_f32=True, out_bf16=False, dtype=self.dtype)
 
@@ -421,7 +456,7 @@ class PolicyEngine:
             state_mask, (kmem, vmem) = state_in[l]
             if state_mask is None:
                 state_mask = torch.zeros(bsz, 1, maxlen, dtype=torch.bool, device=x.device)
-            x1, qkvr, _ = self._ln_linear(x, w[p + "ln1.g"], w[p + "ln1.b"], w[p + "qkvr.w"], self.n_qkvr, bias=w[p + "qkvr.b"], ln_out_f32=True)
+            x1, qkvr, _ = self._ln_linear(x, w[p + "ln1.g"], w[p + "ln1.b"], w[p + "qkvr.w"], self.n_qkvr, bias=w[p + "qkvr.b"], ln_out_f32=True, tiling=tiling)
             if step:
                 if inplace_state and not (kmem.is_contiguous() and vmem.is_contiguous()):
                     raise ValueError("inplace_state needs contiguous state tensors (a .contiguous() copy would receive the update instead of the state)")
@@ -441,15 +476,15 @@ class PolicyEngine:
                 kout, vout = ops.kv_memory_update(qkvr, kmem.contiguous(), vmem.contiguous(), bsz, t, hid)
                 new_mask = torch.cat([state_mask[:, :, t:] & not_first,
                                       torch.ones(bsz, 1, min(t, maxlen), dtype=torch.bool, device=x.device)], dim=-1)
-            x2, _ = ops.linear(att, w[p + "proj.w"], hid, bias=w[p + "proj.b"], res=x1)
+            x2, _ = ops.linear(att, w[p + "proj.w"], hid, bias=w[p + "proj.b"], res=x1, tiling=tiling)
             _, _, h2 = self._ln_linear(x2, w[p + "ln2.g"], w[p + "ln2.b"], w[p + "mlp0.w"], hid * cfg["pointwise_ratio"], relu=True,
-                                       out_f32=False, out_bf16=True)
-            x, _ = ops.linear(h2, w[p + "mlp1.w"], hid, bias=w[p + "mlp1.b"], res=x2)
+                                       out_f32=False, out_bf16=True, tiling=tiling)
+            x, _ = ops.linear(h2, w[p + "mlp1.w"], hid, bias=w[p + "mlp1.b"], res=x2, tiling=tiling)
             state_out.append((new_mask, (kout, vout)))
 
-        _, y, _ = self._ln_linear(x, w["last.g"], w["last.b"], w["last.w"], hid, relu=True, relu_in=True)
+        _, y, _ = self._ln_linear(x, w["last.g"], w["last.b"], w["last.w"], hid, relu=True, relu_in=True, tiling=tiling)
         nb, nc = self.n_buttons, self.n_camera
-        latent, logits, _ = self._ln_linear(y, w["final.g"], w["final.b"], w["heads.w"], nb + nc + 1, bias=w["heads.b"], ln_out_f32=True)
+        latent, logits, _ = self._ln_linear(y, w["final.g"], w["final.b"], w["heads.w"], nb + nc + 1, bias=w["heads.b"], ln_out_f32=True, tiling=tiling)
         temp = cfg["temperature"]
         out = dict(latent=latent.view(bsz, t, hid), state_out=state_out)
         tail = act_tail is not None and sample is not None and t == 1
@@ -487,6 +522,7 @@ class IDMEngine(PolicyEngine):
         self.fuse_pool_sub = 0
         self.fold_n = os.environ.get("VPT_FOLD_N", "1") != "0"
         self.fold_stats_in_producer = os.environ.get("VPT_FOLD_STATS", "1") != "0"
+        self.fold_dense = os.environ.get("VPT_FOLD_DENSE", "1") != "0"
         self._streams = []
         self._rng_state = None
         self.w = {}
@@ -536,6 +572,7 @@ class IDMEngine(PolicyEngine):
         self.packed = True
         self._fold_src = {s: (sd[f"net.img_process.cnn.stacks.{s}.blocks.0.conv0.layer.weight"], sd[f"net.img_process.cnn.stacks.{s}.blocks.0.conv0.norm.weight"])
                           for s in range(len(cfg["chans"]))}
+        self._dense_src = sd["net.img_process.cnn.dense.layer.weight"]
         self._fold_tab = {}
 
     @torch.no_grad()
@@ -556,25 +593,23 @@ class IDMEngine(PolicyEngine):
             fr = frames[i:i + step]
             s0 = torch.zeros(fr.shape[0], 2, dtype=torch.float64, device=fr.device)
             x0 = ops.conv3d_t5(fr, wfrag, bias, self.c3d_out, t, stats_out=s0)
-            xn = self._cnn_chunk(None, x0=x0, s_x0=s0)
-            d32, _ = ops.linear(xn.view(xn.shape[0], -1), w["net.img_process.cnn.dense.w"], 256, splitk=DENSE_SPLITK)
-            outs.append(d32)
-            del x0, xn
+            outs.append(self._cnn_dense(None, x0=x0, s_x0=s0))
+            del x0
         d = outs[0] if len(outs) == 1 else torch.cat(outs, 0)
         p = "net.img_process.linear."
         _, dn = ops.layernorm(d, w[p + "g"], w[p + "b"], relu_in=True, dtype=self.dtype)
-        x, _ = ops.linear(dn, w[p + "w"], hid, relu=True)
+        x, _ = ops.linear(dn, w[p + "w"], hid, relu=True, tiling="throughput")
         if cfg["use_pre_lstm_ln"]:
             x, _ = ops.layernorm(x, w["prelstm.g"], w["prelstm.b"], out_f32=True, out_bf16=False, dtype=self.dtype)
         for l in range(cfg["n_layers"]):
             p = f"net.recurrent_layer.blocks.{l}."
             x1, x1b = ops.layernorm(x, w[p + "ln1.g"], w[p + "ln1.b"], out_f32=True, dtype=self.dtype)
-            qkv, _ = ops.linear(x1b, w[p + "qkv.w"], 3 * hid, bias=w[p + "qkv.b"])
+            qkv, _ = ops.linear(x1b, w[p + "qkv.w"], 3 * hid, bias=w[p + "qkv.b"], tiling="throughput")
             att = ops.full_attention(qkv, bsz, t, heads, hid, dtype=self.dtype)
-            x2, _ = ops.linear(att, w[p + "proj.w"], hid, bias=w[p + "proj.b"], res=x1)
+            x2, _ = ops.linear(att, w[p + "proj.w"], hid, bias=w[p + "proj.b"], res=x1, tiling="throughput")
             _, hb = ops.layernorm(x2, w[p + "ln2.g"], w[p + "ln2.b"], dtype=self.dtype)
-            _, h2 = ops.linear(hb, w[p + "mlp0.w"], hid * cfg["pointwise_ratio"], relu=True, out_f32=False, out_bf16=True)
-            x, _ = ops.linear(h2, w[p + "mlp1.w"], hid, bias=w[p + "mlp1.b"], res=x2)
+            _, h2 = ops.linear(hb, w[p + "mlp0.w"], hid * cfg["pointwise_ratio"], relu=True, out_f32=False, out_bf16=True, tiling="throughput")
+            x, _ = ops.linear(h2, w[p + "mlp1.w"], hid, bias=w[p + "mlp1.b"], res=x2, tiling="throughput")
         latent, lb = ops.layernorm(x, w["final.g"], w["final.b"], relu_in=True, out_f32=True, dtype=self.dtype)
         out = {}
         temp = cfg["temperature"]
@@ -582,7 +617,7 @@ class IDMEngine(PolicyEngine):
         rng = self.rng_state(x.device) if sample == "stochastic" else None
         for h, shape in (("buttons", self.button_shape), ("camera", self.camera_shape)):
             n_groups, n = shape
-            z, _ = ops.linear(lb, w[h + ".w"], n_groups * n, bias=w[h + ".b"])
+            z, _ = ops.linear(lb, w[h + ".w"], n_groups * n, bias=w[h + ".b"], tiling="throughput")
             r = action_heads(z, ((h, 0, n_groups, n),), bsz, t, temp, mask, sample, rng_state=rng)
             out[h] = r[h]
             if sample is not None:

@@ -287,11 +287,25 @@ def frame_affine(x, gain, bias, stats_in, stats_out=None, per_element=False, out
     return out
 
 
+def dense_fold_epilogue(part, stats, count, sg, sb):
+    """Split-K partial slices [S, M, N] of x @ op16(W gain)^T + the frame statistics of x -> LayerNorm(x) @ W^T [M, N] (vpt_dense_fold_epilogue)."""
+    _chk(part, torch.float32, "part"); _chk(stats, torch.float64, "stats"); _chk(sg, torch.float32, "sg"); _chk(sb, torch.float32, "sb")
+    s_, m, n = part.shape
+    out = torch.empty(m, n, dtype=torch.float32, device=part.device)
+    _call("vpt_dense_fold_epilogue", dict(bytes=4.0 * (s_ + 1) * m * n), ptr(part), s_, ptr(stats), int(count), ptr(sg), ptr(sb), ptr(out), m, n, _stream())
+    return out
+
+
+LINEAR_TILING = {"auto": 0, "throughput": 1, "latency": 2}
+
+
 def linear(a_bf16, wpk, n, bias=None, res=None, relu=False, out_f32=True, out_bf16=False, splitk=1, mask=None,
-           out_bf16_ld=None):
+           out_bf16_ld=None, splitk_raw=False, tiling="auto"):
     """a [M,K] bf16 (row stride = K) x packed weight -> ([M,n] fp32 or None, [M,ld] bf16 or None).
     mask: optional bf16 [M, >=n] gate (output zeroed where mask <= 0).  out_bf16_ld: row stride of the bf16
-    output (>= n, extra columns zero) so it can feed the next GEMM as an A operand with K padded to 64."""
+    output (>= n, extra columns zero) so it can feed the next GEMM as an A operand with K padded to 64.
+    tiling: "throughput" = the MFMA GEMM whatever M (the inference engine's batch path: a row's result must not depend on how many rows
+    share the call), "latency" = the weight-streaming kernel (M <= 8: the acting step), "auto" = by M (vpt_linear_forward)."""
     _chk(a_bf16, OP16, "A"); _chk(wpk, OP16, "wpk"); _chk(bias, torch.float32, "bias")
     _chk(res, torch.float32, "res"); _chk(mask, OP16, "mask")
     m, k = a_bf16.shape
@@ -300,15 +314,16 @@ def linear(a_bf16, wpk, n, bias=None, res=None, relu=False, out_f32=True, out_bf
     ld16 = (out_bf16_ld or n) if out_bf16 else n
     # Mid-size M (e.g. one 128-frame IDM window): the 256 x 128 tiling alone gives N/128 workgroups for 256 CUs, so cut K
     # as well and finish with the epilogue kernel (fixed summation order: deterministic).
+    tl = LINEAR_TILING[tiling]
     auto_sk = 1
-    if splitk == 1 and 8 < m <= 512 and k >= 2048:
+    if splitk == 1 and (8 < m or tl == 1) and m <= 512 and k >= 2048 and tl != 2:
         tiles = ((m + 255) // 256) * ((n + 127) // 128)
         if tiles < 128:
             auto_sk = max(1, min(16, k // 512, 256 // tiles))
     if auto_sk > 1:
         part = torch.zeros(auto_sk, m, n, dtype=torch.float32, device=dev)
-        _call("vpt_linear_forward", dict(flops=2.0 * m * n * k, bytes=2.0 * (m * k + n * k) + 4.0 * m * n), ptr(a_bf16), ptr(wpk), None, None, ptr(part), None,
-              m, n, k, k, n, n, n, 0, auto_sk, None, 0, _stream(), fmt=fmt)
+        _call("vpt_linear_forward_tiled", dict(flops=2.0 * m * n * k, bytes=2.0 * (m * k + n * k) + 4.0 * m * n), ptr(a_bf16), ptr(wpk), None, None, ptr(part), None,
+              m, n, k, k, n, n, n, 0, auto_sk, None, 0, tl, _stream(), fmt=fmt, label="vpt_linear_forward")
         o32 = torch.empty(m, n, dtype=torch.float32, device=dev) if out_f32 else None
         o16 = None
         if out_bf16:
@@ -322,11 +337,11 @@ def linear(a_bf16, wpk, n, bias=None, res=None, relu=False, out_f32=True, out_bf
     o16 = None
     if out_bf16:
         o16 = torch.zeros(m, ld16, dtype=dt, device=dev) if ld16 > n else torch.empty(m, n, dtype=dt, device=dev)
-    _call("vpt_linear_forward", dict(flops=2.0 * m * n * k, bytes=2.0 * (m * k + n * k) + 4.0 * m * n), ptr(a_bf16), ptr(wpk), ptr(bias), ptr(res), ptr(o32), ptr(o16),
-          m, n, k, k, n, n, ld16, 1 if relu else 0, splitk, ptr(mask), mask.shape[1] if mask is not None else 0, _stream(), fmt=fmt)
-    if splitk > 1 and o32 is not None:
+    _call("vpt_linear_forward_tiled", dict(flops=2.0 * m * n * k, bytes=2.0 * (m * k + n * k) + 4.0 * m * n), ptr(a_bf16), ptr(wpk), ptr(bias), ptr(res), ptr(o32), ptr(o16),
+          m, n, k, k, n, n, ld16, 1 if relu else 0, splitk, ptr(mask), mask.shape[1] if mask is not None else 0, tl, _stream(), fmt=fmt, label="vpt_linear_forward")
+    if splitk > 1 and o32 is not None and not splitk_raw:
         o32 = o32.sum(0)           # fixed summation order: the result does not depend on scheduling
-    return o32, o16
+    return o32, o16                # (splitk_raw: the [splitk, M, n] partial slices, for an epilogue of the caller's)
 
 
 def linear_wgrad(dy16, x16, n, out=None):
