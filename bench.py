@@ -235,14 +235,14 @@ def _roofline(ops, pol, step, state, args, B, T, mode):
         ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
         # HBM traffic cannot be counted live (PMC needs rocprofv3): the committed PMC measurement of this same workload
         # (separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 per the gfx950 correction), per launch, labelled as such
-        traffic, tsrc, talg = None, None, 173.9e9 / c["calls"]
+        traffic, tsrc, talg = None, None, 152.4e9 / c["calls"]      # 18.6 MB / frame x 8192 (tools/profile_summarize.py has the derivation)
         for tp in TRAFFIC_FILES.get(mode, ()):
             tpath = os.path.join(ROOT, "profiles", tp)
             if args.model == "2x" and B * T == 8192 and os.path.exists(tpath):
                 try:      # per-step totals of the committed measurement over THIS run's launch count (sub-chunking changes the count, not the bytes)
                     tj = json.load(open(tpath))
                     per_step = tj.get("hbm_bytes_per_step", tj["hbm_bytes_per_launch"] * 112.0)
-                    alg_step = tj.get("algorithmic_bytes_per_step", 173.9e9)
+                    alg_step = tj.get("algorithmic_bytes_per_step", 152.4e9)
                     traffic, talg = round(per_step / c["calls"]), alg_step / c["calls"]
                     tsrc = f"committed PMC (profiles/{tp}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, tools/profile_round.sh: {per_step / 1e9:.1f} GB per step / {c['calls']} launches), not measured by this run"
                     break
@@ -257,7 +257,7 @@ def _roofline(ops, pol, step, state, args, B, T, mode):
     return roof, kernels
 
 
-TRAFFIC_FILES = {"bf16": ("r03_bench_conv3x3_traffic.json", "r02_bench_conv3x3_traffic.json"), "fp16": ("r03_bench_conv3x3_traffic_fp16.json",)}
+TRAFFIC_FILES = {"bf16": ("r04_bench_conv3x3_traffic.json",), "fp16": ("r04_bench_conv3x3_traffic_fp16.json",)}
 
 
 def _bc_leg(pol, args, img, first, g, dev, world, distributed, barrier, dist, mode):

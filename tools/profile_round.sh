@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence for the round (run on the GPU box): kernel-trace stats of the bench in both operand formats, PMC passes of the
 # conv kernel.  tools/profile_round.sh [R=r03]; tools/profile_summarize.py turns the raw output into the files under profiles/.
-R=${1:-r03}
+R=${1:-r04}
 out=$PWD/gpurun_out/prof_$R; mkdir -p $out
 export TMPDIR=/tmp
 cd /tmp
@@ -14,12 +14,15 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/fwdbc -- $B --steps
 if [ -z "$VPT_PROF_SKIP_PMC" ]; then
 # (3) PMC passes on the conv micro-benchmark, both formats (separate passes: SQ counters, GRBM)
 for p in bf16 fp16; do
-VPT_PRECISION=$p rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --output-format csv -d $out/pmc_sq_$p -- python $GRAFT_REPO_ROOT/tools/conv_bench.py 256 2 > $out/pmc_sq_$p.log 2>&1
-VPT_PRECISION=$p rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $out/pmc_grbm_$p -- python $GRAFT_REPO_ROOT/tools/conv_bench.py 256 2 > $out/pmc_grbm_$p.log 2>&1
+VPT_BENCH_POOL=0 VPT_PRECISION=$p rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --output-format csv -d $out/pmc_sq_$p -- python $GRAFT_REPO_ROOT/tools/conv_bench.py 256 2 > $out/pmc_sq_$p.log 2>&1
+VPT_BENCH_POOL=0 VPT_PRECISION=$p rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $out/pmc_grbm_$p -- python $GRAFT_REPO_ROOT/tools/conv_bench.py 256 2 > $out/pmc_grbm_$p.log 2>&1
 done
 # (4) HBM traffic of the conv kernel over one bench step (FETCH_SIZE x2 on gfx950, MI355X_MICROARCH.md)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- $B --steps 1 --warmup 0 --bc-steps 0 --no-cpu-baseline > $out/pmc_fetch.json 2> $out/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- $B --steps 1 --warmup 0 --bc-steps 0 --no-cpu-baseline > $out/pmc_write.json 2> $out/pmc_write.err
+# ... and in the parity mode (fp16 operands: same bytes by construction; measured, not assumed)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_fp16 -- $B --precision fp16 --steps 1 --warmup 0 --bc-steps 0 --no-cpu-baseline > $out/pmc_fetch_fp16.json 2> $out/pmc_fetch_fp16.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_fp16 -- $B --precision fp16 --steps 1 --warmup 0 --bc-steps 0 --no-cpu-baseline > $out/pmc_write_fp16.json 2> $out/pmc_write_fp16.err
 fi
 cd $GRAFT_REPO_ROOT
 # the merged-back output is capped at 64 MiB: keep the stats and counter tables, drop the per-dispatch kernel traces of the long runs

@@ -91,34 +91,38 @@ for SFX, FMT, FSFX in _variants:
                   f"wait_inst_any {100 * d.get('wait_inst_any_frac_of_wave_cycles', 0):.0f} %  LDS conflicts {100 * d.get('lds_conflict_frac', 0):.1f} %")
 
 
-# (4) HBM traffic of the conv kernel over the bench workload
-tot = {}
-launches = 0
-for sub, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    f = one(f"{sub}/**/*_counter_collection.csv")
-    if not f:
-        continue
-    s, n = 0.0, 0
-    for r in csv.DictReader(open(f)):
-        if "vpt_conv3x3_kernel" in r["Kernel_Name"] and r["Counter_Name"] == cname:
-            s += float(r["Counter_Value"]); n += 1
-    tot[cname] = s
-    launches = n
-if len(tot) == 2 and launches:
-    hbm = (tot["FETCH_SIZE"] * 2.0 + tot["WRITE_SIZE"]) * 1024.0
-    # launches per forward pass from the bench line of the profiled run itself (112 with whole-chunk launches, 160 with the conv + pool
-    # sub-chunks of stacks 1 / 2, engine.pool_subchunk); the run makes two passes (the timed step and the instrumented one)
-    per_pass = 112.0
-    try:
-        per_pass = float(json.loads(open(os.path.join(SRC, "pmc_fetch.json")).read().strip().splitlines()[-1])["roofline"]["launches"])
-    except Exception:
-        pass
-    passes = launches / per_pass
-    alg_per_step = 173.9e9               # 21.2 MB / frame x 8192 frames
-    t = dict(fetch_size_kb_sum=tot["FETCH_SIZE"], write_size_kb_sum=tot["WRITE_SIZE"], launches=launches, launches_per_step=per_pass,
-             hbm_bytes_total_fetch_x2_plus_write=hbm, hbm_bytes_per_step=hbm / passes, algorithmic_bytes_per_step=alg_per_step,
-             hbm_bytes_per_launch=hbm / launches, algorithmic_bytes_per_launch=alg_per_step / per_pass, ratio_measured_over_algorithmic=hbm / passes / alg_per_step,
-             note="forward pass(es) of the bench workload (2x, 64x128 frames), `rocprofv3 --kernel-trace --pmc "
-                  "FETCH_SIZE` / `--pmc WRITE_SIZE` in separate passes; FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B); KB units x1024")
-    json.dump(t, open(os.path.join(DST, f"{TAG}_bench_conv3x3_traffic.json"), "w"), indent=1)
-    print(f"traffic: {hbm / launches / 1e9:.3f} GB per launch over {launches} launches (x{t['ratio_measured_over_algorithmic']:.3f} of algorithmic)")
+# (4) HBM traffic of the conv kernel over the bench workload, per operand format
+# Algorithmic bytes of all vpt_conv3x3_kernel launches per frame of the 2x model, 16-bit activations, since round 4
+# (pool-fused firstconvs: the pre-pool tensor is not written; pooled tensor + seam rows / columns instead):
+#   stack-0 blocks: 4 x (1 MB in + 1 MB out) + 2 x 1 MB residual = 10 MB;  s1.first: 1 in + 0.5 pooled + 0.19 seams;  stack-1 blocks: 5 MB;
+#   s2.first: 0.5 + 0.125 + 0.03;  stack-2 blocks: 1.25 MB   ->  18.6 MB / frame, 152.4 GB per step of 8192 frames (round 3: 20.25 MB, 173.9 GB)
+ALG_PER_STEP = 18.6e6 * 8192
+for FSFX in ("", "_fp16"):
+    tot = {}
+    launches = 0
+    for sub, cname in ((f"pmc_fetch{FSFX}", "FETCH_SIZE"), (f"pmc_write{FSFX}", "WRITE_SIZE")):
+        f = one(f"{sub}/**/*_counter_collection.csv")
+        if not f:
+            continue
+        s, n = 0.0, 0
+        for r in csv.DictReader(open(f)):
+            if "vpt_conv3x3_kernel" in r["Kernel_Name"] and r["Counter_Name"] == cname:
+                s += float(r["Counter_Value"]); n += 1
+        tot[cname] = s
+        launches = n
+    if len(tot) == 2 and launches:
+        hbm = (tot["FETCH_SIZE"] * 2.0 + tot["WRITE_SIZE"]) * 1024.0
+        per_pass = 112.0
+        try:
+            per_pass = float(json.loads(open(os.path.join(SRC, f"pmc_fetch{FSFX}.json")).read().strip().splitlines()[-1])["roofline"]["launches"])
+        except Exception:
+            pass
+        passes = launches / per_pass
+        t = dict(fetch_size_kb_sum=tot["FETCH_SIZE"], write_size_kb_sum=tot["WRITE_SIZE"], launches=launches, launches_per_step=per_pass,
+                 hbm_bytes_total_fetch_x2_plus_write=hbm, hbm_bytes_per_step=hbm / passes, algorithmic_bytes_per_step=ALG_PER_STEP,
+                 hbm_bytes_per_launch=hbm / launches, algorithmic_bytes_per_launch=ALG_PER_STEP / per_pass, ratio_measured_over_algorithmic=hbm / passes / ALG_PER_STEP,
+                 note="forward pass(es) of the bench workload (2x, 64x128 frames), `rocprofv3 --kernel-trace --pmc "
+                      "FETCH_SIZE` / `--pmc WRITE_SIZE` in separate passes; FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B); KB units x1024; "
+                      "all vpt_conv3x3_kernel launches incl. the pool-fused mode")
+        json.dump(t, open(os.path.join(DST, f"{TAG}_bench_conv3x3_traffic{FSFX}.json"), "w"), indent=1)
+        print(f"traffic{FSFX}: {hbm / launches / 1e9:.3f} GB per launch over {launches} launches (x{t['ratio_measured_over_algorithmic']:.3f} of algorithmic)")
