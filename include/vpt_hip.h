@@ -110,8 +110,10 @@ int vpt_conv3x3_forward(const void* x, const void* wpk, const float* edge_sa, co
 /* The same call with the workgroup tiling named by the caller: 1 = the throughput kernel (16x16 pixels x 128 output channels per
  * workgroup: batches of frames, what bench.py measures and what vpt_conv3x3_forward always runs), 2 = the latency kernel (x 32
  * output channels: 4x the workgroups, a quarter of the serial MFMA chain each -- the acting path of agent.py:190-206, where one
- * frame would otherwise occupy 2-32 of the 256 CUs).  Any other value is an error: the tiling is never derived from the grid size
- * (a frame's result must not depend on how many frames share a launch).  Same layouts, same arithmetic, same K order. */
+ * frame would otherwise occupy 2-32 of the 256 CUs), 3 = the throughput kernel on 32x16-pixel tiles with eight waves where H % 32 == 0
+ * (one weight fetch per 512 pixels; bit-identical outputs, measured at parity with 1 -- kept for A/B measurements).  Any other value
+ * is an error: the tiling is never derived from the grid size (a frame's result must not depend on how many frames share a launch).
+ * Same layouts, same arithmetic, same K order. */
 int vpt_conv3x3_forward_tiled(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg,
                               const double* stats_in, const void* res, void* y, double* stats_out,
                               int frames, int H, int W, int Cin, int Cout, int tiling, void* stream);

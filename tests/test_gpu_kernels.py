@@ -39,7 +39,7 @@ def _stats_of(x_nchw):
     (2, 64, 64, 64, 128, False),    # 1x stack-1 firstconv
     (2, 16, 16, 32, 64, True),      # a single 32-channel block: no peeled first block, the last one starts from zeroed accumulators
 ])
-@pytest.mark.parametrize("tiling", ["throughput", "latency"])   # both workgroup tilings of the same convolution (vpt_conv3x3_forward_tiled)
+@pytest.mark.parametrize("tiling", ["throughput", "latency", "throughput32"])   # the workgroup tilings of the same convolution (vpt_conv3x3_forward_tiled)
 def test_conv3x3(frames, h, w, cin, cout, use_res, tiling):
     g = torch.Generator().manual_seed(1)
     W = torch.randn(cout, cin, 3, 3, generator=g) * (1.6 / (cin * 9) ** 0.5)
@@ -66,6 +66,11 @@ def test_conv3x3(frames, h, w, cin, cout, use_res, tiling):
                          res=packing.nchw_to_blocked(res.float()).to(DEV) if use_res else None, tiling="throughput")
         torch.cuda.synchronize()
         assert _relerr(y.float().cpu(), y2.float().cpu()) < 1e-3
+    if tiling == "throughput32":   # 32-row / eight-wave tiles (where the image has whole 32-row bands) vs the shipped 16-row tiles: the same per-pixel program
+        y2 = ops.conv3x3(packing.nchw_to_blocked(xb.float()).to(DEV), wpk, sa, sg, st_in, cout,
+                         res=packing.nchw_to_blocked(res.float()).to(DEV) if use_res else None, tiling="throughput")
+        torch.cuda.synchronize()
+        assert torch.equal(y.view(torch.int16), y2.view(torch.int16))
     st_ref = _stats_of(ref)
     assert torch.allclose(st_out.cpu(), st_ref, rtol=5e-3, atol=1.0), (st_out.cpu(), st_ref)
 

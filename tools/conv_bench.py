@@ -12,6 +12,7 @@ ge.build()
 from vpt_amd import ops, packing  # noqa: E402
 
 DT = {"bf16": torch.bfloat16, "fp16": torch.float16}[os.environ.get("VPT_PRECISION", "bf16")]   # operand format (library) under test
+TILING = os.environ.get("VPT_BENCH_TILING", "throughput")   # "throughput32": the 32-row / eight-wave tiles
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = "cuda"
@@ -36,14 +37,14 @@ for name, hw, cin, cout, use_res in shapes:
     st_out = None if os.environ.get("VPT_BENCH_NOSTATS") == "1" else torch.zeros(f, 2, dtype=torch.float64, device=dev)
     out = torch.empty(f, cout // 32, hw, hw, 32, dtype=DT, device=dev)
     for _ in range(2):
-        ops.conv3x3(x, wpk, sa, sg, st_in, cout, res=res, stats_out=st_out, out=out)
+        ops.conv3x3(x, wpk, sa, sg, st_in, cout, res=res, stats_out=st_out, out=out, tiling=TILING)
     torch.cuda.synchronize()
     times = []
     for _ in range(5):  # 5 rounds of `reps` launches; report median and best round
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(reps):
-            ops.conv3x3(x, wpk, sa, sg, st_in, cout, res=res, stats_out=st_out, out=out)
+            ops.conv3x3(x, wpk, sa, sg, st_in, cout, res=res, stats_out=st_out, out=out, tiling=TILING)
         b.record()
         torch.cuda.synchronize()
         times.append(a.elapsed_time(b) / reps)

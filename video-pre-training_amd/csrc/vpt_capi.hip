@@ -93,7 +93,7 @@ int vpt_conv3x3_forward_tiled(const void* x, const void* wpk, const float* edge_
                               const double* stats_in, const void* res, void* y, double* stats_out,
                               int frames, int H, int W, int Cin, int Cout, int tiling, void* stream) {
   if (!stats_in) return fail(-1, "vpt_conv3x3_forward: stats_in is required");
-  if (tiling != 1 && tiling != 2) return fail(-1, "vpt_conv3x3_forward_tiled: tiling must be 1 (throughput) or 2 (latency)");
+  if (tiling < 1 || tiling > 3) return fail(-1, "vpt_conv3x3_forward_tiled: tiling must be 1 (throughput), 2 (latency) or 3 (throughput, 32-row tiles)");
   VptConv3x3Args a;
   a.tiling = tiling;
   a.x = (const vpt_op16*)x; a.wpk = (const vpt_op16*)wpk; a.edge_sa = edge_sa; a.edge_sg = edge_sg;

@@ -48,8 +48,8 @@
 #define B_BYTES (3 * 128 * 64)          // 24576 per buffer (unpadded, swizzled)
 #define KK_OFF (A_BYTES + 2 * B_BYTES)  // 75072
 #define KK_BYTES (9 * 128 * 4)          // 4608
-#define BT_OFF (KK_OFF + KK_BYTES + 32)  // 79712: per-channel residual bias of mode 5 (128 floats), after the block statistics' 32 bytes
-#define SMEM_BYTES (BT_OFF + 512)       // 80224: two workgroups per CU = 160448 of 163840 bytes
+#define BT_OFF (KK_OFF + KK_BYTES + 64)  // 79744: per-channel residual bias of mode 5 (128 floats), after the block statistics' 64 bytes
+#define SMEM_BYTES (BT_OFF + 512)       // 80256: two workgroups per CU = 160512 of 163840 bytes
 #define PT_RS 272                       // pixel pitch of the 16 x 16 x 128-channel output tile of the pool-fused mode (256 + 16 bytes)
 static_assert(256 * PT_RS <= KK_OFF, "the pooled mode's output tile must fit below the epilogue table");
 
@@ -69,14 +69,28 @@ __device__ __forceinline__ int sub_row(int i) { return ((i >> 4) ^ (i >> 2) ^ (i
 // written -- complete where the 3 x 3 window lies inside the tile, the in-tile part of the maximum on the tile's first pooled row /
 // column otherwise -- together with the tile's last row and column (the "seams"); vpt_pool_seam_kernel finishes the seam pixels.
 // The pre-pool tensor (2 MB per frame in stack 1: written and read back by vpt_pool_kernel before) never reaches HBM.
-template <bool TRACE, int MODE>
-__global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
+// TR (compile time): pixel rows of the workgroup's tile.  16: four waves (2 row groups x 2 channel halves), two workgroups per CU.
+// 32: EIGHT waves (4 row groups x 2 channel halves) on a 32 x 16-pixel tile, one workgroup per CU -- the same waves per SIMD, the same
+// per-wave program, but the step's 24 KB weight tile is fetched ONCE for 512 pixels instead of once per co-resident workgroup: half
+// the weight DMA (288 KB per 256 pixels and K = 1152 before -- the largest stream on a CU's memory path) and
+// 11 % less halo (34 x 18 instead of 2 x 18 x 18 pixels).
+template <bool TRACE, int MODE, int TR = 16>
+__global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
+  static_assert(TR == 16 || TR == 32, "tile rows");
+  constexpr int NWAVE = TR / 4, NTHR = 64 * NWAVE;
+  constexpr int HPIX = (TR + 2) * 18;                            // halo pixels
+  constexpr int NA = (HPIX * 4 + NTHR - 1) / NTHR;               // 16-byte halo chunks per thread and channel block: 6 / 5
+  constexpr int NDMA = 24 / NWAVE;                               // 1 KB weight-DMA pieces per wave and step: 6 / 3
+  constexpr int A_SZ = HPIX * A_RS, KK_O = A_SZ + 2 * B_BYTES, BT_O = KK_O + KK_BYTES + 64, SMEM_SZ = BT_O + 512;
+  constexpr int NKK = (9 * 128 + NTHR - 1) / NTHR;
+  static_assert(TR != 16 || (A_SZ == A_BYTES && KK_O == KK_OFF && SMEM_SZ <= SMEM_BYTES), "16-row layout");
+  static_assert(MODE != 4 || TR == 16, "the pool-fused epilogue is written for 16 x 16 tiles");
   // 5 forward + residual through a per-frame affine:  out = relu(...) + res_scale[f] * res + res_bias[f][channel]  -- the block that
   // follows a stack's GroupNorm `n` reads the pooled tensor itself (already multiplied by n's gain) instead of a normalised copy
   // (lib/impala_cnn.py:118-121 with the `n` pass folded away).
   constexpr bool BWD = (MODE == 2 || MODE == 3), HAS_RES = (MODE == 1 || MODE == 3 || MODE == 5), USE_X = BWD, POOL = MODE == 4, RES_AFF = MODE == 5;
   constexpr bool DEFER_STORES = MODE != 3;   // mode 3 holds skip + xin pieces as well: no registers left for the packed results
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_SZ];
   const int tid = threadIdx.x, lane = tid & 63;
   // profiling (vpt_conv3x3_set_trace): CU id + 100 MHz timestamps of the tile's phases
   int cu_key = -1;
@@ -87,30 +101,34 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_REG_XCC_ID[3:0]
     cu_key = (int)(((xcc & 15u) << 8) | ((hw >> 8) & 0xffu));
   }
+#ifdef VPT_CONV_DEPHASE   // profiling builds: the SECOND workgroup of a CU's first generation (wave slot 1 of its SIMD) starts VPT_CONV_DEPHASE x ~4 us late
+  if (blockIdx.x < 512 && (__builtin_amdgcn_s_getreg((4 << 11) | 4) & 15u) == 1u)
+    for (int i_ = 0; i_ < VPT_CONV_DEPHASE; ++i_) __builtin_amdgcn_s_sleep(127);
+#endif
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;
   const int hi = lane >> 5, l31 = lane & 31;
-  const int tilesX = a.W >> 4, tilesY = a.H >> 4;
+  const int tilesX = a.W >> 4, tilesY = a.H / TR;
   int L = xcd_remap(blockIdx.x, gridDim.x);
   const int nt = L % a.NT; L /= a.NT;
   const int tx = L % tilesX; L /= tilesX;
   const int ty = L % tilesY;
   const int f = L / tilesY;
-  const int tx0 = tx * 16, ty0 = ty * 16;
+  const int tx0 = tx * 16, ty0 = ty * TR;
   const int NCB = a.Cin >> 5;
   const int HW = a.H * a.W;
 
   // ---- halo staging map: chunk q -> (pixel P = 8*(q>>5) + (q&7), part = (q>>3)&3) ----
-  int a_loff[6];            // LDS byte offset, -1: no chunk (beyond the 324 halo pixels)
-  unsigned a_gbyte[6];      // byte offset inside one channel-block plane (clamped to 0 outside the image)
+  int a_loff[NA];            // LDS byte offset, -1: no chunk (beyond the 324 halo pixels)
+  unsigned a_gbyte[NA];      // byte offset inside one channel-block plane (clamped to 0 outside the image)
   unsigned a_inside = 0;    // bit m: chunk m lies inside the image (else literal zeros: the conv pads the NORMALISED tensor)
 #pragma unroll
-  for (int m = 0; m < 6; ++m) {
-    const int q = tid + 256 * m;
+  for (int m = 0; m < NA; ++m) {
+    const int q = tid + NTHR * m;
     const int P = ((q >> 5) << 3) + (q & 7), part = (q >> 3) & 3;
     a_loff[m] = -1;
     a_gbyte[m] = 0u;
-    if (P < 324) {
+    if (P < HPIX) {
       const int hy = P / 18, hx = P - hy * 18;
       const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
       a_loff[m] = P * A_RS + part * 16;
@@ -121,26 +139,26 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     }
   }
   const op16_t* xplane = a.x + (size_t)f * NCB * HW * 32;
-  // weight DMA: wave w moves pieces (4*m + w), m = 0..5, of the 24 KB step tile; lane = 16-byte chunk
+  // weight DMA: wave w moves pieces (NWAVE*m + w), m = 0..NDMA-1, of the 24 KB step tile; lane = 16-byte chunk
   const op16_t* wbase = a.wpk + (size_t)nt * NCB * 9 * 4096 + (size_t)(w * 64 + lane) * 8;
-  unsigned char* bdst = smem + A_BYTES + w * 1024;
+  unsigned char* bdst = smem + A_SZ + w * 1024;
 
 #define ISSUE_B(step_, buf_)                                                                              \
   do {                                                                                                    \
     const op16_t* wp_ = wbase + (size_t)(step_) * 12288;                                                  \
-    _Pragma("unroll") for (int m_ = 0; m_ < 6; ++m_)                                                      \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp_ + m_ * 2048),  \
-                                       (__attribute__((address_space(3))) void*)(bdst + (buf_) * B_BYTES + m_ * 4096), \
+    _Pragma("unroll") for (int m_ = 0; m_ < NDMA; ++m_)                                                   \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp_ + m_ * (NWAVE * 512)),  \
+                                       (__attribute__((address_space(3))) void*)(bdst + (buf_) * B_BYTES + m_ * (NWAVE * 1024)), \
                                        16, 0, 0);                                                         \
   } while (0)
 
-  u32x4 areg[6];
+  u32x4 areg[NA];
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
   // ---- prologue: weights of step 0 (DMA), halo of channel block 0, epilogue constant table ----
   ISSUE_B(0, 0);
 #pragma unroll
-  for (int m = 0; m < 6; ++m) areg[m] = *(const u32x4*)((const char*)xplane + a_gbyte[m]);
+  for (int m = 0; m < NA; ++m) areg[m] = *(const u32x4*)((const char*)xplane + a_gbyte[m]);
   float mean = 0.f, rstd = 1.f, c0f = 0.f, c1f = 0.f;
   const float* esa = a.edge_sa;
   if (!BWD) {
@@ -155,28 +173,28 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     c1f = a.coef[2 * f + 1];
   }
   {
-    float* kk = (float*)(smem + KK_OFF);
-    float ksa[5], ksg[5];
+    float* kk = (float*)(smem + KK_O);
+    float ksa[NKK], ksg[NKK];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {  // 9*128 = 4.5 * 256 entries: all ten loads in flight together
-      const int idx = tid + 256 * k;
+    for (int k = 0; k < NKK; ++k) {  // 9*128 = 4.5 * 256 entries: all the loads in flight together
+      const int idx = tid + NTHR * k;
       const int o = (idx >> 7) * a.CoutPad + nt * 128 + (idx & 127);
       ksa[k] = (idx < 9 * 128 && !BWD) ? esa[o] : 0.f;
       ksg[k] = (idx < 9 * 128 && !BWD) ? a.edge_sg[o] : 0.f;
     }
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const int idx = tid + 256 * k;
+    for (int k = 0; k < NKK; ++k) {
+      const int idx = tid + NTHR * k;
       if (idx < 9 * 128) kk[idx] = ksa[k] - rstd * mean * ksg[k];
     }
   }
   float res_s = 1.f;
   if (RES_AFF) {
     res_s = a.res_scale[f];
-    if (tid < 128) ((float*)(smem + BT_OFF))[tid] = (nt * 128 + tid < a.Cout) ? a.res_bias[(size_t)f * a.Cout + nt * 128 + tid] : 0.f;
+    if (tid < 128) ((float*)(smem + BT_O))[tid] = (nt * 128 + tid < a.Cout) ? a.res_bias[(size_t)f * a.Cout + nt * 128 + tid] : 0.f;
   }
 #define WRITE_HALO()                                                                                      \
-  _Pragma("unroll") for (int m_ = 0; m_ < 6; ++m_)                                                        \
+  _Pragma("unroll") for (int m_ = 0; m_ < NA; ++m_)                                                       \
     if (a_loff[m_] >= 0) *(u32x4*)(smem + a_loff[m_]) = ((a_inside >> m_) & 1u) ? areg[m_] : zero4
   WRITE_HALO();
   __syncthreads();
@@ -189,8 +207,8 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   // fragment base addresses
   const unsigned char* aL = smem + ((wm * 8 + sub_row(l31)) * 18 + (l31 & 15)) * A_RS + hi * 16;
   const int bsw = (l31 >> 2) & 3;
-  const unsigned char* bL0 = smem + A_BYTES + (wn * 64 + l31) * 64 + (((0 + hi) ^ bsw) << 4);  // ks = 0
-  const unsigned char* bL1 = smem + A_BYTES + (wn * 64 + l31) * 64 + (((2 + hi) ^ bsw) << 4);  // ks = 1
+  const unsigned char* bL0 = smem + A_SZ + (wn * 64 + l31) * 64 + (((0 + hi) ^ bsw) << 4);  // ks = 0
+  const unsigned char* bL1 = smem + A_SZ + (wn * 64 + l31) * 64 + (((2 + hi) ^ bsw) << 4);  // ks = 1
 
   // epilogue addressing (needed early: the residual is requested during the last channel block)
   // Operands are SWAPPED in the MFMA (weights = A rows, pixels = B columns): a lane holds ONE pixel (column l31 of the
@@ -288,10 +306,10 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
 #define VPT_CONV_DMA_PIECES 6   // profiling builds: fewer weight-DMA pieces per wave and step (the results are then wrong; timing only)
 #endif
 #define GLDS(m_)                                                                                          \
-  do { if ((m_) < VPT_CONV_DMA_PIECES)                                                                    \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp_ + (m_) * 2048),    \
-                                   (__attribute__((address_space(3))) void*)(bd_ + (m_) * 4096), 16, 0, 0); } while (0)
-#define XA(m_) do { if (VPT_CONV_HALO_ABLATE != 2) areg[m_] = *(const u32x4*)((const char*)xplane + (cbo_ + a_gbyte[m_])); } while (0)
+  do { if ((m_) < VPT_CONV_DMA_PIECES && (m_) < NDMA)                                                     \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp_ + (m_) * (NWAVE * 512)),    \
+                                   (__attribute__((address_space(3))) void*)(bd_ + (m_) * (NWAVE * 1024)), 16, 0, 0); } while (0)
+#define XA(m_) do { if (VPT_CONV_HALO_ABLATE != 2 && (m_) < NA) areg[(m_) < NA ? (m_) : 0] = *(const u32x4*)((const char*)xplane + (cbo_ + a_gbyte[m_])); } while (0)
 #if VPT_RES_NATIVE
 #define XR(m_, n2_, p_) do { rq[m_][n2_][2 * (p_)] = EPI_LDN(resp, m_, n2_, 2 * (p_)); rq[m_][n2_][2 * (p_) + 1] = EPI_LDN(resp, m_, n2_, 2 * (p_) + 1); } while (0)
 #else
@@ -333,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     if (PRE_A) {                                                                                          \
       GROUP(1, dy_, 4, boff_, do { XA(0); XA(1); } while (0), do { XA(2); } while (0));                   \
       GROUP(0, dy_, 5, boff_, do { XA(3); XA(4); } while (0), do { XA(5); } while (0));                   \
-      if (VPT_CONV_HALO_ABLATE == 2) WAIT_BARRIER(0); else WAIT_BARRIER(6);                               \
+      if (VPT_CONV_HALO_ABLATE == 2) WAIT_BARRIER(0); else if (NA == 6) WAIT_BARRIER(6); else WAIT_BARRIER(5);                               \
     } else if ((PRE_R) && HAS_RES) { /* compile-time: without a residual the loads would be dead code and the count wrong */ \
       GROUP(1, dy_, 4, boff_, do { XR(0, 0, 0); XR(0, 0, 1); } while (0), do { XR(0, 1, 0); XR(0, 1, 1); } while (0)); \
       GROUP(0, dy_, 5, boff_, do { XR(1, 0, 0); XR(1, 0, 1); } while (0), do { XR(1, 1, 0); XR(1, 1, 1); } while (0)); \
@@ -347,10 +365,10 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
       _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_) {                                                  \
         if (VPT_CONV_HALO_ABLATE == 0) {                                                                  \
           if (a_loff[m_] >= 0) *(u32x4*)(smem + a_loff[m_]) = ((a_inside >> m_) & 1u) ? areg[m_] : zero4; \
-          if (m_ + 4 < 6 && a_loff[m_ + 4] >= 0) *(u32x4*)(smem + a_loff[m_ + 4]) = ((a_inside >> (m_ + 4)) & 1u) ? areg[m_ + 4] : zero4; \
+          if (m_ + 4 < NA && a_loff[m_ + 4 < NA ? m_ + 4 : 0] >= 0) *(u32x4*)(smem + a_loff[m_ + 4 < NA ? m_ + 4 : 0]) = ((a_inside >> (m_ + 4)) & 1u) ? areg[m_ + 4 < NA ? m_ + 4 : 0] : zero4; \
         } else if (VPT_CONV_HALO_ABLATE == 1) {                                                           \
           if (a_loff[m_] >= 0) *(u32x4*)(smem + a_loff[m_]) = areg[m_];                                   \
-          if (m_ + 4 < 6 && a_loff[m_ + 4] >= 0) *(u32x4*)(smem + a_loff[m_ + 4]) = areg[m_ + 4];         \
+          if (m_ + 4 < NA && a_loff[m_ + 4 < NA ? m_ + 4 : 0] >= 0) *(u32x4*)(smem + a_loff[m_ + 4 < NA ? m_ + 4 : 0]) = areg[m_ + 4 < NA ? m_ + 4 : 0];         \
         }                                                                                                 \
         SB(); MM(1, m_, 0); SB();                                                                         \
       }                                                                                                   \
@@ -444,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     const int ex = (x == 0) ? 0 : ((x == a.W - 1) ? 2 : 1);
     eoff[m] = (ey * 3 + ex) * 128 + wn * 64 + 4 * hi;
   }
-  const float* kk = (const float*)(smem + KK_OFF);
+  const float* kk = (const float*)(smem + KK_O);
   constexpr bool use_x = USE_X;
   u32x4 xq[2][2][2];          // dgrad: the forward layer's input, [parity of m][n2][pair], one subtile ahead
   u32x4 outv[4][2][2];        // packed results: ALL stores are issued after the last load has been consumed.  gfx950 has one
@@ -479,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
 #pragma unroll
     for (int n2_ = 0; n2_ < NV; ++n2_)
 #pragma unroll
-      for (int g_ = 0; g_ < 4; ++g_) bq[n2_][g_] = *(const f32x4*)((const float*)(smem + BT_OFF) + wn * 64 + n2_ * 32 + 8 * g_ + 4 * hi);
+      for (int g_ = 0; g_ < 4; ++g_) bq[n2_][g_] = *(const f32x4*)((const float*)(smem + BT_O) + wn * 64 + n2_ * 32 + 8 * g_ + 4 * hi);
   }
 
 #pragma unroll
@@ -588,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     // its last fragment read first.  A lane holds 4 consecutive channels of one pixel per accumulator group: one ds_write_b64 each.
     __syncthreads();
     {
-      const float* kk = (const float*)(smem + KK_OFF);
+      const float* kk = (const float*)(smem + KK_O);
       const f32x2 zero2 = {0.f, 0.f};
       const f32x2 rstd2 = {rstd, rstd};
 #pragma unroll
@@ -688,7 +706,7 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
     if (a.chs_out) {
       // threads tid = octet + 16 q share an octet: lanes octet + 16 {0..3} of each wave (two exchanges), then the four waves through the
       // epilogue-table area of the LDS (dead since phase 1), then one fp64 atomic per (channel, moment): 256 per tile
-      float* scr = (float*)(smem + KK_OFF);          // [4 waves][16 octets][16]
+      float* scr = (float*)(smem + KK_O);          // [4 waves][16 octets][16]
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         c1[k] += __shfl_xor(c1[k], 16, 64); c1[k] += __shfl_xor(c1[k], 32, 64);
@@ -712,14 +730,19 @@ __global__ __launch_bounds__(256, 2) void vpt_conv3x3_kernel(VptConv3x3Args a) {
   }
   float s_sum = s_sum2.x + s_sum2.y, s_sq = s_sq2.x + s_sq2.y;
   if (!BWD && a.stats_out) {
-    float* red = (float*)(smem + KK_OFF + KK_BYTES);
+    float* red = (float*)(smem + KK_O + KK_BYTES);
     s_sum = wave_sum(s_sum);
     s_sq = wave_sum(s_sq);
-    if (lane == 0) { red[w] = s_sum; red[4 + w] = s_sq; }
+    if (lane == 0) { red[w] = s_sum; red[NWAVE + w] = s_sq; }
     __syncthreads();
     if (tid == 0) {
-      atomicAdd(a.stats_out + 2 * f, (double)((red[0] + red[1]) + (red[2] + red[3])));
-      atomicAdd(a.stats_out + 2 * f + 1, (double)((red[4] + red[5]) + (red[6] + red[7])));
+      float t1 = (red[0] + red[1]) + (red[2] + red[3]), t2 = (red[NWAVE] + red[NWAVE + 1]) + (red[NWAVE + 2] + red[NWAVE + 3]);
+      if (NWAVE == 8) {
+        t1 += (red[4] + red[5]) + (red[6] + red[7]);
+        t2 += (red[12] + red[13]) + (red[14] + red[15]);
+      }
+      atomicAdd(a.stats_out + 2 * f, (double)t1);
+      atomicAdd(a.stats_out + 2 * f + 1, (double)t2);
     }
   }
   if (TRACE && tid == 0) {
@@ -954,10 +977,10 @@ extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream
   if ((a->res_bias != nullptr) != (a->res_scale != nullptr) || (a->res_bias && (a->bwd || !a->res))) return -1;
   if ((a->kk_frame != nullptr) != (a->rs_frame != nullptr) || (a->kk_frame && a->bwd)) return -1;
   if (a->bwd && (!a->xin || !a->coef)) return -1;   // dgrad always carries the GroupNorm-statistics terms (c0 + c1 * xin)
-  if (a->pool && (a->bwd || a->res || a->tiling != 1 || a->trace || !a->seam_r || !a->seam_c)) return -1;
+  if (a->pool && (a->bwd || a->res || (a->tiling != 1 && a->tiling != 3) || a->trace || !a->seam_r || !a->seam_c)) return -1;
   // the latency tiling (32 output channels per workgroup) is the CALLER's choice, never the grid size's: a frame's result must not
   // depend on how many frames share the launch (the two tilings sum a tile's statistics in different orders)
-  if (!a->bwd && a->tiling != 1 && a->tiling != 2) return -1;
+  if (!a->bwd && a->tiling != 1 && a->tiling != 2 && a->tiling != 3) return -1;
   if (!a->bwd && !a->trace && a->tiling == 2) {
     const long sgrid = (long)a->frames * (a->H >> 4) * (a->W >> 4) * (a->Cout >> 5);
     if (a->res) hipLaunchKernelGGL((vpt_conv3x3_small_kernel<true>), dim3((unsigned)sgrid), dim3(512), 0, stream, *a);
@@ -966,6 +989,16 @@ extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream
   }
 #define LAUNCH_(T_, M_) hipLaunchKernelGGL((vpt_conv3x3_kernel<T_, M_>), dim3((unsigned)grid), dim3(256), extra_lds, stream, *a)
   if (a->trace && mode > 3) return -1;
+  // tiling 3 (forward) = the 32-row, eight-wave tiles wherever the image has whole 32-row bands.  Measured at parity with the 16-row tiles on
+  // every layer shape (profiles/r04_experiments.md section 7: halving the weight DMA buys nothing on a power-limited chip), so the shipped
+  // choice stays the 16-row kernel; the variant is kept selectable because it is bit-identical per pixel and covered by the same tests.
+  if (!a->trace && !a->bwd && mode != 4 && (a->H & 31) == 0 && a->tiling == 3 && !extra_lds) {
+    const long g32 = grid >> 1;
+#define LAUNCH32_(M_) hipLaunchKernelGGL((vpt_conv3x3_kernel<false, M_, 32>), dim3((unsigned)g32), dim3(512), 0, stream, *a)
+    if (mode == 0) LAUNCH32_(0); else if (mode == 1) LAUNCH32_(1); else LAUNCH32_(5);
+#undef LAUNCH32_
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+  }
   if (a->trace) { if (mode == 0) LAUNCH_(true, 0); else if (mode == 1) LAUNCH_(true, 1); else if (mode == 2) LAUNCH_(true, 2); else LAUNCH_(true, 3); }
   else { if (mode == 0) LAUNCH_(false, 0); else if (mode == 1) LAUNCH_(false, 1); else if (mode == 2) LAUNCH_(false, 2); else if (mode == 3) LAUNCH_(false, 3); else if (mode == 4) LAUNCH_(false, 4); else LAUNCH_(false, 5); }
 #undef LAUNCH_

@@ -171,7 +171,7 @@ def conv_first(img_u8, wfrag, cout, stats_out=None, out_gain=None, chs_out=None)
     return y
 
 
-CONV_TILING = {"throughput": 1, "latency": 2}
+CONV_TILING = {"throughput": 1, "latency": 2, "throughput32": 3}   # throughput32: 32-row / eight-wave tiles where H % 32 == 0 (measured at parity; A/B)
 
 
 def conv3x3(x, wpk, edge_sa, edge_sg, stats_in, cout, res=None, stats_out=None, out=None, tiling="throughput"):
@@ -191,7 +191,7 @@ def conv3x3(x, wpk, edge_sa, edge_sg, stats_in, cout, res=None, stats_out=None, 
         raise ValueError(f"conv3x3: tiling must be one of {sorted(CONV_TILING)}, got {tiling!r}")
     _call("vpt_conv3x3_forward_tiled", meta, ptr(x), ptr(wpk), ptr(edge_sa), ptr(edge_sg), ptr(stats_in), ptr(res),
           ptr(out), ptr(stats_out), f, h, w, cb * 32, cout, CONV_TILING[tiling], _stream(), fmt=fmt,
-          label="vpt_conv3x3_forward" if tiling == "throughput" else "vpt_conv3x3_forward_latency")
+          label="vpt_conv3x3_forward_latency" if tiling == "latency" else "vpt_conv3x3_forward")
     return out
 
 
