@@ -20,9 +20,14 @@ Bounds per precision mode (engine.PolicyEngine):
 import numpy as np
 
 BOUNDS = {
-    "fp16": dict(lp_max=1.5e-3, lp_l2=1e-3, c_l2=1.2e-2, c_max=2.0e-2, latent_l2=1.2e-2, v_rel=4.0e-2, kv_l2=1.2e-2),
-    "bf16": dict(lp_max=1e-2, lp_l2=3e-3, c_l2=8e-2, c_max=1.2e-1, latent_l2=8e-2, v_rel=2.5e-1, kv_l2=6e-2),
+    "fp16": dict(lp_max=1.5e-3, lp_l2=1e-3, c_l2=1.2e-2, c_max=2.0e-2, latent_l2=1.2e-2, v_rel=4.0e-2, v_rel_1x=4.0e-2, kv_l2=1.2e-2),
+    "bf16": dict(lp_max=1e-2, lp_l2=3e-3, c_l2=8e-2, c_max=1.2e-1, latent_l2=8e-2, v_rel=6.0e-2, v_rel_1x=2.0e-1, kv_l2=6e-2),
 }
+# v_rel (the value head, |dv| / max(1, |v|): an ABSOLUTE error, the synthetic value head's outputs stay below 1) is gated per model width:
+# the 2x / 3x / 4x models measure 0.017-0.045 in bf16 on every config-sized test (round 4: 2x forward 0.031, config 2 chunks 0.045 / 0.017,
+# vs the reference policy 0.035, 3x 0.021) -> 6e-2; the 1x model -- half the channels and half the trunk width to average the operand
+# rounding over, the same O(1) value-head weights -- measures 0.04-0.11 (golden chunks A-C 0.002 / 0.09 / 0.07, t = 33: 0.11), the CPU
+# emulator of the kernels' rounding points predicts up to 0.1 for it (profiles/r02_precision_sweep_1x.md) -> 2e-1.
 
 
 # BC gradients against the fp32 oracle's autograd (= the reference's own loss.backward(), pinned by tests/golden/make_golden_bc.py).
@@ -101,9 +106,12 @@ def policy_metrics(out, ref):
     return m
 
 
-def check(m, mode, what=""):
-    """Assert every gated number of policy_metrics() against BOUNDS[mode]; exact deterministic actions outside the noise band."""
-    b = BOUNDS[mode]
+def check(m, mode, what="", model="2x"):
+    """Assert every gated number of policy_metrics() against BOUNDS[mode]; exact deterministic actions outside the noise band.
+    model: "1x" selects the 1x model's value-head bound (v_rel_1x), anything else the bound of the wider models."""
+    b = dict(BOUNDS[mode])
+    if model == "1x":
+        b["v_rel"] = b["v_rel_1x"]
     bad = []
     for h in ("buttons", "camera"):
         for k in ("lp_max", "lp_l2", "c_l2", "c_max"):

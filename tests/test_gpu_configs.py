@@ -362,7 +362,7 @@ def test_pre_lstm_ln_option_forward_and_bc():
         so = ref["state_out"]
         (pd, vpred, _), sg = pol({"img": img.to(DEV)}, first.to(DEV), sg)
         torch.cuda.synchronize()
-        P.check(P.policy_metrics(dict(buttons=pd["buttons"], camera=pd["camera"], vpred=vpred), ref), "bf16", f"pre_lstm_ln t={t}")
+        P.check(P.policy_metrics(dict(buttons=pd["buttons"], camera=pd["camera"], vpred=vpred), ref), "bf16", f"pre_lstm_ln t={t}", model="1x")
     # the option must matter: without the extra LayerNorm the same weights give different log-probs
     cfg_off = dict(cfg); cfg_off["use_pre_lstm_ln"] = False
     off = O.policy_forward(sd, cfg_off, img, first, O.initial_state(cfg, b))

@@ -67,7 +67,7 @@ def test_policy_chunks_vs_golden(pol_1x, golden_1x):
         m = P.policy_metrics(dict(buttons=pd["buttons"], camera=pd["camera"], vpred=vpred),
                              dict(buttons=G[f"{tag}_buttons"], camera=G[f"{tag}_camera"], vpred=G[f"{tag}_vpred"]))
         print(f"PARITY[{mode}] vs golden chunk {tag}: {P.fmt(m)}")
-        P.check(m, mode, f"golden chunk {tag}")
+        P.check(m, mode, f"golden chunk {tag}", model="1x")
         for l, (mk, (k, v)) in enumerate(state):
             assert mk.dtype == torch.bool and mk.shape == (b, 1, 128)
             assert np.array_equal(mk.cpu().numpy(), G[f"{tag}_mask{l}"])
@@ -132,7 +132,7 @@ def test_policy_vs_oracle_long_chunk(pol_1x):
         B = P.BOUNDS[pol.precision]
         m = P.policy_metrics(dict(buttons=pd["buttons"], camera=pd["camera"], vpred=vpred), ref)
         print(f"PARITY[{pol.precision}] vs oracle t={t}: {P.fmt(m)}")
-        P.check(m, pol.precision, f"long chunk t={t}")
+        P.check(m, pol.precision, f"long chunk t={t}", model="1x")
         for (m1, (k1, v1)), (m2, (k2, v2)) in zip(sg, so):
             assert torch.equal(m1.cpu(), m2)
             assert _l2(k1, k2) < B["kv_l2"] and _l2(v1, v2) < B["kv_l2"]
@@ -195,7 +195,7 @@ def test_policy_full_chunk_t128(pol_1x):
     B = P.BOUNDS[pol.precision]
     m = P.policy_metrics(dict(buttons=pd["buttons"], camera=pd["camera"], vpred=vpred), ref)
     print(f"PARITY[{pol.precision}] vs oracle t=128: {P.fmt(m)}")
-    P.check(m, pol.precision, "t=128")
+    P.check(m, pol.precision, "t=128", model="1x")
     for (m1, (k1, v1)), (m2, (k2, v2)) in zip(sg, ref["state_out"]):
         assert torch.equal(m1.cpu(), m2) and bool(m2.all())
         assert _l2(k1, k2) < B["kv_l2"]
@@ -237,9 +237,9 @@ def test_step_graph_matches_eager(pol_1x):
             ref = O.policy_forward(sd, cfg, frames[i].cpu()[None], torch.tensor([[firsts[i]]]), so)
             so = ref["state_out"]
             m = P.policy_metrics(dict(buttons=g_[2][None], camera=g_[3][None]), dict(buttons=ref["buttons"], camera=ref["camera"]))
-            P.check(m, pol.precision, f"graphed step {i} vs oracle")
+            P.check(m, pol.precision, f"graphed step {i} vs oracle", model="1x")
             v_ref = float(O.denormalize_value(sd, "value_head.", ref["vpred"]).reshape(-1)[0])
-            assert abs(g_[4] - v_ref) < P.BOUNDS[pol.precision]["v_rel"] * max(1.0, abs(v_ref)) * 1.3, (i, g_[4], v_ref)
+            assert abs(g_[4] - v_ref) < P.BOUNDS[pol.precision]["v_rel_1x"] * max(1.0, abs(v_ref)) * 1.3, (i, g_[4], v_ref)
         for e, g_, g2 in zip(eager, graphed, graphed2):
             assert e[0] == g_[0] == g2[0] and e[1] == g_[1] == g2[1]
             assert torch.allclose(e[2], g_[2], atol=2e-4) and torch.allclose(e[3], g_[3], atol=2e-4) and abs(e[4] - g_[4]) < 1e-3
@@ -284,7 +284,7 @@ def test_policy_vs_oracle_ragged_shapes(pol_1x, b, ts, firsts):
         (pd, vpred, _), sg = pol({"img": img.to(DEV)}, first.to(DEV), sg)
         torch.cuda.synchronize()
         B = P.BOUNDS[pol.precision]
-        P.check(P.policy_metrics(dict(buttons=pd["buttons"], camera=pd["camera"], vpred=vpred), ref), pol.precision, f"ragged t={t}")
+        P.check(P.policy_metrics(dict(buttons=pd["buttons"], camera=pd["camera"], vpred=vpred), ref), pol.precision, f"ragged t={t}", model="1x")
         for (m1, (k1, v1)), (m2, (k2, v2)) in zip(sg, so):
             assert torch.equal(m1.cpu(), m2)
             assert _l2(k1, k2) < B["kv_l2"] and _l2(v1, v2) < B["kv_l2"]
