@@ -64,6 +64,7 @@ __global__ __launch_bounds__(CF_THREADS, 4) void vpt_conv_first_kernel(VptConvFi
     f = (int)(L / tilesY);
   }
   int nnt = nt, ntx = tx, nty = ty, nf = f;   // the tile after the current one
+  int in_group = 0;                           // tiles of the current group done (t_begin is a multiple of `group`: no 64-bit modulo per tile)
   auto advance = [&]() {
     if (++nnt == a.NT) { nnt = 0; if (++ntx == tilesX) { ntx = 0; if (++nty == tilesY) { nty = 0; ++nf; } } }
   };
@@ -184,7 +185,8 @@ __global__ __launch_bounds__(CF_THREADS, 4) void vpt_conv_first_kernel(VptConvFi
       d_sq += (double)wave_sum(s_sq);
     }
     __syncthreads();   // all pooling reads of the conv tile done before the next tile overwrites it
-    if (CHS && ((tile + 1) % group == 0 || tile + 1 >= t_end)) {     // last tile of a group (groups never straddle frames): hand the per-channel sums over
+    if (CHS && (++in_group == group || tile + 1 >= t_end)) {         // last tile of a group (groups never straddle frames): hand the per-channel sums over
+      in_group = 0;
       flush_channel_sums(f);
       __syncthreads();
     }
