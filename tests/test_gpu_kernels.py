@@ -270,6 +270,45 @@ def test_linear_epilogue_variants(bias, relu, res, mask, out_f32, out_bf16, m, n
         assert tuple(o16.shape) == (m, n) and _relerr(o16.cpu().float(), ref) < 1e-2
 
 
+@pytest.mark.parametrize("m,n,k,variant", [
+    (8192, 2048, 256, "bias_f32"),        # 32 x 8 tiles of 256 x 256: the trunk's proj shape (short K)
+    (8100, 1604, 192, "relu_bf16"),       # ragged M, an odd number of 128-column tiles (the last 256-tile's second half does not exist), N % 128 != 0
+    (4096, 3072, 128, "res_f32"),         # 16 x 12 = 192 tiles: the smallest grid that takes the 256 x 256 kernel; two k-steps
+    (8192, 1664, 64, "mask_bf16"),        # one k-step: no DMA in the loop at all
+])
+def test_linear_256x256_tiles_equal_the_256x128_kernel(m, n, k, variant):
+    """vpt_gemm256_kernel (eight waves, LDS-DMA operands, double-buffered) against vpt_gemm_kernel on the same call: the same K order and MFMA
+    sequence per output element, so the outputs must be BIT-identical -- which is what makes the launcher's choice between them (by grid size)
+    harmless for batch invariance -- and both against the fp32 reference."""
+    g = torch.Generator().manual_seed(41)
+    A = torch.randn(m, k, generator=g).to(torch.bfloat16)
+    W = torch.randn(n, k, generator=g) / k ** 0.5
+    b = torch.randn(n, generator=g)
+    r = torch.randn(m, n, generator=g)
+    mk = torch.randn(m, n, generator=g).to(torch.bfloat16)
+    kw = dict(bias_f32=dict(bias=b.to(DEV), out_f32=True, out_bf16=False), relu_bf16=dict(relu=True, out_f32=False, out_bf16=True),
+              res_f32=dict(bias=b.to(DEV), res=r.to(DEV), out_f32=True, out_bf16=False), mask_bf16=dict(mask=mk.to(DEV), out_f32=False, out_bf16=True))[variant]
+    wpk = packing.pack_linear(W.to(DEV))
+    outs = {}
+    for tiling in ("throughput", "throughput128"):
+        o32, o16 = ops.linear(A.to(DEV), wpk, n, tiling=tiling, **kw)
+        torch.cuda.synchronize()
+        outs[tiling] = (o32 if o32 is not None else o16).cpu()
+    ref = A.float() @ W.to(torch.bfloat16).float().t()
+    if variant in ("bias_f32", "res_f32"):
+        ref = ref + b
+    if variant == "relu_bf16":
+        ref = torch.relu(ref)
+    if variant == "mask_bf16":
+        ref = torch.where(mk.float() > 0, ref, torch.zeros_like(ref))
+    if variant == "res_f32":
+        ref = ref + r
+    assert tuple(outs["throughput"].shape) == (m, n)
+    assert _relerr(outs["throughput"].float(), ref) < (2e-3 if outs["throughput"].dtype == torch.float32 else 1e-2)
+    assert torch.equal(outs["throughput"].view(torch.int32 if outs["throughput"].dtype == torch.float32 else torch.int16),
+                       outs["throughput128"].view(torch.int32 if outs["throughput128"].dtype == torch.float32 else torch.int16))
+
+
 @pytest.mark.parametrize("m,d,relu_in", [(5, 256, True), (130, 2048, False), (7, 3072, False)])
 def test_layernorm(m, d, relu_in):
     g = torch.Generator().manual_seed(5)

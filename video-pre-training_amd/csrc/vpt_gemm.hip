@@ -28,6 +28,45 @@
 // GE_GENERIC keeps the round-3 epilogue (runtime flags, any stride) for everything else.
 enum : unsigned { GE_BIAS = 1, GE_RELU = 2, GE_MASK = 4, GE_RES = 8, GE_OUTF = 16, GE_OUTB = 32, GE_SPLIT = 64, GE_VEC = 128, GE_GENERIC = 0x8000 };
 
+// ---- vector epilogue (GE_VEC instantiations; shared by the 256 x 128 and the 256 x 256 kernel): lane = token row (l31 of the 32-row subtile),
+// accumulator group g = output columns 8 g + 4 hi .. + 3 of the wave's 64-column slice that starts at col0 ----
+template <unsigned F>
+__device__ __forceinline__ void gemm_epilogue_vec(const VptGemmArgs& a, const f32x16 (&acc)[4][2], int row_base, int col0, int l31, int split) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int row = row_base + m * 32 + l31;
+    const bool rvalid = row < a.M;
+#pragma unroll
+    for (int n2 = 0; n2 < 2; ++n2) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = col0 + n2 * 32 + 8 * g;
+        if (!(rvalid && col < a.N)) continue;        // (N % 4 == 0: a group of four columns is valid or invalid as a whole)
+        f32x4 v = {acc[m][n2][4 * g + 0], acc[m][n2][4 * g + 1], acc[m][n2][4 * g + 2], acc[m][n2][4 * g + 3]};
+        if constexpr ((F & GE_SPLIT) != 0) {
+          *(f32x4*)(a.out_f32 + ((size_t)split * a.M + row) * a.ldc + col) = v;
+          continue;
+        }
+        if constexpr ((F & GE_BIAS) != 0) v += *(const f32x4*)(a.bias + col);
+        if constexpr ((F & GE_RELU) != 0) v = __builtin_elementwise_max(v, (f32x4){0.f, 0.f, 0.f, 0.f});
+        if constexpr ((F & GE_MASK) != 0) {          // ReLU backward: gate by the saved activation
+          const u32x2 mk = *(const u32x2*)(a.mask + (size_t)row * a.ldm + col);
+          if (!(op16_lo_to_f32(mk.x) > 0.f)) v.x = 0.f;
+          if (!(op16_hi_to_f32(mk.x) > 0.f)) v.y = 0.f;
+          if (!(op16_lo_to_f32(mk.y) > 0.f)) v.z = 0.f;
+          if (!(op16_hi_to_f32(mk.y) > 0.f)) v.w = 0.f;
+        }
+        if constexpr ((F & GE_RES) != 0) v += *(const f32x4*)(a.res + (size_t)row * a.ldr + col);
+        if constexpr ((F & GE_OUTF) != 0) *(f32x4*)(a.out_f32 + (size_t)row * a.ldc + col) = v;
+        if constexpr ((F & GE_OUTB) != 0) {
+          const u32x2 pk = {pack_op16x2(v.x, v.y), pack_op16x2(v.z, v.w)};
+          *(u32x2*)(a.out_bf16 + (size_t)row * a.ldcb + col) = pk;
+        }
+      }
+    }
+  }
+}
+
 template <unsigned F>
 __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
   constexpr bool VEC = (F & GE_VEC) != 0 && F != GE_GENERIC;
@@ -156,41 +195,7 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
 #undef GSB
 
   if constexpr (VEC) {
-    // ---- vector epilogue: lane = token row (l31 of the 32-row subtile), accumulator group g = output columns 8 g + 4 hi .. + 3 ----
-    const int col0 = nt * 128 + wn * 64 + 4 * hi;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int row = m0 + wm * 128 + m * 32 + l31;
-      const bool rvalid = row < a.M;
-#pragma unroll
-      for (int n2 = 0; n2 < 2; ++n2) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int col = col0 + n2 * 32 + 8 * g;
-          if (!(rvalid && col < a.N)) continue;        // (N % 4 == 0: a group of four columns is valid or invalid as a whole)
-          f32x4 v = {acc[m][n2][4 * g + 0], acc[m][n2][4 * g + 1], acc[m][n2][4 * g + 2], acc[m][n2][4 * g + 3]};
-          if constexpr ((F & GE_SPLIT) != 0) {
-            *(f32x4*)(a.out_f32 + ((size_t)split * a.M + row) * a.ldc + col) = v;
-            continue;
-          }
-          if constexpr ((F & GE_BIAS) != 0) v += *(const f32x4*)(a.bias + col);
-          if constexpr ((F & GE_RELU) != 0) v = __builtin_elementwise_max(v, (f32x4){0.f, 0.f, 0.f, 0.f});
-          if constexpr ((F & GE_MASK) != 0) {          // ReLU backward: gate by the saved activation
-            const u32x2 mk = *(const u32x2*)(a.mask + (size_t)row * a.ldm + col);
-            if (!(op16_lo_to_f32(mk.x) > 0.f)) v.x = 0.f;
-            if (!(op16_hi_to_f32(mk.x) > 0.f)) v.y = 0.f;
-            if (!(op16_lo_to_f32(mk.y) > 0.f)) v.z = 0.f;
-            if (!(op16_hi_to_f32(mk.y) > 0.f)) v.w = 0.f;
-          }
-          if constexpr ((F & GE_RES) != 0) v += *(const f32x4*)(a.res + (size_t)row * a.ldr + col);
-          if constexpr ((F & GE_OUTF) != 0) *(f32x4*)(a.out_f32 + (size_t)row * a.ldc + col) = v;
-          if constexpr ((F & GE_OUTB) != 0) {
-            const u32x2 pk = {pack_op16x2(v.x, v.y), pack_op16x2(v.z, v.w)};
-            *(u32x2*)(a.out_bf16 + (size_t)row * a.ldcb + col) = pk;
-          }
-        }
-      }
-    }
+    gemm_epilogue_vec<F>(a, acc, m0 + wm * 128, nt * 128 + wn * 64 + 4 * hi, l31, split);
     return;
   }
   // ---- generic epilogue (direct from the accumulator layout: lane = column, 16 rows per accumulator) ----
@@ -253,6 +258,141 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_kernel(VptGemmArgs a) {
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same GEMM on a 256 x 256 tile with EIGHT waves (2 x 4 of 128 x 64), one workgroup per CU (round 4).  The 256 x 128 kernel above stages
+// both operands through registers into ONE padded LDS tile: 12 global loads + 12 ds_write_b128 per thread and two barriers per 32 MFMAs.  Here
+// both operands of a k-step arrive by LDS-DMA (global_load_lds, 8 x 16 bytes per thread) into a DOUBLE buffer, one step ahead: no staging
+// registers, no LDS write instructions, one barrier per step (in front of the step's last eight MFMAs, as in vpt_conv3x3_kernel: every wave
+// then holds its last fragments, the next step's tile has landed, its first fragments are requested behind the barrier and arrive under those
+// MFMAs), a third less L2 -> LDS traffic per FLOP.  LDS image of a step: A [2 x 32 k][256 rows][64 B], B likewise (the packed weights' own
+// 128-row blocks, two of them) -- unpadded; the DMA is lane-linear, so the XOR swizzle of the four 16-byte pieces of a row by (row >> 2) & 3
+// is applied on the SOURCE address and undone in the fragment address (conflict-free ds_read_b128, the conv kernel's weight-tile scheme).
+// Same K order and MFMA sequence per output element as the 256 x 128 kernel: bit-identical results (tests/test_gpu_kernels.py).
+#define G2_HALF 32768                 // one operand of one step: 2 x 256 rows x 64 B
+#define G2_BUF (2 * G2_HALF)          // A + B of a step
+template <unsigned F>
+__global__ __launch_bounds__(512, 2) void vpt_gemm256_kernel(VptGemmArgs a) {
+  static_assert((F & GE_VEC) != 0 && (F & GE_SPLIT) == 0, "vector epilogue, no split-K");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G2_BUF];   // 128 KB
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 2, wn = w & 3;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int NT2 = (a.N + 255) >> 8, NT128 = (a.N + 127) >> 7;
+  int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = L % NT2;
+  const int mt = L / NT2;
+  const int m0 = mt * 256;
+  const int nsteps = a.K >> 6;
+
+  // ---- DMA source addresses: chunk idx = tid + 512 j  ->  32-k block kb = j >> 1, row r = (tid >> 2) + 128 (j & 1), LDS piece p = tid & 3,
+  // which holds the row's source piece p ^ ((r >> 2) & 3) ----
+  const int r0 = tid >> 2, psrc = (tid & 3) ^ ((r0 >> 2) & 3);        // (r0 + 128 has the same swizzle key)
+  const char* abase = (const char*)(a.A + (size_t)m0 * a.lda);         // wave-uniform
+  unsigned aoff[2];
+#pragma unroll
+  for (int jr = 0; jr < 2; ++jr) aoff[jr] = (unsigned)min(r0 + 128 * jr, a.M - 1 - m0) * (unsigned)a.lda * 2u + psrc * 16u;   // rows beyond M re-read row M - 1
+  const char* wsrc[2];
+#pragma unroll
+  for (int jr = 0; jr < 2; ++jr)
+    wsrc[jr] = (const char*)(a.wpk + (size_t)min(2 * nt + jr, NT128 - 1) * (a.K >> 5) * 4096 + r0 * 32 + psrc * 8);   // (an odd number of 128-column tiles: the missing half re-reads the last one)
+  unsigned char* const dma_dst = smem + w * 1024;
+#define G2_ISSUE(s_, buf_, j_)                                                                             \
+  do {                                                                                                     \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(abase + (size_t)(s_) * 128 + ((j_) >> 1) * 64 + aoff[(j_) & 1]), \
+                                     (__attribute__((address_space(3))) void*)(dma_dst + (buf_) + (j_) * 8192), 16, 0, 0);                     \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[(j_) & 1] + ((size_t)(s_) * 2 + ((j_) >> 1)) * 8192), \
+                                     (__attribute__((address_space(3))) void*)(dma_dst + (buf_) + G2_HALF + (j_) * 8192), 16, 0, 0);           \
+  } while (0)
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  // fragment base addresses: slice kk = (32-k block kk >> 1, 16-k half kk & 1); piece ((kk & 1) * 2 + hi) ^ swizzle key of the lane's row
+  const int sw = (l31 >> 2) & 3;
+  // [buffer][16-k half]: the step's buffer is chosen by swapping these per-lane addresses (the ds_read offset field has 16 bits)
+  const unsigned char* aC[2] = {smem + (wm * 128 + l31) * 64 + (((0 + hi) ^ sw) << 4), smem + (wm * 128 + l31) * 64 + (((2 + hi) ^ sw) << 4)};
+  const unsigned char* bC[2] = {smem + G2_HALF + (wn * 64 + l31) * 64 + (((0 + hi) ^ sw) << 4), smem + G2_HALF + (wn * 64 + l31) * 64 + (((2 + hi) ^ sw) << 4)};
+  const unsigned char* aN[2] = {aC[0] + G2_BUF, aC[1] + G2_BUF};
+  const unsigned char* bN[2] = {bC[0] + G2_BUF, bC[1] + G2_BUF};
+
+  op16x8 fa[4], fb[2][2];
+#define QSB() __builtin_amdgcn_sched_barrier(0)
+#define QMM(setb_, m_, n_) acc[m_][n_] = VPT_MFMA_32X32X16(fb[setb_][n_], fa[m_], acc[m_][n_], 0, 0, 0)
+#define QFA(NXT_, kk_, m_) fa[m_] = *(const op16x8*)(((NXT_) ? aN : aC)[(kk_) & 1] + ((kk_) >> 1) * 16384 + (m_) * 2048)
+#define QFB(NXT_, setb_, kk_, n_) fb[setb_][n_] = *(const op16x8*)(((NXT_) ? bN : bC)[(kk_) & 1] + ((kk_) >> 1) * 16384 + (n_) * 2048)
+#define QNOP() ((void)0)
+  // eight MFMAs of fragment set (fa, fb[setb_]); the fragments of slice nkk_ (buffer offset nboff_) follow into fa (rolling: fragment m right
+  // behind the two MFMAs that consumed it) and fb[1 - setb_]; X0 .. X3: the step's DMA issue slots
+#define QGROUP(setb_, nboff_, nkk_, X0, X1, X2, X3)                                                        \
+  do {                                                                                                     \
+    QMM(setb_, 0, 0); QFB(nboff_, 1 - (setb_), nkk_, 0); QFB(nboff_, 1 - (setb_), nkk_, 1); QSB();         \
+    QMM(setb_, 0, 1); QFA(nboff_, nkk_, 0); QSB();                                                         \
+    QMM(setb_, 1, 0); X0; QSB();                                                                           \
+    QMM(setb_, 1, 1); QFA(nboff_, nkk_, 1); X1; QSB();                                                     \
+    QMM(setb_, 2, 0); X2; QSB();                                                                           \
+    QMM(setb_, 2, 1); QFA(nboff_, nkk_, 2); X3; QSB();                                                     \
+    QMM(setb_, 3, 0); QSB();                                                                               \
+    QMM(setb_, 3, 1); QFA(nboff_, nkk_, 3); QSB();                                                         \
+  } while (0)
+#define QWAIT_BARRIER()                                                                                    \
+  do {                                                                                                     \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                            \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    asm volatile("" ::: "memory");                                                                         \
+    QSB();                                                                                                 \
+  } while (0)
+  // one k-step out of the current buffer; MORE_: a step follows (its tile is requested here into the other buffer, byte offset nbuf_, and its
+  // first fragments are read at the end)
+#define QSTEP(s_, nbuf_, MORE_)                                                                            \
+  do {                                                                                                     \
+    if (MORE_) {                                                                                           \
+      QGROUP(0, 0, 1, G2_ISSUE((s_) + 1, nbuf_, 0), QNOP(), G2_ISSUE((s_) + 1, nbuf_, 1), QNOP());          \
+      QGROUP(1, 0, 2, G2_ISSUE((s_) + 1, nbuf_, 2), QNOP(), G2_ISSUE((s_) + 1, nbuf_, 3), QNOP());          \
+      QGROUP(0, 0, 3, QNOP(), QNOP(), QNOP(), QNOP());                                                     \
+      QWAIT_BARRIER();   /* every wave holds its last fragments; the next tile has landed */                \
+      QGROUP(1, 1, 0, QNOP(), QNOP(), QNOP(), QNOP());                                                     \
+    } else {                                                                                               \
+      QGROUP(0, 0, 1, QNOP(), QNOP(), QNOP(), QNOP());                                                     \
+      QGROUP(1, 0, 2, QNOP(), QNOP(), QNOP(), QNOP());                                                     \
+      QGROUP(0, 0, 3, QNOP(), QNOP(), QNOP(), QNOP());                                                     \
+      _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_) { QMM(1, m_, 0); QMM(1, m_, 1); }                    \
+    }                                                                                                      \
+  } while (0)
+
+  // prologue: tile 0
+#pragma unroll
+  for (int j = 0; j < 4; ++j) G2_ISSUE(0, 0, j);
+  QWAIT_BARRIER();
+  QFB(0, 0, 0, 0); QFA(0, 0, 0); QFB(0, 0, 0, 1); QFA(0, 0, 1); QFA(0, 0, 2); QFA(0, 0, 3);
+  QSB();
+#pragma unroll 1
+  for (int s = 0; s + 1 < nsteps; ++s) {
+    const int nbuf = ((s + 1) & 1) * G2_BUF;     // wave-uniform: the DMA's LDS base goes through M0
+    QSTEP(s, nbuf, true);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                // the next step's buffer becomes the current one
+      const unsigned char* t = aC[h]; aC[h] = aN[h]; aN[h] = t;
+      t = bC[h]; bC[h] = bN[h]; bN[h] = t;
+    }
+  }
+  QSTEP(nsteps - 1, 0, false);
+#undef QSTEP
+#undef QWAIT_BARRIER
+#undef QGROUP
+#undef QNOP
+#undef QFB
+#undef QFA
+#undef QMM
+#undef QSB
+#undef G2_ISSUE
+  gemm_epilogue_vec<F>(a, acc, m0 + wm * 128, nt * 256 + wn * 64 + 4 * hi, l31, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -429,7 +569,7 @@ extern "C" int vpt_gemv_launch(const VptGemmArgs* a, hipStream_t stream);
 
 extern "C" int vpt_gemm_launch(const VptGemmArgs* a, hipStream_t stream) {
   if (a->tiling == 2 && a->M > 8) return -1;
-  if (a->M > 0 && a->M <= 8 && a->tiling != 1) return vpt_gemv_launch(a, stream);   // acting path (T = 1): HBM-bound weight stream, vpt_gemv.hip
+  if (a->M > 0 && a->M <= 8 && a->tiling != 1 && a->tiling != 3) return vpt_gemv_launch(a, stream);   // acting path (T = 1): HBM-bound weight stream, vpt_gemv.hip
   if (a->M <= 0 || a->N <= 0 || (a->K & 63) || a->splitk < 1 || (a->lda & 7)) return -1;
   if (a->splitk > 1 && (!a->atomic_out || a->relu || a->res || a->out_bf16 || a->mask)) return -1;
   const long grid = (long)((a->M + 255) >> 8) * ((a->N + 127) >> 7) * a->splitk;
@@ -440,7 +580,17 @@ extern "C" int vpt_gemm_launch(const VptGemmArgs* a, hipStream_t stream) {
   const bool aligned = !(a->N & 3) && (!a->out_f32 || !(a->ldc & 3)) && (!a->out_bf16 || !(a->ldcb & 3)) && (!a->res || !(a->ldr & 3)) && (!a->mask || !(a->ldm & 3))
                        && (!a->bias || !((uintptr_t)a->bias & 15)) && (!a->out_f32 || !((uintptr_t)a->out_f32 & 15)) && (!a->res || !((uintptr_t)a->res & 15))
                        && (!a->out_bf16 || !((uintptr_t)a->out_bf16 & 7)) && (!a->mask || !((uintptr_t)a->mask & 7));
-#define GE_LAUNCH(F_) hipLaunchKernelGGL((vpt_gemm_kernel<(F_)>), dim3((unsigned)grid), dim3(256), 0, stream, *a)
+  // the 256 x 256 / eight-wave kernel where its grid fills the chip (one workgroup per CU: >= 192 tiles); tiling 3 = never (A/B measurements).
+  // The two kernels give bit-identical results (same K order per output element), so this choice -- unlike the GEMM / GEMV one -- is free.
+  const long grid2 = (long)((a->M + 255) >> 8) * ((a->N + 255) >> 8);
+  const bool big = aligned && a->splitk == 1 && !a->atomic_out && a->tiling != 3 && grid2 >= 192 && !((uintptr_t)a->A & 15);
+#define GE_LAUNCH(F_)                                                                                                             \
+  do {                                                                                                                            \
+    if constexpr (((F_) & GE_VEC) != 0 && ((F_) & GE_SPLIT) == 0) {                                                                \
+      if (big) { hipLaunchKernelGGL((vpt_gemm256_kernel<(F_)>), dim3((unsigned)grid2), dim3(512), 0, stream, *a); break; }        \
+    }                                                                                                                             \
+    hipLaunchKernelGGL((vpt_gemm_kernel<(F_)>), dim3((unsigned)grid), dim3(256), 0, stream, *a);                                  \
+  } while (0)
   bool done = false;
   if (aligned) {
     done = true;

@@ -296,7 +296,7 @@ def dense_fold_epilogue(part, stats, count, sg, sb):
     return out
 
 
-LINEAR_TILING = {"auto": 0, "throughput": 1, "latency": 2}
+LINEAR_TILING = {"auto": 0, "throughput": 1, "latency": 2, "throughput128": 3}   # throughput128: MFMA GEMM, never the 256 x 256 kernel (A/B, tests)
 
 
 def linear(a_bf16, wpk, n, bias=None, res=None, relu=False, out_f32=True, out_bf16=False, splitk=1, mask=None,
@@ -316,7 +316,7 @@ def linear(a_bf16, wpk, n, bias=None, res=None, relu=False, out_f32=True, out_bf
     # as well and finish with the epilogue kernel (fixed summation order: deterministic).
     tl = LINEAR_TILING[tiling]
     auto_sk = 1
-    if splitk == 1 and (8 < m or tl == 1) and m <= 512 and k >= 2048 and tl != 2:
+    if splitk == 1 and (8 < m or tl in (1, 3)) and m <= 512 and k >= 2048 and tl != 2:
         tiles = ((m + 255) // 256) * ((n + 127) // 128)
         if tiles < 128:
             auto_sk = max(1, min(16, k // 512, 256 // tiles))
