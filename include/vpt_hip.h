@@ -177,7 +177,9 @@ int vpt_linear_forward(const void* A, const void* wpk, const float* bias, const 
                        void* stream);
 /* The same with the kernel named by the caller: 1 = the MFMA GEMM whatever M, 2 = the weight-streaming kernel of the acting step (M <= 8
  * rows), 0 = by M (what vpt_linear_forward does: <= 8 rows stream the weights).  The two kernels sum in different orders; a caller
- * whose rows must not depend on how many rows share the call (batches of sequences: chunking, sharding) passes 1. */
+ * whose rows must not depend on how many rows share the call (batches of sequences: chunking, sharding) passes 1.  4 = the MFMA GEMM on
+ * 256 x 256 tiles with eight waves and LDS-DMA operands where that grid fills the chip (bit-identical to 1; measured neutral inside the
+ * engine, kept for A/B measurements). */
 int vpt_linear_forward_tiled(const void* A, const void* wpk, const float* bias, const float* res,
                              float* out_f32, void* out_bf16, int M, int N, int K,
                              int lda, int ldr, int ldc, int ldcb, int relu, int splitk, const void* mask, int ldm,

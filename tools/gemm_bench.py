@@ -27,6 +27,6 @@ for m, n, k in shapes:
     A = torch.randn(m, k, device="cuda").to(torch.bfloat16)
     W = packing.pack_linear(torch.randn(n, k, device="cuda") / k ** 0.5)
     for mode in ("f32", "bf16"):
-        for tiling in ("throughput", "throughput128"):   # 256 x 256 / eight-wave LDS-DMA kernel where the grid fills the chip, vs 256 x 128 tiles always
+        for tiling in ("throughput256", "throughput"):   # 256 x 256 / eight-wave LDS-DMA kernel where the grid fills the chip, vs the shipped 256 x 128 tiles
             t = timeit(lambda: ops.linear(A, W, n, out_f32=(mode == "f32"), out_bf16=(mode == "bf16"), tiling=tiling))
             print(f"M={m:6d} N={n:6d} K={k:6d} out={mode:4s} {tiling:13s}: {t:7.3f} ms  {2.0 * m * n * k / t / 1e9:7.1f} TF/s")

@@ -266,7 +266,7 @@ int vpt_linear_forward_tiled(const void* A, const void* wpk, const float* bias, 
                              float* out_f32, void* out_bf16, int M, int N, int K,
                              int lda, int ldr, int ldc, int ldcb, int relu, int splitk, const void* mask, int ldm,
                              int tiling, void* stream) {
-  if (tiling < 0 || tiling > 3) return fail(-1, "vpt_linear_forward_tiled: tiling must be 0 (by M), 1 (MFMA GEMM), 2 (weight-streaming, M <= 8) or 3 (MFMA GEMM, 256 x 128 tiles only)");
+  if (tiling < 0 || tiling > 4 || tiling == 3) return fail(-1, "vpt_linear_forward_tiled: tiling must be 0 (by M), 1 (MFMA GEMM), 2 (weight-streaming, M <= 8) or 4 (MFMA GEMM, 256 x 256 tiles where the grid fills the chip)");
   VptGemmArgs a{};
   a.tiling = tiling;
   a.mask = (const vpt_op16*)mask; a.ldm = ldm;

@@ -569,7 +569,7 @@ extern "C" int vpt_gemv_launch(const VptGemmArgs* a, hipStream_t stream);
 
 extern "C" int vpt_gemm_launch(const VptGemmArgs* a, hipStream_t stream) {
   if (a->tiling == 2 && a->M > 8) return -1;
-  if (a->M > 0 && a->M <= 8 && a->tiling != 1 && a->tiling != 3) return vpt_gemv_launch(a, stream);   // acting path (T = 1): HBM-bound weight stream, vpt_gemv.hip
+  if (a->M > 0 && a->M <= 8 && (a->tiling == 0 || a->tiling == 2)) return vpt_gemv_launch(a, stream);   // acting path (T = 1): HBM-bound weight stream, vpt_gemv.hip
   if (a->M <= 0 || a->N <= 0 || (a->K & 63) || a->splitk < 1 || (a->lda & 7)) return -1;
   if (a->splitk > 1 && (!a->atomic_out || a->relu || a->res || a->out_bf16 || a->mask)) return -1;
   const long grid = (long)((a->M + 255) >> 8) * ((a->N + 127) >> 7) * a->splitk;
@@ -580,10 +580,12 @@ extern "C" int vpt_gemm_launch(const VptGemmArgs* a, hipStream_t stream) {
   const bool aligned = !(a->N & 3) && (!a->out_f32 || !(a->ldc & 3)) && (!a->out_bf16 || !(a->ldcb & 3)) && (!a->res || !(a->ldr & 3)) && (!a->mask || !(a->ldm & 3))
                        && (!a->bias || !((uintptr_t)a->bias & 15)) && (!a->out_f32 || !((uintptr_t)a->out_f32 & 15)) && (!a->res || !((uintptr_t)a->res & 15))
                        && (!a->out_bf16 || !((uintptr_t)a->out_bf16 & 7)) && (!a->mask || !((uintptr_t)a->mask & 7));
-  // the 256 x 256 / eight-wave kernel where its grid fills the chip (one workgroup per CU: >= 192 tiles); tiling 3 = never (A/B measurements).
-  // The two kernels give bit-identical results (same K order per output element), so this choice -- unlike the GEMM / GEMV one -- is free.
+  // tiling 4: the 256 x 256 / eight-wave kernel where its grid fills the chip (one workgroup per CU: >= 192 tiles).  Bit-identical results (same K
+  // order per output element).  Measured (profiles/r04_experiments.md sections 11, 12): +7-13 % per shape in a warm back-to-back loop, but -0.13 ms
+  // per forward step inside the engine, where every GEMM runs once per step on cold weights and one workgroup per CU exposes its DMA prologue and
+  // its 256 KB of epilogue stores per tile -- so it is NOT the default; kept selectable and under test.
   const long grid2 = (long)((a->M + 255) >> 8) * ((a->N + 255) >> 8);
-  const bool big = aligned && a->splitk == 1 && !a->atomic_out && a->tiling != 3 && grid2 >= 192 && !((uintptr_t)a->A & 15);
+  const bool big = aligned && a->splitk == 1 && !a->atomic_out && a->tiling == 4 && grid2 >= 192 && !((uintptr_t)a->A & 15);
 #define GE_LAUNCH(F_)                                                                                                             \
   do {                                                                                                                            \
     if constexpr (((F_) & GE_VEC) != 0 && ((F_) & GE_SPLIT) == 0) {                                                                \

@@ -134,7 +134,7 @@ struct VptGemmArgs {
   vpt_op16* out_bf16;      // [M][ldcb] or null
   int M, N, K, lda, ldr, ldc, ldcb;
   int relu, splitk, atomic_out;
-  int tiling;              // 0: M <= 8 rows take the weight-streaming kernel (vpt_gemv.hip), more the MFMA GEMM; 1: MFMA GEMM whatever M; 2: weight-streaming (M <= 8); 3: MFMA GEMM on 256 x 128 tiles only (A/B)
+  int tiling;              // 0: M <= 8 rows take the weight-streaming kernel (vpt_gemv.hip), more the MFMA GEMM; 1: MFMA GEMM whatever M; 2: weight-streaming (M <= 8); 4: MFMA GEMM, the 256 x 256 / eight-wave kernel where its grid fills the chip (bit-identical; A/B)
   const vpt_op16* mask;    // optional [M][ldm]: output is zeroed where mask <= 0 (ReLU backward)
   int ldm;
   // fused LayerNorm prologue (skinny path only, M <= 8, K <= 3072): A = op16(LayerNorm(ln_x)) computed by every workgroup

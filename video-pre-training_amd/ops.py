@@ -4,6 +4,7 @@ PyTorch is plumbing here: it owns device memory and the current HIP stream; all 
 libvpt_hip.so.  Every function requires CUDA(HIP) tensors and raises if the native library is absent.
 """
 import ctypes
+import os
 
 import torch
 
@@ -296,7 +297,8 @@ def dense_fold_epilogue(part, stats, count, sg, sb):
     return out
 
 
-LINEAR_TILING = {"auto": 0, "throughput": 1, "latency": 2, "throughput128": 3}   # throughput128: MFMA GEMM, never the 256 x 256 kernel (A/B, tests)
+_GEMM256 = os.environ.get("VPT_LINEAR_256", "0") == "1"      # A/B switch: "throughput" takes the 256 x 256 kernel (bit-identical results either way)
+LINEAR_TILING = {"auto": 0, "throughput": 1, "latency": 2, "throughput256": 4}   # throughput256: vpt_gemm256_kernel where its grid fills the chip (measured neutral in the engine: not the default)
 
 
 def linear(a_bf16, wpk, n, bias=None, res=None, relu=False, out_f32=True, out_bf16=False, splitk=1, mask=None,
@@ -314,9 +316,11 @@ def linear(a_bf16, wpk, n, bias=None, res=None, relu=False, out_f32=True, out_bf
     ld16 = (out_bf16_ld or n) if out_bf16 else n
     # Mid-size M (e.g. one 128-frame IDM window): the 256 x 128 tiling alone gives N/128 workgroups for 256 CUs, so cut K
     # as well and finish with the epilogue kernel (fixed summation order: deterministic).
+    if tiling == "throughput" and _GEMM256:
+        tiling = "throughput256"
     tl = LINEAR_TILING[tiling]
     auto_sk = 1
-    if splitk == 1 and (8 < m or tl in (1, 3)) and m <= 512 and k >= 2048 and tl != 2:
+    if splitk == 1 and (8 < m or tl in (1, 4)) and m <= 512 and k >= 2048 and tl != 2:
         tiles = ((m + 255) // 256) * ((n + 127) // 128)
         if tiles < 128:
             auto_sk = max(1, min(16, k // 512, 256 // tiles))
