@@ -8,25 +8,41 @@
 //     dW[o][kh][kw][ch] = sum_p G[p][o] * img[p + (kh,kw)][ch] / 255 ,   db[o] = sum_p G[p][o]
 // is a GEMM with M = channels, N = 27 taps (+ one column of ones for db), K = the tile's 17 x 17 conv pixels.
 //   1. recompute the conv tile into LDS (bf16, [289 pixels][128 channels]);
-//   2. thread = (channel, half of the tile's 64 pooled pixels): arg-max search, positions kept in registers;
-//   3. the conv tile is dead now: zero it and scatter the pooled gradients into it (ds_pk_add_bf16; a conv pixel can win up
-//      to four overlapping windows, so G sums up to four bf16 values in bf16);
-//   4. wave w contracts pixel slices w, w + 4, ... for all four 32-channel blocks: A = G^T through the LDS transpose read,
-//      B = the patch matrix built from the tile's input bytes (taps x 16 pixels per slice); 4 x 16 fp32 accumulators per lane
-//      persist over the workgroup's tiles and are reduced across the waves and flushed with atomics once at the end.
-// Round 2: the first version did step 4 on the vector ALU -- 27 byte reads, 27 conversions and 27 FMAs per pooled pixel and
-// thread, 3.5 ms per 1024 frames (8 TF/s) against 0.8 ms for the forward; VALU issue slots, not latency, were the limit
-// (profiles/r02_ubench_mfma_valu.md).
+//   2. arg-max search, item = (pooled pixel, channel octet): nine 16-byte reads, per channel a signed key (pattern << 16 | 15 - scan index) and one
+//      v_max_i32 per window position; the winning WINDOW OFFSET k* = 3 dy + dx (0..8; 15 = no gradient) as a 4-bit code;
+//   3. the conv tile is dead now.  Into its LDS go (a) the table [64 pooled pixels][128 channels] of words (pooled gradient | k* << 16) -- the
+//      gradients arrive by one 16-byte global load per item -- and (b) the B operand of step 4: patch values as 16-bit MFMA fragments, identical for
+//      the waves of a pixel group, built cooperatively (36 k-steps x 64 lanes x 16 bytes);
+//   4. NO scatter (round 4).  Write the sum over pooled pixels as nine sums over the window offsets:
+//          dW[o][t] = sum_k sum_pp ( d[pp][o] * [k*(pp, o) == k] ) * X[2 pp + k][t]
+//      -- for a FIXED offset the pooled pixels' conv pixels are distinct, so nothing collides and there is no gradient matrix G to zero, merge
+//      and scatter into.  As a GEMM per wave: M = 32 channels (wave = channel block x pooled rows 0-3 / 4-7), N = 27 taps (+ a column of ones for
+//      db), K = 32 pooled pixels x 9 offsets = 18 k-steps of 16.  K-slot order: k-step q < 16 = the 8 offsets k = 0..7 of pooled pixel q of the
+//      wave's first row pair (slots 0..7, supplied by lanes hi = 0) and of its second (slots 8..15, hi = 1) -- the A fragment of a lane (channel,
+//      row pair) is its OWN pixel's gradient placed at slot k*: a one-hot built in registers from the table word; k-steps 16, 17 = offset 8 of the
+//      pixels 8 s .. 8 s + 7 of each row pair.  Twice the MFMAs of the scatter form (the matrix pipe is idle anyway); every gradient enters the
+//      fp32 accumulation un-merged (the scatter form summed up to four bf16 values into one bf16 entry of G first).
+//      16 fp32 accumulators per lane persist over the workgroup's tiles; the two waves of a channel block are added and flushed with atomics at the end.
+// History.  Round 2: step 4 on the vector ALU (27 byte reads, conversions and FMAs per pooled value): 3.5 ms per 1024 frames.  Round 3: G by
+// merge-and-scatter + one MFMA contraction over the 289 conv pixels, thread = (channel, 32 pooled pixels), four waves: 2.0 ms; its ablation table
+// charged 1.33 ms to the scatter -- but removing the scatter had let the compiler delete the search as dead code too.  Round 4 ablations on this
+// kernel (profiles/r04_experiments.md section 13): the SEARCH was the cost (72 two-byte LDS reads + compare / select chains per thread at two
+// waves per SIMD); wide reads + keys, eight waves, no scatter, gradients and codes through one LDS table: 1.24 ms.
 // Persistent workgroups (2 per CU) sweep the tile list.  Replaces the autograd of lib/impala_cnn.py:86-97,115-117 for stack 0.
 #include "vpt_common.h"
 #include "vpt_kernels.h"
 
 #ifndef VPT_CFB_ABLATE
-#define VPT_CFB_ABLATE 0   // profiling builds: 1 no search, 2 no zero fill, 4 no scatter, 8 no MFMA contraction, 16 no recompute
+#define VPT_CFB_ABLATE 0   // profiling builds: 1 no search, 8 no B build / MFMA contraction, 16 no recompute, 64 search reads one window position only
 #endif
 #include "vpt_conv_first_tile.h"
 
-__global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirstBwdArgs a) {
+// Eight waves per workgroup, two workgroups per CU = four waves per SIMD (round 4; four waves per workgroup before): every phase of a tile is a chain
+// of LDS round trips (search: 9 two-byte reads per pooled value; B build: byte reads; one-hot A + fragment read + MFMA) with a barrier behind it, and
+// two waves per SIMD left the LDS latency exposed -- the same finding as for the forward kernel in round 3.  Needs <= 128 registers: 16 pooled pixels
+// per thread instead of 32.
+#define CFB_THREADS 512
+__global__ __launch_bounds__(CFB_THREADS, 4) void vpt_conv_first_bwd_kernel(VptConvFirstBwdArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[CF_SMEM_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index: scalar (slice / pixel arithmetic of step 4 stays off the vector ALU)
   const int hi = lane >> 5, l31 = lane & 31;
@@ -36,32 +52,23 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
   const int nt = blockIdx.y;
   const int CB_out = a.Cout >> 5;
 
-  op16x8 wfr[4][2];
-#pragma unroll
-  for (int cs = 0; cs < 4; ++cs)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) wfr[cs][ks] = *((const op16x8*)a.wfrag + ((nt * 4 + cs) * 2 + ks) * 64 + lane);
+  const int cbw = w & 3, ph = w >> 2;          // wave = (32-channel block, pooled rows 0-3 / 4-7)
+  const int oc = cbw * 32 + l31, quarter = ph * 2 + hi;   // backward role: output channel within the N tile, two pooled rows (16 pooled pixels)
 
-  const int oc = tid & 127, half = tid >> 7;   // backward role: output channel within the N tile, pooled-pixel half
-  const int og = nt * 128 + oc;
-  const bool ovalid = og < a.Cout;
-  f32x16 gacc[4];            // dW^T partial sums: [32-channel block][16 values]: rows = channels, column l31 = tap (27 = bias)
+
+  f32x16 gacc;               // dW^T partial sums of this wave's channel block: rows = channels, column l31 = tap (27 = bias)
 #pragma unroll
-  for (int ob = 0; ob < 4; ++ob)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) gacc[ob][r] = 0.f;
-  // LDS transpose-read lane map (as in vpt_conv_wgrad.hip): 16-lane group g reads pixels 8 (g >> 1) + (i >> 2) (+ 4), channels 16 (g & 1) + 4 (i & 3)
-  const int g16 = lane >> 4, i16 = lane & 15;
-  const int tr_off = (8 * (g16 >> 1) + (i16 >> 2)) * CT_RS + (16 * (g16 & 1) + 4 * (i16 & 3)) * 2;
-  const int tap = l31;                                   // B operand row of this lane
+  for (int r = 0; r < 16; ++r) gacc[r] = 0.f;
+  // B-fragment build role: fragment (global k-step w + 8 i, lane) for i = 0..4 -- this lane's tap and half, the wave's k-steps
+  const int tap = l31;
   const int tap_c = min(tap, 26);
   const int tap_off = ((tap_c / 9) * 19 + (tap_c % 9) / 3) * 8 + tap_c % 3;   // byte of tap (kh, kw, ch) relative to the pixel's record: record (kh, kw), byte ch (taps >= 27: any valid byte)
-  const unsigned char* in8 = smem + IN_OFF;
+  const unsigned char* inl = smem + IN_OFF + tap_off + hi * (4 * 19 * 8);    // lanes hi = 1: the pixel group's second pair of pooled rows = conv rows + 4
 
   // next tile's input bytes are fetched into registers while the current tile computes (as in the forward kernel)
-  u32x2 nxt[CF_FETCH(256)];
+  u32x2 nxt[CF_FETCH(CFB_THREADS)];
   auto fetch = [&](int f, int ty, int tx) {
-    cf_fetch_input<256>(a.img + (size_t)f * a.H * a.W * 3, a.H, a.W, 2 * (ty * 8) - 2, 2 * (tx * 8) - 2, tid, nxt);
+    cf_fetch_input<CFB_THREADS>(a.img + (size_t)f * a.H * a.W * 3, a.H, a.W, 2 * (ty * 8) - 2, 2 * (tx * 8) - 2, tid, nxt);
   };
   const long per = (T + gridDim.x - 1) / gridDim.x;
   const long t_begin = blockIdx.x * per, t_end = min(t_begin + per, T);
@@ -79,173 +86,180 @@ __global__ __launch_bounds__(256, 2) void vpt_conv_first_bwd_kernel(VptConvFirst
   for (long tile = t_begin; tile < t_end; ++tile, tx = ntx, ty = nty, f = nf) {
     const int py0 = ty * 8, px0 = tx * 8;
     if (++ntx == tilesX) { ntx = 0; if (++nty == tilesY) { nty = 0; ++nf; } }
-    cf_stage_input<256>(smem, nxt, tid);
+    cf_stage_input<CFB_THREADS>(smem, nxt, tid);
     if (tid == 0) *(int*)(smem + CTR_OFF) = 0;
     __syncthreads();
     if (tile + 1 < t_end) fetch(nf, nty, ntx);
-    // this thread's 32 pooled gradients, two bf16 per register, fetched in four groups of 8: group 0 now (its latency
-    // hides behind the recompute), group g + 1 while group g is routed
-    const unsigned short* dP = (const unsigned short*)a.dpooled + ((size_t)(f * CB_out + ((ovalid ? og : 0) >> 5)) * PH * PW) * 32 + ((ovalid ? og : 0) & 31);
-    auto load_group = [&](int g, uint32_t* dst) {
+    // the pooled gradients of this thread's two search items (pooled pixel, channel octet): one 16-byte load each, requested now, used after the search
+    u32x4 dv[2];
 #pragma unroll
-      for (int q = 0; q < 8; q += 2) {
-        const int pp = half * 32 + g * 8 + q;     // pp and pp + 1 are neighbours in the same pooled row
-        const size_t o = (size_t)((py0 + (pp >> 3)) * PW + px0 + (pp & 7)) * 32;
-        dst[q >> 1] = (uint32_t)dP[o] | ((uint32_t)dP[o + 32] << 16);
-      }
-    };
-    uint32_t dreg[4][4];     // this thread's 32 pooled gradients, two bf16 per register (requested after the search)
-    // ---- 1. recompute the conv tile (vpt_conv_first_tile.h: the forward kernel's code) ----
-    if (!(VPT_CFB_ABLATE & 16)) cf_conv_tile(smem, wfr, lane, py0, px0, ty == 0 || tx == 0);
+    for (int it = 0; it < 2; ++it) {
+      const int item = tid + CFB_THREADS * it;
+      const int oct4 = item & 3, pxl = (0x76452310u >> (4 * ((item >> 2) & 7))) & 7, pyl = (item >> 5) & 7, cbl = item >> 8;
+      const int og0 = nt * 128 + cbl * 32 + oct4 * 8;
+      dv[it] = (u32x4){0u, 0u, 0u, 0u};
+      if (og0 < a.Cout)
+        dv[it] = *(const u32x4*)(a.dpooled + ((size_t)(f * CB_out + (og0 >> 5)) * PH * PW + (size_t)((py0 + pyl) * PW + px0 + pxl)) * 32 + (og0 & 31));
+    }
+    // ---- 1. recompute the conv tile (vpt_conv_first_tile.h: the forward kernel's code).  The weight fragments are fetched per tile (8 KB, L2):
+    // resident for the whole workgroup they cost 32 of the 128 registers in every other phase. ----
+    if (!(VPT_CFB_ABLATE & 16)) {
+      op16x8 wfr[4][2];
+      int lane_t = lane;
+      asm volatile("" : "+v"(lane_t));      // opaque per tile: keeps the (loop-invariant) loads inside the loop
+#pragma unroll
+      for (int cs = 0; cs < 4; ++cs)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) wfr[cs][ks] = *((const op16x8*)a.wfrag + ((nt * 4 + cs) * 2 + ks) * 64 + lane_t);
+      cf_conv_tile(smem, wfr, lane, py0, px0, ty == 0 || tx == 0);
+    }
     __syncthreads();
-    // ---- 2. arg-max search: conv pixel (0..288) of every pooled pixel, 0xffff = no gradient (ReLU gate / zero gradient) ----
-    uint32_t cpk[16];
+    // ---- 2. arg-max search: window offset 3 dy + dx of every (pooled pixel, channel), 15 = no gradient (ReLU gate / zero maximum).
+    // item = (pooled pixel, channel octet): nine ds_read_b128 (the 16 lanes of a read group take one conv pixel's 256 contiguous bytes) instead of
+    // 72 two-byte reads -- the search was LDS-instruction-bound (round 4 ablation: 1.0 of the kernel's 2.0 ms per 1024 frames; the round-3 table
+    // had charged that time to the scatter, whose removal had let the compiler delete the search as dead code).  First maximum in scan order
+    // without compare / select chains: a signed 32-bit key = (16-bit pattern << 16) | (15 - scan index) per channel, one v_lshl_or / v_and_or and
+    // one v_max_i32 per value: larger pattern wins, equal patterns keep the EARLIER position; a key below 0x10000 is a maximum <= 0. ----
+    uint32_t kcode[2][2];    // [item][dword]: eight 4-bit codes (channel c of the octet at bits 4 c)
 #pragma unroll
-    for (int k = 0; k < 16; ++k) cpk[k] = 0xffffffffu;
-    if (ovalid && !(VPT_CFB_ABLATE & 1)) {
+    for (int it = 0; it < 2; ++it) {
+      const int item = tid + CFB_THREADS * it;
+      // the forward kernel's pooling map (vpt_conv_first.hip): the four lane quads of a ds_read_b128 service group take pooled columns 0, 2, 4, 6 or
+      // 1, 3, 5, 7 -- conflict-free; 16 contiguous lanes on one pixel's 256 bytes collide two by two (+0.3 ms per 1024 frames, measured)
+      const int oct4 = item & 3, pxl = (0x76452310u >> (4 * ((item >> 2) & 7))) & 7, pyl = (item >> 5) & 7, cbl = item >> 8;
+      unsigned src_o = (unsigned)(((2 * pyl) * 17 + 2 * pxl) * CT_RS + (cbl * 32 + oct4 * 8) * 2);
+      asm volatile("" : "+v"(src_o));             // (opaque per tile, as for the B build below)
+      const unsigned char* src = smem + src_o;
+      int klo[4] = {0, 0, 0, 0}, khi[4] = {0, 0, 0, 0};
+      if (!(VPT_CFB_ABLATE & 1)) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+        for (int dy = 0; dy < ((VPT_CFB_ABLATE & 64) ? 1 : 3); ++dy)
 #pragma unroll
-        for (int q8 = 0; q8 < 8; ++q8) {
-          const int pp = half * 32 + g * 8 + q8;
-          const int pyl = pp >> 3, pxl = pp & 7;
-          const short* ct = (const short*)(smem + ((2 * pyl) * 17 + 2 * pxl) * CT_RS) + oc;
-          short best = 0;                                        // raw bf16 patterns as signed integers: only values > 0 can win (ReLU gate)
-          int bpos = 0;
+          for (int dx = 0; dx < ((VPT_CFB_ABLATE & 64) ? 1 : 3); ++dx) {
+            const u32x4 v = *(const u32x4*)(src + (dy * 17 + dx) * CT_RS);
+            const uint32_t c = 15u - (uint32_t)(dy * 3 + dx);
 #pragma unroll
-          for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-              const short v = ct[(dy * 17 + dx) * (CT_RS / 2)];
-              if (v > best) { best = v; bpos = dy * 17 + dx; }   // strict >: first maximum in scan order
+            for (int j = 0; j < 4; ++j) {
+              klo[j] = max(klo[j], (int)((v[j] << 16) | c));
+              khi[j] = max(khi[j], (int)((v[j] & 0xffff0000u) | c));
             }
-          const bool hit = best != 0;                            // ReLU gate (and windows whose maximum is 0)
-          const uint32_t cpos = hit ? (uint32_t)((2 * pyl) * 17 + 2 * pxl + bpos) : 0xffffu;
-          const int slot = g * 4 + (q8 >> 1);
-          cpk[slot] = (q8 & 1) ? ((cpk[slot] & 0x0000ffffu) | (cpos << 16)) : ((cpk[slot] & 0xffff0000u) | cpos);
+          }
+      }
+      uint32_t codes = 0u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t c0 = (klo[j] >= 0x10000) ? (15u - ((uint32_t)klo[j] & 15u)) : 15u;
+        const uint32_t c1 = (khi[j] >= 0x10000) ? (15u - ((uint32_t)khi[j] & 15u)) : 15u;
+        codes |= (c0 | (c1 << 4)) << (8 * j);
+      }
+      kcode[it][0] = codes; kcode[it][1] = 0u;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();         // every search read of the conv tile is done: its LDS becomes the B operand and the code table
+    // (gradient, code) words -> LDS [64 pooled pixels][128 channels] (32 KB behind the 36 KB of B fragments): word = 16-bit gradient | code << 16,
+    // two 16-byte writes per item; read back channel-major by the (channel, two pooled rows) threads of step 4, which replaces their 16 two-byte
+    // global loads and 16 byte reads per thread.
+#define CFB_WORD_OFF 40960
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int item = tid + CFB_THREADS * it;
+      const int oct4 = item & 3, pxl = (0x76452310u >> (4 * ((item >> 2) & 7))) & 7, pyl = (item >> 5) & 7, cbl = item >> 8;
+      const uint32_t n = kcode[it][0];       // eight nibbles, channel c at bits 4 c
+      u32x4 w0, w1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t lo = (dv[it][j] & 0xffffu) | (((n >> (8 * j)) & 15u) << 16);
+        const uint32_t hi2 = (dv[it][j] >> 16) | (((n >> (8 * j + 4)) & 15u) << 16);
+        if (j < 2) { w0[2 * j] = lo; w0[2 * j + 1] = hi2; } else { w1[2 * (j - 2)] = lo; w1[2 * (j - 2) + 1] = hi2; }
+      }
+      unsigned char* dst = smem + CFB_WORD_OFF + ((pyl * 8 + pxl) * 128 + cbl * 32 + oct4 * 8) * 4;
+      *(u32x4*)dst = w0;
+      *(u32x4*)(dst + 16) = w1;
+    }
+    // ---- 3. B fragments: [pixel group ph][k-step 0..17][lane][16 bytes]; lane (tap, hi) of k-step q < 16 holds X[conv pixel of (pooled pixel
+    // (2 ph + hi) * 16 + q, offset e)][tap], e = 0..7; of k-step 16 + s the offset-8 values of the pooled pixels (2 ph + hi) * 16 + 8 s + j,
+    // j = 0..7.  One byte read + one conversion per element: the lane's tap and hi are in its base pointer, the k-step is wave-uniform, the element
+    // an immediate offset. ----
+    if (!(VPT_CFB_ABLATE & 8)) {
+      unsigned inl_t = (unsigned)(size_t)(inl - smem);   // opaque per tile: left alone the compiler hoists ~50 per-element LDS addresses out of the tile loop (spills)
+      asm volatile("" : "+v"(inl_t));
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int ksg = w + 8 * i;                     // wave-uniform
+        if (ksg < 36) {
+          const int pg = ksg >= 18 ? 1 : 0, ks = ksg - 18 * pg;
+          const unsigned char* pgb = smem + inl_t + pg * (8 * 19 * 8);                          // pixel group 1: pooled rows 4..7 = conv rows 8..
+          float v[8];
+          if (ks < 16) {
+            const unsigned char* p0 = pgb + ((2 * (ks >> 3)) * 19 + 2 * (ks & 7)) * 8;     // pooled pixel (row ks >> 3 of the pair, column ks & 7)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)p0[((e / 3) * 19 + (e % 3)) * 8];
+          } else {
+            const unsigned char* p0 = pgb + ((2 * (ks - 16) + 2) * 19 + 2) * 8;            // offset (2, 2) of pooled row ks - 16 of the pair, columns 0..7
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)p0[(2 * e) * 8];
+          }
+          const uint32_t ones = pack_op16x2_exact(1.0f, 1.0f);
+          u32x4 pk;
+          pk.x = (tap == 27) ? ones : pack_op16x2_exact(v[0], v[1]);
+          pk.y = (tap == 27) ? ones : pack_op16x2_exact(v[2], v[3]);
+          pk.z = (tap == 27) ? ones : pack_op16x2_exact(v[4], v[5]);
+          pk.w = (tap == 27) ? ones : pack_op16x2_exact(v[6], v[7]);
+          *(u32x4*)(smem + (ksg * 64 + lane) * 16) = pk;
         }
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);   // eight byte reads in flight
       }
     }
     __syncthreads();
-    // ---- 3. the conv tile becomes G: zero, then scatter ----
-    if (ovalid) { load_group(0, dreg[0]); load_group(1, dreg[1]); load_group(2, dreg[2]); load_group(3, dreg[3]); }   // arrive under the zero fill
-    if (!(VPT_CFB_ABLATE & 2))
-    for (int i = tid; i < CT_BYTES / 16; i += 256) *(u32x4*)(smem + i * 16) = (u32x4){0u, 0u, 0u, 0u};
-    __syncthreads();
-    if (VPT_CFB_ABLATE & 32) {   // profiling: keep the search alive without the scatter
-      uint32_t x_ = 0;
+    // ---- 4. dW^T += sum over the nine window offsets: A fragments from registers (one-hot placement of the lane's own gradient) ----
+    if (!(VPT_CFB_ABLATE & 8)) {
+      const unsigned char* bfr = smem + (ph * 18 * 64 + lane) * 16;
+      uint32_t wd[16];                         // this thread's 16 (gradient | code << 16) words: channel oc, pooled pixels quarter * 16 + q
+      {
+        unsigned co = (unsigned)(CFB_WORD_OFF + ((quarter * 16) * 128 + oc) * 4);
+        asm volatile("" : "+v"(co));
 #pragma unroll
-      for (int k = 0; k < 16; ++k) x_ ^= cpk[k] + dreg[k >> 2][k & 3];
-      if (x_ == 0x12345u) a.db[0] = 1.f;
-    }
-    if (ovalid && !(VPT_CFB_ABLATE & (4 | 32))) {
-      // A conv pixel can win up to four overlapping windows (a 2 x 2 block of pooled pixels: index distances 1, 7, 8, 9), so G
-      // sums up to four gradients.  They are merged in registers first -- the LAST pooled pixel of a group carries the sum --
-      // and every (conv pixel, channel) entry is then WRITTEN once, no read-modify-write (32 LDS atomics per thread cost 2 ms
-      // per 1024 frames, 32 dependent read-add-write round trips 1.3 ms).  Only conv row 8 is shared with the other half's
-      // thread of this channel (windows of pooled rows 3 and 4): those entries are added with ds_pk_add_bf16.
-      typedef short s16x2 __attribute__((ext_vector_type(2)));
-      float gs[32];
-      uint32_t cp[32];
-#pragma unroll
-      for (int k = 0; k < 32; ++k) {
-        cp[k] = (k & 1) ? (cpk[k >> 1] >> 16) : (cpk[k >> 1] & 0xffffu);
-        const uint32_t dbits = (k & 1) ? (dreg[k >> 3][(k >> 1) & 3] >> 16) : (dreg[k >> 3][(k >> 1) & 3] & 0xffffu);
-        gs[k] = op16_lo_to_f32(dbits);
+        for (int q = 0; q < 16; ++q) wd[q] = *(const uint32_t*)(smem + co + q * 512);
       }
 #pragma unroll
-      for (int k = 0; k < 32; ++k) {
-#pragma unroll
-        for (int dj = 0; dj < 4; ++dj) {
-          const int off = (dj == 0) ? 1 : (6 + dj);            // 1, 7, 8, 9
-          const int j = k - off;
-          // j must be a real neighbour: same pooled row for off 1; previous row and column +1 / 0 / -1 for 7 / 8 / 9
-          const bool nb = j >= 0 && ((off == 1) ? ((k & 7) != 0) : (off == 7) ? ((k & 7) != 7) : (off == 9) ? ((k & 7) != 0) : true);
-          if (!nb) continue;
-          const bool same = cp[j] == cp[k] && cp[k] != 0xffffu;
-          gs[k] += same ? gs[j] : 0.f;
-          cp[j] = same ? 0xffffu : cp[j];
-        }
-      }
-      unsigned char* gcol = smem + oc * 2;
-#pragma unroll
-      for (int k = 0; k < 32; ++k) {
-        if (cp[k] == 0xffffu) continue;
-        const uint32_t vb = pack_op16x2(gs[k], 0.f) & 0xffffu;
-        if (cp[k] - 8u * 17u < 17u) {          // shared row
-          const uint32_t pair = (oc & 1) ? (vb << 16) : vb;
-#ifdef VPT_OPERAND_F16
-          typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
-          __builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) h16x2*)(smem + (oc & ~1) * 2 + cp[k] * CT_RS), __builtin_bit_cast(h16x2, pair));
-#else
-          __builtin_amdgcn_ds_atomic_fadd_v2bf16((__attribute__((address_space(3))) s16x2*)(smem + (oc & ~1) * 2 + cp[k] * CT_RS), __builtin_bit_cast(s16x2, pair));
-#endif
+      for (int ks = 0; ks < 18; ++ks) {
+        u32x4 af;
+        if (ks < 16) {
+          const uint32_t d16 = wd[ks] & 0xffffu, code = wd[ks] >> 16;
+          const uint32_t t = d16 << ((code & 1u) << 4);
+          const uint32_t hs = code >> 1;                 // dword of the slot; 4 (offset 8) and 7 (no gradient) match none
+          af.x = (hs == 0u) ? t : 0u; af.y = (hs == 1u) ? t : 0u; af.z = (hs == 2u) ? t : 0u; af.w = (hs == 3u) ? t : 0u;
         } else {
-          *(unsigned short*)(gcol + cp[k] * CT_RS) = (unsigned short)vb;
-        }
-      }
-    }
-    __syncthreads();
-    // ---- 4. dW^T += G^T x patches on the matrix cores: wave w takes the 16-pixel slices w, w + 4, ... ----
-    if (!(VPT_CFB_ABLATE & 8))
-    for (int ks = w; ks < 19; ks += 4) {
-      // B fragment: row = tap, k = conv pixels 16 ks + 8 hi .. + 7.  ks is wave-uniform, so the input-tile offset of every
-      // (pixel, hi) pair is scalar arithmetic; per element one select (hi), one byte read of the pixel's record (the lane's tap
-      // offset is in the base pointer) and one conversion.  Pixels beyond 288 need no masking here: the A side is exactly zero for them and bytes are
-      // finite; taps 28..31 produce columns that are never flushed; tap 27 is the column of ones (db).
-      u32x4 pk;
-      uint32_t pw[4];
-      const unsigned char* inl = in8 + tap_off;
+          const int sg = ks - 16;
 #pragma unroll
-      for (int e2 = 0; e2 < 4; ++e2) {
-        float v2[2];
-#pragma unroll
-        for (int e1 = 0; e1 < 2; ++e1) {
-          const int c0 = min(ks * 16 + e2 * 2 + e1, 288), c1 = min(ks * 16 + 8 + e2 * 2 + e1, 288);
-          const int o0 = ((c0 / 17) * 19 + (c0 % 17)) * 8, o1 = ((c1 / 17) * 19 + (c1 % 17)) * 8;
-          v2[e1] = (float)inl[hi ? o1 : o0];
+          for (int jj = 0; jj < 4; ++jj) {               // pixels 8 sg + 2 jj, + 1: offset 8
+            const uint32_t a0 = wd[8 * sg + 2 * jj], a1 = wd[8 * sg + 2 * jj + 1];
+            af[jj] = (((a0 >> 16) == 8u) ? (a0 & 0xffffu) : 0u) | (((a1 >> 16) == 8u) ? (a1 << 16) : 0u);
+          }
         }
-        pw[e2] = pack_op16x2_exact(v2[0], v2[1]);
-      }
-      const uint32_t ones = pack_op16x2_exact(1.0f, 1.0f);
-      pk.x = (tap == 27) ? ones : pw[0]; pk.y = (tap == 27) ? ones : pw[1]; pk.z = (tap == 27) ? ones : pw[2]; pk.w = (tap == 27) ? ones : pw[3];
-      const op16x8 bfrag = __builtin_bit_cast(op16x8, pk);
-      // the last slice holds one real pixel (288): the seven rows behind it lie outside the tile -> masked to exact zeros
-      const bool tail = ks == 18;
-#pragma unroll
-      for (int ob = 0; ob < 4; ++ob) {
-        const unsigned char* gp = smem + (ks * 16) * CT_RS + ob * 64 + tr_off;
-        op16x4 a0 = lds_tr16_read(gp), a1 = lds_tr16_read(gp + 4 * CT_RS);
-        if (tail) {
-          u32x2 m0 = __builtin_bit_cast(u32x2, a0);
-          m0.x = (hi == 0) ? (m0.x & 0xffffu) : 0u; m0.y = 0u;
-          a0 = __builtin_bit_cast(op16x4, m0);
-          a1 = __builtin_bit_cast(op16x4, (u32x2){0u, 0u});
-        }
-        const op16x8 afrag = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-        gacc[ob] = VPT_MFMA_32X32X16(afrag, bfrag, gacc[ob], 0, 0, 0);
+        const op16x8 bfrag = *(const op16x8*)(bfr + ks * 1024);
+        gacc = VPT_MFMA_32X32X16(__builtin_bit_cast(op16x8, af), bfrag, gacc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);   // one k-step at a time (left alone the scheduler hoists every fragment: > 128 registers)
       }
     }
     __syncthreads();
   }
-  // ---- flush: reduce the four waves' partial sums through LDS, one atomic per (channel, tap) and workgroup ----
-  float* red = (float*)smem;                               // [wave][128 channels][32 taps] fp32 = 64 KB
+  // ---- flush: the two waves of a channel block (pixel groups 0 / 1) are added through LDS, then one atomic per (channel, tap) and workgroup ----
+  float* red = (float*)smem;                               // [4 channel blocks][16 values][64 lanes] fp32 = 16 KB
+  if (ph == 1) {
 #pragma unroll
-  for (int ob = 0; ob < 4; ++ob)
+    for (int r = 0; r < 16; ++r) red[(cbw * 16 + r) * 64 + lane] = gacc[r];
+  }
+  __syncthreads();
+  if (ph == 0 && l31 < 28) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int ch = ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      red[(w * 128 + ch) * 32 + l31] = gacc[ob][r];
+      const int o = nt * 128 + cbw * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (o >= a.Cout) continue;
+      const float v = gacc[r] + red[(cbw * 16 + r) * 64 + lane];
+      if (l31 < 27) atomicAdd(a.dw + (size_t)o * 27 + l31, v * (1.0f / 255.0f));   // d(conv)/dW = img / 255
+      else atomicAdd(a.db + o, v);
     }
-  __syncthreads();
-  for (int i = tid; i < 128 * 28; i += 256) {
-    const int ch = i / 28, k = i - ch * 28;
-    const int o = nt * 128 + ch;
-    if (o >= a.Cout) continue;
-    const float v = (red[(0 * 128 + ch) * 32 + k] + red[(1 * 128 + ch) * 32 + k]) + (red[(2 * 128 + ch) * 32 + k] + red[(3 * 128 + ch) * 32 + k]);
-    if (k < 27) atomicAdd(a.dw + (size_t)o * 27 + k, v * (1.0f / 255.0f));   // d(conv)/dW = img / 255
-    else atomicAdd(a.db + o, v);
   }
 }
 
@@ -262,6 +276,6 @@ extern "C" int vpt_conv_first_bwd_launch(const VptConvFirstBwdArgs* a, hipStream
   if ((long)a->frames * a->H * a->W * 3 > 0x7fffffffL) return -2;   // 32-bit pixel offsets inside a launch
   long gx = (long)num_cu * 2;
   if (tiles < gx) gx = tiles;
-  hipLaunchKernelGGL(vpt_conv_first_bwd_kernel, dim3((unsigned)gx, (a->Cout + 127) / 128), dim3(256), 0, stream, *a);
+  hipLaunchKernelGGL(vpt_conv_first_bwd_kernel, dim3((unsigned)gx, (a->Cout + 127) / 128), dim3(CFB_THREADS), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
