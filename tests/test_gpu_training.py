@@ -362,25 +362,30 @@ def test_conv_layer_param_grads():
     assert eW < 6e-2 and eg < 1e-1 and eb < 1e-1
 
 
-@pytest.mark.parametrize("frames,cout,h,w", [(2, 128, 128, 128), (1, 64, 128, 128), (12, 128, 128, 128), (7, 64, 32, 80)])   # 12 frames = 768 tiles: every persistent workgroup sweeps several
-def test_conv_first_backward(frames, cout, h, w):
+@pytest.mark.parametrize("fmt", ["bf16", "fp16"])
+@pytest.mark.parametrize("frames,cout,h,w", [(2, 128, 128, 128), (1, 64, 128, 128), (12, 128, 128, 128), (7, 64, 32, 80),
+                                             (3, 192, 64, 64)])   # 12 frames = 768 tiles: every persistent workgroup sweeps several; 192 channels (the 3x model): two channel tiles, the second half empty
+def test_conv_first_backward(frames, cout, h, w, fmt):
+    """vpt_conv_first_backward (recompute -> arg-max search -> nine per-offset GEMMs with one-hot gradient fragments, no scatter) against autograd
+    of conv -> ReLU -> max_pool2d on the same 16-bit-rounded weights and pooled values, both operand formats."""
+    dt = torch.bfloat16 if fmt == "bf16" else torch.float16
     g = torch.Generator().manual_seed(16)
     W = (torch.randn(cout, 3, 3, 3, generator=g) * 0.3).requires_grad_(True)
     b = (0.1 * torch.randn(cout, generator=g)).requires_grad_(True)
     img = torch.randint(0, 256, (frames, h, w, 3), generator=g, dtype=torch.uint8)
-    dP = torch.randn(frames, cout, h // 2, w // 2, generator=g).to(torch.bfloat16).float()
-    Wb = ((W.detach() / 255.0).to(torch.bfloat16).float() * 255.0).requires_grad_(True)  # the kernel rounds W / 255 to bf16; compare like for like
+    dP = torch.randn(frames, cout, h // 2, w // 2, generator=g).to(dt).float()
+    Wb = ((W.detach() / 255.0).to(dt).float() * 255.0).requires_grad_(True)  # the kernel rounds W / 255 to 16 bits; compare like for like
     y = torch.relu(torch.nn.functional.conv2d(img.permute(0, 3, 1, 2).float() / 255.0, Wb, b, padding=1))
-    y = y + (y.detach().to(torch.bfloat16).float() - y.detach())  # the kernel pools bf16-rounded values (straight-through here)
+    y = y + (y.detach().to(dt).float() - y.detach())  # the kernel pools 16-bit-rounded values (straight-through here)
     pooled = torch.nn.functional.max_pool2d(y, 3, 2, 1)
     gW, gb = torch.autograd.grad((pooled * dP).sum(), [Wb, b])
-    dW, db = ops.conv_first_backward(img.to(DEV), packing.pack_conv_first(W.detach().to(DEV), b.detach().to(DEV)),
-                                     packing.nchw_to_blocked(dP).to(DEV), cout)
+    dW, db = ops.conv_first_backward(img.to(DEV), packing.pack_conv_first(W.detach().to(DEV), b.detach().to(DEV), dtype=dt),
+                                     packing.nchw_to_blocked(dP, dtype=dt).to(DEV), cout)
     dW = ops.conv_first_grad_to_reference(dW)
     torch.cuda.synchronize()
     eW, eb = _l2(dW.cpu(), gW), _l2(db.cpu(), gb)
-    print(f"PARITY conv_first backward: dW {eW:.3e} db {eb:.3e}")
-    assert eW < 3e-2 and eb < 3e-2
+    print(f"PARITY[{fmt}] conv_first backward {frames}x{cout}x{h}x{w}: dW {eW:.3e} db {eb:.3e}")
+    assert eW < 5e-3 and eb < 5e-3      # measured 4e-7 ... 4e-4 (every gradient enters the fp32 accumulation un-merged; round 3: 2e-3 through a bf16 scatter)
 
 
 def test_conv_prepare_fused_pool_backward():
