@@ -17,6 +17,9 @@ for p in bf16 fp16; do
 VPT_BENCH_POOL=0 VPT_PRECISION=$p rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --output-format csv -d $out/pmc_sq_$p -- python $GRAFT_REPO_ROOT/tools/conv_bench.py 256 2 > $out/pmc_sq_$p.log 2>&1
 VPT_BENCH_POOL=0 VPT_PRECISION=$p rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $out/pmc_grbm_$p -- python $GRAFT_REPO_ROOT/tools/conv_bench.py 256 2 > $out/pmc_grbm_$p.log 2>&1
 done
+# (3b) the same SQ / GRBM passes on the 32-row / eight-wave tile variant (tiling 3), bf16
+VPT_BENCH_TILING=throughput32 VPT_BENCH_POOL=0 VPT_PRECISION=bf16 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --output-format csv -d $out/pmc_sq_bf16_t32 -- python $GRAFT_REPO_ROOT/tools/conv_bench.py 256 2 > $out/pmc_sq_bf16_t32.log 2>&1
+VPT_BENCH_TILING=throughput32 VPT_BENCH_POOL=0 VPT_PRECISION=bf16 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $out/pmc_grbm_bf16_t32 -- python $GRAFT_REPO_ROOT/tools/conv_bench.py 256 2 > $out/pmc_grbm_bf16_t32.log 2>&1
 # (4) HBM traffic of the conv kernel over one bench step (FETCH_SIZE x2 on gfx950, MI355X_MICROARCH.md)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- $B --steps 1 --warmup 0 --bc-steps 0 --no-cpu-baseline > $out/pmc_fetch.json 2> $out/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- $B --steps 1 --warmup 0 --bc-steps 0 --no-cpu-baseline > $out/pmc_write.json 2> $out/pmc_write.err

@@ -44,7 +44,7 @@ SHAPES = {1048576: "s0.block 64x64 128->128 (256 frames)", 2097152: "256-cout la
           524288: "s2.block 16x16 256->256"}
 import glob as _g
 _variants = [("", "bf16", "")] if _g.glob(os.path.join(SRC, "pmc_sq", "**", "*_counter_collection.csv"), recursive=True) else []
-_variants += [("_bf16", "bf16", ""), ("_fp16", "fp16", "_fp16")]
+_variants += [("_bf16", "bf16", ""), ("_fp16", "fp16", "_fp16"), ("_bf16_t32", "bf16", "_tiles32")]   # _tiles32: the 32-row / eight-wave tile variant (tiling 3)
 for SFX, FMT, FSFX in _variants:
     if not _g.glob(os.path.join(SRC, f"pmc_sq{SFX}", "**", "*_counter_collection.csv"), recursive=True):
         continue
@@ -58,7 +58,7 @@ for SFX, FMT, FSFX in _variants:
         for r in csv.DictReader(open(f)):
             if "vpt_conv3x3_kernel" not in r["Kernel_Name"]:
                 continue
-            res = "res" if ", 1>" in r["Kernel_Name"] else "nores"
+            res = "res" if (", 1>" in r["Kernel_Name"] or "<false, 1," in r["Kernel_Name"] or "<false, 5," in r["Kernel_Name"]) else "nores"   # template <trace, mode[, tile rows]>: modes 1 / 5 carry a residual
             key = f"grid{r['Grid_Size']}_{res}"
             pmc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
             if (sub, r["Dispatch_Id"]) not in seen:
