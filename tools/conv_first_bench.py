@@ -33,5 +33,8 @@ def timeit(fn, reps=5):
 t1 = timeit(lambda: ops.conv_first(img, wfrag, cout, stats_out=st))
 t2 = timeit(lambda: ops.conv_first(img, wfrag, cout, stats_out=None))
 t3 = timeit(lambda: ops.conv_first_backward(img, wfrag, dp, cout))
+gain = (1 + 0.1 * torch.randn(cout, generator=g)).cuda()
+chs = torch.zeros(frames, cout, 2, dtype=torch.float64, device="cuda")
+t4 = timeit(lambda: ops.conv_first(img, wfrag, cout, stats_out=st, out_gain=gain, chs_out=chs))   # the inference engine's call: gain of GroupNorm `n` folded in, per-channel sums
 gb = frames * (128 * 128 * 3 + 64 * 64 * cout * 2) / 1e9
-print(f"conv_first forward {frames} frames: {t1:.3f} ms with stats, {t2:.3f} ms without  ({gb / t1 * 1e3:.0f} GB/s algorithmic)   backward {t3:.3f} ms")
+print(f"conv_first forward {frames} frames: {t1:.3f} ms with stats, {t2:.3f} ms without  ({gb / t1 * 1e3:.0f} GB/s algorithmic)   backward {t3:.3f} ms;  with out_gain + per-channel sums {t4:.3f} ms  {os.environ.get('VPT_HIP_LIB', '').split('/')[-1]}")

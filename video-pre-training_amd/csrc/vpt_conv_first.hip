@@ -20,6 +20,11 @@
 #include "vpt_conv_first_tile.h"
 
 typedef short i16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
 // Eight waves per workgroup, two workgroups per CU (the 79 KB conv tile decides that): four waves per SIMD.  With four waves per
 // workgroup (round 2) a tile took ~11 k cycles against ~5 k of issued work -- LDS round trips, the slice counter and three
 // barriers per tile with nothing else to run.
@@ -129,9 +134,12 @@ __global__ __launch_bounds__(CF_THREADS, 4) void vpt_conv_first_kernel(VptConvFi
 
   // ---- 3x3 / stride 2 max-pool over the conv tile, store + statistics ----
   if (a.stats_out && f != stat_f) {
-    if (stat_f >= 0 && lane == 0) {
-      atomicAdd(a.stats_out + 2 * stat_f, d_sum);
-      atomicAdd(a.stats_out + 2 * stat_f + 1, d_sq);
+    if (stat_f >= 0) {
+      const double t1 = wave_sum_f64(d_sum), t2 = wave_sum_f64(d_sq);
+      if (lane == 0) {
+        atomicAdd(a.stats_out + 2 * stat_f, t1);
+        atomicAdd(a.stats_out + 2 * stat_f + 1, t2);
+      }
     }
     stat_f = f; d_sum = 0.0; d_sq = 0.0;
   }
@@ -180,9 +188,9 @@ __global__ __launch_bounds__(CF_THREADS, 4) void vpt_conv_first_kernel(VptConvFi
       *(u32x4*)(a.y + off) = mv;
     }
   }
-    if (a.stats_out) {
-      d_sum += (double)wave_sum(s_sum);
-      d_sq += (double)wave_sum(s_sq);
+    if (a.stats_out) {   // per LANE in fp64 across tiles; the lanes are combined when the frame changes (a wave reduction per tile cost 0.09 of this kernel's 0.57 ms per 1024 frames)
+      d_sum += (double)s_sum;
+      d_sq += (double)s_sq;
     }
     __syncthreads();   // all pooling reads of the conv tile done before the next tile overwrites it
     if (CHS && (++in_group == group || tile + 1 >= t_end)) {         // last tile of a group (groups never straddle frames): hand the per-channel sums over
@@ -191,9 +199,12 @@ __global__ __launch_bounds__(CF_THREADS, 4) void vpt_conv_first_kernel(VptConvFi
       __syncthreads();
     }
   }
-  if (a.stats_out && stat_f >= 0 && lane == 0) {
-    atomicAdd(a.stats_out + 2 * stat_f, d_sum);
-    atomicAdd(a.stats_out + 2 * stat_f + 1, d_sq);
+  if (a.stats_out && stat_f >= 0) {
+    const double t1 = wave_sum_f64(d_sum), t2 = wave_sum_f64(d_sq);
+    if (lane == 0) {
+      atomicAdd(a.stats_out + 2 * stat_f, t1);
+      atomicAdd(a.stats_out + 2 * stat_f + 1, t2);
+    }
   }
 }
 
