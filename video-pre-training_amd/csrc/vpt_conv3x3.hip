@@ -32,7 +32,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #ifndef VPT_EPI_ABLATE
-#define VPT_EPI_ABLATE 0   // profiling builds: 1 = no output stores, 2 = no residual loads inside the epilogue
+#define VPT_EPI_ABLATE 0   // profiling builds: 1 = no output stores, 2 = no residual loads inside the epilogue, 4 = no residual prefetch in the main loop (registers uninitialised)
 #endif
 // Profiling switches (VPT_CONV_ABLATE = 1: skip the epilogue, 2: skip the main loop; VPT_CONV_EXTRA_LDS: dynamic LDS to force one
 // workgroup per CU) exist ONLY in builds made with -DVPT_CONV_PROFILE (tools/build_variant.sh): the shipped library reads no
@@ -237,6 +237,12 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
 #pragma unroll
   for (int n2 = 0; n2 < 2; ++n2) cbase[n2] = (size_t)(f * CB_out + (nvalid[n2] ? cb0 + n2 : 0)) * HW * 32;
 #define EPI_LD(ptr_, m_, n2_, p_) (*(const u32x4*)((const char*)((ptr_) + cbase[n2_]) + (svoff[p_] + (unsigned)(m_) * gm_b)))
+#ifndef VPT_RES_LATE
+#define VPT_RES_LATE 0     // 1: the residual prefetch rides in the tile's last-but-one step (see the last channel block below); 0: one step earlier (rounds 2-4).  Measured: +1.8 % on s0.block alone, nothing on the step (profiles/r04_experiments.md section 15)
+#endif
+#ifndef VPT_RES_PREFETCH
+#define VPT_RES_PREFETCH 1   // 0: no residual request inside the main loop; all four subtiles are requested at the start of the epilogue
+#endif
 #ifndef VPT_RES_NATIVE
 #define VPT_RES_NATIVE 1   // 1: the residual arrives in the accumulators' own layout (8-byte loads: a lane's 4 channels of a group), no lane exchanges;
 #endif                     // 0: whole 128-byte lines per 16-byte load + v_permlane16/32_swap (round 2-3; the output stores still go that way)
@@ -359,7 +365,9 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
     } else {                                                                                              \
       GROUP(1, dy_, 4, boff_, NOP_(), NOP_());                                                            \
       GROUP(0, dy_, 5, boff_, NOP_(), NOP_());                                                            \
-      WAIT_BARRIER(0);                                                                                    \
+      /* the tile's last step issues no DMA: the residual pieces requested in the step before stay in flight across its barrier */ \
+      if ((LAST) && HAS_RES && VPT_RES_LATE && VPT_RES_PREFETCH && !(VPT_EPI_ABLATE & 4)) { if (VPT_RES_NATIVE) WAIT_BARRIER(16); else WAIT_BARRIER(8); }  \
+      else WAIT_BARRIER(0);                                                                               \
     }                                                                                                     \
     if (WR_A) {   /* the halo of the next channel block replaces the current one: second barrier before its first read */ \
       _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_) {                                                  \
@@ -405,9 +413,12 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
       CONV_STEP(cb, 1, 2, false, false, false, false, false);
       CONV_STEP(cb, 2, 0, false, true, false, false, false);
     }
-    // last channel block: no further halo -> request the residual of the first two subtiles instead
-    CONV_STEP(NCB - 1, 0, 1, false, false, true, false, false);
-    CONV_STEP(NCB - 1, 1, 2, false, false, false, false, false);
+    // last channel block: no further halo -> request the residual of the first two subtiles instead.  A step's barrier waits for its weight DMA with
+    // a counted vmcnt, which retires everything issued BEFORE that DMA too: a residual requested in kernel row 0 is forced home by row 1's barrier (56
+    // MFMAs later, workgroup-wide); requested in row 1 behind that step's DMA (VPT_RES_LATE) nothing waits for it before the epilogue, because the last
+    // step issues no DMA.  Built and measured in round 4: +1.8 % on the K = 1152 layer's micro-benchmark, 0.1 % on the forward step -- the default stays.
+    CONV_STEP(NCB - 1, 0, 1, false, false, !VPT_RES_LATE && !(VPT_EPI_ABLATE & 4) && VPT_RES_PREFETCH, false, false);
+    CONV_STEP(NCB - 1, 1, 2, false, false, VPT_RES_LATE != 0 && !(VPT_EPI_ABLATE & 4) && VPT_RES_PREFETCH, false, false);
     CONV_STEP(NCB - 1, 2, 0, false, false, false, true, false);
   } else {
 #pragma unroll
@@ -445,7 +456,7 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
     if (t == 12345.678f) a.y[0] = (vpt_op16)t;
     return;
   }
-  if (HAS_RES && CONV_ABLATE == 2) { LOAD_RES(0); LOAD_RES(1); }
+  if (HAS_RES && (CONV_ABLATE == 2 || !VPT_RES_PREFETCH)) { LOAD_RES(0); LOAD_RES(1); }
   SB();
 
   f32x2 s_sum2 = {0.f, 0.f}, s_sq2 = {0.f, 0.f};   // packed fp32 (v_pk_add_f32 / v_pk_fma_f32): two values per VALU issue
