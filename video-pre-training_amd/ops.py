@@ -218,7 +218,7 @@ def conv3x3_pool(x, wpk, edge_sa, edge_sg, stats_in, cout, stats_out=None, out=N
     return y
 
 
-def conv3x3_folded(x, wpk, edge_sa, edge_sg, stats_in, cout, kk_frame=None, rs_frame=None, res=None, res_scale=None, res_bias=None, stats_out=None):
+def conv3x3_folded(x, wpk, edge_sa, edge_sg, stats_in, cout, kk_frame=None, rs_frame=None, res=None, res_scale=None, res_bias=None, stats_out=None, out=None):
     """conv3x3() with the GroupNorm `n` of the stack folded in (vpt_conv3x3_forward_folded): (kk_frame [F,9,CoutPad], rs_frame [F]) from
     nfold_coef() replace edge_sa and the statistics of x (conv0 on the gain-scaled pooled tensor Q); (res_scale [F], res_bias [F,cout])
     make the residual res_scale * res + res_bias (conv1 with res = Q)."""
@@ -231,7 +231,8 @@ def conv3x3_folded(x, wpk, edge_sa, edge_sg, stats_in, cout, kk_frame=None, rs_f
         raise ValueError(f"conv3x3_folded: kk_frame must be [F, 9, {edge_sg.shape[1]}], got {tuple(kk_frame.shape)}")
     if res_bias is not None and tuple(res_bias.shape) != (f, cout):
         raise ValueError(f"conv3x3_folded: res_bias must be [F, {cout}], got {tuple(res_bias.shape)}")
-    out = torch.empty(f, cout // 32, h, w, 32, dtype=dt, device=x.device)
+    if out is None:
+        out = torch.empty(f, cout // 32, h, w, 32, dtype=dt, device=x.device)
     meta = dict(flops=2.0 * f * h * w * cout * 9 * cb * 32, bytes=2.0 * f * h * w * (cb * 32 + cout * (2 if res is not None else 1)))
     _call("vpt_conv3x3_forward_folded", meta, ptr(x), ptr(wpk), ptr(edge_sa), ptr(edge_sg), ptr(stats_in), ptr(kk_frame), ptr(rs_frame), ptr(res),
           ptr(res_scale), ptr(res_bias), ptr(out), ptr(stats_out), f, h, w, cb * 32, cout, _stream(), fmt=fmt, label="vpt_conv3x3_forward")
