@@ -19,7 +19,7 @@ import torch
 from . import ops, packing
 
 # split-K of the K = 65536 dense layer (per-split partial slices summed in a fixed order: deterministic)
-DENSE_SPLITK = int(os.environ.get("VPT_DENSE_SPLITK", "16"))
+DENSE_SPLITK = int(os.environ.get("VPT_DENSE_SPLITK", "32"))   # 32 x 16 tiles = one full round of workgroups per 1024-frame chunk (16: half a round; profiles/r04_experiments.md section 20)
 
 
 def config_from_policy_kwargs(policy_kwargs: dict, pi_head_kwargs: Optional[dict] = None) -> dict:
