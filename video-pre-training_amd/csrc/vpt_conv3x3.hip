@@ -520,7 +520,10 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
     for (int n2 = 0; n2 < 2; ++n2) {
       if (!BWD && 2 * m + n2 < 7) { LOAD_KK(2 * m + n2 + 1); SB(); }
       if (n2 >= NV) continue;
-      u32x4 ovp[2], rp[2], xp[2];
+      u32x4 ovp[2], xp[2];
+#if !VPT_RES_NATIVE
+      u32x4 rp[2];
+#endif
       // residual / xin arrive as whole pixel rows (instruction j: the pixels of lanes (l31 & 15) + 16 j); the same exchange as for
       // the stores, run backwards, gives every lane the two 16-byte pieces (p = 0, 1) of its own pixel
 #define ROWS_TO_PIECES(src_, dst_)                                                                        \
