@@ -19,7 +19,16 @@ Extra objects on the line:
                  BASELINE.json configs[0] (1x); kind "port" (the oracle) only if the archive is missing.
   parity       : log-prob / centred-logit / value errors of the bf16 default and of the fp16 parity mode vs the oracle.
   fp16_mode    : the same workload with precision="fp16" (the parity mode) as a full record: timed steps, roofline, per-kernel table.
-  bc_step[_fp16]: BC step (forward + backward + Adam [+ all-reduce]) time, its fraction of the MFMA peak, the three conv passes' TF/s.
+  bc_step[_fp16]: BC step (forward + backward + Adam [+ all-reduce]) time, its fraction of the MFMA peak, the three conv passes' TF/s;
+                 N > 1: `allreduce_detail` (the gradient exchange alone: ms, bytes, collectives, backend, ranks).
+  parity.timed_batch / parity.competitive_heads / parity_mode: parity measured ON two sequences of the timed batch (both formats), on the
+                 input-driven head family, and which throughput has earned the 1e-3 gate (fp16).
+  ingest       : pinned host frames -> device through a two-deep copy pipeline under the forward (128 x 128 frames; 640 x 360 BGR through
+                 vpt_clip_frames): frames/s, ms per step, overlap fraction, the PCIe crossover.  Never the headline value.
+
+`--gpus N` is honoured by the script itself: with N > 1 and no launcher environment it starts its own N ranks (torch.distributed.run);
+under a launcher it refuses a WORLD_SIZE that differs from N, and it refuses N > visible GPUs (RCCL: one device per rank) unless
+VPT_DIST_BACKEND=gloo (tests).  The N > 1 line carries `collective_ranks` from an actual all-reduce of device tensors.
 """
 import argparse
 import json
@@ -257,6 +266,201 @@ def _roofline(ops, pol, step, state, args, B, T, mode):
     return roof, kernels
 
 
+def headline_batch_parity(pol, model, img, first, dev, modes, rows=(0, -1)):
+    """parity measured ON the benchmarked batch.  Two sequences (the first and the last) of the TIMED 64 x 128 batch, with the
+    benchmarked weights, go through the CPU oracle from initial_state (what the first timed step computed for them); the GPU side is the whole-batch
+    forward of each operand format -- the rows are read out of the 64-sequence result, so batch effects would show."""
+    from oracle import vpt_oracle as O
+    from tests import parity as P
+    torch.set_num_threads(_host_threads(32))
+    B, T = img.shape[:2]
+    rows = sorted({r % B for r in rows})
+    cfg = O.config_from_policy_kwargs(O.policy_kwargs_for(model), dict(temperature=2.0))
+    sd = {k: v.detach().float().cpu() for k, v in pol.state_dict().items()}
+    t0 = time.time()
+    ref = O.policy_forward(sd, cfg, img[rows].cpu(), first[rows].cpu(), O.initial_state(cfg, len(rows)))
+    out = {"sample": f"sequences {rows} of the timed {B} x {T} batch (benchmarked weights, initial_state), whole-batch GPU forward vs oracle/vpt_oracle.py on those rows "
+                     f"({time.time() - t0:.1f} s of CPU)"}
+    for mode in modes:
+        pol.set_precision(mode)
+        with torch.no_grad():
+            (pd, vpred, _), _ = pol({"img": img}, first, pol.initial_state(B))
+        torch.cuda.synchronize()
+        m = P.policy_metrics(dict(buttons=pd["buttons"][rows], camera=pd["camera"][rows], vpred=vpred[rows]), ref)
+        out[mode] = {"logprob_rel_l2": round(max(m["buttons.lp_l2"], m["camera.lp_l2"]), 6), "logprob_max_rel": round(max(m["buttons.lp_max"], m["camera.lp_max"]), 6),
+                     "centred_logits_rel_l2": round(max(m["buttons.c_l2"], m["camera.c_l2"]), 5), "value_rel": round(m["v_rel"], 5),
+                     "argmax_mismatch_outside_noise_band": m["buttons.argmax_safe_mismatch"] + m["camera.argmax_safe_mismatch"],
+                     "within_bounds": all(m[f"{h}.{k}"] < P.BOUNDS[mode][k] for h in ("buttons", "camera") for k in ("lp_l2", "lp_max", "c_l2", "c_max")),
+                     "meets_1e-3_logprob_rel_l2": max(m["buttons.lp_l2"], m["camera.lp_l2"]) < 1e-3}
+        del pd, vpred
+    return out
+
+
+def competitive_heads_parity(model, dev, modes):
+    """the head family whose logits are DRIVEN by the latent with an O(1) dynamic range (oracle.fit_scene_heads: 16 live classes,
+    margins of ~4 nat decided by the input) next to the near-uniform one above.  The log-prob error here is the latent's error amplified by the
+    head weights -- "logits within 1e-3" depends on the head weights, and no trained .weights exist in this image."""
+    from oracle import vpt_oracle as O
+    from tests import parity as P
+    from vpt_amd.lib.policy import MinecraftAgentPolicy
+    from vpt_amd.lib.types import minecraft_action_space
+    pk = O.policy_kwargs_for(model)
+    cfg = O.config_from_policy_kwargs(pk, dict(temperature=2.0))
+    sd0 = O.synthetic_state_dict(cfg, seed=0)
+    b, t, n_scenes = 2, 64, 8
+    img, scene = O.scene_frames(b, t, n_scenes, torch.Generator().manual_seed(606))
+    first = torch.zeros(b, t, dtype=torch.bool)
+    trunk = O.policy_forward(sd0, cfg, img, first, O.initial_state(cfg, b))
+    sd = O.fit_scene_heads(sd0, trunk["latent"].reshape(b * t, -1), scene.reshape(-1), 2.0)
+    ref = {h: O.categorical_head(sd, f"pi_head.{h}.", trunk["latent"], 2.0).reshape(b, t, 1, -1) for h in ("buttons", "camera")}
+    pol = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0))
+    pol.load_state_dict(sd, strict=False)
+    pol = pol.to(dev)
+    out = {"sample": f"{model} model, B={b} T={t} frames of {n_scenes} scenes, oracle.fit_scene_heads weights (input-driven, top-2 margin ~4 nat): the head weights "
+                     "amplify the latent's error -- 'logits within 1e-3' is head-weight dependent; no trained .weights exist here"}
+    for mode in modes:
+        pol.set_precision(mode)
+        pol._ensure_packed()
+        with torch.no_grad():
+            o = pol._engine.forward(img.to(dev), first.to(dev), pol.initial_state(b), sample="deterministic")
+        torch.cuda.synchronize()
+        rec = {}
+        for h in ("buttons", "camera"):
+            hm = P.head_metrics(o[h], ref[h])
+            want = ref[h].argmax(-1)[:, :, 0]
+            rec[h] = dict(logprob_rel_l2=round(hm["lp_l2"], 6), logprob_max_rel=round(hm["lp_max"], 6), centred_logits_rel_l2=round(hm["c_l2"], 6),
+                          max_abs_err_nat=round(hm["max_abs_err"], 5), actions_equal_frac=round(float((o["action"][h][:, :, 0].cpu() == want).float().mean()), 4),
+                          distinct_oracle_actions=len(set(want.flatten().tolist())))
+        out[mode] = rec
+    return out
+
+
+def ingest_leg(pol, img, first, dev, steps=3):
+    """host -> device ingest, bounded, NOT the headline (whose frames are resident in HBM when the timed region starts).
+    The reference uploads every observation from host memory (agent.py:147-148: th.from_numpy(...).to(device) per frame; data_loader.py:113-122
+    hands out host frames).  Here: pinned host uint8 frames -> device through a two-deep, stream-ordered pipeline (copy stream + events; the
+    copy of step k + 1 runs under the forward of step k), for
+      (i)  agent-resolution frames [B, T, 128, 128, 3] (49 KB / frame), and
+      (ii) decoded 640 x 360 BGR frames (691 KB / frame) in 2048-frame chunks through vpt_clip_frames (BGR -> RGB + cv2.INTER_LINEAR resize on
+           the device, no cursor) into the batch the forward then consumes.
+    Reported per case: frames/s and ms per step of the pipeline, of the forward alone and of the copies alone, the H2D rate, and
+    overlap_frac = the share of the copy time hidden under compute."""
+    from vpt_amd import ops
+    B, T = img.shape[:2]
+    n = B * T
+    main, copy_s = torch.cuda.current_stream(), torch.cuda.Stream()
+    out = {}
+
+    def fwd(frames, st):
+        with torch.no_grad():
+            (_, _, _), st = pol({"img": frames}, first, st)
+        return st
+
+    def timeit(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    # ---- (i) 128 x 128 frames
+    host = torch.empty(img.shape, dtype=torch.uint8).pin_memory()
+    host.copy_(img)
+    bufs = [torch.empty_like(img), torch.empty_like(img)]
+
+    def copies_only():
+        for k in range(steps):
+            with torch.cuda.stream(copy_s):
+                bufs[k % 2].copy_(host, non_blocking=True)
+
+    def compute_only():
+        st = pol.initial_state(B)
+        for k in range(steps):
+            st = fwd(bufs[k % 2], st)
+
+    def pipelined():
+        st = pol.initial_state(B)
+        done = {}
+        with torch.cuda.stream(copy_s):
+            bufs[0].copy_(host, non_blocking=True)
+            ready = torch.cuda.Event(); ready.record(copy_s)
+        for k in range(steps):
+            main.wait_event(ready)
+            if k + 1 < steps:
+                with torch.cuda.stream(copy_s):
+                    if k - 1 in done:
+                        copy_s.wait_event(done[k - 1])          # the buffer about to be overwritten was read by step k - 1
+                    bufs[(k + 1) % 2].copy_(host, non_blocking=True)
+                    ready = torch.cuda.Event(); ready.record(copy_s)
+            st = fwd(bufs[k % 2], st)
+            done[k] = torch.cuda.Event(); done[k].record(main)
+
+    copies_only(); compute_only()          # warm-up
+    t_copy, t_comp, t_pipe = timeit(copies_only), timeit(compute_only), timeit(pipelined)
+    nbytes = img.numel()
+    out["frames_128x128"] = dict(bytes_per_step=nbytes, frames_per_s=round(n / t_pipe, 1), ms_per_step=round(1e3 * t_pipe, 3), forward_alone_ms=round(1e3 * t_comp, 3),
+                                 copy_alone_ms=round(1e3 * t_copy, 3), h2d_gb_per_s=round(nbytes / t_copy / 1e9, 1),
+                                 overlap_frac=round(1.0 - max(0.0, t_pipe - t_comp) / t_copy, 3), steps=steps)
+    del host, bufs
+    # ---- (ii) decoded 640 x 360 BGR frames through the device clip kernel
+    H, W, chunk = 360, 640, 2048
+    n_chunks = (n + chunk - 1) // chunk
+    raw_dev = [torch.randint(0, 256, (chunk, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+    host = torch.empty(chunk, H, W, 3, dtype=torch.uint8).pin_memory()
+    host.copy_(raw_dev[0])
+    batch = torch.empty(n, 128, 128, 3, dtype=torch.uint8, device=dev)
+
+    def clip_chunk(c, src):
+        lo, hi = c * chunk, min(n, (c + 1) * chunk)
+        ops.clip_frames(src[:hi - lo], out_hw=(128, 128), out=batch[lo:hi])
+
+    def copies_only2():
+        for g in range(steps * n_chunks):
+            with torch.cuda.stream(copy_s):
+                raw_dev[g % 2].copy_(host, non_blocking=True)
+
+    def compute_only2():
+        st = pol.initial_state(B)
+        for k in range(steps):
+            for c in range(n_chunks):
+                clip_chunk(c, raw_dev[c % 2])
+            st = fwd(batch.view(B, T, 128, 128, 3), st)
+
+    def pipelined2():
+        st = pol.initial_state(B)
+        total = steps * n_chunks
+        ready, used = {}, {}
+
+        def issue(g):
+            with torch.cuda.stream(copy_s):
+                if g - 2 in used:
+                    copy_s.wait_event(used[g - 2])
+                raw_dev[g % 2].copy_(host, non_blocking=True)
+                ready[g] = torch.cuda.Event(); ready[g].record(copy_s)
+
+        issue(0); issue(1)
+        for g in range(total):
+            main.wait_event(ready[g])
+            clip_chunk(g % n_chunks, raw_dev[g % 2])
+            used[g] = torch.cuda.Event(); used[g].record(main)
+            if g + 2 < total:
+                issue(g + 2)
+            if g % n_chunks == n_chunks - 1:
+                st = fwd(batch.view(B, T, 128, 128, 3), st)
+
+    copies_only2(); compute_only2()
+    t_copy, t_comp, t_pipe = timeit(copies_only2), timeit(compute_only2), timeit(pipelined2)
+    raw_bytes = n * H * W * 3
+    rate = raw_bytes / t_copy
+    out["frames_640x360_bgr_via_vpt_clip_frames"] = dict(bytes_per_step=raw_bytes, frames_per_s=round(n / t_pipe, 1), ms_per_step=round(1e3 * t_pipe, 3),
+                                                         clip_plus_forward_alone_ms=round(1e3 * t_comp, 3), copy_alone_ms=round(1e3 * t_copy, 3), h2d_gb_per_s=round(rate / 1e9, 1),
+                                                         overlap_frac=round(1.0 - max(0.0, t_pipe - t_comp) / t_copy, 3), pcie_bound=bool(t_copy > t_comp),
+                                                         crossover_frames_per_s=round(rate / (H * W * 3), 1), chunk_frames=chunk, steps=steps,
+                                                         note="crossover = H2D rate / 691200 B: above that forward rate the raw-frame upload, not the GPU, bounds the loader")
+    out["note"] = "pinned host memory, hipMemcpyAsync on a copy stream, two device buffers, events both ways; frames resident in HBM remain the headline's definition"
+    return out
+
+
 TRAFFIC_FILES = {"bf16": ("r04_bench_conv3x3_traffic.json",), "fp16": ("r04_bench_conv3x3_traffic_fp16.json",)}
 
 
@@ -297,6 +501,20 @@ def _bc_leg(pol, args, img, first, g, dev, world, distributed, barrier, dist, mo
               tflops=round(3 * fl * B * T / sec / 1e12, 1), frac_of_mfma_peak=round(3 * fl * B * T / sec / MFMA_BF16_PEAK, 4),
               flop_accounting="3 x forward FLOPs (SURVEY 8d) x frames / step time, per GPU",
               peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1))
+    if distributed and tr._arenas is not None:
+        # the gradient exchange by itself (nothing to overlap with): what the step would pay if none of it were hidden
+        from vpt_amd import distributed as D
+        arenas = tr._arenas[1]
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            D.bucketed_all_reduce_finish(arenas[0].all_reduce_start() + arenas[1].all_reduce_start())
+            torch.cuda.synchronize()
+        ar_ms = (time.perf_counter() - t0) / 3 * 1e3
+        bc["allreduce_detail"] = dict(ms_standalone=round(ar_ms, 3), bytes=int(4 * (arenas[0].flat.numel() + arenas[1].flat.numel())),
+                                      collectives=len(arenas[0].buckets) + len(arenas[1].buckets), backend=dist.get_backend(), ranks=dist.get_world_size(),
+                                      early_wave_bytes=int(4 * arenas[0].flat.numel()), note="early wave (trunk + heads) is launched before the CNN backward and overlaps it; "
+                                      "the late wave (CNN) is exposed; ms_standalone = both waves back to back with nothing to hide behind")
     if int(os.environ.get("RANK", "0")) == 0 and not distributed:
         tr.cnn_streams = 1          # per-kernel durations are only meaningful without cross-stream overlap
         ops.TIMER.enabled = True
@@ -419,16 +637,40 @@ def main():
     ap.add_argument("--bc-steps", type=int, default=10, help="timed behavioural-cloning steps after the forward measurement (0: skip)")
     ap.add_argument("--bc-warmup", type=int, default=1)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"], help="operand format of the HEADLINE value (north star: bf16 tiles); the other format is reported beside it")
+    ap.add_argument("--no-ingest", action="store_true", help="skip the host -> device ingest leg")
     args = ap.parse_args()
+
+    backend = os.environ.get("VPT_DIST_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm; "gloo" lets the N > 1 branch run with every rank on one GPU (tests)
+    n_dev = torch.cuda.device_count()
+    if not (torch.cuda.is_available() and n_dev > 0):
+        sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.gpus < 1:
+        sys.exit(f"bench.py: --gpus must be >= 1, got {args.gpus}")
+    if args.gpus > n_dev and backend != "gloo":
+        # one rank per GPU over RCCL: never print an N-GPU line from fewer devices (VPT_DIST_BACKEND=gloo is the tests' way to run the
+        # N > 1 branch with every rank on one device; it claims no scaling figure)
+        sys.exit(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible (RCCL needs one device per rank; VPT_DIST_BACKEND=gloo runs the branch on one device for tests)")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` by itself: start the N ranks (what `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
+        # does when the driver launches it) and hand their exit code back -- a plain --gpus N never degrades to a 1-GPU line
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} does not match the launcher's WORLD_SIZE={world} (the line's n_gpus is the number of ranks that ran)")
     distributed = world > 1
     dist = None
-    backend = os.environ.get("VPT_DIST_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm; "gloo" lets the N > 1 branch run with every rank on one GPU (tests)
-    n_dev = torch.cuda.device_count()
-    assert torch.cuda.is_available() and n_dev > 0, "bench.py needs a GPU (the HIP path has no CPU fallback)"
     dev_index = local_rank % n_dev
     if distributed:
         import torch.distributed as dist
@@ -440,6 +682,14 @@ def main():
             dist.init_process_group(backend)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    collective_ranks = 1
+    if distributed:      # an ACTUAL collective on device tensors: every rank contributes 1, the sum is the number of ranks the transport reached
+        one = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(one)
+        torch.cuda.synchronize()
+        collective_ranks = int(round(float(one.item())))
+        if collective_ranks != world:
+            sys.exit(f"bench.py: all-reduce over {dist.get_backend()} summed {collective_ranks} ranks, launcher says {world}")
 
     import __graft_entry__ as ge
     if distributed:  # one rank compiles (a no-op when the in-tree .so is current), the others wait
@@ -515,6 +765,14 @@ def main():
         finally:
             pol.set_precision(head)
 
+    timed_parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:      # parity ON the timed batch, with the weights the timed steps ran (before the BC leg's Adam steps move them), both formats
+            timed_parity = headline_batch_parity(pol, args.model, img, first, dev, (head, other))
+        except Exception as e:
+            timed_parity = dict(error=f"{type(e).__name__}: {e}")
+        pol.set_precision(head)
+
     bc = bc_other = None
     if args.bc_steps > 0:
         try:
@@ -537,6 +795,7 @@ def main():
         par = f"dp{world} replicas (no collective in forward; BC step: gradient all-reduce)"
         if distributed:
             par += f"; torch.distributed backend={dist.get_backend()} world_size={dist.get_world_size()}" + (" (RCCL)" if dist.get_backend() == "nccl" else "")
+            par += f"; collective_ranks={collective_ranks} (sum of ones over an all-reduce of device tensors)"
         line = {
             "metric": "frames/sec (fwd) [+ bc_step.ms_per_step], 2x policy, 128x128x3 seq=128",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -559,6 +818,26 @@ def main():
                 line["parity"] = parity_block(args.model, dev)
             except Exception as e:
                 line["parity"] = dict(error=f"{type(e).__name__}: {e}")
+            line["parity"]["timed_batch"] = timed_parity       # (measured before the BC leg, see above)
+            try:
+                line["parity"]["competitive_heads"] = competitive_heads_parity(args.model, dev, (head, other))
+            except Exception as e:
+                line["parity"]["competitive_heads"] = dict(error=f"{type(e).__name__}: {e}")
+            # which throughput has EARNED the north star's 1e-3 gate (log-prob relative L2 on the timed batch): the fp16 record
+            pm = other_rec if other == "fp16" else dict(frames_per_s=round(fps, 1), roofline=roof)
+            if isinstance(pm, dict) and "error" not in pm:
+                tb = line["parity"].get("timed_batch", {}).get("fp16", {})
+                line["parity_mode"] = {"dtype": "fp16", "value": pm.get("frames_per_s"), "unit": "frames/s",
+                                       "roofline_frac": (pm.get("roofline") or {}).get("frac"),
+                                       "logprob_rel_l2_on_timed_batch": tb.get("logprob_rel_l2"), "meets_1e-3": tb.get("meets_1e-3_logprob_rel_l2"),
+                                       "note": "precision='fp16' (the policy classes' default) is the format whose log-probs are within 1e-3 relative L2 of the fp32 reference; the headline "
+                                               "`value` is the north star's bf16-tile format, whose parity figures are in parity.* (1.5-4x the tolerance by construction: bf16 operands carry 8 mantissa bits)"}
+            if not args.no_ingest:
+                try:
+                    pol.set_precision(head)
+                    line["ingest"] = ingest_leg(pol, img, first, dev)
+                except Exception as e:
+                    line["ingest"] = dict(error=f"{type(e).__name__}: {e}")
             del pol, img
             torch.cuda.empty_cache()
             try:

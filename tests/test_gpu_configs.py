@@ -193,6 +193,13 @@ def test_input_driven_actions_on_competitive_heads():
             assert got.dtype == torch.int64 and bool((got[safe] == want[safe]).all())
             assert float(safe.float().mean()) >= 0.9, (mode, h, float(safe.float().mean()))
             assert float(agree.float().mean()) >= 0.9, (mode, h, float(agree.float().mean()))
+            # the log-probs of the one head family whose logits are driven by the latent with an O(1) dynamic range are GATED,
+            # not only printed.  Bounds = 1.5 x the round-4 measurement (fp16 lp_l2 2.4-2.8e-4, lp_max 3.2-3.3e-3, c_l2 4.1-4.5e-4; bf16 2.0-2.3e-3,
+            # 1.9-2.0e-2, 3.4-3.7e-3): fp16 meets the north star's 1e-3 in relative L2 with 3.5x margin here, its max-norm does not (3e-3) -- head
+            # weights amplify the latent's error, "within 1e-3" is head-weight dependent.
+            gate = {"fp16": dict(lp_l2=5e-4, lp_max=5e-3, c_l2=7e-4), "bf16": dict(lp_l2=3.5e-3, lp_max=3e-2, c_l2=5.5e-3)}[mode]
+            for k_, bound in gate.items():
+                assert m[k_] < bound, (mode, h, k_, m[k_], bound)
 
 
 def _idm(precision="bf16", heads="uniform"):

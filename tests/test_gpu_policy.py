@@ -181,6 +181,36 @@ def test_a_sequence_result_does_not_depend_on_the_batch_around_it(pol_1x):
             assert torch.equal(k1, k2[idx]) and torch.equal(v1, v2[idx])
 
 
+def test_a_sequence_result_does_not_depend_on_the_row_count_of_the_linears(pol_1x):
+    """ADVICE r4 / VERDICT r4 item 6: the trunk linears' split-K used to be chosen from M (<= 256, 257..512, > 512 rows summed K in three different
+    orders), so a sequence alone (B = 1, T = 128: M = 128) and the same sequence inside a larger batch (M = 640) were not bit-identical.  The K
+    order is now a function of the named tiling and the layer only (ops.linear: splitk is the caller's, "nk" or an int, never M's).  Also two CNN
+    chunk sizes straddling 512 rows (256 and 1024): the dense layer's split-K is the engine's constant."""
+    pol, cfg, sd = pol_1x
+    t = 128
+    a, other = _inputs(311, 1, t), _inputs(312, 4, t)
+    big = torch.cat([other[:2], a, other[2:]])
+    f1, f5 = torch.zeros(1, t, dtype=torch.bool, device=DEV), torch.zeros(5, t, dtype=torch.bool, device=DEV)
+    eng = pol._engine
+    saved = eng.cnn_chunk
+    res = []
+    try:
+        for chunk, img, f in ((1024, a, f1), (1024, big, f5), (256, big, f5), (256, a, f1)):
+            eng.cnn_chunk = chunk
+            (pd, v, _), st = pol({"img": img.to(DEV)}, f, pol.initial_state(img.shape[0]))
+            i = 0 if img.shape[0] == 1 else 2
+            res.append(({h: pd[h][i].clone() for h in ("buttons", "camera")}, v[i].clone(), [(k[i].clone(), vv[i].clone()) for _, (k, vv) in st]))
+    finally:
+        eng.cnn_chunk = saved
+    torch.cuda.synchronize()
+    for pd_x, v_x, st_x in res[1:]:
+        for h in ("buttons", "camera"):
+            assert torch.equal(res[0][0][h], pd_x[h]), (h, float((res[0][0][h] - pd_x[h]).abs().max()))
+        assert torch.equal(res[0][1], v_x)
+        for (k1, v1), (k2, v2) in zip(res[0][2], st_x):
+            assert torch.equal(k1, k2) and torch.equal(v1, v2)
+
+
 def test_policy_full_chunk_t128(pol_1x):
     """One full training-size chunk (T = 128, B = 2) against the oracle: all four query tiles of the band, the
     memory fully replaced by the chunk, then a T = 1 step on the carried state (the run_agent.py shape)."""
@@ -262,6 +292,59 @@ def test_step_graph_matches_eager(pol_1x):
         pol.auto_step_graph(True)
         with torch.no_grad():
             pol.pi_head.buttons.linear_layer.bias[:200].sub_(2.0)
+
+
+def test_auto_captured_step_returns_fresh_state_two_environments_share_one_policy(pol_1x):
+    """act() captures the acting step BY ITSELF, so the graphed step must keep the reference's contract -- a fresh state_out
+    every step (lib/policy.py:307-328).  Two environments that share one policy object and alternate B = 1 act() calls, and a caller that keeps
+    an older state for rollback, must get what the eager path gives them.  (The explicit enable_step_graph() keeps its documented aliasing.)
+    Also: a value-normaliser update after the capture re-captures (the (scale, shift) pair is a captured launch argument)."""
+    pol, cfg, sd = pol_1x
+    n = 6
+    fa, fb = _inputs(91, n, 1).to(DEV), _inputs(92, n, 1).to(DEV)
+    first = torch.zeros(1, dtype=torch.bool, device=DEV)
+
+    def run():
+        sa, sb, outs, keep = pol.initial_state(1), pol.initial_state(1), [], None
+        for i in range(n):
+            aa, sa, ra = pol.act({"img": fa[i]}, first, sa, stochastic=False, return_pd=True)
+            ab, sb, rb = pol.act({"img": fb[i]}, first, sb, stochastic=False, return_pd=True)
+            if i == 2:
+                keep = sa                                  # a snapshot the caller holds on to (no clone: the reference returns fresh tensors)
+            outs.append((ra["pd"]["buttons"].clone(), rb["pd"]["buttons"].clone(), float(ra["vpred"]), float(rb["vpred"])))
+        # roll environment A back to the state after step 2 and replay step 3
+        a3, _, r3 = pol.act({"img": fa[3]}, first, keep, stochastic=False, return_pd=True)
+        torch.cuda.synchronize()
+        return outs, r3["pd"]["buttons"].clone()
+
+    pol.disable_step_graph()
+    eager, eager_rb = run()
+    pol.auto_step_graph(True)
+    try:
+        auto, auto_rb = run()
+        assert pol._step_graph is not None and pol._step_graph["alias"] is False and "deterministic" in pol._step_graph["graphs"]
+        for i, (e, a) in enumerate(zip(eager, auto)):
+            assert torch.allclose(e[0], a[0], atol=2e-4) and torch.allclose(e[1], a[1], atol=2e-4), i
+            assert abs(e[2] - a[2]) < 1e-3 * max(1.0, abs(e[2])) and abs(e[3] - a[3]) < 1e-3 * max(1.0, abs(e[3]))
+        assert torch.allclose(eager_rb, auto_rb, atol=2e-4)
+        assert torch.allclose(auto_rb, auto[3][0], atol=1e-6)          # the rollback reproduces step 3 of environment A
+        assert not torch.allclose(auto[3][0], auto[3][1], atol=1e-3)   # (the two environments do see different things)
+        # normaliser update -> vpred follows (re-capture), as the eager path does
+        st = pol.initial_state(1)
+        _, st, r0 = pol.act({"img": fa[0]}, first, st, stochastic=False)
+        with torch.no_grad():
+            pol.value_head.normalizer.running_mean.add_(3.0 * pol.value_head.normalizer.debiasing_term)
+        _, _, r1 = pol.act({"img": fa[0]}, first, pol.initial_state(1), stochastic=False)
+        assert pol._step_graph is not None and "deterministic" in pol._step_graph["graphs"]      # (still a graphed step)
+        pol.disable_step_graph()
+        _, _, r1e = pol.act({"img": fa[0]}, first, pol.initial_state(1), stochastic=False)
+        assert abs(float(r1["vpred"]) - float(r1e["vpred"])) < 1e-3 * max(1.0, abs(float(r1e["vpred"]))), (float(r1["vpred"]), float(r1e["vpred"]))
+        assert abs(float(r1["vpred"]) - float(r0["vpred"])) > 0.5, (float(r0["vpred"]), float(r1["vpred"]))
+    finally:
+        with torch.no_grad():
+            pol.value_head.normalizer.running_mean.sub_(3.0 * pol.value_head.normalizer.debiasing_term)
+        pol.disable_step_graph()
+        pol.auto_step_graph(True)
 
 
 @pytest.mark.parametrize("b,ts,firsts", [

@@ -116,3 +116,55 @@ def test_act_stochastic_is_captured_automatically_and_matches_the_eager_draws(mo
     acd, _, resd = pol.act({"img": frames[1]}, first, st, stochastic=False, return_pd=True)
     assert "deterministic" in pol._step_graph["graphs"]
     assert torch.equal(acd["buttons"], resd["pd"]["buttons"].argmax(-1))
+
+
+def test_torch_manual_seed_at_any_time_restarts_the_draws():
+    """the reference's th.rand_like (lib/action_head.py:200) is made reproducible by torch.manual_seed() at ANY time -- seed, run an
+    episode, re-seed, run again.  The in-kernel sampler follows the device generator: a re-seed (even with the same value) since the last
+    stochastic call re-derives {seed, step = 0} in place, eagerly and under the auto-captured graph; seed_sampler() detaches it from torch's
+    generator; set_precision() keeps the sampler; seeds >= 2^63 are masked instead of overflowing."""
+    pk = O.policy_kwargs_for("1x")
+    cfg = O.config_from_policy_kwargs(pk, dict(temperature=2.0))
+    pol = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0), precision="fp16")
+    pol.load_state_dict(O.synthetic_state_dict(cfg, seed=0), strict=False)
+    pol = pol.to(DEV)
+    n = 6
+    frames = torch.randint(0, 256, (n, 1, 128, 128, 3), generator=torch.Generator().manual_seed(6), dtype=torch.uint8).to(DEV)
+    first = torch.zeros(1, dtype=torch.bool, device=DEV)
+
+    def episode():
+        st, outs = pol.initial_state(1), []
+        for i in range(n):
+            ac, st, _ = pol.act({"img": frames[i]}, first, st, stochastic=True)
+            outs.append((int(ac["buttons"]), int(ac["camera"])))
+        return outs
+
+    # a deterministic capture must not create (or consume anything for) the sampler
+    st = pol.initial_state(1)
+    for i in range(4):
+        _, st, _ = pol.act({"img": frames[i]}, first, st, stochastic=False)
+    assert pol._step_graph is not None and pol._engine._rng_state is None
+    torch.manual_seed(1234)
+    a = episode()                      # (calls 1-2 eager, then the captured stochastic step)
+    b = episode()                      # no re-seed: the draws go on
+    torch.manual_seed(1234)
+    c = episode()                      # re-seeded with the SAME value between two graphed steps: the episode repeats
+    torch.manual_seed(99)
+    d = episode()
+    assert a == c and a != b and a != d, (a, b, c, d)
+    pol.disable_step_graph()
+    torch.manual_seed(1234)
+    e = episode()                      # eager launches draw what the graph drew
+    assert e == a
+    pol.seed_sampler(2 ** 63 + 5)      # masked to 63 bits, and from here on independent of torch's generator
+    f = episode()
+    torch.manual_seed(1234)
+    pol.seed_sampler(2 ** 63 + 5)
+    g = episode()
+    assert f == g and f != a
+    pol.seed_sampler(7)
+    h = episode()
+    pol.seed_sampler(7)
+    pol.set_precision("bf16")          # a new engine: seed and step counter carry over
+    assert pol._engine._rng_state is not None and int(pol._engine._rng_state[0]) == 7
+    pol.auto_step_graph(True)

@@ -159,24 +159,54 @@ class PolicyEngine:
         self.fold_dense = os.environ.get("VPT_FOLD_DENSE", "1") != "0"                 # dense.norm (LayerNorm 65536) folded into the dense GEMM
         self._streams = []
         self._attn_done = None      # arrival counters of the in-place acting step (ops.masked_attention_step)
-        self._rng_state = None      # in-kernel sampler state {seed, step} (ops.new_rng_state), created on first stochastic use
+        self._rng_state = None      # in-kernel sampler state {seed, step}, created on first stochastic use (rng_state)
+        self._rng_src, self._pending_seed = None, None
         self.w: Dict[str, torch.Tensor] = {}
         self.packed = False
 
+    _RNG_MARK = 8        # how far the engine advances torch's CUDA generator offset when it derives a seed from it (see rng_state)
+
     def rng_state(self, device):
-        """The device-resident {seed, step} the stochastic heads draw from.  One per engine: a captured acting step holds its address."""
+        """The device-resident {seed, step} the stochastic heads draw from.  One per engine: a captured acting step holds its address.
+        Seeding follows torch's generator the way the reference's th.rand_like does (lib/action_head.py:200): unless seed() was called, the
+        sampler's seed is DERIVED from the device generator's (seed, offset), and the engine leaves a mark on that generator (its offset
+        advanced by _RNG_MARK).  A later torch.manual_seed() -- even with the same seed -- resets the offset, the mark is gone, and the next
+        stochastic call re-derives {seed, step = 0} in place: "seed, run an episode, re-seed, run again" reproduces the draws."""
         cur = self._rng_state
         if cur is None or cur.device.type != device.type or (device.index is not None and cur.device.index != device.index):
-            self._rng_state = ops.new_rng_state(device, seed=getattr(self, "_pending_seed", None))
+            pending = getattr(self, "_pending_seed", None)
+            self._rng_state = torch.zeros(2, dtype=torch.int64, device=device)
+            self._rng_src = None
+            if pending is not None:
+                self._rng_state.copy_(torch.tensor([pending, 0], dtype=torch.int64))
+                self._rng_src = "explicit"
             self._pending_seed = None
+        if self._rng_src != "explicit" and not torch.cuda.is_current_stream_capturing():
+            gen = torch.cuda.default_generators[self._rng_state.device.index]
+            here = (int(gen.initial_seed()), int(gen.get_offset()))
+            if self._rng_src != here:
+                # splitmix-style mix of (seed, offset), masked to 63 bits (the state is int64)
+                z = (here[0] * 0x9E3779B97F4A7C15 + here[1] * 0xBF58476D1CE4E5B9 + 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+                z ^= z >> 31
+                self._rng_state.copy_(torch.tensor([z & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64))
+                gen.set_offset(here[1] + self._RNG_MARK)
+                self._rng_src = (here[0], here[1] + self._RNG_MARK)
         return self._rng_state
 
     def seed(self, seed: int):
-        """Re-seed the sampler in place (the captured graph keeps reading the same buffer) and restart its step counter."""
+        """Re-seed the sampler in place (the captured graph keeps reading the same buffer) and restart its step counter; from here on the
+        sampler no longer follows torch's generator."""
+        seed = int(seed) & 0x7FFFFFFFFFFFFFFF
         if self._rng_state is not None:
-            self._rng_state.copy_(torch.tensor([int(seed), 0], dtype=torch.int64))
+            self._rng_state.copy_(torch.tensor([seed, 0], dtype=torch.int64))
+            self._rng_src = "explicit"
         else:
-            self._pending_seed = int(seed)
+            self._pending_seed = seed
+
+    def adopt_sampler(self, other: "PolicyEngine"):
+        """Take over another engine's sampler state (set_precision() builds a new engine: the seed and the step counter carry over)."""
+        self._rng_state, self._rng_src = other._rng_state, getattr(other, "_rng_src", None)
+        self._pending_seed = getattr(other, "_pending_seed", None)
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -523,8 +553,11 @@ class IDMEngine(PolicyEngine):
         self.fold_n = os.environ.get("VPT_FOLD_N", "1") != "0"
         self.fold_stats_in_producer = os.environ.get("VPT_FOLD_STATS", "1") != "0"
         self.fold_dense = os.environ.get("VPT_FOLD_DENSE", "1") != "0"
+        # split-K of the trunk linears, named here (a function of the layer's (N, K) only, ops.nk_splitk) -- never chosen from the row count
+        self.linear_splitk = "nk"
         self._streams = []
         self._rng_state = None
+        self._rng_src, self._pending_seed = None, None
         self.w = {}
         self.packed = False
 
@@ -584,6 +617,7 @@ class IDMEngine(PolicyEngine):
         if t > 160:
             raise NotImplementedError("the mask='none' attention kernel handles chunks of at most 160 frames")
         hid, heads = cfg["hidsize"], cfg["heads"]
+        sk = self.linear_splitk      # "nk": K cut as a function of the layer alone (one <= 160-frame window = one row tile of the MFMA GEMM)
         frames = img_u8.reshape(bsz * t, *img_u8.shape[2:]).contiguous()
         # temporal conv needs whole sequences; the CNN behind it runs in frame chunks to bound the 4 MB/frame tensor
         wfrag, bias = w["conv3d"]
@@ -598,18 +632,18 @@ class IDMEngine(PolicyEngine):
         d = outs[0] if len(outs) == 1 else torch.cat(outs, 0)
         p = "net.img_process.linear."
         _, dn = ops.layernorm(d, w[p + "g"], w[p + "b"], relu_in=True, dtype=self.dtype)
-        x, _ = ops.linear(dn, w[p + "w"], hid, relu=True, tiling="throughput")
+        x, _ = ops.linear(dn, w[p + "w"], hid, relu=True, tiling="throughput", splitk=sk)
         if cfg["use_pre_lstm_ln"]:
             x, _ = ops.layernorm(x, w["prelstm.g"], w["prelstm.b"], out_f32=True, out_bf16=False, dtype=self.dtype)
         for l in range(cfg["n_layers"]):
             p = f"net.recurrent_layer.blocks.{l}."
             x1, x1b = ops.layernorm(x, w[p + "ln1.g"], w[p + "ln1.b"], out_f32=True, dtype=self.dtype)
-            qkv, _ = ops.linear(x1b, w[p + "qkv.w"], 3 * hid, bias=w[p + "qkv.b"], tiling="throughput")
+            qkv, _ = ops.linear(x1b, w[p + "qkv.w"], 3 * hid, bias=w[p + "qkv.b"], tiling="throughput", splitk=sk)
             att = ops.full_attention(qkv, bsz, t, heads, hid, dtype=self.dtype)
-            x2, _ = ops.linear(att, w[p + "proj.w"], hid, bias=w[p + "proj.b"], res=x1, tiling="throughput")
+            x2, _ = ops.linear(att, w[p + "proj.w"], hid, bias=w[p + "proj.b"], res=x1, tiling="throughput", splitk=sk)
             _, hb = ops.layernorm(x2, w[p + "ln2.g"], w[p + "ln2.b"], dtype=self.dtype)
-            _, h2 = ops.linear(hb, w[p + "mlp0.w"], hid * cfg["pointwise_ratio"], relu=True, out_f32=False, out_bf16=True, tiling="throughput")
-            x, _ = ops.linear(h2, w[p + "mlp1.w"], hid, bias=w[p + "mlp1.b"], res=x2, tiling="throughput")
+            _, h2 = ops.linear(hb, w[p + "mlp0.w"], hid * cfg["pointwise_ratio"], relu=True, out_f32=False, out_bf16=True, tiling="throughput", splitk=sk)
+            x, _ = ops.linear(h2, w[p + "mlp1.w"], hid, bias=w[p + "mlp1.b"], res=x2, tiling="throughput", splitk=sk)
         latent, lb = ops.layernorm(x, w["final.g"], w["final.b"], relu_in=True, out_f32=True, dtype=self.dtype)
         out = {}
         temp = cfg["temperature"]
@@ -617,7 +651,7 @@ class IDMEngine(PolicyEngine):
         rng = self.rng_state(x.device) if sample == "stochastic" else None
         for h, shape in (("buttons", self.button_shape), ("camera", self.camera_shape)):
             n_groups, n = shape
-            z, _ = ops.linear(lb, w[h + ".w"], n_groups * n, bias=w[h + ".b"], tiling="throughput")
+            z, _ = ops.linear(lb, w[h + ".w"], n_groups * n, bias=w[h + ".b"], tiling="throughput", splitk=sk)
             r = action_heads(z, ((h, 0, n_groups, n),), bsz, t, temp, mask, sample, rng_state=rng)
             out[h] = r[h]
             if sample is not None:

@@ -207,7 +207,14 @@ class _PolicyForwardFn(torch.autograd.Function):
                 # over M frames arrives as 1 / M per element).  Power of two, so un-scaling the fp32 results below is exact.
                 # `autograd_lift` (256 to start with) is where the largest incoming element is placed; an overflow halves it.
                 gmax = max([float(x.abs().max()) for x in (gb, gc, gv) if x is not None and x.numel()] or [0.0])
-                if gmax > 0.0 and math.isfinite(gmax):
+                if not math.isfinite(gmax):
+                    # the INCOMING gradient is inf / nan (the caller's loss, not our lift): no gradient from this backward, counted, and
+                    # the lift stays where it is -- halving it would not have helped
+                    import warnings
+                    eng.autograd_overflows += 1
+                    warnings.warn("fp16 backward received a non-finite gradient: this backward returns no gradients", RuntimeWarning)
+                    return (None,) * (7 + len(ctx.names))
+                if gmax > 0.0:
                     scale = 2.0 ** math.floor(math.log2(eng.autograd_lift / gmax))
             dz = ops.heads_logprob_backward(S["lp_b"], S["lp_c"], gb, gc, gv, S["ldz"], eng.engine.cfg["temperature"],
                                             mask_buttons=S["mask"]["buttons"], mask_camera=S["mask"]["camera"], dtype=eng.dtype, grad_scale=scale)
@@ -260,12 +267,21 @@ class MinecraftAgentPolicy(nn.Module):
         """Switch the operand format ("bf16" / "fp16"); weights are re-packed on the next forward."""
         if precision != self._engine.precision:
             self._grad_engines = {}
-            self._engine = PolicyEngine(self._cfg, n_buttons=self._engine.n_buttons, n_camera=self._engine.n_camera,
-                                        precision=precision)
+            old = self._engine
+            self._engine = PolicyEngine(self._cfg, n_buttons=old.n_buttons, n_camera=old.n_camera, precision=precision)
+            self._engine.adopt_sampler(old)         # seed_sampler() / the step counter survive a change of operand format
             self._packed_key = None
             if self._step_graph is not None:
-                self._step_graph = dict(batch=self._step_graph["batch"])      # (static buffers and graphs are rebuilt lazily)
+                self._step_graph = self._fresh_step_graph(self._step_graph)      # (static buffers and graphs are rebuilt lazily)
         return self
+
+    @property
+    def grad_overflows(self) -> int:
+        """How many backward passes through this policy returned NO gradients because an IEEE-half buffer overflowed (fp16 mode) or the
+        incoming gradient was non-finite.  A gradient-accumulation loop (the reference's 8 x backward then optimizer.step(),
+        behavioural_cloning.py:107-122) reads it before and after its backwards and skips optimizer.step() when it moved -- what
+        torch.cuda.amp.GradScaler.step does.  Always 0 in bf16."""
+        return sum(e.autograd_overflows for e in self._grad_engines.values())
 
     # ---- engine plumbing --------------------------------------------------------------------
     def _apply(self, fn, *args, **kwargs):      # .to() / .cuda() / .half(): parameters may be re-created
@@ -295,7 +311,7 @@ class MinecraftAgentPolicy(nn.Module):
             self._engine.pack(dict(named))
             self._packed_key = key
             if self._step_graph is not None:      # the graph holds the old packed weights' addresses: re-capture lazily
-                self._step_graph = dict(batch=self._step_graph["batch"])
+                self._step_graph = self._fresh_step_graph(self._step_graph)
 
     # ---- T = 1 acting path: one hipGraph replay per environment step ---------------------------
     # The reference's entry point is MineRLAgent.get_action -> policy.act(agent_input, first, hidden_state, stochastic=True)
@@ -304,15 +320,23 @@ class MinecraftAgentPolicy(nn.Module):
     # inside the graph (the heads draw their uniforms in the kernel from a device-resident {seed, step}, engine.rng_state).
     AUTO_GRAPH_AFTER = 2     # consecutive same-shape act() calls that run eagerly before the step is captured
 
-    def enable_step_graph(self, batch_size: int = 1):
+    @staticmethod
+    def _fresh_step_graph(old: dict) -> dict:
+        return dict(batch=old["batch"], alias=old.get("alias", False))
+
+    def enable_step_graph(self, batch_size: int = 1, alias_state: bool = True):
         """Capture the T = 1 forward for `batch_size` environments into a hipGraph at the next such call (the ~50 kernel launches of
         one agent step, agent.py:190-206, become one graph launch; one graph per sampling mode, captured on first use).  act() does
         this on its own after AUTO_GRAPH_AFTER same-shape calls; forward() / v() only after this explicit call.  The recurrent state
-        lives in static buffers that the graph updates in place: the `state_out` returned by a graphed step ALIASES them and is
-        overwritten by the next step (the acting loop only ever keeps the latest state, agent.py:201-205; clone it to keep a
-        snapshot).  Any other state_in (initial_state, a restored snapshot) is copied in.  Other (B, T) shapes keep using eager
-        launches."""
-        self._step_graph = dict(batch=int(batch_size))
+        lives in static buffers that the graph updates in place.
+        alias_state=True (this explicit call's default): the `state_out` of a graphed step ALIASES those buffers and is overwritten by
+        the next step -- right for a single acting loop that only ever keeps the latest state (agent.py:201-205), WRONG for two
+        environments sharing one policy object or for a caller that keeps an earlier state for rollback; clone to keep a snapshot.
+        alias_state=False (what act()'s AUTOMATIC capture uses): every step returns a fresh copy of the state, as the reference does
+        (one flat 8 MB copy per step on the 2x model); a state_in that is not the copy handed out by the latest step -- another
+        environment's, an older snapshot, initial_state() -- is copied into the static buffers first.
+        Other (B, T) shapes keep using eager launches."""
+        self._step_graph = dict(batch=int(batch_size), alias=bool(alias_state))
         self._auto_graph = dict(enabled=self._auto_graph["enabled"], batch=None, count=0)
 
     def disable_step_graph(self):
@@ -326,8 +350,9 @@ class MinecraftAgentPolicy(nn.Module):
         self._auto_graph = dict(enabled=bool(enabled), batch=None, count=0)
 
     def seed_sampler(self, seed: int):
-        """Re-seed the in-kernel generator behind act(stochastic=True) / predict(deterministic=False) (default: a seed drawn from
-        torch's generator when first needed, so torch.manual_seed() already makes runs repeatable)."""
+        """Re-seed the in-kernel generator behind act(stochastic=True) / predict(deterministic=False).  Default: the sampler follows the
+        device's torch generator -- torch.manual_seed() at ANY time restarts the draws reproducibly, as it does for the reference's
+        th.rand_like (engine.PolicyEngine.rng_state)."""
         self._engine.seed(seed)
 
     def _auto_graph_tick(self, batch: int):
@@ -342,7 +367,23 @@ class MinecraftAgentPolicy(nn.Module):
         else:
             ag["batch"], ag["count"] = batch, 1
         if ag["count"] > self.AUTO_GRAPH_AFTER:
-            self._step_graph = dict(batch=batch)
+            # nobody asked for aliasing: the automatically captured step hands out COPIES of the recurrent state (reference semantics)
+            self._step_graph = dict(batch=batch, alias=False)
+
+    def _state_views(self, flat: torch.Tensor, b: int):
+        """The recurrent state [(mask, (K, V))] x n_layers as views of ONE flat byte buffer (K / V fp32 first, the bool masks behind
+        them): a snapshot of the whole state is one copy kernel."""
+        cfg = self._cfg
+        kv, mk = b * cfg["maxlen"] * cfg["hidsize"] * 4, b * cfg["maxlen"]
+        state, off, moff = [], 0, 2 * cfg["n_layers"] * kv
+        for _ in range(cfg["n_layers"]):
+            k = flat[off:off + kv].view(torch.float32).view(b, cfg["maxlen"], cfg["hidsize"])
+            v = flat[off + kv:off + 2 * kv].view(torch.float32).view(b, cfg["maxlen"], cfg["hidsize"])
+            m = flat[moff:moff + mk].view(torch.bool).view(b, 1, cfg["maxlen"])
+            state.append((m, (k, v)))
+            off += 2 * kv
+            moff += mk
+        return state
 
     def _static_step_buffers(self):
         sg, dev, cfg = self._step_graph, self._device(), self._cfg
@@ -350,10 +391,10 @@ class MinecraftAgentPolicy(nn.Module):
             b = sg["batch"]
             sg["img"] = torch.zeros(b, 1, *cfg["img_shape"], dtype=torch.uint8, device=dev)
             sg["first"] = torch.zeros(b, 1, dtype=torch.bool, device=dev)
-            sg["state"] = [(torch.zeros(b, 1, cfg["maxlen"], dtype=torch.bool, device=dev),
-                            (torch.zeros(b, cfg["maxlen"], cfg["hidsize"], dtype=torch.float32, device=dev),
-                             torch.zeros(b, cfg["maxlen"], cfg["hidsize"], dtype=torch.float32, device=dev)))
-                           for _ in range(cfg["n_layers"])]
+            nbytes = cfg["n_layers"] * (2 * b * cfg["maxlen"] * cfg["hidsize"] * 4 + b * cfg["maxlen"])
+            sg["flat"] = torch.zeros((nbytes + 15) // 16 * 16, dtype=torch.uint8, device=dev)
+            sg["state"] = self._state_views(sg["flat"], b)
+            sg["last_copy"] = None      # (alias=False) the flat copy handed out by the latest step, and its version counter
             sg["graphs"] = {}
         return sg
 
@@ -367,8 +408,8 @@ class MinecraftAgentPolicy(nn.Module):
         # the static state may hold a LIVE episode (the other mode's graph, or the eager steps before an automatic capture, copied in by
         # _graphed_forward): the warm-up and the capture itself execute nothing / must change nothing the caller can see
         snap = [(m.clone(), (k.clone(), v.clone())) for m, (k, v) in sg["state"]]
-        rng = eng.rng_state(self._device())
-        rng_snap = rng.clone()
+        rng = eng.rng_state(self._device()) if mode == "stochastic" else None      # (a deterministic capture neither creates nor touches the sampler)
+        rng_snap = rng.clone() if rng is not None else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):           # warm-up outside capture, with the captured call's exact arguments (lazy kernel loading, allocator
@@ -391,27 +432,46 @@ class MinecraftAgentPolicy(nn.Module):
                     k_in.copy_(k_out); v_in.copy_(v_out)
         for (m_in, (k_in, v_in)), (m_s, (k_s, v_s)) in zip(sg["state"], snap):    # the warm-up runs advanced the static state and the sampler
             m_in.copy_(m_s); k_in.copy_(k_s); v_in.copy_(v_s)
-        rng.copy_(rng_snap)
-        sg["graphs"][mode] = (graph, out)
+        if rng is not None:
+            rng.copy_(rng_snap)
+        sg["graphs"][mode] = (graph, out, (scale, shift))
 
     def _graphed_forward(self, img, first, state_in, mode: str):
         sg = self._static_step_buffers()
-        # the caller's state first (a capture below must see -- and preserve -- the live episode)
-        for (m_s, (k_s, v_s)), (m, (k, v)) in zip(sg["state"], state_in):
-            if k.data_ptr() != k_s.data_ptr():   # not the aliased state of the previous graphed step
+        # the caller's state first (a capture below must see -- and preserve -- the live episode).  It is already IN the static buffers
+        # only if it is (alias) the static state itself, or (copies) exactly the copy the latest step handed out, unmodified since.
+        last = sg["last_copy"]
+        live = False
+        if not sg["alias"] and last is not None:
+            k0 = state_in[0][1][0]
+            live = k0.data_ptr() == last[0].data_ptr() and last[0]._version == last[1] and len(state_in) == len(sg["state"])
+        if not live:
+            for (m_s, (k_s, v_s)), (m, (k, v)) in zip(sg["state"], state_in):
+                if sg["alias"] and k.data_ptr() == k_s.data_ptr():   # the aliased state of the previous graphed step
+                    continue
                 k_s.copy_(k); v_s.copy_(v)
                 if m is None:
                     m_s.zero_()
                 else:
                     m_s.copy_(m)
+        # the captured launch arguments include the value normaliser's (scale, shift): a normaliser update re-captures
+        if mode in sg["graphs"] and sg["graphs"][mode][2] != self.value_head.normalizer.affine():
+            del sg["graphs"][mode]
         if mode not in sg["graphs"]:
             self._capture_step_graph(mode)
+        if mode == "stochastic":
+            self._engine.rng_state(self._device())     # (host-side check only: a torch.manual_seed() since the last step re-derives the sampler's seed in place)
         sg["img"].copy_(img)
         sg["first"].copy_(first)
-        graph, gout = sg["graphs"][mode]
+        graph, gout, _ = sg["graphs"][mode]
         graph.replay()
         out = dict(gout)
-        out["state_out"] = sg["state"]
+        if sg["alias"]:
+            out["state_out"] = sg["state"]
+        else:       # reference semantics: a fresh state every step (ONE copy kernel over the flat buffer)
+            c = sg["flat"].clone()
+            out["state_out"] = self._state_views(c, sg["batch"])
+            sg["last_copy"] = (c, c._version)
         if "_keep" in out:       # handed to the caller: must survive the next replay (the other outputs are consumed at once)
             from ..engine import unpack_act_tail
             out.update(unpack_act_tail(out["_keep"].clone(), sg["batch"]))
@@ -570,7 +630,9 @@ class InverseActionPolicy(nn.Module):
 
     def set_precision(self, precision: str):
         if precision != self._engine.precision:
-            self._engine = IDMEngine(self._cfg, self._engine.button_shape, self._engine.camera_shape, precision=precision)
+            old = self._engine
+            self._engine = IDMEngine(self._cfg, old.button_shape, old.camera_shape, precision=precision)
+            self._engine.adopt_sampler(old)
             self._packed_key = None
         return self
 

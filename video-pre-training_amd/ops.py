@@ -302,26 +302,42 @@ _GEMM256 = os.environ.get("VPT_LINEAR_256", "0") == "1"      # A/B switch: "thro
 LINEAR_TILING = {"auto": 0, "throughput": 1, "latency": 2, "throughput256": 4}   # throughput256: vpt_gemm256_kernel where its grid fills the chip (measured neutral in the engine: not the default)
 
 
+def nk_splitk(n: int, k: int) -> int:
+    """The split-K factor of a mid-size-M linear as a function of the LAYER (N, K) alone: enough K slices that one row tile's N/128 column tiles
+    fill the chip.  Named by the caller (`splitk="nk"`: IDMEngine, whose workload is one <= 160-frame window), never derived from M."""
+    tiles = (n + 127) // 128
+    if k < 2048 or tiles >= 128:
+        return 1
+    return max(1, min(16, k // 512, 256 // tiles))
+
+
 def linear(a_bf16, wpk, n, bias=None, res=None, relu=False, out_f32=True, out_bf16=False, splitk=1, mask=None,
            out_bf16_ld=None, splitk_raw=False, tiling="auto"):
     """a [M,K] bf16 (row stride = K) x packed weight -> ([M,n] fp32 or None, [M,ld] bf16 or None).
     mask: optional bf16 [M, >=n] gate (output zeroed where mask <= 0).  out_bf16_ld: row stride of the bf16
     output (>= n, extra columns zero) so it can feed the next GEMM as an A operand with K padded to 64.
     tiling: "throughput" = the MFMA GEMM whatever M (the inference engine's batch path: a row's result must not depend on how many rows
-    share the call), "latency" = the weight-streaming kernel (M <= 8: the acting step), "auto" = by M (vpt_linear_forward)."""
+    share the call), "latency" = the weight-streaming kernel (M <= 8: the acting step), "auto" = by M (vpt_linear_forward).
+    splitk: an int (the caller's explicit factor: the dense layer), or "nk" = nk_splitk(n, k) finished by the epilogue kernel.  Under the
+    named tilings ("throughput", "latency") the summation order over K is a function of (tiling, splitk, N, K) ONLY -- never of M:
+    the M-based automatic split below applies to tiling="auto" alone (the BC step's small test shapes)."""
     _chk(a_bf16, OP16, "A"); _chk(wpk, OP16, "wpk"); _chk(bias, torch.float32, "bias")
     _chk(res, torch.float32, "res"); _chk(mask, OP16, "mask")
     m, k = a_bf16.shape
     dev = a_bf16.device
     dt, fmt = _fmt(a_bf16, wpk, mask)
     ld16 = (out_bf16_ld or n) if out_bf16 else n
-    # Mid-size M (e.g. one 128-frame IDM window): the 256 x 128 tiling alone gives N/128 workgroups for 256 CUs, so cut K
-    # as well and finish with the epilogue kernel (fixed summation order: deterministic).
     if tiling == "throughput" and _GEMM256:
         tiling = "throughput256"
     tl = LINEAR_TILING[tiling]
     auto_sk = 1
-    if splitk == 1 and (8 < m or tl in (1, 4)) and m <= 512 and k >= 2048 and tl != 2:
+    if splitk == "nk":
+        splitk = 1
+        if tl != 2:
+            auto_sk = nk_splitk(n, k)
+    elif splitk == 1 and tl == 0 and 8 < m <= 512 and k >= 2048:
+        # tiling "auto" only.  Mid-size M: the 256 x 128 tiling alone gives N/128 workgroups for 256 CUs, so cut K as well and finish
+        # with the epilogue kernel (fixed summation order: deterministic)
         tiles = ((m + 255) // 256) * ((n + 127) // 128)
         if tiles < 128:
             auto_sk = max(1, min(16, k // 512, 256 // tiles))
@@ -582,7 +598,9 @@ def grads_nonfinite(grads):
     """int32 [1] device flag: 1 if any element of the fp32 tensors in `grads` is inf / nan (vpt_grads_nonfinite_multi, one launch; what
     torch.cuda.amp.GradScaler.unscale_ computes).  No host synchronisation here: the caller reads the flag when it needs it."""
     import numpy as np
-    grads = [g for g in grads if g is not None and g.numel()]
+    grads = [g if g.is_contiguous() else g.contiguous() for g in grads if g is not None and g.numel()]
+    if not grads:
+        raise ValueError("grads_nonfinite: no gradient tensors to check")
     flag = torch.zeros(1, dtype=torch.int32, device=grads[0].device)
     rec = np.zeros(len(grads), dtype=[("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<u8"), ("fb", "<i8")])
     blk = 0

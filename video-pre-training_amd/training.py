@@ -98,6 +98,7 @@ class BCTrainer:
         # bookkeeping.  The streams are created ONCE per trainer and only ever appended to (never replaced): the activations a
         # forward_saving() left for a later backward stay tied to the stream object that produced them.
         self.cnn_streams = int(os.environ.get("VPT_BC_STREAMS", self.engine.cnn_streams))
+        self._arenas = None      # (key, (GradArena trunk + heads, GradArena CNN)) of the data-parallel step, built on first use
         self._streams: List[torch.cuda.Stream] = []
         self.params: Dict[str, torch.nn.Parameter] = dict(policy.named_parameters())
         self.trainable = [n for n in self.params if self._is_trainable(n)]
@@ -564,9 +565,10 @@ class BCTrainer:
         pending, state = [], dict(early_sent=False)
         # the gradients live in two flat fp32 arenas that persist across steps (distributed.GradArena): each tensor is copied in once when it
         # is final, the collectives run in place on 64 MB slices of the arena, the optimiser reads the views -- no cat, no copy back
-        if getattr(self, "_arenas", None) is None:
-            self._arenas = tuple(D.GradArena(ns, [self.params[n].shape for n in ns], dev) for ns in (early, late))
-        arena_early, arena_late = self._arenas
+        akey = (tuple(early), tuple(late), tuple(tuple(self.params[n].shape) for n in early + late), str(dev))
+        if self._arenas is None or self._arenas[0] != akey:      # rebuilt when the trainable set, a shape or the device changes
+            self._arenas = (akey, tuple(D.GradArena(ns, [self.params[n].shape for n in ns], dev) for ns in (early, late)))
+        arena_early, arena_late = self._arenas[1]
 
         def start_trunk_exchange(g):
             arena_early.adopt(g)
