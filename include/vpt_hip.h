@@ -356,6 +356,19 @@ int vpt_conv_backward_prepare(const void* dy, const void* dpooled, const uint8_t
 int vpt_conv3x3_dgrad(const void* dacc, const void* wpk_t, const void* skip, const void* xin, const float* coef, void* dx,
                       int frames, int H, int W, int Cout, int Cin, void* stream);
 
+/* Round 5: a block's conv1 -> conv0 backward without the per-element pass in between (lib/impala_cnn.py:50-52 under
+ * behavioural_cloning.py:117-119).  vpt_conv3x3_dgrad_gated is vpt_conv3x3_dgrad (no skip) whose epilogue applies the NEXT layer-to-
+ * differentiate's ReLU gate and statistic scale: xin is conv0's output y (conv1's input), conv0 has no residual, so
+ *     dacc_out = rstd_g[f] * (conv^T(W', dacc) + c0 + c1 xin) * [xin > 0]
+ * IS conv0's backward operand (what vpt_conv_backward_prepare(dy, y, res = NULL) would have written), rstd_g from gate_stats = the frame
+ * statistics of conv0's INPUT over gate_cin * H * W elements; gate_u[f] += rstd_g * sum dy * xin (accumulated: caller zeroes).
+ * vpt_conv_backward_reduce then produces what prepare produces besides dacc -- t12, coef, d_sa / d_sg -- from dacc_out and gate_u alone
+ * (one read of one tensor instead of two reads and a write).  scratch as for vpt_conv_backward_prepare. */
+int vpt_conv3x3_dgrad_gated(const void* dacc, const void* wpk_t, const void* xin, const float* coef, const double* gate_stats, int gate_cin,
+                            void* dacc_out, double* gate_u, int frames, int H, int W, int Cout, int Cin, void* stream);
+int vpt_conv_backward_reduce(const void* dacc, const double* gate_u, const double* stats_in, const float* edge_sa, const float* edge_sg,
+                             double* t12, float* coef, float* d_sa, float* d_sg, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream);
+
 /* Backward of vpt_conv_first_forward w.r.t. its weight and bias (the input is the uint8 image): recomputes the pre-pool
  * tile, routes dpooled to the arg-max conv pixel of every pooling window and accumulates dw[Cout][27] (kh, kw, ch order)
  * and db[Cout] (fp32 atomics; caller zeroes). */

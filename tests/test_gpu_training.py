@@ -319,6 +319,52 @@ def test_conv_layer_backward_dx_and_bias(frames, h, cin, cout, use_res):
     assert _l2(dbeta, gb) < 1e-1
 
 
+@pytest.mark.parametrize("fmt", ["bf16", "fp16"])
+@pytest.mark.parametrize("frames,h,c", [(3, 16, 64), (2, 32, 128), (2, 64, 32), (1, 16, 160)])
+def test_block_backward_gated_dgrad_equals_the_two_step_path(frames, h, c, fmt):
+    """Round 5: conv1's dgrad writes conv0's backward operand directly (vpt_conv3x3_dgrad_gated = vpt_conv3x3_kernel mode 6) and
+    vpt_conv_backward_reduce replaces conv0's per-element prepare pass.  On IDENTICAL inputs -- a CnnBasicBlock x + conv1(conv0(x)),
+    lib/impala_cnn.py:50-52 -- the pair must reproduce what dgrad -> prepare gave: the operand dacc0 (the same values up to ONE 16-bit
+    rounding: the old path rounds dy, then rstd * dy; the new one rounds once), the coefficients (c0, c1), T1 / T2 and the edge-table sums,
+    and the block's input gradient."""
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[fmt]
+    g = torch.Generator().manual_seed(131 + h + c)
+    mk = lambda: ((torch.randn(c, c, 3, 3, generator=g) * (1.6 / (c * 9) ** 0.5)).to(DEV), (1 + 0.2 * torch.randn(c, generator=g)).to(DEV), (0.1 * torch.randn(c, generator=g)).to(DEV))
+    (W0, g0, b0), (W1, g1, b1) = mk(), mk()
+    x = (torch.relu(torch.randn(frames, c, h, h, generator=g)) + 0.2 * torch.randn(frames, c, h, h, generator=g)).to(dt).float()
+    dout = (torch.randn(frames, c, h, h, generator=g) * (1e-2 if fmt == "fp16" else 1.0)).to(dt).float()
+    wpk0, sa0, sg0 = packing.pack_conv3x3(W0, g0, b0, dtype=dt)
+    wpk1, sa1, sg1 = packing.pack_conv3x3(W1, g1, b1, dtype=dt)
+    xb = packing.nchw_to_blocked(x, dtype=dt).to(DEV)
+    st_x = _stats_of(x).to(DEV)
+    st_y = torch.zeros(frames, 2, dtype=torch.float64, device=DEV)
+    yb = ops.conv3x3(xb, wpk0, sa0, sg0, st_x, c, stats_out=st_y)
+    ob = ops.conv3x3(yb, wpk1, sa1, sg1, st_y, c, res=xb)
+    doutb = packing.nchw_to_blocked(dout, dtype=dt).to(DEV)
+    wt0, wt1 = packing.pack_conv3x3_dgrad(W0, g0, dtype=dt), packing.pack_conv3x3_dgrad(W1, g1, dtype=dt)
+    # conv1 (residual layer): common to both paths
+    dacc1, coef1, _, _ = ops.conv_backward_prepare(doutb, ob, xb, st_y, sa1, sg1, c)
+    # two-step: plain dgrad, then conv0's prepare
+    dy = ops.conv3x3_dgrad(dacc1, wt1, c, xin=yb, coef=coef1)
+    dacc0_ref, coef0_ref, dsa_ref, dsg_ref, t12_ref = ops.conv_backward_prepare(dy, yb, None, st_x, sa0, sg0, c, want_t12=True)
+    dx_ref = ops.conv3x3_dgrad(dacc0_ref, wt0, c, skip=doutb, xin=xb, coef=coef0_ref)
+    # fused: gated dgrad, then the reduction
+    dacc0, gate_u = ops.conv3x3_dgrad_gated(dacc1, wt1, c, yb, coef1, st_x, c)
+    coef0, dsa, dsg, t12 = ops.conv_backward_reduce(dacc0, gate_u, st_x, sa0, sg0, c, want_t12=True)
+    dx = ops.conv3x3_dgrad(dacc0, wt0, c, skip=doutb, xin=xb, coef=coef0)
+    torch.cuda.synchronize()
+    eps = 2.0 ** -8 if fmt == "bf16" else 2.0 ** -11
+    a, r = dacc0.float(), dacc0_ref.float()
+    assert torch.equal(a == 0, r == 0) or float(((a == 0) != (r == 0)).float().mean()) < 1e-4     # same gates (a value may round to 0 on one side only)
+    atol = 2e-7 if fmt == "fp16" else 1e-30          # (IEEE half: values below 6e-5 are subnormal, their step is 6e-8)
+    assert float(((a - r).abs() <= 3.5 * eps * r.abs() + atol).float().mean()) > 0.999, float((a - r).abs().max())
+    e = dict(dacc=_l2(a, r), t12=_l2(t12, t12_ref), coef=_l2(coef0, coef0_ref), dsa=_l2(dsa, dsa_ref), dsg=_l2(dsg, dsg_ref), dx=_l2(dx.float(), dx_ref.float()))
+    print(f"PARITY gated dgrad vs dgrad + prepare [{fmt}] {frames}x{c}x{h}x{h}: " + " ".join(f"{k} {v:.2e}" for k, v in e.items()))
+    tol = 4 * eps
+    assert e["dacc"] < tol and e["dx"] < 2 * tol, e
+    assert e["t12"] < 4 * tol and e["coef"] < 4 * tol and e["dsa"] < 4 * tol and e["dsg"] < 4 * tol, e
+
+
 @pytest.mark.parametrize("frames,h,cin,cout", [(3, 16, 64, 96), (2, 32, 32, 128), (1, 64, 64, 32)])
 def test_conv_wgrad_kernel(frames, h, cin, cout):
     g = torch.Generator().manual_seed(14)

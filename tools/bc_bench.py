@@ -14,6 +14,7 @@ from vpt_amd import configs
 ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="2x"); ap.add_argument("--batch", type=int, default=64); ap.add_argument("--seq", type=int, default=128)
 ap.add_argument("--steps", type=int, default=2); ap.add_argument("--no-cnn", action="store_true")
+ap.add_argument("--streams1", action="store_true", help="the instrumented step on ONE stream (per-kernel durations without cross-stream overlap, as bench.py reports them)")
 a = ap.parse_args()
 dev = "cuda"
 pk = configs.policy_kwargs_for(a.model)
@@ -34,6 +35,8 @@ for _ in range(a.steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
 print(f"BC step {dt*1e3:.1f} ms  ({B*T/dt:.0f} frames/s)  loss {loss:.4f}")
+if a.streams1:
+    tr.cnn_streams = 1
 ops.TIMER.enabled = True; ops.TIMER.reset()
 t0 = time.perf_counter()
 tr.step(img, first, st, ab, ac)

@@ -49,6 +49,8 @@ SIGNATURES = {
     "vpt_uniform_noise": [_P, ctypes.c_uint32, _P, _I, _I, _P],
     "vpt_conv_backward_prepare": [_P] * 14 + [_I, _I, _I, _I, _I, _P],
     "vpt_conv3x3_dgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vpt_conv3x3_dgrad_gated": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vpt_conv_backward_reduce": [_P] * 10 + [_I, _I, _I, _I, _I, _P],
     "vpt_conv_first_backward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_conv3x3_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_conv3x3_wgrad_scratch_floats": [_I, _I, _I],
@@ -102,8 +104,16 @@ def load(fmt: str = "bf16"):
         abi = None
     if abi != ABI_VERSION:      # a stale .so would take a stream handle for a flag pointer, etc.: refuse before the first call
         raise NativeLibraryError(f"{path} has C-ABI version {abi}, this package binds version {ABI_VERSION}: rebuild it (`python __graft_entry__.py`)")
+    override = fmt == "bf16" and bool(os.environ.get("VPT_HIP_LIB"))
     for name, argtypes in SIGNATURES.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            # only an A/B reference build named by VPT_HIP_LIB (tools/build_ref_lib.sh: an OLDER revision of the same ABI) may lack entry points
+            # added since -- calling one raises below; the in-tree library must export every symbol
+            if override:
+                continue
+            raise NativeLibraryError(f"{path} does not export {name}: rebuild it (`python __graft_entry__.py`)")
         fn.argtypes = argtypes
         fn.restype = _I
     lib.vpt_version.restype = ctypes.c_char_p

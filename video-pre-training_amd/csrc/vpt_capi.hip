@@ -95,6 +95,7 @@ int vpt_conv3x3_forward_tiled(const void* x, const void* wpk, const float* edge_
   if (!stats_in) return fail(-1, "vpt_conv3x3_forward: stats_in is required");
   if (tiling < 1 || tiling > 3) return fail(-1, "vpt_conv3x3_forward_tiled: tiling must be 1 (throughput), 2 (latency) or 3 (throughput, 32-row tiles)");
   VptConv3x3Args a;
+  a.gate_stats = nullptr; a.gate_u = nullptr; a.inv_count_gate = 0.0;
   a.tiling = tiling;
   a.x = (const vpt_op16*)x; a.wpk = (const vpt_op16*)wpk; a.edge_sa = edge_sa; a.edge_sg = edge_sg;
   a.stats_in = stats_in; a.res = (const vpt_op16*)res; a.y = (vpt_op16*)y; a.stats_out = stats_out;
@@ -114,6 +115,7 @@ int vpt_conv3x3_forward_folded(const void* x, const void* wpk, const float* edge
   if (res_bias && (!res || !res_scale)) return fail(-1, "vpt_conv3x3_forward_folded: res_bias needs res and res_scale");
   if (!edge_sg || (!kk_frame && !edge_sa)) return fail(-1, "vpt_conv3x3_forward_folded: edge tables missing");
   VptConv3x3Args a;
+  a.gate_stats = nullptr; a.gate_u = nullptr; a.inv_count_gate = 0.0;
   a.tiling = 1;
   a.x = (const vpt_op16*)x; a.wpk = (const vpt_op16*)wpk; a.edge_sa = edge_sa; a.edge_sg = edge_sg;
   a.stats_in = stats_in; a.res = (const vpt_op16*)res; a.y = (vpt_op16*)y; a.stats_out = stats_out;
@@ -153,6 +155,7 @@ int vpt_conv3x3_pool_forward(const void* x, const void* wpk, const float* edge_s
   if (phases < 1 || phases > 3) return fail(-1, "vpt_conv3x3_pool_forward: phases = 1 (tiles), 2 (seams) or 3 (both)");
   if ((H & 15) || (W & 15) || (Cout & 31)) return fail(-1, "vpt_conv3x3_pool_forward: H, W multiples of 16, Cout of 32");
   VptConv3x3Args a;
+  a.gate_stats = nullptr; a.gate_u = nullptr; a.inv_count_gate = 0.0;
   a.tiling = 1;
   a.x = (const vpt_op16*)x; a.wpk = (const vpt_op16*)wpk; a.edge_sa = edge_sa; a.edge_sg = edge_sg;
   a.stats_in = stats_in; a.res = nullptr; a.y = (vpt_op16*)pooled; a.stats_out = stats_out;
@@ -176,6 +179,7 @@ int vpt_conv3x3_pool_forward(const void* x, const void* wpk, const float* edge_s
 int vpt_conv3x3_dgrad(const void* dacc, const void* wpk_t, const void* skip, const void* xin, const float* coef, void* dx,
                       int frames, int H, int W, int Cout, int Cin, void* stream) {
   VptConv3x3Args a;
+  a.gate_stats = nullptr; a.gate_u = nullptr; a.inv_count_gate = 0.0;
   a.x = (const vpt_op16*)dacc; a.wpk = (const vpt_op16*)wpk_t; a.edge_sa = nullptr; a.edge_sg = nullptr;
   a.stats_in = nullptr; a.res = (const vpt_op16*)skip; a.y = (vpt_op16*)dx; a.stats_out = nullptr;
   a.frames = frames; a.H = H; a.W = W; a.Cin = Cout; a.Cout = Cin;   // roles swap in the transposed convolution
@@ -183,6 +187,34 @@ int vpt_conv3x3_dgrad(const void* dacc, const void* wpk_t, const void* skip, con
   a.bwd = 1; a.xin = (const vpt_op16*)xin; a.coef = coef; a.tiling = 1; a.pool = 0; a.seam_r = nullptr; a.seam_c = nullptr; a.out_gain = nullptr; a.chs_out = nullptr;
   a.kk_frame = a.rs_frame = a.res_scale = a.res_bias = nullptr;
   CHECK_LAUNCH(vpt_conv3x3_launch(&a, (hipStream_t)stream), "vpt_conv3x3_dgrad");
+}
+
+int vpt_conv3x3_dgrad_gated(const void* dacc, const void* wpk_t, const void* xin, const float* coef, const double* gate_stats, int gate_cin,
+                            void* dacc_out, double* gate_u, int frames, int H, int W, int Cout, int Cin, void* stream) {
+  if (!gate_stats || !gate_u || gate_cin <= 0) return fail(-1, "vpt_conv3x3_dgrad_gated: gate_stats, gate_u and gate_cin are required");
+  VptConv3x3Args a;
+  a.x = (const vpt_op16*)dacc; a.wpk = (const vpt_op16*)wpk_t; a.edge_sa = nullptr; a.edge_sg = nullptr;
+  a.stats_in = nullptr; a.res = nullptr; a.y = (vpt_op16*)dacc_out; a.stats_out = nullptr;
+  a.frames = frames; a.H = H; a.W = W; a.Cin = Cout; a.Cout = Cin;   // roles swap in the transposed convolution
+  a.NT = (Cin + 127) / 128; a.CoutPad = a.NT * 128; a.inv_count_in = 1.0;
+  a.bwd = 1; a.xin = (const vpt_op16*)xin; a.coef = coef; a.tiling = 1; a.pool = 0; a.seam_r = nullptr; a.seam_c = nullptr; a.out_gain = nullptr; a.chs_out = nullptr;
+  a.kk_frame = a.rs_frame = a.res_scale = a.res_bias = nullptr;
+  a.gate_stats = gate_stats; a.gate_u = gate_u; a.inv_count_gate = 1.0 / ((double)gate_cin * H * W);
+  CHECK_LAUNCH(vpt_conv3x3_launch(&a, (hipStream_t)stream), "vpt_conv3x3_dgrad_gated");
+}
+
+int vpt_conv_backward_reduce(const void* dacc, const double* gate_u, const double* stats_in, const float* edge_sa, const float* edge_sg,
+                             double* t12, float* coef, float* d_sa, float* d_sg, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream) {
+  if (Cout & 31) return fail(-1, "vpt_conv_backward_reduce: Cout must be a multiple of 32");
+  if (!dacc || !gate_u) return fail(-1, "vpt_conv_backward_reduce: dacc and gate_u are required");
+  VptConvBwdPrepArgs a;
+  a.dpooled = nullptr; a.argmax = nullptr; a.sbuf = scratch; a.wshift = 0; a.coef = coef;
+  a.dy = (const vpt_op16*)dacc; a.y = nullptr; a.res = nullptr; a.stats_in = stats_in;
+  a.edge_sa = edge_sa; a.edge_sg = edge_sg; a.dacc = nullptr; a.t12 = t12; a.d_sa = d_sa; a.d_sg = d_sg;
+  a.frames = frames; a.CB = Cout / 32; a.H = H; a.W = W; a.CoutPad = ((Cout + 127) / 128) * 128;
+  a.inv_count_in = 1.0 / ((double)Cin * H * W);
+  a.gate_u = gate_u;
+  CHECK_LAUNCH(vpt_conv_bwd_prep_launch(&a, (hipStream_t)stream), "vpt_conv_backward_reduce");
 }
 
 int vpt_conv_backward_prepare(const void* dy, const void* dpooled, const uint8_t* argmax, const void* y, const void* res,
@@ -195,6 +227,7 @@ int vpt_conv_backward_prepare(const void* dy, const void* dpooled, const uint8_t
   a.edge_sa = edge_sa; a.edge_sg = edge_sg; a.dacc = (vpt_op16*)dacc; a.t12 = t12; a.d_sa = d_sa; a.d_sg = d_sg;
   a.frames = frames; a.CB = Cout / 32; a.H = H; a.W = W; a.CoutPad = ((Cout + 127) / 128) * 128;
   a.inv_count_in = 1.0 / ((double)Cin * H * W);
+  a.gate_u = nullptr;
   CHECK_LAUNCH(vpt_conv_bwd_prep_launch(&a, (hipStream_t)stream), "vpt_conv_backward_prepare");
 }
 

@@ -296,8 +296,12 @@ struct PrepRow {
   uint64_t am[4];
 };
 
-template <bool HAS_DY, bool HAS_RES>
+// PRE (round 5): `dy` is the operand dacc = rstd dz ITSELF, written by the producing dgrad's epilogue (vpt_conv3x3_kernel mode 6: a block's
+// conv1 -> conv0, no residual): one tensor read, nothing written; the sums are those of dacc, scaled back by 1 / rstd when they are
+// stored, and the data term sum dz v arrives per frame (gate_u).
+template <bool HAS_DY, bool HAS_RES, bool PRE = false>
 __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_kernel(VptConvBwdPrepArgs a) {
+  static_assert(!PRE || (HAS_DY && !HAS_RES), "the pre-gated variant reads dacc only");
   __shared__ float tab_[9 * 32];
   const int HW = a.H * a.W;
   const int cb = blockIdx.x % a.CB, f = blockIdx.x / a.CB;
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_kernel(VptConvBwdPrepAr
   const unsigned cxA = (unsigned)(x & 1) + 1u;   // window column code of x: x - 2 px + 1 (B: always 0)
   auto load_row = [&](int y, PrepRow& r) {
     const size_t off = plane + (size_t)(y * a.W + x) * 32;
-    r.y = VPT_LD_STREAM((const u32x4*)(a.y + off));
+    if (!PRE) r.y = VPT_LD_STREAM((const u32x4*)(a.y + off));
     if (HAS_RES) r.res = VPT_LD_STREAM((const u32x4*)(a.res + off));
     if (HAS_DY) {
       r.dy = VPT_LD_STREAM((const u32x4*)(a.dy + off));
@@ -336,6 +340,17 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_kernel(VptConvBwdPrepAr
   float tv = 0.f;
   auto process = [&](int y, const PrepRow& cur) {
     float dy[8], v[8], o[8];
+    if constexpr (PRE) {
+      unpack8(cur.dy, dy);
+      const bool is_top = (y == 0), is_bot = (y == a.H - 1);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        all[k] += dy[k];
+        top[k] = is_top ? dy[k] : top[k];
+        bot[k] = is_bot ? dy[k] : bot[k];
+      }
+      return;
+    }
     unpack8(cur.y, v);
     if (HAS_DY) {
       unpack8(cur.dy, dy);
@@ -388,6 +403,11 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_kernel(VptConvBwdPrepAr
   }
   // S[ey][ex][channel]: reduce over the threads of this column class
   const int ex = (x == 0) ? 0 : ((x == a.W - 1) ? 2 : 1);
+  if (PRE) {       // sums of dacc = rstd dz -> sums of dz
+    const float inv = 1.0f / rstd;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { all[k] *= inv; top[k] *= inv; bot[k] *= inv; }
+  }
 #pragma unroll
   for (int k = 0; k < 8; ++k) all[k] -= top[k] + bot[k];
   // interior columns are most lanes: shuffle-reduce them per wave first (edge-column lanes contribute zero)
@@ -424,7 +444,10 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_kernel(VptConvBwdPrepAr
   __syncthreads();
   const int Cout = a.CB * 32;
   float* srow = a.sbuf + (size_t)f * (9 * Cout + a.CB);
-  if (threadIdx.x == 0) srow[9 * Cout + cb] = (red_[0] + red_[1]) + (red_[2] + red_[3]);
+  if (threadIdx.x == 0) {
+    if (PRE) srow[9 * Cout + cb] = (cb == 0) ? (float)(a.gate_u[f] / (double)rstd) : 0.f;     // the frame's sum dz v, once
+    else srow[9 * Cout + cb] = (red_[0] + red_[1]) + (red_[2] + red_[3]);
+  }
   for (int i = threadIdx.x; i < 9 * 32; i += 256) srow[(i >> 5) * Cout + cb * 32 + (i & 31)] = tab_[i];
 }
 
@@ -491,12 +514,14 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_finish_kernel(VptConvBwdPrep
 extern "C" int vpt_conv_bwd_prep_launch(const VptConvBwdPrepArgs* a0, hipStream_t stream) {
   VptConvBwdPrepArgs a = *a0;
   if (a.frames <= 0 || !a.sbuf || !a.coef) return -1;
+  if (a.gate_u && (!a.dy || a.res)) return -1;
   if (a.W < 8 || a.W > 64 || (a.W & (a.W - 1))) return -1;  // column-per-thread mapping: W in {8,16,32,64}
   if (!a.dy && (!a.dpooled || !a.argmax || (a.H & 1) || (a.W & 1))) return -1;
   a.wshift = 31 - __builtin_clz((unsigned)a.W);
   const long grid = (long)a.frames * a.CB;
   if (grid > 0x7fffffffL) return -2;
-  if (a.dy) {
+  if (a.gate_u) hipLaunchKernelGGL((vpt_conv_bwd_prep_kernel<true, false, true>), dim3((unsigned)grid), dim3(256), 0, stream, a);
+  else if (a.dy) {
     if (a.res) hipLaunchKernelGGL((vpt_conv_bwd_prep_kernel<true, true>), dim3((unsigned)grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((vpt_conv_bwd_prep_kernel<true, false>), dim3((unsigned)grid), dim3(256), 0, stream, a);
   } else {

@@ -88,7 +88,12 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
   // 5 forward + residual through a per-frame affine:  out = relu(...) + res_scale[f] * res + res_bias[f][channel]  -- the block that
   // follows a stack's GroupNorm `n` reads the pooled tensor itself (already multiplied by n's gain) instead of a normalised copy
   // (lib/impala_cnn.py:118-121 with the `n` pass folded away).
-  constexpr bool BWD = (MODE == 2 || MODE == 3), HAS_RES = (MODE == 1 || MODE == 3 || MODE == 5), USE_X = BWD, POOL = MODE == 4, RES_AFF = MODE == 5;
+  // 6 dgrad of a block's conv1 that hands the block's conv0 its backward operand directly (round 5):  dy = conv^T + c0 + c1 * xin is the
+  // gradient w.r.t. conv0's output y = xin, conv0 has no residual, so its ReLU gate is [xin > 0] and its operand dacc0 = rstd0 * dy * [xin > 0]
+  // (rstd0: the statistics of conv0's INPUT, gate_stats) is written instead of dy -- vpt_conv_bwd_prep_kernel's pass over (dy, y) -> dacc
+  // shrinks to a reduction over dacc0 alone; gate_u[f] += sum rstd0 * dy * xin (= rstd0 * sum dz v: T1's data term; closed gates add 0).
+  constexpr bool GATE = MODE == 6;
+  constexpr bool BWD = (MODE == 2 || MODE == 3 || MODE == 6), HAS_RES = (MODE == 1 || MODE == 3 || MODE == 5), USE_X = BWD, POOL = MODE == 4, RES_AFF = MODE == 5;
   constexpr bool DEFER_STORES = MODE != 3;   // mode 3 holds skip + xin pieces as well: no registers left for the packed results
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_SZ];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -171,6 +176,13 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
   } else if (a.coef) {
     c0f = a.coef[2 * f];
     c1f = a.coef[2 * f + 1];
+  }
+  float rgate = 1.f;
+  if (GATE) {      // everything the epilogue adds is linear in the scale: fold rstd0 into the coefficients
+    float mg;
+    frame_mean_rstd(a.gate_stats, f, a.inv_count_gate, mg, rgate);
+    c0f *= rgate;
+    c1f *= rgate;
   }
   {
     float* kk = (float*)(smem + KK_O);
@@ -502,14 +514,11 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
     (e_).x = s0_[0]; (o_).x = s0_[1]; (e_).y = s1_[0]; (o_).y = s1_[1];                                   \
   } while (0)
   const f32x2 zero2 = {0.f, 0.f};
-  const f32x2 rstd2 = {rstd, rstd}, c0f2 = {c0f, c0f}, c1f2 = {c1f, c1f}, ress2 = {res_s, res_s};
-  f32x4 bq[2][4];             // mode 5: the residual's per-channel bias of this lane's 32 channels (independent of the subtile)
-  if (RES_AFF) {
-#pragma unroll
-    for (int n2_ = 0; n2_ < NV; ++n2_)
-#pragma unroll
-      for (int g_ = 0; g_ < 4; ++g_) bq[n2_][g_] = *(const f32x4*)((const float*)(smem + BT_O) + wn * 64 + n2_ * 32 + 8 * g_ + 4 * hi);
-  }
+  const f32x2 rstd2 = {rstd, rstd}, c0f2 = {c0f, c0f}, c1f2 = {c1f, c1f}, ress2 = {res_s, res_s}, rgate2 = {rgate, rgate};
+  // mode 5: the residual's per-channel bias of this lane's channels.  Read per chunk (4 x ds_read_b128 right behind the chunk's table prefetch, ~20
+  // VALU instructions before their first use) instead of held for the whole epilogue: 16 registers instead of 32 -- round 4's version spilled 2 VGPRs.
+  f32x4 bq[4];
+  const float* btab = (const float*)(smem + BT_O) + wn * 64 + 4 * hi;
 
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
@@ -520,6 +529,11 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
     for (int n2 = 0; n2 < 2; ++n2) {
       if (!BWD && 2 * m + n2 < 7) { LOAD_KK(2 * m + n2 + 1); SB(); }
       if (n2 >= NV) continue;
+      if (RES_AFF) {
+#pragma unroll
+        for (int g_ = 0; g_ < 4; ++g_) bq[g_] = *(const f32x4*)(btab + n2 * 32 + 8 * g_);
+        SB();
+      }
       u32x4 ovp[2], xp[2];
 #if !VPT_RES_NATIVE
       u32x4 rp[2];
@@ -556,13 +570,22 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
             v23 = __builtin_elementwise_max(rstd2 * v23 + k23, zero2);
           } else if (use_x) {  // dgrad: + d(mu, rstd)/dx terms of the GroupNorm statistics
             const f32x2 x01 = {op16_lo_to_f32(x2[q].x), op16_hi_to_f32(x2[q].x)}, x23 = {op16_lo_to_f32(x2[q].y), op16_hi_to_f32(x2[q].y)};
-            v01 += c1f2 * x01 + c0f2;
-            v23 += c1f2 * x23 + c0f2;
+            if (GATE) {
+              v01 = rgate2 * v01 + (c1f2 * x01 + c0f2);     // rstd0 * dy  (c0, c1 carry rstd0 already)
+              v23 = rgate2 * v23 + (c1f2 * x23 + c0f2);
+              s_sum2 = v01 * x01 + s_sum2;                  // sum rstd0 dy xin: where the gate is closed xin = 0 contributes nothing
+              s_sq2 = v23 * x23 + s_sq2;
+              v01.x = x01.x > 0.f ? v01.x : 0.f; v01.y = x01.y > 0.f ? v01.y : 0.f;
+              v23.x = x23.x > 0.f ? v23.x : 0.f; v23.y = x23.y > 0.f ? v23.y : 0.f;
+            } else {
+              v01 += c1f2 * x01 + c0f2;
+              v23 += c1f2 * x23 + c0f2;
+            }
           }
           if (HAS_RES) {
             const f32x2 r01 = {op16_lo_to_f32(r2[q].x), op16_hi_to_f32(r2[q].x)}, r23 = {op16_lo_to_f32(r2[q].y), op16_hi_to_f32(r2[q].y)};
             if (RES_AFF) {
-              const f32x4 b4 = bq[n2][g];
+              const f32x4 b4 = bq[g];
               const f32x2 b01 = {b4.x, b4.y}, b23 = {b4.z, b4.w};
               v01 = ress2 * r01 + (v01 + b01);
               v23 = ress2 * r23 + (v23 + b23);
@@ -743,6 +766,13 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
   else if (nvalid[0]) epilogue(std::integral_constant<int, 1>{});
   }
   float s_sum = s_sum2.x + s_sum2.y, s_sq = s_sq2.x + s_sq2.y;
+  if (GATE) {      // one fp64 atomic per tile: this tile's share of sum rstd0 dy xin
+    float* red = (float*)(smem + KK_O + KK_BYTES);
+    s_sum = wave_sum(s_sum + s_sq);
+    if (lane == 0) red[w] = s_sum;
+    __syncthreads();
+    if (tid == 0) atomicAdd(a.gate_u + f, (double)((red[0] + red[1]) + (red[2] + red[3])));
+  }
   if (!BWD && a.stats_out) {
     float* red = (float*)(smem + KK_O + KK_BYTES);
     s_sum = wave_sum(s_sum);
@@ -987,7 +1017,8 @@ extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream
   if ((a->H & 15) || (a->W & 15) || (a->Cin & 31) || (a->Cout & 31) || a->frames <= 0) return -1;
   const long grid = (long)a->frames * (a->H >> 4) * (a->W >> 4) * a->NT;
   if (grid > 0x7fffffffL) return -2;
-  const int mode = a->bwd ? (a->res ? 3 : 2) : (a->pool ? 4 : (a->res ? (a->res_bias ? 5 : 1) : 0));
+  const int mode = a->bwd ? (a->res ? 3 : (a->gate_stats ? 6 : 2)) : (a->pool ? 4 : (a->res ? (a->res_bias ? 5 : 1) : 0));
+  if (a->gate_stats && (!a->bwd || a->res || !a->gate_u || a->trace)) return -1;   // the gated dgrad: no skip connection (a block's conv1 -> conv0)
   if ((a->res_bias != nullptr) != (a->res_scale != nullptr) || (a->res_bias && (a->bwd || !a->res))) return -1;
   if ((a->kk_frame != nullptr) != (a->rs_frame != nullptr) || (a->kk_frame && a->bwd)) return -1;
   if (a->bwd && (!a->xin || !a->coef)) return -1;   // dgrad always carries the GroupNorm-statistics terms (c0 + c1 * xin)
@@ -1003,6 +1034,7 @@ extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream
   }
 #define LAUNCH_(T_, M_) hipLaunchKernelGGL((vpt_conv3x3_kernel<T_, M_>), dim3((unsigned)grid), dim3(256), extra_lds, stream, *a)
   if (a->trace && mode > 3) return -1;
+  if (mode == 6) { LAUNCH_(false, 6); return hipGetLastError() == hipSuccess ? 0 : -3; }
   // tiling 3 (forward) = the 32-row, eight-wave tiles wherever the image has whole 32-row bands.  Measured at parity with the 16-row tiles on
   // every layer shape (profiles/r04_experiments.md section 7: halving the weight DMA buys nothing on a power-limited chip), so the shipped
   // choice stays the 16-row kernel; the variant is kept selectable because it is bit-identical per pixel and covered by the same tests.

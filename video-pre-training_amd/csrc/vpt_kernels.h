@@ -43,6 +43,12 @@ struct VptConv3x3Args {
   int bwd;
   const vpt_op16* xin;     // the forward layer's input x (same shape as this call's output)
   const float* coef;       // [F][2]
+  // gated dgrad (bwd != 0, no res; round 5): the output is the backward operand of the res-free layer whose output is xin --
+  // out = rstd_g[f] * (conv + c0 + c1 * xin) * [xin > 0], rstd_g from gate_stats (that layer's input statistics); gate_u [F] += sum of
+  // rstd_g * (conv + c0 + c1 * xin) * xin (accumulated; caller zeroes)
+  const double* gate_stats;
+  double inv_count_gate;
+  double* gate_u;
 };
 
 struct VptChannelStatsArgs {   // per-frame, per-channel sums of a blocked tensor: chs[f][c] = (sum_p x, sum_p x^2), accumulated in fp64
@@ -233,6 +239,9 @@ struct VptConvBwdPrepArgs {
   float* d_sg;
   int frames, CB, H, W, CoutPad;
   double inv_count_in;     // 1 / (Cin*H*W)
+  // pre-gated variant (round 5): `dy` IS the operand dacc = rstd dz already (written by the gated dgrad, vpt_conv3x3_kernel mode 6); y, res and
+  // dacc are unused, nothing is written but the per-frame sums: S[e][o] = (sum dacc) / rstd, and the data term sum dz v = gate_u[f] / rstd
+  const double* gate_u;
 };
 
 struct VptConvFirstBwdArgs {

@@ -717,6 +717,37 @@ def conv3x3_dgrad(dacc, wpk_t, cin, skip=None, xin=None, coef=None):
     return dx
 
 
+def conv3x3_dgrad_gated(dacc, wpk_t, cin, xin, coef, gate_stats, gate_cin):
+    """A block's conv1 -> conv0 backward in one epilogue (vpt_conv3x3_dgrad_gated): the transposed convolution of `dacc` (conv1's operand) whose
+    output is conv0's OPERAND  rstd0 * (conv^T + c0 + c1 xin) * [xin > 0]  (xin = conv0's output, gate_stats = the frame statistics of conv0's
+    input over gate_cin * H * W elements) instead of the plain gradient.  -> (dacc0 blocked [F, cin/32, H, W, 32], gate_u fp64 [F])."""
+    _chk(dacc, OP16, "dacc"); _chk(wpk_t, OP16, "wpk_t"); _chk(xin, OP16, "xin"); _chk(coef, torch.float32, "coef"); _chk(gate_stats, torch.float64, "gate_stats")
+    f, cb, h, w, _ = dacc.shape
+    dt, fmt = _fmt(dacc, wpk_t, xin)
+    out = torch.empty(f, cin // 32, h, w, 32, dtype=dt, device=dacc.device)
+    gate_u = torch.zeros(f, dtype=torch.float64, device=dacc.device)
+    _call("vpt_conv3x3_dgrad_gated", dict(flops=2.0 * f * h * w * cin * 9 * cb * 32), ptr(dacc), ptr(wpk_t), ptr(xin), ptr(coef), ptr(gate_stats), int(gate_cin),
+          ptr(out), ptr(gate_u), f, h, w, cb * 32, cin, _stream(), fmt=fmt, label="vpt_conv3x3_dgrad")
+    return out, gate_u
+
+
+def conv_backward_reduce(dacc, gate_u, stats_in, edge_sa, edge_sg, cin, d_sa=None, d_sg=None, want_t12=False):
+    """What conv_backward_prepare returns besides dacc, for an operand that conv3x3_dgrad_gated already wrote: (coef fp32 [F,2], d_sa, d_sg[, t12])
+    from one read of dacc (vpt_conv_backward_reduce).  stats_in: the layer's input statistics (cin * H * W elements)."""
+    _chk(dacc, OP16, "dacc"); _chk(gate_u, torch.float64, "gate_u"); _chk(stats_in, torch.float64, "stats_in")
+    _chk(edge_sa, torch.float32, "edge_sa"); _chk(edge_sg, torch.float32, "edge_sg"); _chk(d_sa, torch.float32, "d_sa"); _chk(d_sg, torch.float32, "d_sg")
+    f, cb, h, w, _ = dacc.shape
+    dev = dacc.device
+    coef = torch.empty(f, 2, dtype=torch.float32, device=dev)
+    t12 = torch.empty(f, 2, dtype=torch.float64, device=dev) if want_t12 else None
+    if d_sa is None:
+        d_sa, d_sg = torch.zeros_like(edge_sa), torch.zeros_like(edge_sg)
+    scratch = torch.empty(f, 9 * cb * 32 + cb, dtype=torch.float32, device=dev)
+    _call("vpt_conv_backward_reduce", dict(bytes=2.0 * dacc.numel()), ptr(dacc), ptr(gate_u), ptr(stats_in), ptr(edge_sa), ptr(edge_sg),
+          ptr(t12), ptr(coef), ptr(d_sa), ptr(d_sg), ptr(scratch), f, h, w, cin, cb * 32, _stream(), fmt=_fmt(dacc)[1], label="vpt_conv_backward_prepare")
+    return (coef, d_sa, d_sg, t12) if want_t12 else (coef, d_sa, d_sg)
+
+
 def maxpool_backward(pre, pooled, dpooled):
     for t, nme in ((pre, "pre"), (pooled, "pooled"), (dpooled, "dpooled")):
         _chk(t, OP16, nme)

@@ -98,6 +98,8 @@ class BCTrainer:
         # bookkeeping.  The streams are created ONCE per trainer and only ever appended to (never replaced): the activations a
         # forward_saving() left for a later backward stay tied to the stream object that produced them.
         self.cnn_streams = int(os.environ.get("VPT_BC_STREAMS", self.engine.cnn_streams))
+        # a block's conv1 -> conv0 backward through ONE dgrad epilogue (_block_backward); 0 = the round-4 path (A/B)
+        self.gated_dgrad = os.environ.get("VPT_BC_GATED_DGRAD", "1") != "0"
         self._arenas = None      # (key, (GradArena trunk + heads, GradArena CNN)) of the data-parallel step, built on first use
         self._streams: List[torch.cuda.Stream] = []
         self.params: Dict[str, torch.nn.Parameter] = dict(policy.named_parameters())
@@ -487,6 +489,39 @@ class BCTrainer:
             return None
         return ops.conv3x3_dgrad(dacc, acc["wt"][q], cin, skip=skip, xin=x_in, coef=coef)
 
+    def _block_backward(self, p, b, blk, acc, dx):
+        """CnnBasicBlock backward (lib/impala_cnn.py:50-52: x + conv1(conv0(x))): dx w.r.t. the block output -> dx w.r.t. its input.
+        gated_dgrad (round 5, default): conv1's dgrad writes conv0's backward operand directly (ops.conv3x3_dgrad_gated: conv0 has no residual,
+        its output is conv1's input, so its ReLU gate and rstd scale fit into that epilogue), and conv0's per-element prepare pass (read dy, read y,
+        write dacc) becomes a reduction over the operand (ops.conv_backward_reduce: one read)."""
+        q1, q0 = f"{p}blocks.{b}.conv1", f"{p}blocks.{b}.conv0"
+        if not self.gated_dgrad:
+            dy = self._conv_layer_backward(q1, acc, dx, blk["x_out"], blk["x_in"], blk["y"], blk["s_y"], None)
+            return self._conv_layer_backward(q0, acc, dy, blk["y"], None, blk["x_in"], blk["s_in"], dx)
+        w = self.engine.w
+        x_in, y, x_out = blk["x_in"], blk["y"], blk["x_out"]
+        c_in, c_mid = x_in.shape[1] * 32, y.shape[1] * 32
+        # conv1 (residual layer): prepare -> wgrad -> gated dgrad
+        _, sa1, sg1 = w[q1]
+        r1 = self._raw_acc(acc, q1, x_out.shape[1] * 32, c_mid, sa1, sg1)
+        dacc1, coef1, _, _ = ops.conv_backward_prepare(dx, x_out, x_in, blk["s_y"], sa1, sg1, c_mid, d_sa=r1[1], d_sg=r1[2])
+        ops.conv3x3_wgrad(dacc1, y, out=r1[0])
+        dacc0, gate_u = ops.conv3x3_dgrad_gated(dacc1, acc["wt"][q1], c_mid, y, coef1, blk["s_in"], c_in)
+        del dacc1
+        # conv0 (no residual): its operand exists already; sums only
+        _, sa0, sg0 = w[q0]
+        r0 = self._raw_acc(acc, q0, c_mid, c_in, sa0, sg0)
+        coef0, _, _ = ops.conv_backward_reduce(dacc0, gate_u, blk["s_in"], sa0, sg0, c_in, d_sa=r0[1], d_sg=r0[2])
+        ops.conv3x3_wgrad(dacc0, x_in, out=r0[0])
+        return ops.conv3x3_dgrad(dacc0, acc["wt"][q0], c_in, skip=dx, xin=x_in, coef=coef0)
+
+    @staticmethod
+    def _raw_acc(acc, q, cout, cin, sa, sg):
+        r = acc["raw"].get(q)
+        if r is None:   # [dw_raw, d_sa, d_sg]: the kernels accumulate into them across the frame chunks
+            r = acc["raw"][q] = [torch.zeros(cout, 9, cin, dtype=torch.float32, device=sa.device), torch.zeros_like(sa), torch.zeros_like(sg)]
+        return r
+
     def _cnn_backward_chunk(self, sv, dd, acc):
         """dd: fp32 [f, 256] gradient w.r.t. the dense layer's pre-activation output for this chunk's frames."""
         eng = self.engine
@@ -507,10 +542,7 @@ class BCTrainer:
             p = f"net.img_process.cnn.stacks.{s}."
             rec = sv["stacks"][s]
             for b in (1, 0):
-                blk = rec["blocks"][b]
-                dy = self._conv_layer_backward(f"{p}blocks.{b}.conv1", acc, dx, blk["x_out"], blk["x_in"], blk["y"], blk["s_y"], None)
-                dx = self._conv_layer_backward(f"{p}blocks.{b}.conv0", acc, dy, blk["y"], None, blk["x_in"], blk["s_in"], dx)
-                del dy
+                dx = self._block_backward(p, b, rec["blocks"][b], acc, dx)
             dgn, dbn = acc["n"][s]
             dpooled = ops.frame_affine_backward(rec["pooled"], dx, w[p + "n.g"], rec["s_pool"], dgn, dbn)
             if s == 0:
