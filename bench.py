@@ -335,7 +335,7 @@ def competitive_heads_parity(model, dev, modes):
     return out
 
 
-def ingest_leg(pol, img, first, dev, steps=3):
+def ingest_leg(pol, img, first, dev, copy_s=None, steps=5):
     """host -> device ingest, bounded, NOT the headline (whose frames are resident in HBM when the timed region starts).
     The reference uploads every observation from host memory (agent.py:147-148: th.from_numpy(...).to(device) per frame; data_loader.py:113-122
     hands out host frames).  Here: pinned host uint8 frames -> device through a two-deep, stream-ordered pipeline (copy stream + events; the
@@ -348,7 +348,10 @@ def ingest_leg(pol, img, first, dev, steps=3):
     from vpt_amd import ops
     B, T = img.shape[:2]
     n = B * T
-    main, copy_s = torch.cuda.current_stream(), torch.cuda.Stream()
+    # the copy stream is created FIRST in the process (main()): HIP maps streams onto a few hardware queues in creation order, and a copy queued
+    # behind a compute stream's kernels on the same hardware queue does not overlap with anything (measured: tools/ingest_probe.py, round 5)
+    main = torch.cuda.current_stream()
+    copy_s = copy_s if copy_s is not None else torch.cuda.Stream()
     out = {}
 
     def fwd(frames, st):
@@ -638,6 +641,7 @@ def main():
     ap.add_argument("--bc-warmup", type=int, default=1)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"], help="operand format of the HEADLINE value (north star: bf16 tiles); the other format is reported beside it")
     ap.add_argument("--no-ingest", action="store_true", help="skip the host -> device ingest leg")
+    ap.add_argument("--ingest-only", action="store_true", help="(profiling) only the timed forward and the ingest leg; prints the ingest record")
     args = ap.parse_args()
 
     backend = os.environ.get("VPT_DIST_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm; "gloo" lets the N > 1 branch run with every rank on one GPU (tests)
@@ -682,6 +686,7 @@ def main():
             dist.init_process_group(backend)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    copy_stream = torch.cuda.Stream()      # the ingest leg's host -> device copy stream: the process's first side stream (see ingest_leg)
     collective_ranks = 1
     if distributed:      # an ACTUAL collective on device tensors: every rank contributes 1, the sum is the number of ranks the transport reached
         one = torch.ones(1, dtype=torch.float32, device=dev)
@@ -743,6 +748,9 @@ def main():
         return el, state
 
     elapsed, state = timed_forward(args.steps, args.warmup)
+    if args.ingest_only:
+        print(json.dumps(dict(forward_ms=round(1e3 * elapsed / args.steps, 3), ingest=ingest_leg(pol, img, first, dev, copy_stream))))
+        return
     roof = kernels = None
     if rank == 0:
         roof, kernels = _roofline(ops, pol, step, state, args, B, T, head)
@@ -835,7 +843,7 @@ def main():
             if not args.no_ingest:
                 try:
                     pol.set_precision(head)
-                    line["ingest"] = ingest_leg(pol, img, first, dev)
+                    line["ingest"] = ingest_leg(pol, img, first, dev, copy_stream)
                 except Exception as e:
                     line["ingest"] = dict(error=f"{type(e).__name__}: {e}")
             del pol, img

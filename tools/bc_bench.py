@@ -48,3 +48,8 @@ print(f"kernel time total {tot:.1f} ms")
 for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
     tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["flops"] and v["ms"] else 0
     print(f"  {k:36s} {v['ms']:9.2f} ms {v['calls']:5d} calls  {tf:8.1f} TF/s")
+if a.streams1:       # per layer shape: which of the three convolution passes loses where
+    for pre in ("vpt_conv3x3", "vpt_conv_backward_prepare"):
+        for (k, work), v in sorted(ops.TIMER.by_shape(pre).items(), key=lambda kv: (kv[0][0], -kv[1]["ms"])):
+            rate = f"{v['flops'] / (v['ms'] * 1e-3) / 1e12:8.1f} TF/s" if v["flops"] else f"{v['bytes'] / (v['ms'] * 1e-3) / 1e12:8.2f} TB/s"
+            print(f"    {k:30s} work/call {work:10.3e}  {v['ms']:8.2f} ms {v['calls']:4d} calls  {rate}")

@@ -55,7 +55,8 @@ for name, hw, cin, cout, use_res in shapes:
     if name.endswith(".first") and os.environ.get("VPT_BENCH_POOL", "1") == "1":
         # the stack's firstconv -> max-pool pair: two kernels (the pre-pool tensor through HBM) vs the pool-fused convolution + seam kernel
         stp = torch.zeros(f, 2, dtype=torch.float64, device=dev)
-        pooled = torch.empty(f, cout // 32, hw // 2, hw // 2, 32, dtype=DT, device=dev)
+        # VPT_BENCH_POOL_PROBE=1: room behind the pooled tensor for the arg-max masks a -DVPT_POOL_ARGMASK_PROBE build writes (timing experiment)
+        pooled = torch.empty((2 if os.environ.get("VPT_BENCH_POOL_PROBE") == "1" else 1) * f, cout // 32, hw // 2, hw // 2, 32, dtype=DT, device=dev)[:f]
 
         def pair():
             ops.conv3x3(x, wpk, sa, sg, st_in, cout, out=out)

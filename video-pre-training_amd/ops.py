@@ -38,6 +38,21 @@ class KernelTimer:
             d["bytes"] += meta.get("bytes", 0.0)
         return out
 
+    def by_shape(self, prefix="vpt_conv3x3"):
+        """Per (label, work size): the same records split by their FLOP / byte count, i.e. by layer shape (profiling: which shapes lose)."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b, meta in self.records:
+            if not name.startswith(prefix):
+                continue
+            key = (name, meta.get("flops", 0.0) or meta.get("bytes", 0.0))
+            d = out.setdefault(key, dict(ms=0.0, calls=0, flops=0.0, bytes=0.0))
+            d["ms"] += a.elapsed_time(b)
+            d["calls"] += 1
+            d["flops"] += meta.get("flops", 0.0)
+            d["bytes"] += meta.get("bytes", 0.0)
+        return out
+
 
 TIMER = KernelTimer()
 
