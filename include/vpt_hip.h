@@ -132,6 +132,15 @@ int vpt_conv3x3_pool_forward(const void* x, const void* wpk, const float* edge_s
                              void* pooled, void* seam_scratch, double* stats_out, const float* out_gain, double* chs_out, int frames, int H,
                              int W, int Cin, int Cout, int phases, void* stream);
 
+/* Round 5, the TRAINING forward of a stack's firstconv -> max_pool2d (lib/impala_cnn.py:114-117 under behavioural_cloning.py:101): the same pass
+ * that ALSO records, per pooled value, which positions of its 3 x 3 window hold the maximum -- pool_mask [F][Cout/32][H/2][W/2][32] uint16, bit
+ * 8 - k set = scan position k = 3 (dy + 1) + (dx + 1) differs from the maximum or lies outside the image.  The backward
+ * (vpt_conv_backward_prepare_pooled) routes the pooled gradient to the first zero bit -- torch's first-maximum rule -- so neither the
+ * pre-pool tensor (2 MB per frame in stack 1) nor vpt_maxpool_forward's arg-max bytes exist in the BC step.  Pooled values and statistics
+ * are those of vpt_conv3x3_pool_forward, bit for bit.  phases as there. */
+int vpt_conv3x3_pool_argmax_forward(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg, const double* stats_in,
+                                    void* pooled, void* pool_mask, void* seam_scratch, double* stats_out, int frames, int H, int W, int Cin, int Cout, int phases, void* stream);
+
 /* ---- GroupNorm `n` of a stack folded into its first residual block (CnnDownStack.forward, lib/impala_cnn.py:118-121: x = self.n(x);
  * for block in self.blocks: x = block(x)) -- inference.  The producer of the pooled tensor P stores Q = n.weight[c] * P (out_gain above);
  * x = n(P) = r_P Q + b[c] is never written:
@@ -366,6 +375,11 @@ int vpt_conv3x3_dgrad(const void* dacc, const void* wpk_t, const void* skip, con
  * (one read of one tensor instead of two reads and a write).  scratch as for vpt_conv_backward_prepare. */
 int vpt_conv3x3_dgrad_gated(const void* dacc, const void* wpk_t, const void* xin, const float* coef, const double* gate_stats, int gate_cin,
                             void* dacc_out, double* gate_u, int frames, int H, int W, int Cout, int Cin, void* stream);
+/* vpt_conv_backward_prepare for the layer in front of the max-pool when its forward was vpt_conv3x3_pool_argmax_forward: (dpooled, pooled,
+ * pool_mask) [F][Cout/32][H/2][W/2][32] in, dacc [F][Cout/32][H][W][32] and the same sums out.  The ReLU gate is [pooled > 0], the value at
+ * the arg-max is the pooled value itself.  H, W: the PRE-pool size (W in {16, 32, 64}). */
+int vpt_conv_backward_prepare_pooled(const void* dpooled, const void* pooled, const void* pool_mask, const double* stats_in, const float* edge_sa, const float* edge_sg,
+                                     void* dacc, double* t12, float* coef, float* d_sa, float* d_sg, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream);
 int vpt_conv_backward_reduce(const void* dacc, const double* gate_u, const double* stats_in, const float* edge_sa, const float* edge_sg,
                              double* t12, float* coef, float* d_sa, float* d_sg, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream);
 

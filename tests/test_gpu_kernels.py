@@ -133,6 +133,53 @@ def test_conv3x3_pool_fused(frames, h, w, cin, cout, fmt):
     assert torch.equal(big[1:1 + frames].view(torch.int16), want.view(torch.int16)) and not bool(big[0].any()) and not bool(big[-1].any())
 
 
+@pytest.mark.parametrize("frames,h,w,cin,cout", [(2, 64, 64, 64, 96), (3, 32, 32, 32, 256), (1, 16, 16, 64, 32), (2, 48, 32, 32, 160), (3, 16, 80, 96, 64), (1, 128, 128, 32, 128)])
+@pytest.mark.parametrize("fmt", ["bf16", "fp16"])
+def test_conv3x3_pool_argmax_masks(frames, h, w, cin, cout, fmt):
+    """Round 5, the TRAINING forward of firstconv -> max_pool2d (lib/impala_cnn.py:114-117): vpt_conv3x3_pool_argmax_forward gives the pooled
+    tensor of the two-kernel path BIT FOR BIT plus, per pooled value, the mask of window positions that hold the maximum.  Decoded with
+    torch's rule (first maximum in scan order = highest zero bit) the masks equal vpt_maxpool_forward's arg-max bytes wherever a gradient can
+    flow (pooled > 0; an all-zero window passes none either way), on tiles with row seams, column seams, both and none; and a bit is 0 exactly
+    where the pre-pool value equals the maximum (ties included), 1 outside the image."""
+    dt = torch.bfloat16 if fmt == "bf16" else torch.float16
+    g = torch.Generator().manual_seed(171)
+    W = torch.randn(cout, cin, 3, 3, generator=g) * (1.6 / (cin * 9) ** 0.5)
+    gain = 1 + 0.2 * torch.randn(cin, generator=g)
+    bias = 0.1 * torch.randn(cin, generator=g) - 0.6          # (shifted: a good share of exact zeros after the ReLU -> ties and all-zero windows)
+    x = (torch.relu(torch.randn(frames, cin, h, w, generator=g)) + 0.2 * torch.randn(frames, cin, h, w, generator=g)).to(dt)
+    wpk, sa, sg = ops.pack_conv3x3(W.to(DEV), gain.to(DEV), bias.to(DEV), dtype=dt)
+    xb = packing.nchw_to_blocked(x.float(), dtype=dt).to(DEV)
+    st_in = _stats_of(x.float()).to(DEV)
+    pre = ops.conv3x3(xb, wpk, sa, sg, st_in, cout)
+    st_a = torch.zeros(frames, 2, dtype=torch.float64, device=DEV)
+    want, am = ops.maxpool(pre, stats_out=st_a, want_argmax=True)
+    st_b = torch.zeros(frames, 2, dtype=torch.float64, device=DEV)
+    got, mask = ops.conv3x3_pool_argmax(xb, wpk, sa, sg, st_in, cout, stats_out=st_b)
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert torch.allclose(st_a, st_b, rtol=1e-6, atol=1e-3)
+    m = mask.to(torch.int32) & 0xffff
+    assert int(m.max()) <= 0x1ff
+    inv = (~m) & 0x1ff
+    assert bool((inv != 0).all())                                   # every window has a position that holds its maximum
+    code = 8 - torch.floor(torch.log2(inv.float())).to(torch.int32)   # first (scan order) zero bit: bit 8 - k for position k
+    live = want.float() > 0
+    assert float(live.float().mean()) > 0.2 and float((~live).float().mean()) > 0.01, float(live.float().mean())
+    assert torch.equal(code[live], am.to(torch.int32)[live]), f"{int((code[live] != am.to(torch.int32)[live]).sum())} arg-max positions differ"
+    assert bool((am[~live] == 15).all())
+    # every bit against the pre-pool tensor: 0 <=> inside the image and equal to the window maximum
+    pre_n = packing.blocked_to_nchw(pre.cpu(), cout, h, w).float()
+    pooled_n = packing.blocked_to_nchw(want.cpu(), cout, h // 2, w // 2).float()
+    mask_n = packing.blocked_to_nchw(m.cpu().to(torch.float32), cout, h // 2, w // 2).to(torch.int32)
+    padv = torch.nn.functional.pad(pre_n, (1, 1, 1, 1), value=float("nan"))
+    for k in range(9):
+        dy, dx = k // 3, k % 3
+        win = padv[:, :, dy:dy + h:2, dx:dx + w:2][:, :, :h // 2, :w // 2]
+        differs = ~(win == pooled_n)                                 # nan (outside the image) compares unequal
+        bit = (mask_n >> (8 - k)) & 1
+        assert torch.equal(bit.bool(), differs), (k, int((bit.bool() != differs).sum()))
+
+
 @pytest.mark.parametrize("frames,cout,h,w", [(2, 128, 128, 128), (1, 64, 128, 128), (1, 192, 128, 128), (5, 64, 32, 80), (3, 128, 48, 16)])
 def test_conv_first_pool(frames, cout, h, w):
     """(non-square frames: the persistent workgroups count tile coordinates up -- tile column, tile row, frame -- instead of decoding them)"""

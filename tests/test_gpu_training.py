@@ -465,6 +465,37 @@ def test_conv_prepare_fused_pool_backward():
     assert _l2(packing.blocked_to_nchw(got[0].cpu(), cout, h, h), exact) < 3e-3
 
 
+@pytest.mark.parametrize("fmt", ["bf16", "fp16"])
+@pytest.mark.parametrize("f,cin,cout,h,w", [(3, 64, 64, 32, 32), (2, 32, 128, 64, 64), (2, 64, 96, 16, 16), (1, 32, 32, 48, 32)])
+def test_conv_prepare_pooled_equals_prepare_with_argmax(f, cin, cout, h, w, fmt):
+    """Round 5: the backward of a pool-fused firstconv from (dpooled, pooled, arg-max masks) alone (vpt_conv_backward_prepare_pooled) against
+    round 4's path on the same layer -- vpt_conv_backward_prepare with the pre-pool tensor and vpt_maxpool_forward's arg-max bytes: the same
+    operand dacc (sums of at most four 16-bit gradients in fp32, one rounding), the same T1 / T2, coefficients and edge-table sums."""
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[fmt]
+    g = torch.Generator().manual_seed(177)
+    W = torch.randn(cout, cin, 3, 3, generator=g) * (1.6 / (cin * 9) ** 0.5)
+    gain, bias = 1 + 0.2 * torch.randn(cin, generator=g), 0.1 * torch.randn(cin, generator=g) - 0.4
+    x = torch.relu(torch.randn(f, cin, h, w, generator=g)).to(dt).float()
+    wpk, sa, sg = packing.pack_conv3x3(W.to(DEV), gain.to(DEV), bias.to(DEV), dtype=dt)
+    xb, st_in = packing.nchw_to_blocked(x, dtype=dt).to(DEV), _stats_of(x).to(DEV)
+    pre = ops.conv3x3(xb, wpk, sa, sg, st_in, cout)
+    pooled, am = ops.maxpool(pre, want_argmax=True)
+    pooled2, mask = ops.conv3x3_pool_argmax(xb, wpk, sa, sg, st_in, cout)
+    assert torch.equal(pooled.view(torch.int16), pooled2.view(torch.int16))
+    dp = packing.nchw_to_blocked(torch.randn(f, cout, h // 2, w // 2, generator=g) * (1e-2 if fmt == "fp16" else 1.0), dtype=dt).to(DEV)
+    ref = ops.conv_backward_prepare(None, pre, None, st_in, sa, sg, cin, dpooled=dp, argmax=am, want_t12=True)
+    got = ops.conv_backward_prepare_pooled(dp, pooled2, mask, st_in, sa, sg, cin, want_t12=True)
+    torch.cuda.synchronize()
+    a, r = got[0].float(), ref[0].float()
+    assert a.shape == r.shape == pre.shape
+    same = (got[0].view(torch.int16) == ref[0].view(torch.int16)) | ((a == 0) & (r == 0))
+    print(f"PARITY pooled prepare vs prepare + arg-max [{fmt}] {f}x{cin}->{cout} {h}x{w}: dacc identical at {float(same.float().mean()):.6f}, rel-L2 {_l2(a.cpu(), r.cpu()):.2e}; "
+          + " ".join(f"{n} {_l2(o.double().cpu(), q.double().cpu()):.2e}" for n, o, q in zip(("coef", "dsa", "dsg", "t12"), got[1:], ref[1:])))
+    assert float(same.float().mean()) > 0.9999 and _l2(a.cpu(), r.cpu()) < 1e-4
+    for o, q in zip(got[1:], ref[1:]):
+        assert _l2(o.double().cpu(), q.double().cpu()) < 1e-4
+
+
 def test_trainer_checkpoint_resume(trainer_1x, tmp_path):
     """Policy weights (.weights format) + BCTrainer.state_dict() restore a run: the resumed step equals the uninterrupted
     one up to the order of the fp32 atomics inside the backward (same inputs, same Adam moments and step count)."""

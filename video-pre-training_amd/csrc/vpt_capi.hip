@@ -95,7 +95,7 @@ int vpt_conv3x3_forward_tiled(const void* x, const void* wpk, const float* edge_
   if (!stats_in) return fail(-1, "vpt_conv3x3_forward: stats_in is required");
   if (tiling < 1 || tiling > 3) return fail(-1, "vpt_conv3x3_forward_tiled: tiling must be 1 (throughput), 2 (latency) or 3 (throughput, 32-row tiles)");
   VptConv3x3Args a;
-  a.gate_stats = nullptr; a.gate_u = nullptr; a.inv_count_gate = 0.0;
+  a.gate_stats = nullptr; a.gate_u = nullptr; a.inv_count_gate = 0.0; a.pool_mask = nullptr;
   a.tiling = tiling;
   a.x = (const vpt_op16*)x; a.wpk = (const vpt_op16*)wpk; a.edge_sa = edge_sa; a.edge_sg = edge_sg;
   a.stats_in = stats_in; a.res = (const vpt_op16*)res; a.y = (vpt_op16*)y; a.stats_out = stats_out;
@@ -115,7 +115,7 @@ int vpt_conv3x3_forward_folded(const void* x, const void* wpk, const float* edge
   if (res_bias && (!res || !res_scale)) return fail(-1, "vpt_conv3x3_forward_folded: res_bias needs res and res_scale");
   if (!edge_sg || (!kk_frame && !edge_sa)) return fail(-1, "vpt_conv3x3_forward_folded: edge tables missing");
   VptConv3x3Args a;
-  a.gate_stats = nullptr; a.gate_u = nullptr; a.inv_count_gate = 0.0;
+  a.gate_stats = nullptr; a.gate_u = nullptr; a.inv_count_gate = 0.0; a.pool_mask = nullptr;
   a.tiling = 1;
   a.x = (const vpt_op16*)x; a.wpk = (const vpt_op16*)wpk; a.edge_sa = edge_sa; a.edge_sg = edge_sg;
   a.stats_in = stats_in; a.res = (const vpt_op16*)res; a.y = (vpt_op16*)y; a.stats_out = stats_out;
@@ -148,21 +148,21 @@ int vpt_nfold_coef(const double* tot, const double* chs, const float* gain, cons
 
 int64_t vpt_conv3x3_pool_seam_elems(int frames, int H, int W, int Cout) { return (int64_t)frames * Cout * ((int64_t)(H / 16) * W + (int64_t)(W / 16) * H); }
 
-int vpt_conv3x3_pool_forward(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg, const double* stats_in,
-                             void* pooled, void* seam_scratch, double* stats_out, const float* out_gain, double* chs_out, int frames, int H, int W,
-                             int Cin, int Cout, int phases, void* stream) {
+static int conv3x3_pool_forward_impl(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg, const double* stats_in,
+                                     void* pooled, void* pool_mask, void* seam_scratch, double* stats_out, const float* out_gain, double* chs_out, int frames, int H, int W,
+                                     int Cin, int Cout, int phases, void* stream) {
   if (!stats_in || !pooled || !seam_scratch) return fail(-1, "vpt_conv3x3_pool_forward: stats_in, pooled and seam_scratch are required");
   if (phases < 1 || phases > 3) return fail(-1, "vpt_conv3x3_pool_forward: phases = 1 (tiles), 2 (seams) or 3 (both)");
   if ((H & 15) || (W & 15) || (Cout & 31)) return fail(-1, "vpt_conv3x3_pool_forward: H, W multiples of 16, Cout of 32");
   VptConv3x3Args a;
-  a.gate_stats = nullptr; a.gate_u = nullptr; a.inv_count_gate = 0.0;
+  a.gate_stats = nullptr; a.gate_u = nullptr; a.inv_count_gate = 0.0; a.pool_mask = nullptr;
   a.tiling = 1;
   a.x = (const vpt_op16*)x; a.wpk = (const vpt_op16*)wpk; a.edge_sa = edge_sa; a.edge_sg = edge_sg;
   a.stats_in = stats_in; a.res = nullptr; a.y = (vpt_op16*)pooled; a.stats_out = stats_out;
   a.frames = frames; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.NT = (Cout + 127) / 128; a.CoutPad = a.NT * 128;
   a.inv_count_in = 1.0 / ((double)Cin * H * W);
-  a.bwd = 0; a.xin = nullptr; a.coef = nullptr; a.pool = 1; a.out_gain = out_gain; a.chs_out = chs_out;
+  a.bwd = 0; a.xin = nullptr; a.coef = nullptr; a.pool = 1; a.out_gain = out_gain; a.chs_out = chs_out; a.pool_mask = (vpt_op16*)pool_mask;
   a.kk_frame = a.rs_frame = a.res_scale = a.res_bias = nullptr;
   a.seam_r = (vpt_op16*)seam_scratch;
   a.seam_c = a.seam_r + (size_t)frames * Cout * (H / 16) * W;
@@ -173,13 +173,26 @@ int vpt_conv3x3_pool_forward(const void* x, const void* wpk, const float* edge_s
   if (!(phases & 2)) return 0;
   VptPoolSeamArgs p;
   p.y = a.y; p.seam_r = a.seam_r; p.seam_c = a.seam_c; p.stats_out = stats_out; p.gain = out_gain; p.chs_out = chs_out; p.frames = frames; p.CB = Cout / 32; p.H = H; p.W = W;
+  p.mask = (vpt_op16*)pool_mask;
   CHECK_LAUNCH(vpt_pool_seam_launch(&p, (hipStream_t)stream), "vpt_conv3x3_pool_forward (seams)");
+}
+
+int vpt_conv3x3_pool_forward(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg, const double* stats_in,
+                             void* pooled, void* seam_scratch, double* stats_out, const float* out_gain, double* chs_out, int frames, int H, int W,
+                             int Cin, int Cout, int phases, void* stream) {
+  return conv3x3_pool_forward_impl(x, wpk, edge_sa, edge_sg, stats_in, pooled, nullptr, seam_scratch, stats_out, out_gain, chs_out, frames, H, W, Cin, Cout, phases, stream);
+}
+
+int vpt_conv3x3_pool_argmax_forward(const void* x, const void* wpk, const float* edge_sa, const float* edge_sg, const double* stats_in,
+                                    void* pooled, void* pool_mask, void* seam_scratch, double* stats_out, int frames, int H, int W, int Cin, int Cout, int phases, void* stream) {
+  if (!pool_mask) return fail(-1, "vpt_conv3x3_pool_argmax_forward: pool_mask is required");
+  return conv3x3_pool_forward_impl(x, wpk, edge_sa, edge_sg, stats_in, pooled, pool_mask, seam_scratch, stats_out, nullptr, nullptr, frames, H, W, Cin, Cout, phases, stream);
 }
 
 int vpt_conv3x3_dgrad(const void* dacc, const void* wpk_t, const void* skip, const void* xin, const float* coef, void* dx,
                       int frames, int H, int W, int Cout, int Cin, void* stream) {
   VptConv3x3Args a;
-  a.gate_stats = nullptr; a.gate_u = nullptr; a.inv_count_gate = 0.0;
+  a.gate_stats = nullptr; a.gate_u = nullptr; a.inv_count_gate = 0.0; a.pool_mask = nullptr;
   a.x = (const vpt_op16*)dacc; a.wpk = (const vpt_op16*)wpk_t; a.edge_sa = nullptr; a.edge_sg = nullptr;
   a.stats_in = nullptr; a.res = (const vpt_op16*)skip; a.y = (vpt_op16*)dx; a.stats_out = nullptr;
   a.frames = frames; a.H = H; a.W = W; a.Cin = Cout; a.Cout = Cin;   // roles swap in the transposed convolution
@@ -213,8 +226,22 @@ int vpt_conv_backward_reduce(const void* dacc, const double* gate_u, const doubl
   a.edge_sa = edge_sa; a.edge_sg = edge_sg; a.dacc = nullptr; a.t12 = t12; a.d_sa = d_sa; a.d_sg = d_sg;
   a.frames = frames; a.CB = Cout / 32; a.H = H; a.W = W; a.CoutPad = ((Cout + 127) / 128) * 128;
   a.inv_count_in = 1.0 / ((double)Cin * H * W);
-  a.gate_u = gate_u;
+  a.gate_u = gate_u; a.pooled = nullptr; a.pool_mask = nullptr;
   CHECK_LAUNCH(vpt_conv_bwd_prep_launch(&a, (hipStream_t)stream), "vpt_conv_backward_reduce");
+}
+
+int vpt_conv_backward_prepare_pooled(const void* dpooled, const void* pooled, const void* pool_mask, const double* stats_in, const float* edge_sa, const float* edge_sg,
+                                     void* dacc, double* t12, float* coef, float* d_sa, float* d_sg, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream) {
+  if (Cout & 31) return fail(-1, "vpt_conv_backward_prepare_pooled: Cout must be a multiple of 32");
+  if (!dpooled || !pooled || !pool_mask || !dacc) return fail(-1, "vpt_conv_backward_prepare_pooled: dpooled, pooled, pool_mask and dacc are required");
+  VptConvBwdPrepArgs a;
+  a.dpooled = (const vpt_op16*)dpooled; a.argmax = nullptr; a.sbuf = scratch; a.wshift = 0; a.coef = coef;
+  a.dy = nullptr; a.y = nullptr; a.res = nullptr; a.stats_in = stats_in;
+  a.edge_sa = edge_sa; a.edge_sg = edge_sg; a.dacc = (vpt_op16*)dacc; a.t12 = t12; a.d_sa = d_sa; a.d_sg = d_sg;
+  a.frames = frames; a.CB = Cout / 32; a.H = H; a.W = W; a.CoutPad = ((Cout + 127) / 128) * 128;
+  a.inv_count_in = 1.0 / ((double)Cin * H * W);
+  a.gate_u = nullptr; a.pooled = (const vpt_op16*)pooled; a.pool_mask = (const vpt_op16*)pool_mask;
+  CHECK_LAUNCH(vpt_conv_bwd_prep_launch(&a, (hipStream_t)stream), "vpt_conv_backward_prepare_pooled");
 }
 
 int vpt_conv_backward_prepare(const void* dy, const void* dpooled, const uint8_t* argmax, const void* y, const void* res,
@@ -227,7 +254,7 @@ int vpt_conv_backward_prepare(const void* dy, const void* dpooled, const uint8_t
   a.edge_sa = edge_sa; a.edge_sg = edge_sg; a.dacc = (vpt_op16*)dacc; a.t12 = t12; a.d_sa = d_sa; a.d_sg = d_sg;
   a.frames = frames; a.CB = Cout / 32; a.H = H; a.W = W; a.CoutPad = ((Cout + 127) / 128) * 128;
   a.inv_count_in = 1.0 / ((double)Cin * H * W);
-  a.gate_u = nullptr;
+  a.gate_u = nullptr; a.pooled = nullptr; a.pool_mask = nullptr;
   CHECK_LAUNCH(vpt_conv_bwd_prep_launch(&a, (hipStream_t)stream), "vpt_conv_backward_prepare");
 }
 

@@ -451,6 +451,165 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_kernel(VptConvBwdPrepAr
   for (int i = threadIdx.x; i < 9 * 32; i += 256) srow[(i >> 5) * Cout + cb * 32 + (i & 31)] = tab_[i];
 }
 
+// ------------------------------------------------------------------------------------------------
+// vpt_conv_bwd_prep_pooled (round 5): the same preparation for the layer in front of the max-pool when its forward was the pool-fused
+// convolution with arg-max masks (vpt_conv3x3_kernel mode 7) -- no pre-pool tensor, no arg-max bytes.  Inputs at POOLED resolution:
+// dpooled, the pooled tensor P (the ReLU gate is [P > 0] and the layer's value at the arg-max is P itself) and the 9-bit masks.
+// Thread = (channel octet, pooled column, row phase) OWNS pooled pixel (py, px) and the 2 x 2 block of pre-pool pixels (2 py + a, 2 px + b):
+// every pooled value is loaded once (the gather form above reads each four times), turned into (gated gradient, arg-max position) and
+// shared with the three neighbours that own parts of its window through LDS.  Pre-pool pixel (2py+a, 2px+b) collects
+//     (0,0): window (py,px) position 4          (0,1): (py,px) 5 + (py,px+1) 3
+//     (1,0): (py,px) 7 + (py+1,px) 1            (1,1): (py,px) 8 + (py,px+1) 6 + (py+1,px) 2 + (py+1,px+1) 0
+// -- positions 0..3 and 6 of a window lie in the blocks of the threads above / to the left.  Rows are processed in passes of 64 / PW pooled
+// rows; a pass's entries go to one of two LDS buffers, the row below the pass's last row comes from the next pass's buffer.
+struct PoolEntry { u32x4 g; uint32_t codes; };   // gated gradient (8 x 16 bit), arg-max position per channel (8 x 4 bit)
+
+__global__ __launch_bounds__(256) void vpt_conv_bwd_prep_pooled_kernel(VptConvBwdPrepArgs a) {
+  __shared__ float tab_[9 * 32];
+  __shared__ __attribute__((aligned(16))) u32x4 gbuf_[2][64][4];
+  __shared__ uint32_t cbuf_[2][64][4];
+  __shared__ float red_[4];
+  const int PH = a.H >> 1, PW = a.W >> 1, pwshift = a.wshift - 1;
+  const int cb = blockIdx.x % a.CB, f = blockIdx.x / a.CB;
+  float mean, rstd;
+  frame_mean_rstd(a.stats_in, f, a.inv_count_in, mean, rstd);
+  for (int i = threadIdx.x; i < 9 * 32; i += 256) tab_[i] = 0.f;
+  const int oct = threadIdx.x & 3, slot = threadIdx.x >> 2;
+  const int px = slot & (PW - 1), ph = slot >> pwshift, R = 64 >> pwshift;     // R pooled rows per pass
+  const int NP = PH / R;
+  const size_t pplane = ((size_t)(f * a.CB + cb) * PH * PW) * 32 + oct * 8;
+  const size_t plane = ((size_t)(f * a.CB + cb) * a.H * a.W) * 32 + oct * 8;
+  float allE[8], allO[8], topE[8], topO[8], botE[8], botO[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) allE[k] = allO[k] = topE[k] = topO[k] = botE[k] = botO[k] = 0.f;
+  float tv = 0.f;
+  u32x4 rd, rp, rm;                         // this thread's pooled pixel of the pass being loaded: gradient, pooled value, mask
+  auto load_pass = [&](int p) {
+    const size_t off = pplane + (size_t)((p * R + ph) * PW + px) * 32;
+    rd = VPT_LD_STREAM((const u32x4*)(a.dpooled + off));
+    rp = VPT_LD_STREAM((const u32x4*)(a.pooled + off));
+    rm = VPT_LD_STREAM((const u32x4*)(a.pool_mask + off));
+  };
+  auto make_entry = [&](int p) -> PoolEntry {     // the thread's own entry stays in registers; the neighbours read the LDS copy
+    PoolEntry e;
+    float df[8], pf[8];
+    unpack8(rd, df);
+    unpack8(rp, pf);
+    uint32_t codes = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t pw_ = rp[j], mw = rm[j];
+      const bool o0 = (short)(pw_ & 0xffffu) > 0, o1 = (short)(pw_ >> 16) > 0;          // ReLU gate: the pooled value is the layer's output at the arg-max
+      e.g[j] = rd[j] & ((o0 ? 0xffffu : 0u) | (o1 ? 0xffff0000u : 0u));
+      tv = fmaf(o0 ? df[2 * j] : 0.f, pf[2 * j], tv);
+      tv = fmaf(o1 ? df[2 * j + 1] : 0.f, pf[2 * j + 1], tv);
+      // first position (scan order) that holds the maximum = highest zero bit of the 9-bit mask
+      const uint32_t i0 = ~mw & 0x1ffu, i1 = ~(mw >> 16) & 0x1ffu;
+      const uint32_t k0 = (uint32_t)__builtin_clz(i0 | 1u) - 23u, k1 = (uint32_t)__builtin_clz(i1 | 1u) - 23u;   // (| 1: a mask without a zero bit cannot occur; stay defined)
+      codes |= (k0 | (k1 << 4)) << (8 * j);
+    }
+    e.codes = codes;
+    gbuf_[p & 1][slot][oct] = e.g;
+    cbuf_[p & 1][slot][oct] = codes;
+    return e;
+  };
+  // contribution of entry (g, codes) to the pre-pool pixel where it sits at window position `pos`
+  auto add_if = [&](float (&dz)[8], const u32x4& g, uint32_t codes, uint32_t pos) {
+    float gf[8];
+    unpack8(g, gf);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dz[k] += (((codes >> (4 * k)) & 15u) == pos) ? gf[k] : 0.f;
+  };
+  auto emit_pass = [&](int p, const PoolEntry& e00) {
+    const int py = p * R + ph;
+    const bool has_r = px + 1 < PW, has_b = py + 1 < PH;
+    // neighbours: right (same row), below / below-right (next row: the next slot row of this pass, or row 0 of the next pass)
+    const int bb = (ph + 1 < R) ? (p & 1) : ((p + 1) & 1);
+    const int bslot = (ph + 1 < R) ? slot + PW : px;
+    u32x4 g01 = {0u, 0u, 0u, 0u}, g10 = g01, g11 = g01;
+    uint32_t c01 = 0xffffffffu, c10 = 0xffffffffu, c11 = 0xffffffffu;                 // position 15 matches nothing
+    if (has_r) { g01 = gbuf_[p & 1][slot + 1][oct]; c01 = cbuf_[p & 1][slot + 1][oct]; }
+    if (has_b) { g10 = gbuf_[bb][bslot][oct]; c10 = cbuf_[bb][bslot][oct]; }
+    if (has_r && has_b) { g11 = gbuf_[bb][bslot + 1][oct]; c11 = cbuf_[bb][bslot + 1][oct]; }
+    float d00[8], d01[8], d10[8], d11[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d00[k] = d01[k] = d10[k] = d11[k] = 0.f;
+    add_if(d00, e00.g, e00.codes, 4u);
+    add_if(d01, e00.g, e00.codes, 5u); add_if(d01, g01, c01, 3u);
+    add_if(d10, e00.g, e00.codes, 7u); add_if(d10, g10, c10, 1u);
+    add_if(d11, e00.g, e00.codes, 8u); add_if(d11, g01, c01, 6u); add_if(d11, g10, c10, 2u); add_if(d11, g11, c11, 0u);
+    const bool is_top = (py == 0), is_bot = (py == PH - 1);
+    float o00[8], o01[8], o10[8], o11[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      allE[k] += d00[k] + d10[k];
+      allO[k] += d01[k] + d11[k];
+      topE[k] = is_top ? d00[k] : topE[k];
+      topO[k] = is_top ? d01[k] : topO[k];
+      botE[k] = is_bot ? d10[k] : botE[k];
+      botO[k] = is_bot ? d11[k] : botO[k];
+      o00[k] = d00[k] * rstd; o01[k] = d01[k] * rstd; o10[k] = d10[k] * rstd; o11[k] = d11[k] * rstd;
+    }
+    vpt_op16* dst = a.dacc + plane + (size_t)((2 * py) * a.W + 2 * px) * 32;
+    VPT_ST_STREAM(pack8(o00), (u32x4*)dst);
+    VPT_ST_STREAM(pack8(o01), (u32x4*)(dst + 32));
+    VPT_ST_STREAM(pack8(o10), (u32x4*)(dst + (size_t)a.W * 32));
+    VPT_ST_STREAM(pack8(o11), (u32x4*)(dst + (size_t)a.W * 32 + 32));
+  };
+  load_pass(0);
+  PoolEntry cur = make_entry(0), nxt = cur;
+  if (NP > 1) load_pass(1);
+  __syncthreads();
+  for (int p = 0; p < NP; ++p) {
+    if (p + 1 < NP) nxt = make_entry(p + 1); // (waits for the loads issued one iteration ago)
+    if (p + 2 < NP) load_pass(p + 2);
+    __syncthreads();                         // entries of pass p + 1 visible
+    emit_pass(p, cur);
+    cur = nxt;
+    __syncthreads();                         // buffer p & 1 is free for pass p + 2
+  }
+  // ---- S[ey][ex][channel] of the thread's even / odd pre-pool column, as in the kernel above ----
+  const int lane = threadIdx.x & 63;
+  auto reduce_col = [&](int ex, float (&all)[8], float (&top)[8], float (&bot)[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) all[k] -= top[k] + bot[k];
+    float red[24];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      red[k] = (ex == 1) ? top[k] : 0.f;
+      red[8 + k] = (ex == 1) ? all[k] : 0.f;
+      red[16 + k] = (ex == 1) ? bot[k] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 24; ++i) red[i] = sum_oct16(red[i]);
+    if (lane < 4) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        atomicAdd(&tab_[(0 * 3 + 1) * 32 + oct * 8 + k], red[k]);
+        atomicAdd(&tab_[(1 * 3 + 1) * 32 + oct * 8 + k], red[8 + k]);
+        atomicAdd(&tab_[(2 * 3 + 1) * 32 + oct * 8 + k], red[16 + k]);
+      }
+    }
+    if (ex != 1) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        atomicAdd(&tab_[(0 * 3 + ex) * 32 + oct * 8 + k], top[k]);
+        atomicAdd(&tab_[(1 * 3 + ex) * 32 + oct * 8 + k], all[k]);
+        atomicAdd(&tab_[(2 * 3 + ex) * 32 + oct * 8 + k], bot[k]);
+      }
+    }
+  };
+  reduce_col(px == 0 ? 0 : 1, allE, topE, botE);
+  reduce_col(px == PW - 1 ? 2 : 1, allO, topO, botO);
+  tv = wave_sum(tv);
+  if (lane == 0) red_[threadIdx.x >> 6] = tv;
+  __syncthreads();
+  const int Cout = a.CB * 32;
+  float* srow = a.sbuf + (size_t)f * (9 * Cout + a.CB);
+  if (threadIdx.x == 0) srow[9 * Cout + cb] = (red_[0] + red_[1]) + (red_[2] + red_[3]);
+  for (int i = threadIdx.x; i < 9 * 32; i += 256) srow[(i >> 5) * Cout + cb * 32 + (i & 31)] = tab_[i];
+}
+
 #define FIN_FB 32  // frames per column-sum workgroup
 // finish, one launch with two kinds of workgroups (all independent, so the launch is one round of loads deep):
 //   blocks [0, ceil(F/4)):  one WAVE per frame: T1, T2 and the (c0, c1) coefficients from that frame's row of sbuf;
@@ -515,6 +674,18 @@ extern "C" int vpt_conv_bwd_prep_launch(const VptConvBwdPrepArgs* a0, hipStream_
   VptConvBwdPrepArgs a = *a0;
   if (a.frames <= 0 || !a.sbuf || !a.coef) return -1;
   if (a.gate_u && (!a.dy || a.res)) return -1;
+  if (a.pooled) {      // pool-fused forward with arg-max masks: the pooled-resolution kernel
+    if (a.dy || a.res || !a.dpooled || !a.pool_mask || !a.dacc || a.W < 16 || a.W > 64 || (a.W & (a.W - 1)) || (a.H & 1)) return -1;
+    a.wshift = 31 - __builtin_clz((unsigned)a.W);
+    const int PW = a.W >> 1, PH = a.H >> 1, R = 64 / PW;
+    if (PH % R) return -1;
+    const long gridp = (long)a.frames * a.CB;
+    if (gridp > 0x7fffffffL) return -2;
+    hipLaunchKernelGGL(vpt_conv_bwd_prep_pooled_kernel, dim3((unsigned)gridp), dim3(256), 0, stream, a);
+    const int fin_blocks_p = (a.frames + 3) / 4 + ((9 * a.CB * 32 + 255) / 256) * ((a.frames + FIN_FB - 1) / FIN_FB);
+    hipLaunchKernelGGL(vpt_conv_bwd_finish_kernel, dim3((unsigned)fin_blocks_p), dim3(256), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+  }
   if (a.W < 8 || a.W > 64 || (a.W & (a.W - 1))) return -1;  // column-per-thread mapping: W in {8,16,32,64}
   if (!a.dy && (!a.dpooled || !a.argmax || (a.H & 1) || (a.W & 1))) return -1;
   a.wshift = 31 - __builtin_clz((unsigned)a.W);

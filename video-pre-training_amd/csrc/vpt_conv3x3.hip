@@ -84,7 +84,7 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
   constexpr int A_SZ = HPIX * A_RS, KK_O = A_SZ + 2 * B_BYTES, BT_O = KK_O + KK_BYTES + 64, SMEM_SZ = BT_O + 512;
   constexpr int NKK = (9 * 128 + NTHR - 1) / NTHR;
   static_assert(TR != 16 || (A_SZ == A_BYTES && KK_O == KK_OFF && SMEM_SZ <= SMEM_BYTES), "16-row layout");
-  static_assert(MODE != 4 || TR == 16, "the pool-fused epilogue is written for 16 x 16 tiles");
+  static_assert((MODE != 4 && MODE != 7) || TR == 16, "the pool-fused epilogue is written for 16 x 16 tiles");
   // 5 forward + residual through a per-frame affine:  out = relu(...) + res_scale[f] * res + res_bias[f][channel]  -- the block that
   // follows a stack's GroupNorm `n` reads the pooled tensor itself (already multiplied by n's gain) instead of a normalised copy
   // (lib/impala_cnn.py:118-121 with the `n` pass folded away).
@@ -93,7 +93,13 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
   // (rstd0: the statistics of conv0's INPUT, gate_stats) is written instead of dy -- vpt_conv_bwd_prep_kernel's pass over (dy, y) -> dacc
   // shrinks to a reduction over dacc0 alone; gate_u[f] += sum rstd0 * dy * xin (= rstd0 * sum dz v: T1's data term; closed gates add 0).
   constexpr bool GATE = MODE == 6;
-  constexpr bool BWD = (MODE == 2 || MODE == 3 || MODE == 6), HAS_RES = (MODE == 1 || MODE == 3 || MODE == 5), USE_X = BWD, POOL = MODE == 4, RES_AFF = MODE == 5;
+  // 7 = mode 4 for the TRAINING forward (round 5): the pooled tensor plus, per pooled value, which window positions hold the maximum -- a 9-bit
+  // "differs from the maximum" mask per 16-bit lane (bit 8 - k for scan position k = 3 (dy + 1) + (dx + 1); positions outside the tile or the
+  // image: 1), pool_mask [F][Cout/32][H/2][W/2][32] uint16.  The backward routes the pooled gradient to the FIRST zero bit (torch's tie rule)
+  // and needs neither the pre-pool tensor nor vpt_pool_kernel (vpt_conv_bwd_prep_pooled_kernel).  Measured cost of the masks: +5 % of the
+  // K = 1152 pool-fused launch, +2.5 % of the K = 2304 one (profiles/r05_experiments.md).
+  constexpr bool PMASK = MODE == 7;
+  constexpr bool BWD = (MODE == 2 || MODE == 3 || MODE == 6), HAS_RES = (MODE == 1 || MODE == 3 || MODE == 5), USE_X = BWD, POOL = (MODE == 4 || MODE == 7), RES_AFF = MODE == 5;
   constexpr bool DEFER_STORES = MODE != 3;   // mode 3 holds skip + xin pieces as well: no registers left for the packed results
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_SZ];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -689,9 +695,7 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
       const int cg = nt * 128 + oct * 8;
       const unsigned char* src = smem + oct * 16;
       i16x8 mx = {0, 0, 0, 0, 0, 0, 0, 0};
-#ifdef VPT_POOL_ARGMASK_PROBE
-      i16x8 vv[9];
-#endif
+      i16x8 vv[PMASK ? 9 : 1];
 #pragma unroll
       for (int dy = -1; dy <= 1; ++dy) {
         const int r = 2 * pj + dy;
@@ -700,39 +704,34 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
           const int c = 2 * pi + dx;
           const i16x8 v = *(const i16x8*)(src + (max(r, 0) * 16 + max(c, 0)) * PT_RS);     // (clamped: the duplicate does not change a maximum)
           mx = __builtin_elementwise_max(mx, v);
-#ifdef VPT_POOL_ARGMASK_PROBE
-          vv[(dy + 1) * 3 + dx + 1] = v;
-#endif
+          if (PMASK) vv[PMASK ? (dy + 1) * 3 + dx + 1 : 0] = v;
         }
       }
-#ifdef VPT_POOL_ARGMASK_PROBE
-      // PROFILING BUILD ONLY (tools/build_variant.sh argmask -DVPT_POOL_ARGMASK_PROBE; round 5, VERDICT r4 item 1a "measure the +VALU"): what would
-      // it cost this epilogue to ALSO emit, per pooled value, which window positions hold the maximum -- the cheapest formulation found: a
-      // 9-bit "differs from the maximum" mask per 16-bit lane (xor, packed min with 1, packed 2 m + b: three packed instructions per
-      // position and channel pair; the backward would take the first zero bit) stored as a second 16-bit tensor behind the pooled one
-      // (the caller of a probe build allocates y twice as large).  Timing only: the seam pixels' masks are the in-tile ones.
-      {
-        // (inline asm: left to the compiler the 16-bit lanes are scalarised into v_cmp_ne_u16 + v_cndmask pairs, 930 instructions instead of 430)
+      if constexpr (PMASK) {
+        // which positions hold the maximum: per position and channel pair xor, packed min with 1 (0: equal), m = 2 m + b -- three packed
+        // instructions (inline asm: left to the compiler the 16-bit lanes are scalarised into v_cmp_ne_u16 + v_cndmask pairs, 930 instructions
+        // per thread instead of 430).  Positions outside the tile (clamped reads above: duplicates) or the image count as "differs"; the seam
+        // kernel fills in the bits of the neighbouring tiles' row / column for the pixels it finishes.
         const u32x4 mxu = __builtin_bit_cast(u32x4, mx);
         u32x4 mk = {0u, 0u, 0u, 0u};
         const uint32_t one2 = 0x00010001u, two2 = 0x00020002u;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
           const u32x4 vk = __builtin_bit_cast(u32x4, vv[k]);
+          const bool inside = (2 * pj + k / 3 - 1 >= 0) && (2 * pi + k % 3 - 1 >= 0);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            uint32_t t = vk[j] ^ mxu[j], b, m2;
+            uint32_t t = inside ? (vk[j] ^ mxu[j]) : 0xffffffffu, b, m2;
             asm("v_pk_min_u16 %0, %1, %2" : "=v"(b) : "v"(t), "s"(one2));
             asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(m2) : "v"(mk[j]), "s"(two2), "v"(b));
             mk[j] = m2;
           }
         }
         if (cg < a.Cout) {
-          const size_t moff = (size_t)a.frames * a.Cout * PH * PW + ((size_t)(f * CB_out + (cg >> 5)) * PH * PW + (size_t)(((ty0 >> 1) + pj) * PW + (tx0 >> 1) + pi)) * 32 + (cg & 31);
-          *(u32x4*)(a.y + moff) = __builtin_bit_cast(u32x4, mk);
+          const size_t moff = ((size_t)(f * CB_out + (cg >> 5)) * PH * PW + (size_t)(((ty0 >> 1) + pj) * PW + (tx0 >> 1) + pi)) * 32 + (cg & 31);
+          *(u32x4*)(a.pool_mask + moff) = mk;
         }
       }
-#endif
       if (cg < a.Cout) {
         u32x4 mv = __builtin_bit_cast(u32x4, mx);
         const size_t off = ((size_t)(f * CB_out + (cg >> 5)) * PH * PW + (size_t)(((ty0 >> 1) + pj) * PW + (tx0 >> 1) + pi)) * 32 + (cg & 31);
@@ -1051,7 +1050,8 @@ extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream
   if ((a->H & 15) || (a->W & 15) || (a->Cin & 31) || (a->Cout & 31) || a->frames <= 0) return -1;
   const long grid = (long)a->frames * (a->H >> 4) * (a->W >> 4) * a->NT;
   if (grid > 0x7fffffffL) return -2;
-  const int mode = a->bwd ? (a->res ? 3 : (a->gate_stats ? 6 : 2)) : (a->pool ? 4 : (a->res ? (a->res_bias ? 5 : 1) : 0));
+  const int mode = a->bwd ? (a->res ? 3 : (a->gate_stats ? 6 : 2)) : (a->pool ? (a->pool_mask ? 7 : 4) : (a->res ? (a->res_bias ? 5 : 1) : 0));
+  if (a->pool_mask && !a->pool) return -1;
   if (a->gate_stats && (!a->bwd || a->res || !a->gate_u || a->trace)) return -1;   // the gated dgrad: no skip connection (a block's conv1 -> conv0)
   if ((a->res_bias != nullptr) != (a->res_scale != nullptr) || (a->res_bias && (a->bwd || !a->res))) return -1;
   if ((a->kk_frame != nullptr) != (a->rs_frame != nullptr) || (a->kk_frame && a->bwd)) return -1;
@@ -1069,6 +1069,7 @@ extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream
 #define LAUNCH_(T_, M_) hipLaunchKernelGGL((vpt_conv3x3_kernel<T_, M_>), dim3((unsigned)grid), dim3(256), extra_lds, stream, *a)
   if (a->trace && mode > 3) return -1;
   if (mode == 6) { LAUNCH_(false, 6); return hipGetLastError() == hipSuccess ? 0 : -3; }
+  if (mode == 7) { LAUNCH_(false, 7); return hipGetLastError() == hipSuccess ? 0 : -3; }
   // tiling 3 (forward) = the 32-row, eight-wave tiles wherever the image has whole 32-row bands.  Measured at parity with the 16-row tiles on
   // every layer shape (profiles/r04_experiments.md section 7: halving the weight DMA buys nothing on a power-limited chip), so the shipped
   // choice stays the 16-row kernel; the variant is kept selectable because it is bit-identical per pixel and covered by the same tests.
@@ -1119,12 +1120,15 @@ __global__ __launch_bounds__(256) void vpt_pool_seam_kernel(VptPoolSeamArgs a) {
     }
     vpt_op16* yp = a.y + (plane * PH * PW + (size_t)(J * PW + I)) * 32 + oct * 8;
     i16x8 m = *(const i16x8*)yp;
+    const i16x8 m_in = m;                      // the in-tile part of the maximum (what the convolution's epilogue stored)
+    i16x8 sv[6];                               // the window positions outside the tile: row above (k = 0, 1, 2), column to the left (k = 0, 3, 6)
+    bool have[6] = {false, false, false, false, false, false};
     if ((J & 7) == 0 && J > 0) {
       const vpt_op16* sr = a.seam_r + ((plane * TY + (J >> 3) - 1) * a.W) * 32 + oct * 8;
 #pragma unroll
       for (int dx = -1; dx <= 1; ++dx) {
         const int x = 2 * I + dx;
-        if (x >= 0) m = __builtin_elementwise_max(m, *(const i16x8*)(sr + (size_t)x * 32));
+        if (x >= 0) { sv[dx + 1] = *(const i16x8*)(sr + (size_t)x * 32); have[dx + 1] = true; m = __builtin_elementwise_max(m, sv[dx + 1]); }
       }
     }
     if ((I & 7) == 0 && I > 0) {
@@ -1132,8 +1136,26 @@ __global__ __launch_bounds__(256) void vpt_pool_seam_kernel(VptPoolSeamArgs a) {
 #pragma unroll
       for (int dy = -1; dy <= 1; ++dy) {
         const int y = 2 * J + dy;
-        if (y >= 0) m = __builtin_elementwise_max(m, *(const i16x8*)(sc + (size_t)y * 32));
+        if (y >= 0) { sv[3 + dy + 1] = *(const i16x8*)(sc + (size_t)y * 32); have[3 + dy + 1] = true; m = __builtin_elementwise_max(m, sv[3 + dy + 1]); }
       }
+    }
+    if (a.mask) {
+      // arg-max masks of the training forward (vpt_conv3x3_kernel mode 7: bit 8 - k set = position k differs from the maximum): the in-tile bits
+      // stay valid only where the in-tile maximum IS the window's maximum; the positions this kernel adds get their bits here
+      typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+      unsigned short* mp = (unsigned short*)a.mask + (plane * PH * PW + (size_t)(J * PW + I)) * 32 + oct * 8;
+      u16x8 mk = *(const u16x8*)mp;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        unsigned bits = (m_in[c] == m[c]) ? (unsigned)mk[c] : 0x1ffu;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const int k = q < 3 ? q : 3 * (q - 3);            // scan position of seam value q
+          if (have[q] && sv[q][c] == m[c]) bits &= ~(1u << (8 - k));
+        }
+        mk[c] = (unsigned short)bits;
+      }
+      *(u16x8*)mp = mk;
     }
     float vals[8];
     u32x4 mv = __builtin_bit_cast(u32x4, m);

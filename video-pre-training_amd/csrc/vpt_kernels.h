@@ -36,6 +36,7 @@ struct VptConv3x3Args {
   int pool;
   vpt_op16* seam_r;
   vpt_op16* seam_c;
+  vpt_op16* pool_mask;     // pool mode, optional (training forward, mode 7): per pooled value the 9-bit "window position differs from the maximum" mask, uint16
   double* chs_out;         // pool mode, optional [F][Cout][2], accumulated: per-channel (sum, sum of squares) of the stored complete pixels
   const float* out_gain;   // pool mode, optional [Cout]: the pooled pixels that are complete in-tile are stored multiplied by it (GroupNorm `n`'s gain,
                            // folded: the seam kernel does the same for the others); the statistics are those of the unscaled values
@@ -81,6 +82,7 @@ struct VptPoolSeamArgs {    // finishes the pooled pixels whose 3x3 window cross
   const float* gain;       // optional [CB*32]: the finished pixels are stored multiplied by it (statistics: of the unscaled values)
   double* chs_out;         // optional [F][CB*32][2], accumulated: per-channel (sum, sum of squares) of the finished pixels as stored
   int frames, CB, H, W;    // H, W: the PRE-pool size
+  vpt_op16* mask;          // optional (training forward): the arg-max masks [F][CB][H/2][W/2][32] uint16 of vpt_conv3x3_kernel mode 7, finished here
 };
 
 struct VptPackConvArgs {
@@ -242,6 +244,10 @@ struct VptConvBwdPrepArgs {
   // pre-gated variant (round 5): `dy` IS the operand dacc = rstd dz already (written by the gated dgrad, vpt_conv3x3_kernel mode 6); y, res and
   // dacc are unused, nothing is written but the per-frame sums: S[e][o] = (sum dacc) / rstd, and the data term sum dz v = gate_u[f] / rstd
   const double* gate_u;
+  // pooled variant (round 5; dy, y, res, argmax unused): the layer feeds the max-pool and was run pool-fused with arg-max masks (vpt_conv3x3_kernel
+  // mode 7): pooled P [F][CB][H/2][W/2][32] and pool_mask (same shape, uint16) replace the pre-pool tensor and the arg-max bytes
+  const vpt_op16* pooled;
+  const vpt_op16* pool_mask;
 };
 
 struct VptConvFirstBwdArgs {

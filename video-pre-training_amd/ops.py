@@ -233,6 +233,50 @@ def conv3x3_pool(x, wpk, edge_sa, edge_sg, stats_in, cout, stats_out=None, out=N
     return y
 
 
+def conv3x3_pool_argmax(x, wpk, edge_sa, edge_sg, stats_in, cout, stats_out=None):
+    """conv3x3_pool() for the TRAINING forward (vpt_conv3x3_pool_argmax_forward): -> (pooled [F,cout/32,H/2,W/2,32], mask int16 of the same shape).
+    mask: per pooled value the 9-bit "window position differs from the maximum" word (bit 8 - k for scan position k; outside the image: 1) --
+    conv_backward_prepare_pooled() routes the pooled gradient to the first zero bit; the pre-pool tensor never exists."""
+    _chk(x, OP16, "x"); _chk(wpk, OP16, "wpk"); _chk(edge_sa, torch.float32, "edge_sa"); _chk(edge_sg, torch.float32, "edge_sg")
+    _chk(stats_in, torch.float64, "stats_in"); _chk(stats_out, torch.float64, "stats_out")
+    f, cb, h, w, _ = x.shape
+    dt, fmt = _fmt(x, wpk)
+    y = torch.empty(f, cout // 32, h // 2, w // 2, 32, dtype=dt, device=x.device)
+    mask = torch.empty(f, cout // 32, h // 2, w // 2, 32, dtype=torch.int16, device=x.device)
+    seam = torch.empty(_native.load(fmt).vpt_conv3x3_pool_seam_elems(f, h, w, cout), dtype=dt, device=x.device)
+    meta = dict(flops=2.0 * f * h * w * cout * 9 * cb * 32, bytes=2.0 * f * h * w * (cb * 32 + cout * 0.5))
+    args = (ptr(x), ptr(wpk), ptr(edge_sa), ptr(edge_sg), ptr(stats_in), ptr(y), ptr(mask), ptr(seam), ptr(stats_out), f, h, w, cb * 32, cout)
+    if TIMER.enabled:    # the two launches timed apart, as in conv3x3_pool()
+        _call("vpt_conv3x3_pool_argmax_forward", meta, *args, 1, _stream(), fmt=fmt, label="vpt_conv3x3_pool_forward")
+        _call("vpt_conv3x3_pool_argmax_forward", dict(bytes=2.0 * y.numel() * 0.8), *args, 2, _stream(), fmt=fmt, label="vpt_pool_seam")
+    else:
+        _call("vpt_conv3x3_pool_argmax_forward", meta, *args, 3, _stream(), fmt=fmt)
+    return y, mask
+
+
+def conv_backward_prepare_pooled(dpooled, pooled, mask, stats_in, edge_sa, edge_sg, cin, d_sa=None, d_sg=None, want_t12=False):
+    """conv_backward_prepare() for the layer in front of the max-pool when its forward was conv3x3_pool_argmax(): (dpooled, pooled, mask) at the
+    pooled resolution -> (dacc blocked [F,Cout/32,2h,2w,32], coef, d_sa, d_sg[, t12]) (vpt_conv_backward_prepare_pooled)."""
+    _chk(dpooled, OP16, "dpooled"); _chk(pooled, OP16, "pooled"); _chk(mask, torch.int16, "mask")
+    _chk(stats_in, torch.float64, "stats_in"); _chk(edge_sa, torch.float32, "edge_sa"); _chk(edge_sg, torch.float32, "edge_sg")
+    _chk(d_sa, torch.float32, "d_sa"); _chk(d_sg, torch.float32, "d_sg")
+    if dpooled.shape != pooled.shape or mask.shape != pooled.shape:
+        raise ValueError("conv_backward_prepare_pooled: dpooled, pooled and mask must have one shape")
+    f, cb, ph, pw, _ = pooled.shape
+    h, w = 2 * ph, 2 * pw
+    dev = pooled.device
+    dt, fmt = _fmt(dpooled, pooled)
+    dacc = torch.empty(f, cb, h, w, 32, dtype=dt, device=dev)
+    coef = torch.empty(f, 2, dtype=torch.float32, device=dev)
+    t12 = torch.empty(f, 2, dtype=torch.float64, device=dev) if want_t12 else None
+    if d_sa is None:
+        d_sa, d_sg = torch.zeros_like(edge_sa), torch.zeros_like(edge_sg)
+    scratch = torch.empty(f, 9 * cb * 32 + cb, dtype=torch.float32, device=dev)
+    _call("vpt_conv_backward_prepare_pooled", dict(bytes=2.0 * dacc.numel() + 6.0 * pooled.numel()), ptr(dpooled), ptr(pooled), ptr(mask), ptr(stats_in), ptr(edge_sa), ptr(edge_sg),
+          ptr(dacc), ptr(t12), ptr(coef), ptr(d_sa), ptr(d_sg), ptr(scratch), f, h, w, cin, cb * 32, _stream(), fmt=fmt, label="vpt_conv_backward_prepare")
+    return (dacc, coef, d_sa, d_sg, t12) if want_t12 else (dacc, coef, d_sa, d_sg)
+
+
 def conv3x3_folded(x, wpk, edge_sa, edge_sg, stats_in, cout, kk_frame=None, rs_frame=None, res=None, res_scale=None, res_bias=None, stats_out=None, out=None):
     """conv3x3() with the GroupNorm `n` of the stack folded in (vpt_conv3x3_forward_folded): (kk_frame [F,9,CoutPad], rs_frame [F]) from
     nfold_coef() replace edge_sa and the statistics of x (conv0 on the gain-scaled pooled tensor Q); (res_scale [F], res_bias [F,cout])

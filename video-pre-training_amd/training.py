@@ -100,6 +100,9 @@ class BCTrainer:
         self.cnn_streams = int(os.environ.get("VPT_BC_STREAMS", self.engine.cnn_streams))
         # a block's conv1 -> conv0 backward through ONE dgrad epilogue (_block_backward); 0 = the round-4 path (A/B)
         self.gated_dgrad = os.environ.get("VPT_BC_GATED_DGRAD", "1") != "0"
+        # stacks 1..: firstconv + max-pool as ONE pass that records the arg-max positions (ops.conv3x3_pool_argmax), its backward from the pooled
+        # tensors alone (ops.conv_backward_prepare_pooled); 0 = conv -> vpt_pool_kernel with the pre-pool tensor kept (round 4, A/B)
+        self.fused_pool = os.environ.get("VPT_BC_FUSED_POOL", "1") != "0"
         self._arenas = None      # (key, (GradArena trunk + heads, GradArena CNN)) of the data-parallel step, built on first use
         self._streams: List[torch.cuda.Stream] = []
         self.params: Dict[str, torch.nn.Parameter] = dict(policy.named_parameters())
@@ -424,8 +427,11 @@ class BCTrainer:
                 pooled = ops.conv_first(img, w[p + "firstconv"], c, stats_out=s_pool)
             else:
                 wpk, sa, sg = w[p + "firstconv"]
-                rec["pre"] = ops.conv3x3(x, wpk, sa, sg, s_x, c)
-                pooled, rec["argmax"] = ops.maxpool(rec["pre"], stats_out=s_pool, want_argmax=True)
+                if self.fused_pool:    # firstconv + ReLU + max-pool in one pass that also records where each maximum sits (round 5): no pre-pool tensor
+                    pooled, rec["mask"] = ops.conv3x3_pool_argmax(x, wpk, sa, sg, s_x, c, stats_out=s_pool)
+                else:
+                    rec["pre"] = ops.conv3x3(x, wpk, sa, sg, s_x, c)
+                    pooled, rec["argmax"] = ops.maxpool(rec["pre"], stats_out=s_pool, want_argmax=True)
             s_x = nxt()
             x = ops.frame_affine(pooled, w[p + "n.g"], w[p + "n.b"], s_pool, stats_out=s_x)
             rec.update(pooled=pooled, s_pool=s_pool, blocks=[])
@@ -548,6 +554,16 @@ class BCTrainer:
             if s == 0:
                 c = cfg["chans"][0]
                 acc["first"] = ops.conv_first_backward(sv["img"], w[p + "firstconv"], dpooled, c, out=acc.get("first"))
+            elif "mask" in rec:
+                q = p + "firstconv"
+                _, sa, sg = w[q]
+                x_prev = rec["x_prev"]
+                c_prev = x_prev.shape[1] * 32
+                r = self._raw_acc(acc, q, rec["pooled"].shape[1] * 32, c_prev, sa, sg)
+                dacc, coef, _, _ = ops.conv_backward_prepare_pooled(dpooled, rec["pooled"], rec["mask"], rec["s_prev"], sa, sg, c_prev, d_sa=r[1], d_sg=r[2])
+                ops.conv3x3_wgrad(dacc, x_prev, out=r[0])
+                dx = ops.conv3x3_dgrad(dacc, acc["wt"][q], c_prev, xin=x_prev, coef=coef)
+                del dacc
             else:
                 dx = self._conv_layer_backward(p + "firstconv", acc, None, rec["pre"], None, rec["x_prev"], rec["s_prev"], None,
                                                pool=(dpooled, rec["argmax"]))
