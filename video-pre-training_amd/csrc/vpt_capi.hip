@@ -28,7 +28,7 @@ int vpt_pack_conv3x3(const float* weight, const float* gain, const float* bias, 
                      int Cout, int Cin, void* stream) {
   if ((edge_sa == nullptr) != (edge_sg == nullptr)) return fail(-1, "vpt_pack_conv3x3: give both edge tables or neither");
   if (edge_sa && !bias) return fail(-1, "vpt_pack_conv3x3: the edge tables need the GroupNorm bias");
-  VptPackConvArgs a;
+  VptPackConvArgs a = {};
   a.weight = weight; a.gain = gain; a.bias = bias; a.wpk = (vpt_op16*)wpk; a.edge_sa = edge_sa; a.edge_sg = edge_sg;
   a.Cout = Cout; a.Cin = Cin; a.NT = (Cout + 127) / 128;
   CHECK_LAUNCH(vpt_pack_conv3x3_launch(&a, (hipStream_t)stream), "vpt_pack_conv3x3");
@@ -69,7 +69,7 @@ int64_t vpt_workspace_bytes(int op, int frames, int H, int W, int Cin, int Cout)
 int vpt_conv_first_forward(const uint8_t* img, const void* wfrag, void* y, double* stats_out, const float* out_gain, double* chs_out,
                            int frames, int H, int W, int Cout, void* stream) {
   if (chs_out && Cout > 128) return fail(-1, "vpt_conv_first_forward: chs_out needs Cout <= 128 (use vpt_channel_stats)");
-  VptConvFirstArgs a;
+  VptConvFirstArgs a = {};
   a.img = img; a.wfrag = (const vpt_op16*)wfrag; a.y = (vpt_op16*)y; a.stats_out = stats_out; a.out_gain = out_gain; a.chs_out = chs_out;
   a.frames = frames; a.H = H; a.W = W; a.Cout = Cout; a.NT = (Cout + 127) / 128;
   CHECK_LAUNCH(vpt_conv_first_launch(&a, (hipStream_t)stream), "vpt_conv_first_forward");
@@ -77,7 +77,7 @@ int vpt_conv_first_forward(const uint8_t* img, const void* wfrag, void* y, doubl
 
 int vpt_conv3d_t5_forward(const uint8_t* img, const void* wfrag, const float* bias, void* y, double* stats_out,
                           int frames, int T, int H, int W, int Cout, void* stream) {
-  VptConv3dArgs a;
+  VptConv3dArgs a = {};
   a.img = img; a.wfrag = (const vpt_op16*)wfrag; a.bias = bias; a.y = (vpt_op16*)y; a.stats_out = stats_out;
   a.frames = frames; a.T = T; a.H = H; a.W = W; a.Cout = Cout; a.NT = (Cout + 127) / 128;
   CHECK_LAUNCH(vpt_conv3d_launch(&a, (hipStream_t)stream), "vpt_conv3d_t5_forward");
@@ -94,7 +94,7 @@ int vpt_conv3x3_forward_tiled(const void* x, const void* wpk, const float* edge_
                               int frames, int H, int W, int Cin, int Cout, int tiling, void* stream) {
   if (!stats_in) return fail(-1, "vpt_conv3x3_forward: stats_in is required");
   if (tiling < 1 || tiling > 3) return fail(-1, "vpt_conv3x3_forward_tiled: tiling must be 1 (throughput), 2 (latency) or 3 (throughput, 32-row tiles)");
-  VptConv3x3Args a;
+  VptConv3x3Args a = {};
   a.gate_stats = nullptr; a.gate_u = nullptr; a.inv_count_gate = 0.0; a.pool_mask = nullptr;
   a.tiling = tiling;
   a.x = (const vpt_op16*)x; a.wpk = (const vpt_op16*)wpk; a.edge_sa = edge_sa; a.edge_sg = edge_sg;
@@ -114,7 +114,7 @@ int vpt_conv3x3_forward_folded(const void* x, const void* wpk, const float* edge
   if (!kk_frame && !stats_in) return fail(-1, "vpt_conv3x3_forward_folded: stats_in is required unless kk_frame replaces it");
   if (res_bias && (!res || !res_scale)) return fail(-1, "vpt_conv3x3_forward_folded: res_bias needs res and res_scale");
   if (!edge_sg || (!kk_frame && !edge_sa)) return fail(-1, "vpt_conv3x3_forward_folded: edge tables missing");
-  VptConv3x3Args a;
+  VptConv3x3Args a = {};
   a.gate_stats = nullptr; a.gate_u = nullptr; a.inv_count_gate = 0.0; a.pool_mask = nullptr;
   a.tiling = 1;
   a.x = (const vpt_op16*)x; a.wpk = (const vpt_op16*)wpk; a.edge_sa = edge_sa; a.edge_sg = edge_sg;
@@ -129,7 +129,7 @@ int vpt_conv3x3_forward_folded(const void* x, const void* wpk, const float* edge
 
 int vpt_channel_stats(const void* x, double* chs, int frames, int C, int HW, void* stream) {
   if (!x || !chs || (C & 31)) return fail(-1, "vpt_channel_stats: null pointer or C not a multiple of 32");
-  VptChannelStatsArgs a;
+  VptChannelStatsArgs a = {};
   a.x = (const vpt_op16*)x; a.chs = chs; a.frames = frames; a.CB = C / 32; a.HW = HW; a.split = 1;
   CHECK_LAUNCH(vpt_channel_stats_launch(&a, (hipStream_t)stream), "vpt_channel_stats");
 }
@@ -139,7 +139,7 @@ int vpt_nfold_coef(const double* tot, const double* chs, const float* gain, cons
                    int frames, int C, int HW, int Cout, void* stream) {
   if (!tot || !chs || !gain || !bias || !sa || !sg || !tb || !tg || !kk_frame || !rs_frame || !res_scale || !res_bias)
     return fail(-1, "vpt_nfold_coef: null pointer");
-  VptNfoldCoefArgs a;
+  VptNfoldCoefArgs a = {};
   a.tot = tot; a.chs = chs; a.gain = gain; a.bias = bias; a.sa = sa; a.sg = sg; a.tb = tb; a.tg = tg;
   a.kk_frame = kk_frame; a.rs_frame = rs_frame; a.res_scale = res_scale; a.res_bias = res_bias;
   a.frames = frames; a.C = C; a.HW = HW; a.CoutPad = ((Cout + 127) / 128) * 128;
@@ -154,7 +154,7 @@ static int conv3x3_pool_forward_impl(const void* x, const void* wpk, const float
   if (!stats_in || !pooled || !seam_scratch) return fail(-1, "vpt_conv3x3_pool_forward: stats_in, pooled and seam_scratch are required");
   if (phases < 1 || phases > 3) return fail(-1, "vpt_conv3x3_pool_forward: phases = 1 (tiles), 2 (seams) or 3 (both)");
   if ((H & 15) || (W & 15) || (Cout & 31)) return fail(-1, "vpt_conv3x3_pool_forward: H, W multiples of 16, Cout of 32");
-  VptConv3x3Args a;
+  VptConv3x3Args a = {};
   a.gate_stats = nullptr; a.gate_u = nullptr; a.inv_count_gate = 0.0; a.pool_mask = nullptr;
   a.tiling = 1;
   a.x = (const vpt_op16*)x; a.wpk = (const vpt_op16*)wpk; a.edge_sa = edge_sa; a.edge_sg = edge_sg;
@@ -171,7 +171,7 @@ static int conv3x3_pool_forward_impl(const void* x, const void* wpk, const float
     if (rc != 0) return fail(rc, "vpt_conv3x3_pool_forward (convolution)");
   }
   if (!(phases & 2)) return 0;
-  VptPoolSeamArgs p;
+  VptPoolSeamArgs p = {};
   p.y = a.y; p.seam_r = a.seam_r; p.seam_c = a.seam_c; p.stats_out = stats_out; p.gain = out_gain; p.chs_out = chs_out; p.frames = frames; p.CB = Cout / 32; p.H = H; p.W = W;
   p.mask = (vpt_op16*)pool_mask;
   CHECK_LAUNCH(vpt_pool_seam_launch(&p, (hipStream_t)stream), "vpt_conv3x3_pool_forward (seams)");
@@ -191,7 +191,7 @@ int vpt_conv3x3_pool_argmax_forward(const void* x, const void* wpk, const float*
 
 int vpt_conv3x3_dgrad(const void* dacc, const void* wpk_t, const void* skip, const void* xin, const float* coef, void* dx,
                       int frames, int H, int W, int Cout, int Cin, void* stream) {
-  VptConv3x3Args a;
+  VptConv3x3Args a = {};
   a.gate_stats = nullptr; a.gate_u = nullptr; a.inv_count_gate = 0.0; a.pool_mask = nullptr;
   a.x = (const vpt_op16*)dacc; a.wpk = (const vpt_op16*)wpk_t; a.edge_sa = nullptr; a.edge_sg = nullptr;
   a.stats_in = nullptr; a.res = (const vpt_op16*)skip; a.y = (vpt_op16*)dx; a.stats_out = nullptr;
@@ -205,7 +205,7 @@ int vpt_conv3x3_dgrad(const void* dacc, const void* wpk_t, const void* skip, con
 int vpt_conv3x3_dgrad_gated(const void* dacc, const void* wpk_t, const void* xin, const float* coef, const double* gate_stats, int gate_cin,
                             void* dacc_out, double* gate_u, int frames, int H, int W, int Cout, int Cin, void* stream) {
   if (!gate_stats || !gate_u || gate_cin <= 0) return fail(-1, "vpt_conv3x3_dgrad_gated: gate_stats, gate_u and gate_cin are required");
-  VptConv3x3Args a;
+  VptConv3x3Args a = {};
   a.x = (const vpt_op16*)dacc; a.wpk = (const vpt_op16*)wpk_t; a.edge_sa = nullptr; a.edge_sg = nullptr;
   a.stats_in = nullptr; a.res = nullptr; a.y = (vpt_op16*)dacc_out; a.stats_out = nullptr;
   a.frames = frames; a.H = H; a.W = W; a.Cin = Cout; a.Cout = Cin;   // roles swap in the transposed convolution
@@ -220,7 +220,7 @@ int vpt_conv_backward_reduce(const void* dacc, const double* gate_u, const doubl
                              double* t12, float* coef, float* d_sa, float* d_sg, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream) {
   if (Cout & 31) return fail(-1, "vpt_conv_backward_reduce: Cout must be a multiple of 32");
   if (!dacc || !gate_u) return fail(-1, "vpt_conv_backward_reduce: dacc and gate_u are required");
-  VptConvBwdPrepArgs a;
+  VptConvBwdPrepArgs a = {};
   a.dpooled = nullptr; a.argmax = nullptr; a.sbuf = scratch; a.wshift = 0; a.coef = coef;
   a.dy = (const vpt_op16*)dacc; a.y = nullptr; a.res = nullptr; a.stats_in = stats_in;
   a.edge_sa = edge_sa; a.edge_sg = edge_sg; a.dacc = nullptr; a.t12 = t12; a.d_sa = d_sa; a.d_sg = d_sg;
@@ -234,7 +234,7 @@ int vpt_conv_backward_prepare_pooled(const void* dpooled, const void* pooled, co
                                      void* dacc, double* t12, float* coef, float* d_sa, float* d_sg, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream) {
   if (Cout & 31) return fail(-1, "vpt_conv_backward_prepare_pooled: Cout must be a multiple of 32");
   if (!dpooled || !pooled || !pool_mask || !dacc) return fail(-1, "vpt_conv_backward_prepare_pooled: dpooled, pooled, pool_mask and dacc are required");
-  VptConvBwdPrepArgs a;
+  VptConvBwdPrepArgs a = {};
   a.dpooled = (const vpt_op16*)dpooled; a.argmax = nullptr; a.sbuf = scratch; a.wshift = 0; a.coef = coef;
   a.dy = nullptr; a.y = nullptr; a.res = nullptr; a.stats_in = stats_in;
   a.edge_sa = edge_sa; a.edge_sg = edge_sg; a.dacc = (vpt_op16*)dacc; a.t12 = t12; a.d_sa = d_sa; a.d_sg = d_sg;
@@ -248,7 +248,7 @@ int vpt_conv_backward_prepare(const void* dy, const void* dpooled, const uint8_t
                               const double* stats_in, const float* edge_sa, const float* edge_sg, void* dacc, double* t12,
                               float* coef, float* d_sa, float* d_sg, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream) {
   if (Cout & 31) return fail(-1, "vpt_conv_backward_prepare: Cout must be a multiple of 32");
-  VptConvBwdPrepArgs a;
+  VptConvBwdPrepArgs a = {};
   a.dpooled = (const vpt_op16*)dpooled; a.argmax = argmax; a.sbuf = scratch; a.wshift = 0; a.coef = coef;
   a.dy = (const vpt_op16*)dy; a.y = (const vpt_op16*)y; a.res = (const vpt_op16*)res; a.stats_in = stats_in;
   a.edge_sa = edge_sa; a.edge_sg = edge_sg; a.dacc = (vpt_op16*)dacc; a.t12 = t12; a.d_sa = d_sa; a.d_sg = d_sg;
@@ -260,7 +260,7 @@ int vpt_conv_backward_prepare(const void* dy, const void* dpooled, const uint8_t
 
 int vpt_conv_first_backward(const uint8_t* img, const void* wfrag, const void* dpooled, float* dw, float* db,
                             int frames, int H, int W, int Cout, void* stream) {
-  VptConvFirstBwdArgs a;
+  VptConvFirstBwdArgs a = {};
   a.img = img; a.wfrag = (const vpt_op16*)wfrag; a.dpooled = (const vpt_op16*)dpooled; a.dw = dw; a.db = db;
   a.frames = frames; a.H = H; a.W = W; a.Cout = Cout;
   CHECK_LAUNCH(vpt_conv_first_bwd_launch(&a, (hipStream_t)stream), "vpt_conv_first_backward");
@@ -271,7 +271,7 @@ long vpt_conv3x3_wgrad_scratch_floats(int frames, int Cin, int Cout) {
 }
 
 int vpt_conv3x3_wgrad(const void* dacc, const void* x, float* dw, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream) {
-  VptConvWgradArgs a;
+  VptConvWgradArgs a = {};
   a.dacc = (const vpt_op16*)dacc; a.x = (const vpt_op16*)x; a.dw = dw; a.partial = scratch;
   a.frames = frames; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.OT = 0; a.frames_per_wg = 0;
   CHECK_LAUNCH(vpt_conv_wgrad_launch(&a, (hipStream_t)stream), "vpt_conv3x3_wgrad");
@@ -279,7 +279,7 @@ int vpt_conv3x3_wgrad(const void* dacc, const void* x, float* dw, float* scratch
 
 int vpt_maxpool_backward(const void* pre, const void* pooled, const void* dpooled, void* dpre,
                          int frames, int C, int H, int W, void* stream) {
-  VptPoolBwdArgs a;
+  VptPoolBwdArgs a = {};
   a.pre = (const vpt_op16*)pre; a.pooled = (const vpt_op16*)pooled; a.dpooled = (const vpt_op16*)dpooled;
   a.dpre = (vpt_op16*)dpre; a.frames = frames; a.CB = C / 32; a.H = H; a.W = W;
   CHECK_LAUNCH(vpt_pool_bwd_launch(&a, (hipStream_t)stream), "vpt_maxpool_backward");
@@ -288,7 +288,7 @@ int vpt_maxpool_backward(const void* pre, const void* pooled, const void* dpoole
 int vpt_frame_affine_backward(const void* x, const void* dy, const void* dx_add, void* dx, const float* gain,
                               const double* stats_in, double* ab, float* dgain, float* dbias,
                               int frames, int C, int HW, int per_element, int pass, void* stream) {
-  VptAffineBwdArgs a;
+  VptAffineBwdArgs a = {};
   a.x = (const vpt_op16*)x; a.dy = (const vpt_op16*)dy; a.dx_add = (const vpt_op16*)dx_add; a.dx = (vpt_op16*)dx;
   a.gain = gain; a.stats_in = stats_in; a.ab = ab; a.dgain = dgain; a.dbias = dbias;
   a.frames = frames; a.CB = C / 32; a.HW = HW; a.per_element = per_element; a.inv_count = 1.0 / ((double)C * HW);
@@ -297,7 +297,7 @@ int vpt_frame_affine_backward(const void* x, const void* dy, const void* dx_add,
 
 int vpt_maxpool_forward(const void* x, void* y, double* stats_out, uint8_t* argmax, int frames, int C, int H, int W, void* stream) {
   if (C & 31) return fail(-1, "vpt_maxpool_forward: C must be a multiple of 32");
-  VptPoolArgs a;
+  VptPoolArgs a = {};
   a.x = (const vpt_op16*)x; a.y = (vpt_op16*)y; a.stats_out = stats_out; a.argmax = argmax;
   a.frames = frames; a.CB = C / 32; a.H = H; a.W = W;
   CHECK_LAUNCH(vpt_pool_launch(&a, (hipStream_t)stream), "vpt_maxpool_forward");
@@ -307,7 +307,7 @@ int vpt_frame_affine_forward(const void* x, void* y, const float* gain, const fl
                              const double* stats_in, double* stats_out,
                              int frames, int C, int HW, int per_element, void* stream) {
   if (C & 31) return fail(-1, "vpt_frame_affine_forward: C must be a multiple of 32");
-  VptAffineArgs a;
+  VptAffineArgs a = {};
   a.x = (const vpt_op16*)x; a.y = (vpt_op16*)y; a.gain = gain; a.bias = bias;
   a.stats_in = stats_in; a.stats_out = stats_out;
   a.frames = frames; a.CB = C / 32; a.HW = HW; a.per_element = per_element;
@@ -350,7 +350,7 @@ int vpt_layernorm_linear_forward(const float* x, const float* ln_gain, const flo
 }
 
 int vpt_linear_wgrad(const void* dy, const void* x, float* dw, int M, int N, int K, int ldy, int ldx, int ldw, int accumulate, void* stream) {
-  VptGemmTnArgs a;
+  VptGemmTnArgs a = {};
   a.A = (const vpt_op16*)dy; a.B = (const vpt_op16*)x; a.C = dw; a.M = M; a.N1 = N; a.N2 = K; a.lda = ldy; a.ldb = ldx; a.ldc = ldw;
   a.accumulate = accumulate;
   CHECK_LAUNCH(vpt_gemm_tn_launch(&a, (hipStream_t)stream), "vpt_linear_wgrad");
@@ -373,7 +373,7 @@ int vpt_linear_splitk_epilogue(const float* part, int splitk, const float* bias,
 
 int vpt_layernorm_forward(const float* x, const float* gain, const float* bias, float* out_f32, void* out_bf16,
                           int M, int D, int relu_in, void* stream) {
-  VptLayerNormArgs a;
+  VptLayerNormArgs a = {};
   a.x = x; a.gain = gain; a.bias = bias; a.out_f32 = out_f32; a.out_bf16 = (vpt_op16*)out_bf16;
   a.M = M; a.D = D; a.relu_in = relu_in;
   CHECK_LAUNCH(vpt_layernorm_launch(&a, (hipStream_t)stream), "vpt_layernorm_forward");
@@ -382,7 +382,7 @@ int vpt_layernorm_forward(const float* x, const float* gain, const float* bias, 
 int vpt_masked_attention_forward(const float* qkvr, const float* kmem, const float* vmem, const uint8_t* memvalid,
                                  const float* b_nd, void* out, int B, int t, int heads, int hid, int ld,
                                  int maxlen, int causal, void* stream) {
-  VptAttnArgs a;
+  VptAttnArgs a = {};
   a.qkvr = qkvr; a.kmem = kmem; a.vmem = vmem; a.memvalid = memvalid; a.b_nd = b_nd; a.out = (vpt_op16*)out;
   a.B = B; a.t = t; a.heads = heads; a.hid = hid; a.ld = ld; a.maxlen = maxlen; a.causal = causal;
   CHECK_LAUNCH(vpt_attn_launch(&a, (hipStream_t)stream), "vpt_masked_attention_forward");
@@ -391,7 +391,7 @@ int vpt_masked_attention_forward(const float* qkvr, const float* kmem, const flo
 int vpt_masked_attention_step(const float* qkvr, const float* kmem, const float* vmem, const uint8_t* state_mask, const uint8_t* first,
                               const float* b_nd, void* out, float* kout, float* vout, uint8_t* mask_out,
                               int B, int heads, int hid, int ld, int maxlen, void* stream) {
-  VptAttnArgs a;
+  VptAttnArgs a = {};
   a.qkvr = qkvr; a.kmem = kmem; a.vmem = vmem; a.memvalid = nullptr; a.b_nd = b_nd; a.out = (vpt_op16*)out;
   a.B = B; a.t = 1; a.heads = heads; a.hid = hid; a.ld = ld; a.maxlen = maxlen; a.causal = 1;
   CHECK_LAUNCH(vpt_attn_step_launch(&a, state_mask, first, mask_out, kout, vout, nullptr, (hipStream_t)stream), "vpt_masked_attention_step");
@@ -400,7 +400,7 @@ int vpt_masked_attention_step(const float* qkvr, const float* kmem, const float*
 int vpt_masked_attention_step_inplace(const float* qkvr, float* kmem, float* vmem, uint8_t* state_mask, const uint8_t* first,
                                       const float* b_nd, void* out, int* done_counter, int B, int heads, int hid, int ld, int maxlen, void* stream) {
   if (!done_counter) return fail(-1, "vpt_masked_attention_step_inplace: done_counter ([B] ints, zero before the first launch) is required");
-  VptAttnArgs a;
+  VptAttnArgs a = {};
   a.qkvr = qkvr; a.kmem = kmem; a.vmem = vmem; a.memvalid = nullptr; a.b_nd = b_nd; a.out = (vpt_op16*)out;
   a.B = B; a.t = 1; a.heads = heads; a.hid = hid; a.ld = ld; a.maxlen = maxlen; a.causal = 1;
   CHECK_LAUNCH(vpt_attn_step_launch(&a, state_mask, first, state_mask, kmem, vmem, done_counter, (hipStream_t)stream), "vpt_masked_attention_step_inplace");
@@ -419,7 +419,7 @@ int vpt_uniform_noise(const uint64_t* rng_state, uint32_t rng_stream, float* out
 
 int vpt_kv_memory_update(const float* qkvr, const float* kmem, const float* vmem, float* kout, float* vout,
                          int B, int t, int hid, int ld, int maxlen, void* stream) {
-  VptKvUpdateArgs a;
+  VptKvUpdateArgs a = {};
   a.qkvr = qkvr; a.kmem = kmem; a.vmem = vmem; a.kout = kout; a.vout = vout;
   a.B = B; a.t = t; a.hid = hid; a.ld = ld; a.maxlen = maxlen;
   CHECK_LAUNCH(vpt_kv_update_launch(&a, (hipStream_t)stream), "vpt_kv_memory_update");
@@ -427,7 +427,7 @@ int vpt_kv_memory_update(const float* qkvr, const float* kmem, const float* vmem
 
 int vpt_log_softmax_forward(const float* logits, float* out, int M, int ld, int col0, int n, float temperature,
                             void* stream) {
-  VptLogSoftmaxArgs a;
+  VptLogSoftmaxArgs a = {};
   a.logits = logits; a.out = out; a.M = M; a.ld = ld; a.col0 = col0; a.n = n; a.temperature = temperature;
   a.mask = nullptr; a.noise = nullptr; a.action = nullptr; a.action_logp = nullptr; a.rng_state = nullptr; a.rng_stream = 0;
   CHECK_LAUNCH(vpt_logsoftmax_launch(&a, (hipStream_t)stream), "vpt_log_softmax_forward");
@@ -437,7 +437,7 @@ int vpt_action_head_forward(const float* logits, const uint8_t* mask, const floa
                             float* out, int64_t* action, float* action_logp, int M, int ld, int col0, int n, float temperature, void* stream) {
   if (action_logp && !action) return fail(-1, "vpt_action_head_forward: action_logp needs action");
   if (noise && rng_state) return fail(-1, "vpt_action_head_forward: give the uniforms (noise) or the generator state (rng_state), not both");
-  VptLogSoftmaxArgs a;
+  VptLogSoftmaxArgs a = {};
   a.logits = logits; a.out = out; a.M = M; a.ld = ld; a.col0 = col0; a.n = n; a.temperature = temperature;
   a.mask = mask; a.noise = noise; a.action = (long*)action; a.action_logp = action_logp; a.rng_state = rng_state; a.rng_stream = rng_stream;
   CHECK_LAUNCH(vpt_logsoftmax_launch(&a, (hipStream_t)stream), "vpt_action_head_forward");
@@ -446,7 +446,7 @@ int vpt_action_head_forward(const float* logits, const uint8_t* mask, const floa
 int vpt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, int step,
                   float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
   if (step < 1) return fail(-1, "vpt_adam_step: step counts from 1");
-  VptAdamArgs a;
+  VptAdamArgs a = {};
   a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = (size_t)n; a.skip_flag = nullptr;
   a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.grad_scale = grad_scale;
   a.step_size = (float)((double)lr / (1.0 - pow((double)beta1, (double)step)));
@@ -458,7 +458,7 @@ int vpt_adam_step_multi(const void* table, int ntensors, int64_t total_blocks, i
                         float eps, float weight_decay, float grad_scale, const int32_t* skip_flag, void* stream) {
   if (step < 1) return fail(-1, "vpt_adam_step_multi: step counts from 1");
   if (!table && ntensors > 0) return fail(-1, "vpt_adam_step_multi: null table");
-  VptAdamArgs a;
+  VptAdamArgs a = {};
   a.p = nullptr; a.g = nullptr; a.m = nullptr; a.v = nullptr; a.n = 0; a.skip_flag = (const int*)skip_flag;
   a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.grad_scale = grad_scale;
   a.step_size = (float)((double)lr / (1.0 - pow((double)beta1, (double)step)));
@@ -473,7 +473,7 @@ int vpt_grads_nonfinite_multi(const void* table, int ntensors, int64_t total_blo
 
 int vpt_bc_nll_backward(const float* lp_buttons, const float* lp_camera, const int64_t* act_buttons,
                         const int64_t* act_camera, void* dz, int M, int nb, int nc, int ldz, float scale, void* stream) {
-  VptNllBwdArgs a;
+  VptNllBwdArgs a = {};
   a.lp_buttons = lp_buttons; a.lp_camera = lp_camera; a.act_buttons = (const long*)act_buttons;
   a.act_camera = (const long*)act_camera; a.dz = (vpt_op16*)dz; a.M = M; a.nb = nb; a.nc = nc; a.ldz = ldz; a.scale = scale;
   CHECK_LAUNCH(vpt_nll_bwd_launch(&a, (hipStream_t)stream), "vpt_bc_nll_backward");
@@ -483,7 +483,7 @@ int vpt_heads_logprob_backward(const float* lp_buttons, const float* lp_camera, 
                                const float* g_value, const uint8_t* mask_buttons, const uint8_t* mask_camera, void* dz,
                                int M, int nb, int nc, int ldz, float temperature, float grad_scale, void* stream) {
   if (!(temperature > 0.f)) return fail(-1, "vpt_heads_logprob_backward: temperature must be positive");
-  VptHeadsBwdArgs a;
+  VptHeadsBwdArgs a = {};
   a.lp_buttons = lp_buttons; a.lp_camera = lp_camera; a.g_buttons = g_buttons; a.g_camera = g_camera; a.g_value = g_value;
   a.mask_buttons = mask_buttons; a.mask_camera = mask_camera;
   a.dz = (vpt_op16*)dz; a.M = M; a.nb = nb; a.nc = nc; a.ldz = ldz; a.inv_temp = 1.0f / temperature; a.grad_scale = grad_scale;
@@ -492,20 +492,20 @@ int vpt_heads_logprob_backward(const float* lp_buttons, const float* lp_camera, 
 
 int vpt_layernorm_backward(const float* x, const float* gain, const float* dy, const float* dx_add, float* dx,
                            float* dgain, float* dbias, int M, int D, int relu_in, void* stream) {
-  VptLnBwdArgs a;
+  VptLnBwdArgs a = {};
   a.x = x; a.gain = gain; a.dy = dy; a.dx_add = dx_add; a.dx = dx; a.dgain = dgain; a.dbias = dbias;
   a.M = M; a.D = D; a.relu_in = relu_in;
   CHECK_LAUNCH(vpt_ln_bwd_launch(&a, (hipStream_t)stream), "vpt_layernorm_backward");
 }
 
 int vpt_gate_cast(const float* x, const void* mask, void* out, int M, int N, int ldx, int ldm, int ldo, void* stream) {
-  VptGateCastArgs a;
+  VptGateCastArgs a = {};
   a.x = x; a.mask = (const vpt_op16*)mask; a.out = (vpt_op16*)out; a.M = M; a.N = N; a.ldx = ldx; a.ldm = ldm; a.ldo = ldo;
   CHECK_LAUNCH(vpt_gate_cast_launch(&a, (hipStream_t)stream), "vpt_gate_cast");
 }
 
 int vpt_column_sum(const void* x_bf16, float* out, int M, int N, int ld, void* stream) {
-  VptColsumArgs a;
+  VptColsumArgs a = {};
   a.x = (const vpt_op16*)x_bf16; a.out = out; a.M = M; a.N = N; a.ld = ld;
   CHECK_LAUNCH(vpt_colsum_launch(&a, (hipStream_t)stream), "vpt_column_sum");
 }
@@ -513,7 +513,7 @@ int vpt_column_sum(const void* x_bf16, float* out, int M, int N, int ld, void* s
 int vpt_masked_attention_backward(const float* qkvr, const float* kmem, const float* vmem, const uint8_t* memvalid,
                                   const float* b_nd, const float* dout, float* dqkvr, float* db_nd,
                                   int B, int t, int heads, int hid, int ld, int maxlen, void* stream) {
-  VptAttnBwdArgs a;
+  VptAttnBwdArgs a = {};
   a.qkvr = qkvr; a.kmem = kmem; a.vmem = vmem; a.memvalid = memvalid; a.b_nd = b_nd; a.dout = dout;
   a.dqkvr = dqkvr; a.db_nd = db_nd; a.B = B; a.t = t; a.heads = heads; a.hid = hid; a.ld = ld; a.maxlen = maxlen;
   CHECK_LAUNCH(vpt_attn_bwd_launch(&a, (hipStream_t)stream), "vpt_masked_attention_backward");
