@@ -377,9 +377,14 @@ int vpt_conv3x3_dgrad_gated(const void* dacc, const void* wpk_t, const void* xin
                             void* dacc_out, double* gate_u, int frames, int H, int W, int Cout, int Cin, void* stream);
 /* vpt_conv_backward_prepare for the layer in front of the max-pool when its forward was vpt_conv3x3_pool_argmax_forward: (dpooled, pooled,
  * pool_mask) [F][Cout/32][H/2][W/2][32] in, dacc [F][Cout/32][H][W][32] and the same sums out.  The ReLU gate is [pooled > 0], the value at
- * the arg-max is the pooled value itself.  H, W: the PRE-pool size (W in {16, 32, 64}). */
+ * the arg-max is the pooled value itself.  H, W: the PRE-pool size (W in {16, 32, 64}).
+ * n_gain != NULL: the stack's GroupNorm `n` (lib/impala_cnn.py:118-119) sits between the pool and the incoming gradient and its backward is applied
+ * on the fly -- `dpooled` is then G = d loss / d n(pooled), pool_stats [F][2] the frame statistics of pooled and pool_ab [F][2] the sums of
+ * vpt_frame_affine_backward's pass 1 (sum G gain, sum G gain xhat): d(pooled) = r (G gain - ab0 / n - xhat ab1 / n) is formed per element with the
+ * separate pass's arithmetic and 16-bit rounding point, and vpt_frame_affine_backward's pass 2 is not run for this stack. */
 int vpt_conv_backward_prepare_pooled(const void* dpooled, const void* pooled, const void* pool_mask, const double* stats_in, const float* edge_sa, const float* edge_sg,
-                                     void* dacc, double* t12, float* coef, float* d_sa, float* d_sg, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream);
+                                     void* dacc, double* t12, float* coef, float* d_sa, float* d_sg, float* scratch,
+                                     const float* n_gain, const double* pool_stats, const double* pool_ab, int frames, int H, int W, int Cin, int Cout, void* stream);
 int vpt_conv_backward_reduce(const void* dacc, const double* gate_u, const double* stats_in, const float* edge_sa, const float* edge_sg,
                              double* t12, float* coef, float* d_sa, float* d_sg, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream);
 

@@ -50,7 +50,7 @@ SIGNATURES = {
     "vpt_conv_backward_prepare": [_P] * 14 + [_I, _I, _I, _I, _I, _P],
     "vpt_conv3x3_dgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_conv3x3_pool_argmax_forward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "vpt_conv_backward_prepare_pooled": [_P] * 12 + [_I, _I, _I, _I, _I, _P],
+    "vpt_conv_backward_prepare_pooled": [_P] * 15 + [_I, _I, _I, _I, _I, _P],
     "vpt_conv3x3_dgrad_gated": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_conv_backward_reduce": [_P] * 10 + [_I, _I, _I, _I, _I, _P],
     "vpt_conv_first_backward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

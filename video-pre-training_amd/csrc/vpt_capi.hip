@@ -231,7 +231,8 @@ int vpt_conv_backward_reduce(const void* dacc, const double* gate_u, const doubl
 }
 
 int vpt_conv_backward_prepare_pooled(const void* dpooled, const void* pooled, const void* pool_mask, const double* stats_in, const float* edge_sa, const float* edge_sg,
-                                     void* dacc, double* t12, float* coef, float* d_sa, float* d_sg, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream) {
+                                     void* dacc, double* t12, float* coef, float* d_sa, float* d_sg, float* scratch,
+                                     const float* n_gain, const double* pool_stats, const double* pool_ab, int frames, int H, int W, int Cin, int Cout, void* stream) {
   if (Cout & 31) return fail(-1, "vpt_conv_backward_prepare_pooled: Cout must be a multiple of 32");
   if (!dpooled || !pooled || !pool_mask || !dacc) return fail(-1, "vpt_conv_backward_prepare_pooled: dpooled, pooled, pool_mask and dacc are required");
   VptConvBwdPrepArgs a = {};
@@ -241,6 +242,7 @@ int vpt_conv_backward_prepare_pooled(const void* dpooled, const void* pooled, co
   a.frames = frames; a.CB = Cout / 32; a.H = H; a.W = W; a.CoutPad = ((Cout + 127) / 128) * 128;
   a.inv_count_in = 1.0 / ((double)Cin * H * W);
   a.gate_u = nullptr; a.pooled = (const vpt_op16*)pooled; a.pool_mask = (const vpt_op16*)pool_mask;
+  a.n_gain = n_gain; a.pool_stats = pool_stats; a.pool_ab = pool_ab; a.inv_count_pool = 1.0 / ((double)Cout * (H / 2) * (W / 2));
   CHECK_LAUNCH(vpt_conv_bwd_prep_launch(&a, (hipStream_t)stream), "vpt_conv_backward_prepare_pooled");
 }
 

@@ -464,6 +464,7 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_kernel(VptConvBwdPrepAr
 // rows; a pass's entries go to one of two LDS buffers, the row below the pass's last row comes from the next pass's buffer.
 struct PoolEntry { u32x4 g; uint32_t codes; };   // gated gradient (8 x 16 bit), arg-max position per channel (8 x 4 bit)
 
+template <bool NFOLD>
 __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_pooled_kernel(VptConvBwdPrepArgs a) {
   __shared__ float tab_[9 * 32];
   __shared__ __attribute__((aligned(16))) u32x4 gbuf_[2][64][4];
@@ -483,6 +484,16 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_pooled_kernel(VptConvBw
 #pragma unroll
   for (int k = 0; k < 8; ++k) allE[k] = allO[k] = topE[k] = topO[k] = botE[k] = botO[k] = 0.f;
   float tv = 0.f;
+  // NFOLD: the backward of GroupNorm `n` (x = (P - mu_P) r_P gain + bias) applied to the incoming gradient G, exactly vpt_affine_bwd_apply_kernel's
+  // arithmetic and rounding point (one 16-bit rounding of d(pooled))
+  float ng[8], mp = 0.f, rpool = 1.f, nA = 0.f, nB = 0.f;
+  if (NFOLD) {
+    frame_mean_rstd(a.pool_stats, f, a.inv_count_pool, mp, rpool);
+    nA = (float)(a.pool_ab[2 * f] * a.inv_count_pool);
+    nB = (float)(a.pool_ab[2 * f + 1] * a.inv_count_pool);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ng[k] = a.n_gain[cb * 32 + oct * 8 + k];
+  }
   u32x4 rd, rp, rm;                         // this thread's pooled pixel of the pass being loaded: gradient, pooled value, mask
   auto load_pass = [&](int p) {
     const size_t off = pplane + (size_t)((p * R + ph) * PW + px) * 32;
@@ -495,6 +506,15 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_pooled_kernel(VptConvBw
     float df[8], pf[8];
     unpack8(rd, df);
     unpack8(rp, pf);
+    if (NFOLD) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float xh = (pf[k] - mp) * rpool;
+        df[k] = rpool * (df[k] * ng[k] - nA - xh * nB);
+      }
+      rd = pack8(df);          // d(pooled), rounded to 16 bits where the separate pass stored it
+      unpack8(rd, df);
+    }
     uint32_t codes = 0u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -681,7 +701,10 @@ extern "C" int vpt_conv_bwd_prep_launch(const VptConvBwdPrepArgs* a0, hipStream_
     if (PH % R) return -1;
     const long gridp = (long)a.frames * a.CB;
     if (gridp > 0x7fffffffL) return -2;
-    hipLaunchKernelGGL(vpt_conv_bwd_prep_pooled_kernel, dim3((unsigned)gridp), dim3(256), 0, stream, a);
+    if (a.n_gain) {
+      if (!a.pool_stats || !a.pool_ab) return -1;
+      hipLaunchKernelGGL(vpt_conv_bwd_prep_pooled_kernel<true>, dim3((unsigned)gridp), dim3(256), 0, stream, a);
+    } else hipLaunchKernelGGL(vpt_conv_bwd_prep_pooled_kernel<false>, dim3((unsigned)gridp), dim3(256), 0, stream, a);
     const int fin_blocks_p = (a.frames + 3) / 4 + ((9 * a.CB * 32 + 255) / 256) * ((a.frames + FIN_FB - 1) / FIN_FB);
     hipLaunchKernelGGL(vpt_conv_bwd_finish_kernel, dim3((unsigned)fin_blocks_p), dim3(256), 0, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;

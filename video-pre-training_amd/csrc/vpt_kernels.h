@@ -248,6 +248,13 @@ struct VptConvBwdPrepArgs {
   // mode 7): pooled P [F][CB][H/2][W/2][32] and pool_mask (same shape, uint16) replace the pre-pool tensor and the arg-max bytes
   const vpt_op16* pooled;
   const vpt_op16* pool_mask;
+  // ... with the stack's GroupNorm `n` backward applied on the fly (n_gain != null): `dpooled` then holds G = the gradient w.r.t. x = n(P), and
+  // d(pooled) = r_P (G gain - A - xhat B), xhat = (P - mu_P) r_P, (A, B) = pool_ab[f] / count from vpt_affine_bwd_reduce_kernel -- the affine
+  // backward's second pass (read P, read G, write dP) disappears: this kernel reads P and a gradient tensor anyway
+  const float* n_gain;     // [Cout]
+  const double* pool_stats; // [F][2] sum / sum of squares of P
+  const double* pool_ab;   // [F][2]
+  double inv_count_pool;   // 1 / (Cout * H/2 * W/2)
 };
 
 struct VptConvFirstBwdArgs {

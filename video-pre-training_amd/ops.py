@@ -254,9 +254,13 @@ def conv3x3_pool_argmax(x, wpk, edge_sa, edge_sg, stats_in, cout, stats_out=None
     return y, mask
 
 
-def conv_backward_prepare_pooled(dpooled, pooled, mask, stats_in, edge_sa, edge_sg, cin, d_sa=None, d_sg=None, want_t12=False):
+def conv_backward_prepare_pooled(dpooled, pooled, mask, stats_in, edge_sa, edge_sg, cin, d_sa=None, d_sg=None, want_t12=False, nfold=None):
     """conv_backward_prepare() for the layer in front of the max-pool when its forward was conv3x3_pool_argmax(): (dpooled, pooled, mask) at the
-    pooled resolution -> (dacc blocked [F,Cout/32,2h,2w,32], coef, d_sa, d_sg[, t12]) (vpt_conv_backward_prepare_pooled)."""
+    pooled resolution -> (dacc blocked [F,Cout/32,2h,2w,32], coef, d_sa, d_sg[, t12]) (vpt_conv_backward_prepare_pooled).
+    nfold = (n_gain fp32 [Cout], pool_stats fp64 [F,2], ab fp64 [F,2] from frame_affine_backward_reduce): `dpooled` is the gradient w.r.t.
+    n(pooled) and the GroupNorm `n` backward is applied on the fly (no second affine-backward pass)."""
+    ng, pst, pab = nfold if nfold is not None else (None, None, None)
+    _chk(ng, torch.float32, "n_gain"); _chk(pst, torch.float64, "pool_stats"); _chk(pab, torch.float64, "pool_ab")
     _chk(dpooled, OP16, "dpooled"); _chk(pooled, OP16, "pooled"); _chk(mask, torch.int16, "mask")
     _chk(stats_in, torch.float64, "stats_in"); _chk(edge_sa, torch.float32, "edge_sa"); _chk(edge_sg, torch.float32, "edge_sg")
     _chk(d_sa, torch.float32, "d_sa"); _chk(d_sg, torch.float32, "d_sg")
@@ -273,7 +277,7 @@ def conv_backward_prepare_pooled(dpooled, pooled, mask, stats_in, edge_sa, edge_
         d_sa, d_sg = torch.zeros_like(edge_sa), torch.zeros_like(edge_sg)
     scratch = torch.empty(f, 9 * cb * 32 + cb, dtype=torch.float32, device=dev)
     _call("vpt_conv_backward_prepare_pooled", dict(bytes=2.0 * dacc.numel() + 6.0 * pooled.numel()), ptr(dpooled), ptr(pooled), ptr(mask), ptr(stats_in), ptr(edge_sa), ptr(edge_sg),
-          ptr(dacc), ptr(t12), ptr(coef), ptr(d_sa), ptr(d_sg), ptr(scratch), f, h, w, cin, cb * 32, _stream(), fmt=fmt, label="vpt_conv_backward_prepare")
+          ptr(dacc), ptr(t12), ptr(coef), ptr(d_sa), ptr(d_sg), ptr(scratch), ptr(ng), ptr(pst), ptr(pab), f, h, w, cin, cb * 32, _stream(), fmt=fmt, label="vpt_conv_backward_prepare")
     return (dacc, coef, d_sa, d_sg, t12) if want_t12 else (dacc, coef, d_sa, d_sg)
 
 
@@ -814,6 +818,18 @@ def maxpool_backward(pre, pooled, dpooled):
     dpre = torch.empty_like(pre)
     _call("vpt_maxpool_backward", dict(bytes=5.0 * pre.numel()), ptr(pre), ptr(pooled), ptr(dpooled), ptr(dpre), f, cb * 32, h, w, _stream(), fmt=_fmt(pre, pooled, dpooled)[1])
     return dpre
+
+
+def frame_affine_backward_reduce(x, dy, gain, stats_in, dgain, dbias):
+    """Pass 1 of frame_affine_backward alone (per-channel gain): dgain / dbias accumulated in place, returns ab fp64 [F,2] = (sum dy g, sum dy g xhat)
+    for a consumer that applies dx = rstd (dy g - ab0/n - xhat ab1/n) itself (conv_backward_prepare_pooled(nfold=...))."""
+    _chk(x, OP16, "x"); _chk(dy, OP16, "dy"); _chk(gain, torch.float32, "gain"); _chk(stats_in, torch.float64, "stats_in")
+    _chk(dgain, torch.float32, "dgain"); _chk(dbias, torch.float32, "dbias")
+    f, cb, h, w, _ = x.shape
+    ab = torch.zeros(f, 2, dtype=torch.float64, device=x.device)
+    _call("vpt_frame_affine_backward", dict(bytes=4.0 * x.numel()), ptr(x), ptr(dy), None, None, ptr(gain), ptr(stats_in), ptr(ab), ptr(dgain), ptr(dbias),
+          f, cb * 32, h * w, 0, 1, _stream(), fmt=_fmt(x, dy)[1])
+    return ab
 
 
 def frame_affine_backward(x, dy, gain, stats_in, dgain, dbias, per_element=False, dx_add=None):

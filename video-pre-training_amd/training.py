@@ -103,6 +103,8 @@ class BCTrainer:
         # stacks 1..: firstconv + max-pool as ONE pass that records the arg-max positions (ops.conv3x3_pool_argmax), its backward from the pooled
         # tensors alone (ops.conv_backward_prepare_pooled); 0 = conv -> vpt_pool_kernel with the pre-pool tensor kept (round 4, A/B)
         self.fused_pool = os.environ.get("VPT_BC_FUSED_POOL", "1") != "0"
+        # ... and with it the second pass of the GroupNorm-`n` backward of stacks 1.. folded into that consumer (needs fused_pool); 0: two passes (A/B)
+        self.fold_n_backward = os.environ.get("VPT_BC_FOLD_N_BWD", "1") != "0"
         self._arenas = None      # (key, (GradArena trunk + heads, GradArena CNN)) of the data-parallel step, built on first use
         self._streams: List[torch.cuda.Stream] = []
         self.params: Dict[str, torch.nn.Parameter] = dict(policy.named_parameters())
@@ -550,7 +552,13 @@ class BCTrainer:
             for b in (1, 0):
                 dx = self._block_backward(p, b, rec["blocks"][b], acc, dx)
             dgn, dbn = acc["n"][s]
-            dpooled = ops.frame_affine_backward(rec["pooled"], dx, w[p + "n.g"], rec["s_pool"], dgn, dbn)
+            nfold = None
+            if "mask" in rec and self.fold_n_backward:
+                # GroupNorm `n` backward: the reduction pass only; the consumer below forms d(pooled) from (G, pooled) per element itself
+                nfold = (w[p + "n.g"], rec["s_pool"], ops.frame_affine_backward_reduce(rec["pooled"], dx, w[p + "n.g"], rec["s_pool"], dgn, dbn))
+                dpooled = dx
+            else:
+                dpooled = ops.frame_affine_backward(rec["pooled"], dx, w[p + "n.g"], rec["s_pool"], dgn, dbn)
             if s == 0:
                 c = cfg["chans"][0]
                 acc["first"] = ops.conv_first_backward(sv["img"], w[p + "firstconv"], dpooled, c, out=acc.get("first"))
@@ -560,7 +568,7 @@ class BCTrainer:
                 x_prev = rec["x_prev"]
                 c_prev = x_prev.shape[1] * 32
                 r = self._raw_acc(acc, q, rec["pooled"].shape[1] * 32, c_prev, sa, sg)
-                dacc, coef, _, _ = ops.conv_backward_prepare_pooled(dpooled, rec["pooled"], rec["mask"], rec["s_prev"], sa, sg, c_prev, d_sa=r[1], d_sg=r[2])
+                dacc, coef, _, _ = ops.conv_backward_prepare_pooled(dpooled, rec["pooled"], rec["mask"], rec["s_prev"], sa, sg, c_prev, d_sa=r[1], d_sg=r[2], nfold=nfold)
                 ops.conv3x3_wgrad(dacc, x_prev, out=r[0])
                 dx = ops.conv3x3_dgrad(dacc, acc["wt"][q], c_prev, xin=x_prev, coef=coef)
                 del dacc
