@@ -505,7 +505,7 @@ def test_conv_prepare_pooled_equals_prepare_with_argmax(f, cin, cout, h, w, fmt)
     ab = ops.frame_affine_backward_reduce(pooled2, G, ng, s_pool, dg2, db2)
     got2 = ops.conv_backward_prepare_pooled(G, pooled2, mask, st_in, sa, sg, cin, want_t12=True, nfold=(ng, s_pool, ab))
     torch.cuda.synchronize()
-    assert torch.equal(dg1, dg2) and torch.equal(db1, db2)
+    assert torch.allclose(dg1, dg2, rtol=1e-5, atol=1e-6) and torch.allclose(db1, db2, rtol=1e-5, atol=1e-6)      # (the same pass 1; fp32 atomics in arrival order)
     a2, r2 = got2[0].float(), ref2[0].float()
     same2 = (got2[0].view(torch.int16) == ref2[0].view(torch.int16)) | ((a2 == 0) & (r2 == 0))
     print(f"PARITY pooled prepare with the n backward folded in [{fmt}]: dacc identical at {float(same2.float().mean()):.6f}, rel-L2 {_l2(a2.cpu(), r2.cpu()):.2e}; "
