@@ -66,3 +66,28 @@ for name in ("fused", "fused+nfold"):
     for e, k in rows:
         if "firstconv" in k or ".n." in k:
             print(f"      {k:70s} {e:.3e}")
+
+# ---- is either path closer to the fp32 oracle?  Several input seeds, mean rel-L2 over all tensors to the CPU oracle's gradients (the figure
+# test_bc_gradients_vs_oracle prints): two noise realisations of the same arithmetic should scatter around the same value
+if os.environ.get("VPT_DIAG_ORACLE", "1") == "1":
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    for seed in (5, 6, 7, 8):
+        g = torch.Generator().manual_seed(seed)
+        img_c = torch.randint(0, 256, (b, t, 128, 128, 3), generator=g, dtype=torch.uint8)
+        first_c = torch.zeros(b, t, dtype=torch.bool)
+        ab_c, ac_c = torch.randint(0, 8641, (b, t), generator=g), torch.randint(0, 121, (b, t), generator=g)
+        _, grads_ref = O.bc_loss_and_grads(sd, cfg, img_c, first_c, O.initial_state(cfg, b), ab_c, ac_c)[:2]
+        out = []
+        for name, fp in (("conv->pool", False), ("fused", True)):
+            tr.fused_pool, tr.fold_n_backward = fp, fp
+            _, grads, _ = tr.loss_and_grads(img_c.to(DEV), first_c.to(DEV), pol.initial_state(b), ab_c.to(DEV), ac_c.to(DEV))
+            torch.cuda.synchronize()
+            ds, cs = [], []
+            for k in tr.trainable:
+                r = grads_ref[k]
+                if float(r.norm()) == 0.0:
+                    continue
+                m = grads[k].cpu().reshape(r.shape).float()
+                ds.append(l2(m, r)); cs.append(float((m * r).sum() / (m.norm() * r.norm())))
+            out.append(f"{name}: mean rel-L2 {sum(ds) / len(ds):.4f}, mean cosine {sum(cs) / len(cs):.4f}, worst {min(cs):.3f}")
+        print(f"seed {seed} [{mode}] vs the fp32 oracle -- " + " | ".join(out), flush=True)
