@@ -854,14 +854,24 @@ def main():
                                        "logprob_rel_l2_on_timed_batch": tb.get("logprob_rel_l2"), "meets_1e-3": tb.get("meets_1e-3_logprob_rel_l2"),
                                        "note": "precision='fp16' (the policy classes' default) is the format whose log-probs are within 1e-3 relative L2 of the fp32 reference; the headline "
                                                "`value` is the north star's bf16-tile format, whose parity figures are in parity.* (1.5-4x the tolerance by construction: bf16 operands carry 8 mantissa bits)"}
-            if not args.no_ingest:
-                try:
-                    pol.set_precision(head)
-                    line["ingest"] = ingest_leg(pol, img, first, dev, copy_stream)
-                except Exception as e:
-                    line["ingest"] = dict(error=f"{type(e).__name__}: {e}")
             del pol, img
             torch.cuda.empty_cache()
+            if not args.no_ingest:
+                # The ingest leg runs in a process of its own (`bench.py --ingest-only`, same batch / model / precision): a loader process holds the
+                # forward's streams and ONE copy stream, and that is what decides whether the copy gets a hardware queue to itself -- measured inside this
+                # process, after the BC legs had created a dozen streams, the same pipeline showed no overlap at all (profiles/r05_experiments.md section 5)
+                try:
+                    import subprocess
+                    cmd = [sys.executable, os.path.abspath(__file__), "--ingest-only", "--model", args.model, "--batch", str(B), "--seq", str(T), "--steps", "3", "--warmup", "1",
+                           "--precision", head]
+                    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+                    recs = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+                    if p.returncode != 0 or not recs:
+                        raise RuntimeError(f"rc {p.returncode}: {p.stderr[-400:]}")
+                    sub = json.loads(recs[-1])
+                    line["ingest"] = dict(sub["ingest"], forward_ms_in_that_process=sub["forward_ms"], process="separate (bench.py --ingest-only)")
+                except Exception as e:
+                    line["ingest"] = dict(error=f"{type(e).__name__}: {e}")
             try:
                 line["configs"] = configs_block(dev)
             except Exception as e:

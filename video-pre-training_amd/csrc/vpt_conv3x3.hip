@@ -1093,6 +1093,7 @@ extern "C" int vpt_conv3x3_launch(const VptConv3x3Args* a_in, hipStream_t stream
 // 2J - 1 .. 2J + 1.  A pixel on both kinds of seam is handled once, by its row item.  Adds these pixels' share of the frame statistics.
 // Work per frame: ((H/16 - 1) * W/2 + (W/16 - 1) * (H/2 - (H/16 - 1))) pixels x C/8 sixteen-byte items -- 18 % of the pooled tensor at
 // 64 x 64, instead of the whole pre-pool tensor written and read back.
+template <bool MASK>      // MASK: the training forward's arg-max masks are finished too (the inference instantiation carries none of that code)
 __global__ __launch_bounds__(256) void vpt_pool_seam_kernel(VptPoolSeamArgs a) {
   // one workgroup per (frame, 32-channel block): thread = (seam pixel slot tid >> 2, channel octet tid & 3), a slot walks the seam pixels in steps of 64
   typedef short i16x8 __attribute__((ext_vector_type(8)));
@@ -1128,7 +1129,11 @@ __global__ __launch_bounds__(256) void vpt_pool_seam_kernel(VptPoolSeamArgs a) {
 #pragma unroll
       for (int dx = -1; dx <= 1; ++dx) {
         const int x = 2 * I + dx;
-        if (x >= 0) { sv[dx + 1] = *(const i16x8*)(sr + (size_t)x * 32); have[dx + 1] = true; m = __builtin_elementwise_max(m, sv[dx + 1]); }
+        if (x >= 0) {
+          const i16x8 v = *(const i16x8*)(sr + (size_t)x * 32);
+          m = __builtin_elementwise_max(m, v);
+          if (MASK) { sv[dx + 1] = v; have[dx + 1] = true; }
+        }
       }
     }
     if ((I & 7) == 0 && I > 0) {
@@ -1136,10 +1141,14 @@ __global__ __launch_bounds__(256) void vpt_pool_seam_kernel(VptPoolSeamArgs a) {
 #pragma unroll
       for (int dy = -1; dy <= 1; ++dy) {
         const int y = 2 * J + dy;
-        if (y >= 0) { sv[3 + dy + 1] = *(const i16x8*)(sc + (size_t)y * 32); have[3 + dy + 1] = true; m = __builtin_elementwise_max(m, sv[3 + dy + 1]); }
+        if (y >= 0) {
+          const i16x8 v = *(const i16x8*)(sc + (size_t)y * 32);
+          m = __builtin_elementwise_max(m, v);
+          if (MASK) { sv[3 + dy + 1] = v; have[3 + dy + 1] = true; }
+        }
       }
     }
-    if (a.mask) {
+    if constexpr (MASK) {
       // arg-max masks of the training forward (vpt_conv3x3_kernel mode 7: bit 8 - k set = position k differs from the maximum): the in-tile bits
       // stay valid only where the in-tile maximum IS the window's maximum; the positions this kernel adds get their bits here
       typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
@@ -1206,6 +1215,7 @@ extern "C" int vpt_pool_seam_launch(const VptPoolSeamArgs* a, hipStream_t stream
   if (n_pix == 0) return 0;                          // a single tile per frame: every window is inside it
   const long grid = (long)a->frames * a->CB;
   if (grid > 0x7fffffffL) return -2;
-  hipLaunchKernelGGL(vpt_pool_seam_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *a);
+  if (a->mask) hipLaunchKernelGGL(vpt_pool_seam_kernel<true>, dim3((unsigned)grid), dim3(256), 0, stream, *a);
+  else hipLaunchKernelGGL(vpt_pool_seam_kernel<false>, dim3((unsigned)grid), dim3(256), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
