@@ -642,6 +642,27 @@ def configs_block(dev):
     return out
 
 
+def launch_plan(gpus: int, env, n_dev: int, backend: str):
+    """What `bench.py --gpus N` does, as a pure function of (N, launcher environment, visible devices, transport) -- no GPU needed to test it:
+         ("refuse", message)  never an N-GPU line from fewer ranks or devices than N, never a silent 1-GPU line for N > 1;
+         ("spawn", N)         N > 1 and no launcher environment: start N ranks ourselves (torch.distributed.run) and return their exit code;
+         ("run", world)       this process is one of `world` == N ranks (or the single process of N = 1)."""
+    if n_dev <= 0:
+        return "refuse", "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    if gpus < 1:
+        return "refuse", f"bench.py: --gpus must be >= 1, got {gpus}"
+    if gpus > n_dev and backend != "gloo":
+        # one rank per GPU over RCCL (VPT_DIST_BACKEND=gloo is the tests' way to run the N > 1 branch with every rank on one device; it claims no scaling figure)
+        return "refuse", (f"bench.py: --gpus {gpus} but only {n_dev} GPU(s) visible (RCCL needs one device per rank; VPT_DIST_BACKEND=gloo runs the branch "
+                          "on one device for tests)")
+    if "WORLD_SIZE" not in env:
+        return ("spawn", gpus) if gpus > 1 else ("run", 1)
+    world = int(env["WORLD_SIZE"])
+    if world != gpus:
+        return "refuse", f"bench.py: --gpus {gpus} does not match the launcher's WORLD_SIZE={world} (the line's n_gpus is the number of ranks that ran)"
+    return "run", world
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -659,16 +680,11 @@ def main():
     args = ap.parse_args()
 
     backend = os.environ.get("VPT_DIST_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm; "gloo" lets the N > 1 branch run with every rank on one GPU (tests)
-    n_dev = torch.cuda.device_count()
-    if not (torch.cuda.is_available() and n_dev > 0):
-        sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    if args.gpus < 1:
-        sys.exit(f"bench.py: --gpus must be >= 1, got {args.gpus}")
-    if args.gpus > n_dev and backend != "gloo":
-        # one rank per GPU over RCCL: never print an N-GPU line from fewer devices (VPT_DIST_BACKEND=gloo is the tests' way to run the
-        # N > 1 branch with every rank on one device; it claims no scaling figure)
-        sys.exit(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible (RCCL needs one device per rank; VPT_DIST_BACKEND=gloo runs the branch on one device for tests)")
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    what, arg = launch_plan(args.gpus, os.environ, n_dev, backend)
+    if what == "refuse":
+        sys.exit(arg)
+    if what == "spawn":
         # `python bench.py --gpus N` by itself: start the N ranks (what `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
         # does when the driver launches it) and hand their exit code back -- a plain --gpus N never degrades to a 1-GPU line
         import socket
@@ -678,15 +694,13 @@ def main():
             port = sk.getsockname()[1]
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(arg), "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        sys.exit(f"bench.py: --gpus {args.gpus} does not match the launcher's WORLD_SIZE={world} (the line's n_gpus is the number of ranks that ran)")
+    world = arg
     distributed = world > 1
     dist = None
     dev_index = local_rank % n_dev

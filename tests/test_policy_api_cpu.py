@@ -76,3 +76,18 @@ def test_act_keep_record_views():
     assert ab.tolist() == [5957, 0] and ac.tolist() == [60, 120]
     assert torch.equal(lp, torch.tensor([-3.25, -0.001])) and torch.equal(vd, torch.tensor([1.5, -2.0])) and torch.equal(v, torch.tensor([-0.75, 8.0]))
     assert lp.data_ptr() - keep.data_ptr() == 16 and vd.data_ptr() - keep.data_ptr() == 24      # views of the record, no copies
+
+
+def test_named_split_k_is_a_function_of_the_layer_only():
+    """under the named tilings the K summation order of a linear may depend on (tiling, splitk, N, K) but never on the row count.
+    ops.nk_splitk -- what IDMEngine names -- has no M argument at all; its values for the 4x IDM's layers are pinned here."""
+    import inspect
+    from vpt_amd import ops
+    assert list(inspect.signature(ops.nk_splitk).parameters) == ["n", "k"]
+    assert ops.nk_splitk(12288, 4096) == 2          # QKV: 96 column tiles
+    assert ops.nk_splitk(4096, 4096) == 8           # proj: 32 tiles
+    assert ops.nk_splitk(16384, 4096) == 1          # mlp0: 128 tiles fill the chip already
+    assert ops.nk_splitk(4096, 16384) == 8          # mlp1
+    assert ops.nk_splitk(40, 4096) == 8 and ops.nk_splitk(4096, 256) == 1
+    src = inspect.getsource(ops.linear)
+    assert "tl == 0" in src and "nk_splitk" in src  # the M-based automatic split is reachable under tiling="auto" only
