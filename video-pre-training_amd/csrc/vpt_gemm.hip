@@ -469,25 +469,45 @@ __global__ __launch_bounds__(256, 2) void vpt_gemm_tn_kernel(VptGemmTnArgs a) {
   load(0);
   store();
   __syncthreads();
+  // Round 5: while the eight MFMAs of 16-row slice kk issue, the six fragments of slice kk + 1 are requested, each behind the last MFMA
+  // that reads the register it lands in, pinned with sched_barrier (left alone the scheduler sinks every transpose read next to its use and the
+  // matrix pipe drains for an LDS round trip per slice -- the finding of vpt_conv3x3_kernel round 2 and vpt_conv_wgrad_kernel; the first
+  // version of this loop read all six fragments, waited, then issued its MFMAs: 645 TF/s).  Only slice 0 of a step -- its tile is stored behind
+  // the barrier -- is exposed.
+  op16x8 af[4], bfr[2];         // ONE fragment set that rolls: a fragment of the next slice is requested behind the last MFMA that used its register
+#define TN_SB() __builtin_amdgcn_sched_barrier(0)
+#define TN_LDA(kk_, m_) af[m_] = tn_frag(aL + (kk_) * 16 * TA_RS + (m_) * 64, TA_RS)
+#define TN_LDB(kk_, n_) bfr[n_] = tn_frag(bL + (kk_) * 16 * TB_RS + (n_) * 64, TB_RS)
+#define TN_MM(m_, n_) acc[m_][n_] = VPT_MFMA_32X32X16(af[m_], bfr[n_], acc[m_][n_], 0, 0, 0)
+#define TN_SLICE(kk_, NEXT)                                                                               \
+  do {                                                                                                    \
+    TN_MM(0, 0); TN_SB();                                                                                 \
+    TN_MM(1, 0); TN_SB();                                                                                 \
+    TN_MM(2, 0); TN_SB();                                                                                 \
+    TN_MM(3, 0); if (NEXT) TN_LDB((kk_) + 1, 0); TN_SB();                                                 \
+    TN_MM(0, 1); if (NEXT) TN_LDA((kk_) + 1, 0); TN_SB();                                                 \
+    TN_MM(1, 1); if (NEXT) TN_LDA((kk_) + 1, 1); TN_SB();                                                 \
+    TN_MM(2, 1); if (NEXT) TN_LDA((kk_) + 1, 2); TN_SB();                                                 \
+    TN_MM(3, 1); if (NEXT) { TN_LDA((kk_) + 1, 3); TN_LDB((kk_) + 1, 1); } TN_SB();                       \
+  } while (0)
   for (int s = 0; s < nsteps; ++s) {
     const bool more = s + 1 < nsteps;
     if (more) load(s + 1);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      op16x8 af[4], bfr[2];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) af[m] = tn_frag(aL + kk * 16 * TA_RS + m * 64, TA_RS);
-#pragma unroll
-      for (int n = 0; n < 2; ++n) bfr[n] = tn_frag(bL + kk * 16 * TB_RS + n * 64, TB_RS);
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = VPT_MFMA_32X32X16(af[m], bfr[n], acc[m][n], 0, 0, 0);
-    }
+    TN_LDA(0, 0); TN_LDB(0, 0); TN_LDA(0, 1); TN_LDA(0, 2); TN_LDA(0, 3); TN_LDB(0, 1);
+    TN_SB();
+    TN_SLICE(0, true);
+    TN_SLICE(1, true);
+    TN_SLICE(2, true);
+    TN_SLICE(3, false);
     __syncthreads();
     if (more) store();
     __syncthreads();
   }
+#undef TN_SLICE
+#undef TN_MM
+#undef TN_LDB
+#undef TN_LDA
+#undef TN_SB
   // epilogue: lane = column (n2), 16 rows (n1) per accumulator; optional accumulate into the existing output
   const int rbase = c1 + wm * 128 + 4 * hi;
 #pragma unroll
