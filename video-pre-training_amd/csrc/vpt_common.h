@@ -66,6 +66,18 @@ __device__ __forceinline__ float dot2_op16(uint32_t a, uint32_t b, float c) {
 #endif
 }
 
+// ReLU of a packed pair on its bit patterns: one v_pk_max_i16 (positive 16-bit floats order like signed integers, negative ones and -0 are < 0)
+__device__ __forceinline__ uint32_t relu_op16x2(uint32_t p) {
+  typedef short s16x2_ __attribute__((ext_vector_type(2)));
+  const s16x2_ z = {0, 0};
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_, p), z));
+}
+#ifdef VPT_OPERAND_F16
+#define OP16_ONE2 0x3c003c00u
+#else
+#define OP16_ONE2 0x3f803f80u
+#endif
+
 // LDS transpose read (ds_read_b64_tr_b16): 4 consecutive 16-bit elements of this lane's column
 __device__ __forceinline__ op16x4 lds_tr16_read(const unsigned char* p) {
   return __builtin_bit_cast(op16x4, VPT_DS_READ_TR16_B64((__attribute__((address_space(3))) tr16x4*)(p)));

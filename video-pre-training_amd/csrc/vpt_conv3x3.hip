@@ -99,6 +99,7 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
   // and needs neither the pre-pool tensor nor vpt_pool_kernel (vpt_conv_bwd_prep_pooled_kernel).  Measured cost of the masks: +5 % of the
   // K = 1152 pool-fused launch, +2.5 % of the K = 2304 one (profiles/r05_experiments.md).
   constexpr bool PMASK = MODE == 7;
+  constexpr bool PACKED_RELU = MODE == 0;    // forward without residual: ReLU + statistics on the packed 16-bit pairs (see the epilogue)
   constexpr bool BWD = (MODE == 2 || MODE == 3 || MODE == 6), HAS_RES = (MODE == 1 || MODE == 3 || MODE == 5), USE_X = BWD, POOL = (MODE == 4 || MODE == 7), RES_AFF = MODE == 5;
   constexpr bool DEFER_STORES = MODE != 3;   // mode 3 holds skip + xin pieces as well: no registers left for the packed results
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_SZ];
@@ -572,8 +573,13 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
           if (!BWD) {
             const f32x4 k4 = kq[n2][g];
             const f32x2 k01 = {k4.x, k4.y}, k23 = {k4.z, k4.w};
-            v01 = __builtin_elementwise_max(rstd2 * v01 + k01, zero2);
-            v23 = __builtin_elementwise_max(rstd2 * v23 + k23, zero2);
+            if (PACKED_RELU) {   // the ReLU follows the 16-bit pack (below): there is no packed fp32 maximum on gfx950, two v_max_f32 per pair were a quarter of this mode's epilogue
+              v01 = rstd2 * v01 + k01;
+              v23 = rstd2 * v23 + k23;
+            } else {
+              v01 = __builtin_elementwise_max(rstd2 * v01 + k01, zero2);
+              v23 = __builtin_elementwise_max(rstd2 * v23 + k23, zero2);
+            }
           } else if (use_x) {  // dgrad: + d(mu, rstd)/dx terms of the GroupNorm statistics
             const f32x2 x01 = {op16_lo_to_f32(x2[q].x), op16_hi_to_f32(x2[q].x)}, x23 = {op16_lo_to_f32(x2[q].y), op16_hi_to_f32(x2[q].y)};
             if (GATE) {
@@ -600,12 +606,25 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
               v23 += r23;
             }
           }
-          if (!BWD) {   // frame statistics of the output (the next layer's GroupNorm); dgrad has no consumer for them
+          if (!BWD && !PACKED_RELU) {   // frame statistics of the output (the next layer's GroupNorm); dgrad has no consumer for them
             s_sum2 += v01 + v23;
             s_sq2 = v01 * v01 + (v23 * v23 + s_sq2);
           }
           pk[q].x = pack_op16x2(v01.x, v01.y);
           pk[q].y = pack_op16x2(v23.x, v23.y);
+          if (PACKED_RELU) {
+            // Round 5: ReLU as ONE packed signed-16-bit maximum per pair on the rounded bit patterns (positive 16-bit floats
+            // order like integers, negative ones -- and -0 -- are negative integers; rounding is monotone, so max(round(v), 0) == round(max(v, 0)):
+            // bit-identical outputs), and the frame statistics from the packed pair by v_dot2 (products of two 16-bit operands are exact in fp32):
+            // 5 instructions per value pair instead of 6, and the statistics are those of the STORED tensor -- what the next layer's GroupNorm
+            // normalises and what the reference's nn.GroupNorm sees.  Two independent accumulator chains per moment.
+            pk[q].x = relu_op16x2(pk[q].x);
+            pk[q].y = relu_op16x2(pk[q].y);
+            s_sum2.x = dot2_op16(pk[q].x, OP16_ONE2, s_sum2.x);
+            s_sum2.y = dot2_op16(pk[q].y, OP16_ONE2, s_sum2.y);
+            s_sq2.x = dot2_op16(pk[q].x, pk[q].x, s_sq2.x);
+            s_sq2.y = dot2_op16(pk[q].y, pk[q].y, s_sq2.y);
+          }
         }
         // back to 16 contiguous bytes per lane (the swap is an involution) and out
         const auto o0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
@@ -668,8 +687,13 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
             const f32x4 k4 = *(const f32x4*)(ke + n2 * 32 + 8 * g);
             const f32x2 k01 = {k4.x, k4.y}, k23 = {k4.z, k4.w};
             f32x2 v01 = {acc[m][n2][4 * g + 0], acc[m][n2][4 * g + 1]}, v23 = {acc[m][n2][4 * g + 2], acc[m][n2][4 * g + 3]};
-            v01 = __builtin_elementwise_max(rstd2 * v01 + k01, zero2);
-            v23 = __builtin_elementwise_max(rstd2 * v23 + k23, zero2);
+            if (PMASK) {      // (the masks compare post-ReLU values: a window of negatives must read as a window of zeros)
+              v01 = __builtin_elementwise_max(rstd2 * v01 + k01, zero2);
+              v23 = __builtin_elementwise_max(rstd2 * v23 + k23, zero2);
+            } else {          // inference: the pool's packed maximum starts from 0 and the seam kernel's from a pooled value >= 0 -- that IS the ReLU
+              v01 = rstd2 * v01 + k01;
+              v23 = rstd2 * v23 + k23;
+            }
             const u32x2 pk = {pack_op16x2(v01.x, v01.y), pack_op16x2(v23.x, v23.y)};
             *(u32x2*)(dst + (n2 * 32 + 8 * g) * 2) = pk;
           }
