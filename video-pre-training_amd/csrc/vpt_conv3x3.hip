@@ -606,12 +606,14 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
               v23 += r23;
             }
           }
-          if (!BWD && !PACKED_RELU) {   // frame statistics of the output (the next layer's GroupNorm); dgrad has no consumer for them
-            s_sum2 += v01 + v23;
-            s_sq2 = v01 * v01 + (v23 * v23 + s_sq2);
-          }
           pk[q].x = pack_op16x2(v01.x, v01.y);
           pk[q].y = pack_op16x2(v23.x, v23.y);
+          if (!BWD && !PACKED_RELU) {   // frame statistics of the output (the next layer's GroupNorm), from the stored pairs; dgrad has no consumer for them
+            s_sum2.x = dot2_op16(pk[q].x, OP16_ONE2, s_sum2.x);
+            s_sum2.y = dot2_op16(pk[q].y, OP16_ONE2, s_sum2.y);
+            s_sq2.x = dot2_op16(pk[q].x, pk[q].x, s_sq2.x);
+            s_sq2.y = dot2_op16(pk[q].y, pk[q].y, s_sq2.y);
+          }
           if (PACKED_RELU) {
             // Round 5: ReLU as ONE packed signed-16-bit maximum per pair on the rounded bit patterns (positive 16-bit floats
             // order like integers, negative ones -- and -0 -- are negative integers; rounding is monotone, so max(round(v), 0) == round(max(v, 0)):
@@ -761,11 +763,14 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
         const size_t off = ((size_t)(f * CB_out + (cg >> 5)) * PH * PW + (size_t)(((ty0 >> 1) + pj) * PW + (tx0 >> 1) + pi)) * 32 + (cg & 31);
         const bool complete = (pj > 0 || !top_open) && (pi > 0 || !left_open);
         if (complete) {      // the seam kernel accounts for the others once they are final
-          float vals[8];
-          unpack8(mv, vals);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) { p_sum += vals[k]; p_sq = fmaf(vals[k], vals[k], p_sq); }
+          for (int k = 0; k < 4; ++k) {     // packed pairs: one v_dot2 per two values and moment (products of 16-bit operands are exact in fp32)
+            p_sum = dot2_op16(mv[k], OP16_ONE2, p_sum);
+            p_sq = dot2_op16(mv[k], mv[k], p_sq);
+          }
           if (a.out_gain) {  // GroupNorm `n`'s gain folded into the stored tensor (a thread's items share the channel octet: 8 cached loads)
+            float vals[8];
+            unpack8(mv, vals);
             const f32x4 g0 = *(const f32x4*)(a.out_gain + cg), g1 = *(const f32x4*)(a.out_gain + cg + 4);
             vals[0] *= g0.x; vals[1] *= g0.y; vals[2] *= g0.z; vals[3] *= g0.w; vals[4] *= g1.x; vals[5] *= g1.y; vals[6] *= g1.z; vals[7] *= g1.w;
             mv = pack8(vals);
