@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_kernel(VptConvBwdPrepAr
 struct PoolEntry { u32x4 g; uint32_t codes; };   // gated gradient (8 x 16 bit), arg-max position per channel (8 x 4 bit)
 
 template <bool NFOLD>
-__global__ __launch_bounds__(256, 4) void vpt_conv_bwd_prep_pooled_kernel(VptConvBwdPrepArgs a) {
+__global__ __launch_bounds__(256) void vpt_conv_bwd_prep_pooled_kernel(VptConvBwdPrepArgs a) {
   __shared__ float tab_[9 * 32];
   __shared__ __attribute__((aligned(16))) u32x4 gbuf_[2][64][4];
   __shared__ uint32_t cbuf_[2][64][4];
@@ -474,33 +474,25 @@ __global__ __launch_bounds__(256, 4) void vpt_conv_bwd_prep_pooled_kernel(VptCon
   const int cb = blockIdx.x % a.CB, f = blockIdx.x / a.CB;
   float mean, rstd;
   frame_mean_rstd(a.stats_in, f, a.inv_count_in, mean, rstd);
-  rstd = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rstd)));
   for (int i = threadIdx.x; i < 9 * 32; i += 256) tab_[i] = 0.f;
   const int oct = threadIdx.x & 3, slot = threadIdx.x >> 2;
   const int px = slot & (PW - 1), ph = slot >> pwshift, R = 64 >> pwshift;     // R pooled rows per pass
   const int NP = PH / R;
   const size_t pplane = ((size_t)(f * a.CB + cb) * PH * PW) * 32 + oct * 8;
   const size_t plane = ((size_t)(f * a.CB + cb) * a.H * a.W) * 32 + oct * 8;
-  float allE[8], allO[8];      // interior-row sums of the thread's even / odd pre-pool column (the image's first / last row goes to LDS at once: 32 registers less)
+  float allE[8], allO[8], topE[8], topO[8], botE[8], botO[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) allE[k] = allO[k] = 0.f;
-  const int exE = (px == 0) ? 0 : 1, exO = (px == PW - 1) ? 2 : 1;
+  for (int k = 0; k < 8; ++k) allE[k] = allO[k] = topE[k] = topO[k] = botE[k] = botO[k] = 0.f;
   float tv = 0.f;
   // NFOLD: the backward of GroupNorm `n` (x = (P - mu_P) r_P gain + bias) applied to the incoming gradient G, exactly vpt_affine_bwd_apply_kernel's
   // arithmetic and rounding point (one 16-bit rounding of d(pooled))
-  __shared__ __attribute__((aligned(16))) float ng_[32];      // the plane's 32 gains (LDS: eight registers less per thread)
-  float mp = 0.f, rpool = 1.f, nA = 0.f, nB = 0.f;
+  float ng[8], mp = 0.f, rpool = 1.f, nA = 0.f, nB = 0.f;
   if (NFOLD) {
     frame_mean_rstd(a.pool_stats, f, a.inv_count_pool, mp, rpool);
     nA = (float)(a.pool_ab[2 * f] * a.inv_count_pool);
     nB = (float)(a.pool_ab[2 * f + 1] * a.inv_count_pool);
-    // (wave-uniform values computed on the vector ALU: keep them in scalar registers -- the kernel runs at exactly 128 VGPRs)
-    mp = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, mp)));
-    rpool = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rpool)));
-    nA = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, nA)));
-    nB = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, nB)));
-    if (threadIdx.x < 32) ng_[threadIdx.x] = a.n_gain[cb * 32 + threadIdx.x];
-    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ng[k] = a.n_gain[cb * 32 + oct * 8 + k];
   }
   u32x4 rd, rp, rm;                         // this thread's pooled pixel of the pass being loaded: gradient, pooled value, mask
   auto load_pass = [&](int p) {
@@ -515,8 +507,6 @@ __global__ __launch_bounds__(256, 4) void vpt_conv_bwd_prep_pooled_kernel(VptCon
     unpack8(rd, df);
     unpack8(rp, pf);
     if (NFOLD) {
-      const f32x4 g0 = *(const f32x4*)(ng_ + oct * 8), g1 = *(const f32x4*)(ng_ + oct * 8 + 4);
-      const float ng[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float xh = (pf[k] - mp) * rpool;
@@ -561,47 +551,44 @@ __global__ __launch_bounds__(256, 4) void vpt_conv_bwd_prep_pooled_kernel(VptCon
     if (has_r) { g01 = gbuf_[p & 1][slot + 1][oct]; c01 = cbuf_[p & 1][slot + 1][oct]; }
     if (has_b) { g10 = gbuf_[bb][bslot][oct]; c10 = cbuf_[bb][bslot][oct]; }
     if (has_r && has_b) { g11 = gbuf_[bb][bslot + 1][oct]; c11 = cbuf_[bb][bslot + 1][oct]; }
+    float d00[8], d01[8], d10[8], d11[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d00[k] = d01[k] = d10[k] = d11[k] = 0.f;
+    add_if(d00, e00.g, e00.codes, 4u);
+    add_if(d01, e00.g, e00.codes, 5u); add_if(d01, g01, c01, 3u);
+    add_if(d10, e00.g, e00.codes, 7u); add_if(d10, g10, c10, 1u);
+    add_if(d11, e00.g, e00.codes, 8u); add_if(d11, g01, c01, 6u); add_if(d11, g10, c10, 2u); add_if(d11, g11, c11, 0u);
     const bool is_top = (py == 0), is_bot = (py == PH - 1);
-    vpt_op16* dst = a.dacc + plane + (size_t)((2 * py) * a.W + 2 * px) * 32;
-    // one pre-pool pixel at a time (sum, class sums, scale, store), fenced: computed side by side the four pixels' 64 values plus the unpacked
-    // neighbour entries kept the kernel at 141 registers = three waves per SIMD
-    auto finish = [&](const float (&dz)[8], float (&all)[8], int ey, int ex, vpt_op16* out) {
-      float o[8];
-      if (ey != 1) {       // first / last image row: only the threads of pooled row 0 / PH - 1, once per kernel
+    float o00[8], o01[8], o10[8], o11[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) atomicAdd(&tab_[(ey * 3 + ex) * 32 + oct * 8 + k], dz[k]);
-      } else {
+    for (int k = 0; k < 8; ++k) {
+      allE[k] += d00[k] + d10[k];
+      allO[k] += d01[k] + d11[k];
+      topE[k] = is_top ? d00[k] : topE[k];
+      topO[k] = is_top ? d01[k] : topO[k];
+      botE[k] = is_bot ? d10[k] : botE[k];
+      botO[k] = is_bot ? d11[k] : botO[k];
+      o00[k] = d00[k] * rstd; o01[k] = d01[k] * rstd; o10[k] = d10[k] * rstd; o11[k] = d11[k] * rstd;
+    }
+    // Whole 128-byte lines per store instruction: the four pre-pool pixels X .. X + 3 of a pair of neighbouring pooled columns are 256 contiguous
+    // bytes; the even column's lanes own pixels X, X + 1, the odd column's X + 2, X + 3.  One exchange per row between the pair's lanes (lane ^ 4)
+    // -- even sends its second pixel and receives the partner's first -- and the first instruction writes (X, X + 1) from all eight lanes, the second
+    // (X + 2, X + 3).  (Each thread storing its own two pixels wrote 64-byte halves of every line with both instructions.)
+    const bool odd = px & 1;
+    vpt_op16* row0 = a.dacc + plane + (size_t)((2 * py) * a.W + 2 * (px & ~1)) * 32;     // pixel X of this row
+    auto store_row = [&](const float (&oa)[8], const float (&ob)[8], vpt_op16* base) {
+      const u32x4 A = pack8(oa), B = pack8(ob);
+      const u32x4 send = odd ? A : B;
+      u32x4 recv;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) all[k] += dz[k];
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) o[k] = dz[k] * rstd;
-      VPT_ST_STREAM(pack8(o), (u32x4*)out);
+      for (int j = 0; j < 4; ++j) recv[j] = (uint32_t)__shfl_xor((int)send[j], 4, 64);
+      const u32x4 first = odd ? recv : A;        // line (X, X + 1): even lanes pixel X (own A), odd lanes pixel X + 1 (the even partner's B)
+      const u32x4 second = odd ? B : recv;       // line (X + 2, X + 3): even lanes pixel X + 2 (the odd partner's A), odd lanes pixel X + 3 (own B)
+      VPT_ST_STREAM(first, (u32x4*)(base + (odd ? 32 : 0)));
+      VPT_ST_STREAM(second, (u32x4*)(base + 64 + (odd ? 32 : 0)));
     };
-    const int ey0 = is_top ? 0 : 1, ey1 = is_bot ? 2 : 1;
-    {
-      float dz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      add_if(dz, e00.g, e00.codes, 4u);
-      finish(dz, allE, ey0, exE, dst);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      float dz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      add_if(dz, e00.g, e00.codes, 5u); add_if(dz, g01, c01, 3u);
-      finish(dz, allO, ey0, exO, dst + 32);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      float dz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      add_if(dz, e00.g, e00.codes, 7u); add_if(dz, g10, c10, 1u);
-      finish(dz, allE, ey1, exE, dst + (size_t)a.W * 32);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      float dz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      add_if(dz, e00.g, e00.codes, 8u); add_if(dz, g01, c01, 6u); add_if(dz, g10, c10, 2u); add_if(dz, g11, c11, 0u);
-      finish(dz, allO, ey1, exO, dst + (size_t)a.W * 32 + 32);
-    }
+    store_row(o00, o01, row0);
+    store_row(o10, o11, row0 + (size_t)a.W * 32);
   };
   load_pass(0);
   PoolEntry cur = make_entry(0), nxt = cur;
@@ -615,24 +602,39 @@ __global__ __launch_bounds__(256, 4) void vpt_conv_bwd_prep_pooled_kernel(VptCon
     cur = nxt;
     __syncthreads();                         // buffer p & 1 is free for pass p + 2
   }
-  // ---- S[1][ex][channel] (interior rows) of the thread's even / odd pre-pool column: interior columns are most lanes -- shuffle-reduce them per
-  // wave first (edge-column lanes contribute zero there and add their own sums directly) ----
+  // ---- S[ey][ex][channel] of the thread's even / odd pre-pool column, as in the kernel above ----
   const int lane = threadIdx.x & 63;
-  auto reduce_col = [&](int ex, float (&all)[8]) {
-    float red[8];
+  auto reduce_col = [&](int ex, float (&all)[8], float (&top)[8], float (&bot)[8]) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) red[k] = sum_oct16((ex == 1) ? all[k] : 0.f);
+    for (int k = 0; k < 8; ++k) all[k] -= top[k] + bot[k];
+    float red[24];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      red[k] = (ex == 1) ? top[k] : 0.f;
+      red[8 + k] = (ex == 1) ? all[k] : 0.f;
+      red[16 + k] = (ex == 1) ? bot[k] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 24; ++i) red[i] = sum_oct16(red[i]);
     if (lane < 4) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) atomicAdd(&tab_[(1 * 3 + 1) * 32 + oct * 8 + k], red[k]);
+      for (int k = 0; k < 8; ++k) {
+        atomicAdd(&tab_[(0 * 3 + 1) * 32 + oct * 8 + k], red[k]);
+        atomicAdd(&tab_[(1 * 3 + 1) * 32 + oct * 8 + k], red[8 + k]);
+        atomicAdd(&tab_[(2 * 3 + 1) * 32 + oct * 8 + k], red[16 + k]);
+      }
     }
     if (ex != 1) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) atomicAdd(&tab_[(1 * 3 + ex) * 32 + oct * 8 + k], all[k]);
+      for (int k = 0; k < 8; ++k) {
+        atomicAdd(&tab_[(0 * 3 + ex) * 32 + oct * 8 + k], top[k]);
+        atomicAdd(&tab_[(1 * 3 + ex) * 32 + oct * 8 + k], all[k]);
+        atomicAdd(&tab_[(2 * 3 + ex) * 32 + oct * 8 + k], bot[k]);
+      }
     }
   };
-  reduce_col(exE, allE);
-  reduce_col(exO, allO);
+  reduce_col(px == 0 ? 0 : 1, allE, topE, botE);
+  reduce_col(px == PW - 1 ? 2 : 1, allO, topO, botO);
   tv = wave_sum(tv);
   if (lane == 0) red_[threadIdx.x >> 6] = tv;
   __syncthreads();
