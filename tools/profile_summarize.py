@@ -39,6 +39,15 @@ for sub, name in (("fwd1", "fwd_singlestream"), ("fwd1_fp16", "fwd_singlestream_
         n = sum(int(r["Calls"]) for r in rows)
         print(f"{sub}: vpt_conv3x3_kernel {n} launches, {tot / 1e6:.1f} ms total, {tot / max(n, 1) / 1e3:.1f} us average")
 
+# (2b) single-stream BC step (round 5)
+f = one("bc1/**/*_kernel_stats.csv")
+if f:
+    shutil.copy(f, os.path.join(DST, f"{TAG}_bc_singlestream_kernel_stats.csv"))
+    if os.path.exists(os.path.join(SRC, "bc1.log")):
+        shutil.copy(os.path.join(SRC, "bc1.log"), os.path.join(DST, f"{TAG}_bc_singlestream_bc_bench.log"))
+if os.path.exists(os.path.join(SRC, "latency.log")):
+    shutil.copy(os.path.join(SRC, "latency.log"), os.path.join(DST, f"{TAG}_latency_bench.log"))
+
 # (3) PMC of the conv micro-benchmark: per-launch averages by (grid size, kernel instantiation)
 SHAPES = {1048576: "s0.block 64x64 128->128 (256 frames)", 2097152: "256-cout layers (s1.first / s1.block / s2.first)",
           524288: "s2.block 16x16 256->256"}
