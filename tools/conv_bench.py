@@ -55,8 +55,7 @@ for name, hw, cin, cout, use_res in shapes:
     if name.endswith(".first") and os.environ.get("VPT_BENCH_POOL", "1") == "1":
         # the stack's firstconv -> max-pool pair: two kernels (the pre-pool tensor through HBM) vs the pool-fused convolution + seam kernel
         stp = torch.zeros(f, 2, dtype=torch.float64, device=dev)
-        # VPT_BENCH_POOL_PROBE=1: room behind the pooled tensor for the arg-max masks a -DVPT_POOL_ARGMASK_PROBE build writes (timing experiment)
-        pooled = torch.empty((2 if os.environ.get("VPT_BENCH_POOL_PROBE") == "1" else 1) * f, cout // 32, hw // 2, hw // 2, 32, dtype=DT, device=dev)[:f]
+        pooled = torch.empty(f, cout // 32, hw // 2, hw // 2, 32, dtype=DT, device=dev)
 
         def pair():
             ops.conv3x3(x, wpk, sa, sg, st_in, cout, out=out)
@@ -65,7 +64,10 @@ for name, hw, cin, cout, use_res in shapes:
         def fused():
             ops.conv3x3_pool(x, wpk, sa, sg, st_in, cout, stats_out=stp, out=pooled)
 
-        for label, fn in (("conv+pool", pair), ("fused", fused), ("conv+pool", pair), ("fused", fused)):
+        def fused_masks():      # the training forward (round 5): the same pass + the arg-max masks (vpt_conv3x3_kernel mode 7)
+            ops.conv3x3_pool_argmax(x, wpk, sa, sg, st_in, cout, stats_out=stp)
+
+        for label, fn in (("conv+pool", pair), ("fused", fused), ("fused+masks", fused_masks), ("conv+pool", pair), ("fused", fused), ("fused+masks", fused_masks)):
             fn(); torch.cuda.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
@@ -74,5 +76,5 @@ for name, hw, cin, cout, use_res in shapes:
             b.record()
             torch.cuda.synchronize()
             t = a.elapsed_time(b) / reps
-            print(f"[{os.environ.get('VPT_PRECISION', 'bf16')}] {name:9s} {label:9s}: {t:7.3f} ms per layer incl. pool ({flops / t / 1e9:7.1f} TF/s conv-equivalent)")
+            print(f"[{os.environ.get('VPT_PRECISION', 'bf16')}] {name:9s} {label:11s}: {t:7.3f} ms per layer incl. pool ({flops / t / 1e9:7.1f} TF/s conv-equivalent)")
     print(f"[{os.environ.get('VPT_PRECISION', 'bf16')}] {name:9s} frames={f:5d} {hw}x{hw} {cin}->{cout}: median {ms:7.3f} ms {flops / ms / 1e9:7.1f} TF/s | best {flops / best / 1e9:7.1f} TF/s  {tag}")
