@@ -375,6 +375,9 @@ int vpt_conv3x3_dgrad(const void* dacc, const void* wpk_t, const void* skip, con
  * (one read of one tensor instead of two reads and a write).  scratch as for vpt_conv_backward_prepare. */
 int vpt_conv3x3_dgrad_gated(const void* dacc, const void* wpk_t, const void* xin, const float* coef, const double* gate_stats, int gate_cin,
                             void* dacc_out, double* gate_u, int frames, int H, int W, int Cout, int Cin, void* stream);
+int vpt_conv_backward_reduce(const void* dacc, const double* gate_u, const double* stats_in, const float* edge_sa, const float* edge_sg,
+                             double* t12, float* coef, float* d_sa, float* d_sg, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream);
+
 /* vpt_conv_backward_prepare for the layer in front of the max-pool when its forward was vpt_conv3x3_pool_argmax_forward: (dpooled, pooled,
  * pool_mask) [F][Cout/32][H/2][W/2][32] in, dacc [F][Cout/32][H][W][32] and the same sums out.  The ReLU gate is [pooled > 0], the value at
  * the arg-max is the pooled value itself.  H, W: the PRE-pool size (W in {16, 32, 64}).
@@ -385,8 +388,6 @@ int vpt_conv3x3_dgrad_gated(const void* dacc, const void* wpk_t, const void* xin
 int vpt_conv_backward_prepare_pooled(const void* dpooled, const void* pooled, const void* pool_mask, const double* stats_in, const float* edge_sa, const float* edge_sg,
                                      void* dacc, double* t12, float* coef, float* d_sa, float* d_sg, float* scratch,
                                      const float* n_gain, const double* pool_stats, const double* pool_ab, int frames, int H, int W, int Cin, int Cout, void* stream);
-int vpt_conv_backward_reduce(const void* dacc, const double* gate_u, const double* stats_in, const float* edge_sa, const float* edge_sg,
-                             double* t12, float* coef, float* d_sa, float* d_sg, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream);
 
 /* Backward of vpt_conv_first_forward w.r.t. its weight and bias (the input is the uint8 image): recomputes the pre-pool
  * tile, routes dpooled to the arg-max conv pixel of every pooling window and accumulates dw[Cout][27] (kh, kw, ch order)
