@@ -600,7 +600,11 @@ def test_bc_gradients_independent_of_cnn_chunking(trainer_1x):
         # see above); 3e-4 (was 1e-4) for the other CNN tensors in fp16 -- the same order-of-fp32-additions effect reaches them too (measured 1.5e-4 on
         # stacks.1.firstconv.layer.weight with the gated dgrad, whose values differ in the last 16-bit rounding from round 4's; the bf16 run of this
         # very test, where the sums are exact, stays at 9e-7: a chunk-dependent term would show there at the same size).
-        assert e < ((1e-3 if stack0 else (3e-4 if k.startswith("net.img_process.cnn.") else 1e-4)) if pol.precision == "fp16" else (3e-4 if k.startswith("net.img_process.cnn.stacks.0.firstconv.layer.") else 1e-4)), (k, e)
+        # End of round 5: seven runs of the final tree gave 5e-5 ... 5e-4 on stack 0 in fp16 -- a tail ten times the typical figure.  The driver runs
+        # the suite with -x, so the fp16 bounds are set at 3e-3 / 1e-3: what this test exists to catch (a chunk's contribution dropped or doubled, a
+        # statistic that depends on the chunk) is O(0.1 ... 1) in fp16 as well, and the bf16 run -- exact sums, 1e-4 / 3e-4 -- is the one that pins
+        # chunk-independence to the order of fp32 additions.
+        assert e < ((3e-3 if stack0 else (1e-3 if k.startswith("net.img_process.cnn.") else 1e-4)) if pol.precision == "fp16" else (3e-4 if k.startswith("net.img_process.cnn.stacks.0.firstconv.layer.") else 1e-4)), (k, e)
     print(f"PARITY BC gradients, 3 CNN chunks vs 1: worst rel-L2 {worst:.2e}")
 
 
@@ -699,7 +703,9 @@ def test_reference_bc_loop_runs_unchanged(mode):
             continue
         e = _l2(gl, acc[n])
         worst = max(worst, e)
-        assert e < 1e-3, (n, e)                      # autograd boundary == hand-driven trainer (fp32 summation order only)
+        # autograd boundary == hand-driven trainer (fp32 summation order only): bf16 2e-7 in every run; fp16 2e-7 ... 1.6e-4 over twenty runs (the
+        # order-of-fp32-atomics tail of test_bc_gradients_independent_of_cnn_chunking), hence its wider bound -- a boundary bug is O(1)
+        assert e < (3e-3 if mode == "fp16" else 1e-3), (n, e)
         ref = acc_ref[n]
         if float(ref.norm()) > 0:
             cos = float((gl.cpu() * ref).sum() / (gl.cpu().norm() * ref.norm()))
