@@ -56,6 +56,14 @@ __device__ __forceinline__ uint32_t pack_op16x2_exact(float lo, float hi) {
 
 // packed pair dot product with fp32 accumulate: c + a.lo * b.lo + a.hi * b.hi (v_dot2c_f32_bf16 / v_dot2c_f32_f16) -- the
 // weight-streaming linears of the acting path: one instruction per two MACs, no 16-bit -> fp32 conversions
+// clamp(a.x * b + c, 0, 1) per element: v_pk_fma_f32 with the clamp result modifier and a.x broadcast to both halves (op_sel_hi 0).  The compiler
+// does not form it (its clamp fold goes through v_max_f32 x, x clamp, which has no packed fp32 form), hence the inline assembly; the operands are
+// VALU / long-retired MFMA results at every use (the hazard recogniser does not look inside inline assembly).
+__device__ __forceinline__ f32x2 pk_fma_clamp01(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 __device__ __forceinline__ float dot2_op16(uint32_t a, uint32_t b, float c) {
 #ifdef VPT_OPERAND_F16
   typedef _Float16 h2_ __attribute__((ext_vector_type(2)));

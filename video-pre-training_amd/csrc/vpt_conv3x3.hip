@@ -31,6 +31,9 @@
 #include "vpt_kernels.h"
 #include <stdlib.h>
 #include <type_traits>
+#ifndef VPT_EPI_NO_CLAMP_RELU
+#define VPT_EPI_NO_CLAMP_RELU 0   // A/B builds: 1 = residual modes with the fp32 v_max ReLU of rounds 1-4 (bit-identical outputs)
+#endif
 #ifndef VPT_EPI_ABLATE
 #define VPT_EPI_ABLATE 0   // profiling builds: 1 = no output stores, 2 = no residual loads inside the epilogue, 4 = no residual prefetch in the main loop (registers uninitialised)
 #endif
@@ -100,6 +103,14 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
   // K = 1152 pool-fused launch, +2.5 % of the K = 2304 one (profiles/r05_experiments.md).
   constexpr bool PMASK = MODE == 7;
   constexpr bool PACKED_RELU = MODE == 0;    // forward without residual: ReLU + statistics on the packed 16-bit pairs (see the epilogue)
+  // Forward WITH residual (modes 1, 5): the ReLU must precede the residual add in fp32, and gfx950 has no packed fp32 maximum -- but every VALU
+  // instruction has a clamp-to-[0, 1] result modifier.  The epilogue's affine step runs SCALED by 2^-40 (rstd and the constant table carry the
+  // factor: exact, a power of two commutes with the rounding of the FMA) with the clamp set, which is 2^-40 * ReLU for every value below 2^40, and
+  // the residual add that follows is an FMA with 2^40 -- exact product, ONE rounding, bit for bit `ReLU(v) + r`: two packed instructions per value
+  // pair where there were a packed FMA, two v_max_f32 and a packed add (192 of the mode's 1121 vector instructions per wave and tile).  Outside
+  // [2^-86, 2^40] the result would differ from an unscaled ReLU (denormal / saturated): no GroupNorm-fed convolution output lives there.
+  constexpr bool CLAMP_RELU = (MODE == 1 || MODE == 5) && !VPT_EPI_NO_CLAMP_RELU;
+  constexpr float RELU_S = CLAMP_RELU ? 0x1p-40f : 1.f, RELU_INV = 0x1p40f;
   constexpr bool BWD = (MODE == 2 || MODE == 3 || MODE == 6), HAS_RES = (MODE == 1 || MODE == 3 || MODE == 5), USE_X = BWD, POOL = (MODE == 4 || MODE == 7), RES_AFF = MODE == 5;
   constexpr bool DEFER_STORES = MODE != 3;   // mode 3 holds skip + xin pieces as well: no registers left for the packed results
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_SZ];
@@ -204,7 +215,7 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
 #pragma unroll
     for (int k = 0; k < NKK; ++k) {
       const int idx = tid + NTHR * k;
-      if (idx < 9 * 128) kk[idx] = ksa[k] - rstd * mean * ksg[k];
+      if (idx < 9 * 128) kk[idx] = (ksa[k] - rstd * mean * ksg[k]) * RELU_S;
     }
   }
   float res_s = 1.f;
@@ -521,7 +532,8 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
     (e_).x = s0_[0]; (o_).x = s0_[1]; (e_).y = s1_[0]; (o_).y = s1_[1];                                   \
   } while (0)
   const f32x2 zero2 = {0.f, 0.f};
-  const f32x2 rstd2 = {rstd, rstd}, c0f2 = {c0f, c0f}, c1f2 = {c1f, c1f}, ress2 = {res_s, res_s}, rgate2 = {rgate, rgate};
+  const f32x2 rstd2 = {rstd * RELU_S, rstd * RELU_S}, c0f2 = {c0f, c0f}, c1f2 = {c1f, c1f}, ress2 = {res_s, res_s}, rgate2 = {rgate, rgate};
+  const f32x2 relu_inv2 = {RELU_INV, RELU_INV};
   // mode 5: the residual's per-channel bias of this lane's channels.  Read per chunk (4 x ds_read_b128 right behind the chunk's table prefetch, ~20
   // VALU instructions before their first use) instead of held for the whole epilogue: 16 registers instead of 32 -- round 4's version spilled 2 VGPRs.
   f32x4 bq[4];
@@ -576,6 +588,9 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
             if (PACKED_RELU) {   // the ReLU follows the 16-bit pack (below): there is no packed fp32 maximum on gfx950, two v_max_f32 per pair were a quarter of this mode's epilogue
               v01 = rstd2 * v01 + k01;
               v23 = rstd2 * v23 + k23;
+            } else if (CLAMP_RELU) {   // 2^-40 * ReLU(rstd v + k) through the clamp modifier (see CLAMP_RELU above)
+              v01 = pk_fma_clamp01(rstd2, v01, k01);
+              v23 = pk_fma_clamp01(rstd2, v23, k23);
             } else {
               v01 = __builtin_elementwise_max(rstd2 * v01 + k01, zero2);
               v23 = __builtin_elementwise_max(rstd2 * v23 + k23, zero2);
@@ -599,8 +614,16 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
             if (RES_AFF) {
               const f32x4 b4 = bq[g];
               const f32x2 b01 = {b4.x, b4.y}, b23 = {b4.z, b4.w};
-              v01 = ress2 * r01 + (v01 + b01);
-              v23 = ress2 * r23 + (v23 + b23);
+              if (CLAMP_RELU) {
+                v01 = ress2 * r01 + __builtin_elementwise_fma(v01, relu_inv2, b01);
+                v23 = ress2 * r23 + __builtin_elementwise_fma(v23, relu_inv2, b23);
+              } else {
+                v01 = ress2 * r01 + (v01 + b01);
+                v23 = ress2 * r23 + (v23 + b23);
+              }
+            } else if (CLAMP_RELU) {
+              v01 = __builtin_elementwise_fma(v01, relu_inv2, r01);
+              v23 = __builtin_elementwise_fma(v23, relu_inv2, r23);
             } else {
               v01 += r01;
               v23 += r23;
