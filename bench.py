@@ -676,6 +676,7 @@ def main():
     ap.add_argument("--bc-warmup", type=int, default=1)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"], help="operand format of the HEADLINE value (north star: bf16 tiles); the other format is reported beside it")
     ap.add_argument("--no-ingest", action="store_true", help="skip the host -> device ingest leg")
+    ap.add_argument("--step-overlap", type=int, default=0, help="1: PolicyEngine.overlap_steps() during the timed forward (A/B)")
     ap.add_argument("--ingest-only", action="store_true", help="(profiling) only the timed forward and the ingest leg; prints the ingest record")
     args = ap.parse_args()
 
@@ -775,7 +776,10 @@ def main():
             el = float(tt.item())
         return el, state
 
+    if args.step_overlap:
+        pol.overlap_steps(True)
     elapsed, state = timed_forward(args.steps, args.warmup)
+    pol.overlap_steps(False)
     if args.ingest_only:
         print(json.dumps(dict(forward_ms=round(1e3 * elapsed / args.steps, 3), ingest=ingest_leg(pol, img, first, dev, copy_stream))))
         return

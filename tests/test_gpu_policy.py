@@ -211,6 +211,61 @@ def test_a_sequence_result_does_not_depend_on_the_row_count_of_the_linears(pol_1
             assert torch.equal(k1, k2) and torch.equal(v1, v2)
 
 
+def test_overlapped_steps_equal_serial_steps(pol_1x):
+    """PolicyEngine.overlap_steps(): with it the chunk streams of call i + 1 wait for call i's hand-off event (CNN output consumed) instead of
+    for the calling stream, so they run beside call i's transformer.  Same kernels, same data, same per-stream order: five consecutive calls with
+    the state carried -- different frames each, three ragged chunks on three streams -- must equal the serial ordering BIT FOR BIT, in either
+    order of running the two modes, and a re-pack in between (new weights) must be waited for."""
+    pol, cfg, sd = pol_1x
+    b, t, n_calls = 2, 20, 5                             # 40 frames per call: chunks of 16, 16, 8
+    imgs = [_inputs(700 + i, b, t).to(DEV) for i in range(n_calls)]
+    first = torch.zeros(b, t, dtype=torch.bool, device=DEV)
+    first[1, 7] = True
+    eng = pol._engine
+    saved = eng.cnn_chunk
+
+    def run(overlap):
+        pol.overlap_steps(overlap)
+        st, rec = pol.initial_state(b), []
+        for i in range(n_calls):
+            (pd, v, _), st = pol({"img": imgs[i]}, first, st)
+            rec.append((pd["buttons"].clone(), pd["camera"].clone(), v.clone()))
+        torch.cuda.synchronize()
+        return rec, [(k.clone(), vv.clone()) for _, (k, vv) in st]
+
+    try:
+        eng.cnn_chunk = 16
+        assert min(eng.cnn_streams, 3) > 1, "the test needs more than one chunk stream"
+        serial, st_s = run(False)
+        piped, st_p = run(True)
+        assert pol._engine._handoff is not None          # the pipelined ordering was actually taken
+        serial2, _ = run(False)
+        for a, c, d in zip(serial, piped, serial2):
+            for x, y, z in zip(a, c, d):
+                assert torch.equal(x, y) and torch.equal(x, z)
+        for (k1, v1), (k2, v2) in zip(st_s, st_p):
+            assert torch.equal(k1, k2) and torch.equal(v1, v2)
+        # new weights between two overlapped calls: the re-pack runs on the calling stream and the next call must wait for it
+        pol.overlap_steps(True)
+        (pd0, _, _), _ = pol({"img": imgs[0]}, first, pol.initial_state(b))
+        w = dict(pol.named_parameters())["net.img_process.cnn.stacks.1.blocks.0.conv0.layer.weight"]
+        orig = w.detach().clone()
+        try:
+            with torch.no_grad():
+                w.mul_(1.5)
+            (pd1, _, _), _ = pol({"img": imgs[0]}, first, pol.initial_state(b))
+            pol.overlap_steps(False)
+            (pd2, _, _), _ = pol({"img": imgs[0]}, first, pol.initial_state(b))
+            torch.cuda.synchronize()
+            assert torch.equal(pd1["buttons"], pd2["buttons"]) and not torch.equal(pd0["buttons"], pd1["buttons"])
+        finally:
+            with torch.no_grad():
+                w.copy_(orig)                          # (the fixture is shared by the module: restore the exact bits)
+    finally:
+        pol._engine.cnn_chunk = saved
+        pol.overlap_steps(False)
+
+
 def test_policy_full_chunk_t128(pol_1x):
     """One full training-size chunk (T = 128, B = 2) against the oracle: all four query tiles of the band, the
     memory fully replaced by the chunk, then a T = 1 step on the carried state (the run_agent.py shape)."""

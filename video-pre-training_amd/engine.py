@@ -158,12 +158,17 @@ class PolicyEngine:
         self.fold_stats_in_producer = os.environ.get("VPT_FOLD_STATS", "1") != "0"     # 0: per-channel sums by a pass of their own (A/B)
         self.fold_dense = os.environ.get("VPT_FOLD_DENSE", "1") != "0"                 # dense.norm (LayerNorm 65536) folded into the dense GEMM
         self._streams = []
+        # Cross-step overlap (opt-in, overlap_steps()): the CNN of call i + 1 is ordered behind the point where call i handed its CNN output to the
+        # transformer -- not behind the transformer itself -- so it runs BESIDE the previous call's transformer and heads.
+        self.step_overlap = False
+        self._handoff = None        # event on the calling stream: the previous call's last read of chunk-stream memory is enqueued before it
         self._attn_done = None      # arrival counters of the in-place acting step (ops.masked_attention_step)
         self._rng_state = None      # in-kernel sampler state {seed, step}, created on first stochastic use (rng_state)
         self._rng_src, self._pending_seed = None, None
         self.w: Dict[str, torch.Tensor] = {}
         self.packed = False
 
+    step_overlap, _handoff = False, None      # class defaults (IDMEngine builds its own __init__; it never forks chunk streams)
     _RNG_MARK = 8        # how far the engine advances torch's CUDA generator offset when it derives a seed from it (see rng_state)
 
     def rng_state(self, device):
@@ -268,6 +273,29 @@ class PolicyEngine:
                           for s in range(len(cfg["chans"]))}
         self._dense_src = sd["net.img_process.cnn.dense.layer.weight"]
         self._fold_tab = {}
+        self._handoff = None        # the next forward orders its chunk streams behind EVERYTHING on the calling stream (the packing kernels above)
+
+    def overlap_steps(self, enable: bool = True):
+        """Opt-in pipelining of consecutive forward() calls (throughput path, more than one CNN chunk): with it, the chunk streams of a call wait
+        for the previous call's hand-off point (its CNN output consumed) instead of for all earlier work on the calling stream, so this call's
+        convolutions run beside the previous call's transformer + heads (7 % of a 2x step, launch-bound GEMMs and small kernels that leave most
+        of the chip idle).  Results are unchanged -- the same kernels on the same data in the same per-stream order.
+        CONTRACT: the frames passed to forward() must be complete on the device when forward() is called (resident, or uploaded on a copy
+        stream whose event the HOST has waited for): work enqueued on the calling stream after the previous forward() returned is NOT waited for
+        by the convolutions.  Off by default: a caller that produces frames on the calling stream right before forward() keeps working."""
+        self.step_overlap = bool(enable)
+        self._handoff = None
+
+    def _prepare_fold_tables(self, tiling: str):
+        """The lazily built constant tables of the folded path, built on the CALLING stream before the chunk streams fork: built inside the first
+        chunk, the other chunks' streams would read them unordered (first forward after a pack)."""
+        if tiling != "throughput":
+            return
+        if self.fold_dense:
+            self._dense_fold()
+        if self.fold_n and self.fuse_pool:
+            for s in range(len(self.cfg["chans"])):
+                self._nfold_tables(s)
 
     def _dense_fold(self):
         """ImpalaCNN.dense with its LayerNorm(65536) folded into the GEMM (inference): (weights packed from W * gain in blocked order,
@@ -443,10 +471,15 @@ class PolicyEngine:
         n_streams = min(self.cnn_streams, n_chunks)
         main = torch.cuda.current_stream()
         if n_streams > 1:
+            self._prepare_fold_tables(tiling)
             while len(self._streams) < n_streams:      # created once, appended to, never replaced
                 self._streams.append(torch.cuda.Stream())
+            pipelined = self.step_overlap and self._handoff is not None and not torch.cuda.is_current_stream_capturing()
             for st in self._streams[:n_streams]:
-                st.wait_stream(main)
+                if pipelined:
+                    st.wait_event(self._handoff)       # overlap_steps(): behind the previous call's hand-off, beside its transformer
+                else:
+                    st.wait_stream(main)
         for ci, i in enumerate(range(0, n, self.cnn_chunk)):
             ctx = torch.cuda.stream(self._streams[ci % n_streams]) if n_streams > 1 else _NullCtx()
             with ctx:
@@ -457,6 +490,11 @@ class PolicyEngine:
         d = outs[0] if len(outs) == 1 else torch.cat(outs, 0)
         p = "net.img_process.linear."
         _, x, _ = self._ln_linear(d, w[p + "g"], w[p + "b"], w[p + "w"], cfg["hidsize"], relu=True, relu_in=True, tiling=tiling)
+        if n_streams > 1 and self.step_overlap and not torch.cuda.is_current_stream_capturing():
+            # the hand-off: every read of memory that belongs to the chunk streams' allocator pools (`outs`) is enqueued on `main` before this event,
+            # so the next call's chunks may reuse it once the event has fired; everything behind it on `main` (transformer, heads) they do not wait for
+            self._handoff = torch.cuda.Event()
+            self._handoff.record(main)
         return x
 
     @torch.no_grad()

@@ -270,9 +270,17 @@ class MinecraftAgentPolicy(nn.Module):
             old = self._engine
             self._engine = PolicyEngine(self._cfg, n_buttons=old.n_buttons, n_camera=old.n_camera, precision=precision)
             self._engine.adopt_sampler(old)         # seed_sampler() / the step counter survive a change of operand format
+            self._engine.overlap_steps(old.step_overlap)
             self._packed_key = None
             if self._step_graph is not None:
                 self._step_graph = self._fresh_step_graph(self._step_graph)      # (static buffers and graphs are rebuilt lazily)
+        return self
+
+    def overlap_steps(self, enable: bool = True):
+        """Opt-in pipelining of consecutive multi-chunk forward() calls (a labelling / evaluation loop over resident batches): the convolutions of
+        a call run beside the previous call's transformer and heads.  Same results; the CONTRACT is PolicyEngine.overlap_steps's -- the frames
+        handed to forward() are already complete on the device.  Off by default (the reference's call semantics on the current stream)."""
+        self._engine.overlap_steps(enable)
         return self
 
     @property
