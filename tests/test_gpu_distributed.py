@@ -77,9 +77,15 @@ def test_two_rank_bc_step_matches_single_process(b, precision):                 
             continue
         e = float((r0["grads"][k].reshape(g1.shape) - g1).norm() / g1.norm())
         errs.append(e)
-        assert e < 1e-3, (k, e)
+        # 5e-2, not the 1e-6 this comparison shows nine times out of ten: the BC backward in bf16 / fp16 is NOT bit-reproducible from run to run
+        # (DESIGN.md "Known issue", tools/diag_shards.py: ~15 % of gradient computations of the SAME batch in the SAME process land 3.6e-5 away on
+        # the stack-0 tensors, ~2 % 5e-4, and about one in thirty 2-rank calls 1e-3 ... 1e-2 on most tensors -- discrete alternative outcomes, not
+        # root-caused; two orders of magnitude inside the 16-bit formats' own distance to the fp32 gradient).  What this test is for shows at O(1): a bucket left out of the exchange (a tensor at half its value), the mean taken over the
+        # local instead of the global frame count (a factor 2), a shard processed twice.
+        assert e < 5e-2, (k, e)
         assert torch.equal(r0["grads"][k], r1["grads"][k]), k   # the all-reduce leaves both ranks with the same bits
-    print(f"PARITY 2-rank all-reduced BC gradients vs single process: worst rel-L2 {max(errs):.3e}, mean {sum(errs) / len(errs):.3e}")
+    errs_sorted = sorted(errs)
+    print(f"PARITY 2-rank all-reduced BC gradients vs single process: worst rel-L2 {max(errs):.3e}, median {errs_sorted[len(errs) // 2]:.3e}, mean {sum(errs) / len(errs):.3e}")
     for k in r0["params"]:
         assert torch.equal(r0["params"][k], r1["params"][k]), k     # replicas stay bit-identical after the step
 
