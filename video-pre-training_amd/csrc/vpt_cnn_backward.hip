@@ -43,6 +43,45 @@ __device__ __forceinline__ float sum_oct16(float v) {  // over the 16 lanes shar
   return v;
 }
 
+// Deterministic accumulation of a thread column's edge-class sums into the workgroup's table (all 256 threads call it): every wave stages its own
+// contribution in LDS, and after one barrier each table entry adds the four waves' values in a FIXED order.  Until the end of round 5 these were LDS
+// float atomics: S then depended on the order in which the four waves arrived, and through T1 = (sum dz v) - <SA, S> -- a difference of nearly equal
+// numbers -- so did the frame's coefficients (c0, c1): repeating the SAME gradient computation landed on a handful of discrete alternative outcomes
+// (3.6e-5 ... 5e-4 on the stack-0 tensors in ~15 % of the runs, once the lighter reduce-only / pooled kernels let the waves finish almost together:
+// tools/diag_shards.py, DESIGN.md "Known issue").
+// stage_: [4 waves][9 classes][32 channels], zero on entry and zero again on return.  red: the interior columns' sums after the per-wave butterfly
+// (lanes 0-3, one per channel octet); top / all / bot: the thread's own sums, used when its column is an edge column (ex != 1).  jrow / J: the thread's
+// pixel row inside its wave's 16 pixels and how many rows a wave holds (J > 1 only for images narrower than 16 pixels: two lanes of a wave then share
+// an edge entry and add in row order).
+#define EDGE_STAGE_FLOATS (4 * 9 * 32)
+__device__ __forceinline__ void add_edge_sums_ordered(float* tab_, float* stage_, int ex, int oct, int lane, int wave, int jrow, int J,
+                                                      const float (&top)[8], const float (&all)[8], const float (&bot)[8]) {
+  float* mine = stage_ + wave * (9 * 32) + oct * 8;
+  // one row class (top / interior rows / bottom) at a time, butterfly and store back to back: eight values in flight, not twenty-four
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const float (&src)[8] = (g == 0) ? top : ((g == 1) ? all : bot);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float r = sum_oct16((ex == 1) ? src[k] : 0.f);     // interior columns: most lanes (edge-column lanes contribute zero)
+      if (lane < 4) mine[(g * 3 + 1) * 32 + k] = r;
+    }
+    for (int j = 0; j < J; ++j) {
+      if (ex != 1 && jrow == j) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mine[(g * 3 + ex) * 32 + k] += src[k];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 9 * 32; i += 256) {
+    tab_[i] += (stage_[i] + stage_[288 + i]) + (stage_[576 + i] + stage_[864 + i]);
+    stage_[i] = 0.f; stage_[288 + i] = 0.f; stage_[576 + i] = 0.f; stage_[864 + i] = 0.f;
+  }
+  __syncthreads();
+}
+
 template <bool PER_ELEMENT>
 __global__ __launch_bounds__(256) void vpt_affine_bwd_reduce_kernel(VptAffineBwdArgs a) {
   __shared__ float part_[4 * 64];
@@ -303,11 +342,13 @@ template <bool HAS_DY, bool HAS_RES, bool PRE = false>
 __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_kernel(VptConvBwdPrepArgs a) {
   static_assert(!PRE || (HAS_DY && !HAS_RES), "the pre-gated variant reads dacc only");
   __shared__ float tab_[9 * 32];
+  __shared__ float stage_[EDGE_STAGE_FLOATS];
   const int HW = a.H * a.W;
   const int cb = blockIdx.x % a.CB, f = blockIdx.x / a.CB;
   float mean, rstd;
   frame_mean_rstd(a.stats_in, f, a.inv_count_in, mean, rstd);
   for (int i = threadIdx.x; i < 9 * 32; i += 256) tab_[i] = 0.f;
+  for (int i = threadIdx.x; i < EDGE_STAGE_FLOATS; i += 256) stage_[i] = 0.f;
   __syncthreads();
   const int oct = threadIdx.x & 3, pi = threadIdx.x >> 2;
   const int x = pi & (a.W - 1), ry = pi >> a.wshift, R = 64 >> a.wshift;
@@ -410,33 +451,8 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_kernel(VptConvBwdPrepAr
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) all[k] -= top[k] + bot[k];
-  // interior columns are most lanes: shuffle-reduce them per wave first (edge-column lanes contribute zero)
-  float red[24];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    red[k] = (ex == 1) ? top[k] : 0.f;
-    red[8 + k] = (ex == 1) ? all[k] : 0.f;
-    red[16 + k] = (ex == 1) ? bot[k] : 0.f;
-  }
-#pragma unroll
-  for (int i = 0; i < 24; ++i) red[i] = sum_oct16(red[i]);
   const int lane = threadIdx.x & 63;
-  if (lane < 4) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      atomicAdd(&tab_[(0 * 3 + 1) * 32 + oct * 8 + k], red[k]);
-      atomicAdd(&tab_[(1 * 3 + 1) * 32 + oct * 8 + k], red[8 + k]);
-      atomicAdd(&tab_[(2 * 3 + 1) * 32 + oct * 8 + k], red[16 + k]);
-    }
-  }
-  if (ex != 1) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      atomicAdd(&tab_[(0 * 3 + ex) * 32 + oct * 8 + k], top[k]);
-      atomicAdd(&tab_[(1 * 3 + ex) * 32 + oct * 8 + k], all[k]);
-      atomicAdd(&tab_[(2 * 3 + ex) * 32 + oct * 8 + k], bot[k]);
-    }
-  }
+  add_edge_sums_ordered(tab_, stage_, ex, oct, lane, threadIdx.x >> 6, (pi & 15) >> a.wshift, max(1, 16 >> a.wshift), top, all, bot);
   // sum dz v of this plane -> sbuf column 9*Cout + cb (the finish kernel adds the planes and the <SA, S> correction)
   tv = wave_sum(tv);
   __shared__ float red_[4];
@@ -465,8 +481,9 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_kernel(VptConvBwdPrepAr
 struct PoolEntry { u32x4 g; uint32_t codes; };   // gated gradient (8 x 16 bit), arg-max position per channel (8 x 4 bit)
 
 template <bool NFOLD>
-__global__ __launch_bounds__(256) void vpt_conv_bwd_prep_pooled_kernel(VptConvBwdPrepArgs a) {
+__global__ __launch_bounds__(256, 3) void vpt_conv_bwd_prep_pooled_kernel(VptConvBwdPrepArgs a) {
   __shared__ float tab_[9 * 32];
+  __shared__ float stage_[EDGE_STAGE_FLOATS];
   __shared__ __attribute__((aligned(16))) u32x4 gbuf_[2][64][4];
   __shared__ uint32_t cbuf_[2][64][4];
   __shared__ float red_[4];
@@ -475,6 +492,7 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_pooled_kernel(VptConvBw
   float mean, rstd;
   frame_mean_rstd(a.stats_in, f, a.inv_count_in, mean, rstd);
   for (int i = threadIdx.x; i < 9 * 32; i += 256) tab_[i] = 0.f;
+  for (int i = threadIdx.x; i < EDGE_STAGE_FLOATS; i += 256) stage_[i] = 0.f;
   const int oct = threadIdx.x & 3, slot = threadIdx.x >> 2;
   const int px = slot & (PW - 1), ph = slot >> pwshift, R = 64 >> pwshift;     // R pooled rows per pass
   const int NP = PH / R;
@@ -607,31 +625,7 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_prep_pooled_kernel(VptConvBw
   auto reduce_col = [&](int ex, float (&all)[8], float (&top)[8], float (&bot)[8]) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) all[k] -= top[k] + bot[k];
-    float red[24];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      red[k] = (ex == 1) ? top[k] : 0.f;
-      red[8 + k] = (ex == 1) ? all[k] : 0.f;
-      red[16 + k] = (ex == 1) ? bot[k] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < 24; ++i) red[i] = sum_oct16(red[i]);
-    if (lane < 4) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        atomicAdd(&tab_[(0 * 3 + 1) * 32 + oct * 8 + k], red[k]);
-        atomicAdd(&tab_[(1 * 3 + 1) * 32 + oct * 8 + k], red[8 + k]);
-        atomicAdd(&tab_[(2 * 3 + 1) * 32 + oct * 8 + k], red[16 + k]);
-      }
-    }
-    if (ex != 1) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        atomicAdd(&tab_[(0 * 3 + ex) * 32 + oct * 8 + k], top[k]);
-        atomicAdd(&tab_[(1 * 3 + ex) * 32 + oct * 8 + k], all[k]);
-        atomicAdd(&tab_[(2 * 3 + ex) * 32 + oct * 8 + k], bot[k]);
-      }
-    }
+    add_edge_sums_ordered(tab_, stage_, ex, oct, lane, threadIdx.x >> 6, (slot & 15) >> pwshift, max(1, 16 >> pwshift), top, all, bot);
   };
   reduce_col(px == 0 ? 0 : 1, allE, topE, botE);
   reduce_col(px == PW - 1 ? 2 : 1, allO, topO, botO);
