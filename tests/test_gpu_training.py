@@ -604,10 +604,11 @@ def test_bc_gradients_independent_of_cnn_chunking(trainer_1x):
         # the suite with -x, so the fp16 bounds are set at 3e-3 / 1e-3: what this test exists to catch (a chunk's contribution dropped or doubled, a
         # statistic that depends on the chunk) is O(0.1 ... 1) in fp16 as well, and the bf16 run -- exact sums, 1e-4 / 3e-4 -- is the one that pins
         # chunk-independence to the order of fp32 additions.
-        # Very end of round 5 (tools/diag_shards.py, DESIGN.md "Known issue"): the tail is not fp16's alone.  Repeating the SAME bf16 gradient computation
-        # lands on a discrete alternative outcome in ~15 % of the runs (3.6e-5 on the ten stack-0 tensors), ~2 % at 5e-4, and about one 2-rank call in thirty
-        # deviates by 1e-3 ... 1e-2 on most tensors (not root-caused).  The bounds below are therefore 2e-2 for
-        # every tensor in both formats: a chunk dropped, doubled or normalised with a chunk-dependent statistic shows at O(0.1 ... 1).  `worst` is printed.
+        # Very end of round 5 (tools/diag_shards.py, DESIGN.md "Known issue"): the tail was not fp16's alone and not cancellation alone -- LDS float atomics
+        # in the two `prepare` kernels made the SAME bf16 gradient computation land on a discrete alternative outcome in ~15 % of the runs (3.6e-5 on the
+        # ten stack-0 tensors, 5e-4 in ~2 %).  They are an ordered reduction now (0 of 40 repetitions above 5e-6); the bounds stay at 2e-2 for every tensor
+        # in both formats because the suite runs with -x and the fix has 40 repetitions behind it, not 400: a chunk dropped, doubled or normalised with a
+        # chunk-dependent statistic shows at O(0.1 ... 1).  `worst` is printed.
         assert e < 2e-2, (k, e)
     print(f"PARITY BC gradients, 3 CNN chunks vs 1: worst rel-L2 {worst:.2e}")
 
@@ -709,7 +710,7 @@ def test_reference_bc_loop_runs_unchanged(mode):
         worst = max(worst, e)
         # autograd boundary == hand-driven trainer (fp32 summation order only): bf16 2e-7 in every run; fp16 2e-7 ... 1.6e-4 over twenty runs (the
         # order-of-fp32-atomics tail of test_bc_gradients_independent_of_cnn_chunking), hence its wider bound -- a boundary bug is O(1)
-        # (end of round 5: 2e-2 in both formats -- the BC backward's run-to-run alternatives, DESIGN.md "Known issue")
+        # (end of round 5: 2e-2 in both formats -- see test_bc_gradients_independent_of_cnn_chunking and DESIGN.md "Known issue")
         assert e < 2e-2, (n, e)
         ref = acc_ref[n]
         if float(ref.norm()) > 0:
