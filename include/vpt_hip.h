@@ -32,7 +32,7 @@ const char* vpt_version(void);
  * was built against before the first call -- _native.py does -- instead of finding out through a mis-typed argument.
  * History: 3 = round 3 (vpt_adam_step_multi + skip_flag, vpt_heads_logprob_backward + grad_scale, vpt_gate_cast renamed);
  * 4 = round 4 (vpt_conv3x3_forward_tiled rejects tiling 0; vpt_action_head_forward takes a counter-based noise source). */
-#define VPT_HIP_ABI 4
+#define VPT_HIP_ABI 5
 int vpt_abi_version(void);
 /* "bf16" (libvpt_hip.so, the default) or "fp16" (libvpt_hip_f16.so: the same sources built with -DVPT_OPERAND_F16): the format
  * of every 16-bit buffer this library reads or writes -- activations, packed weights, MFMA operands.  Same ABI, same
@@ -72,10 +72,17 @@ int vpt_chw_to_blocked(const float* src, float* dst, int64_t rows, int C, int H,
 
 /* Workspace query: bytes of caller-owned scratch for the entry points that take a `scratch` / partial-sum buffer.
  *   VPT_WS_CONV3X3_WGRAD         (frames, -, -, Cin, Cout)   vpt_conv3x3_wgrad's scratch
- *   VPT_WS_CONV_BACKWARD_PREPARE (frames, -, -, -, Cout)     vpt_conv_backward_prepare's scratch
+ *   VPT_WS_CONV_BACKWARD_PREPARE (frames, -, -, -, Cout)     scratch of vpt_conv_backward_prepare / _prepare_pooled / _reduce
  *   VPT_WS_LINEAR_SPLITK         (splitk, M, N, -, -)        the [splitk][M][N] fp32 slices vpt_linear_forward writes when splitk > 1
+ *   VPT_WS_LAYERNORM_BACKWARD    (M, D, -, -, -)             vpt_layernorm_backward's partials
+ *   VPT_WS_COLUMN_SUM            (M, N, -, -, -)             vpt_column_sum's partials (0: none needed)
+ *   VPT_WS_ATTENTION_BACKWARD_DKV  (B, t, hid, -, -)         vpt_masked_attention_backward's dkv_slab
+ *   VPT_WS_ATTENTION_BACKWARD_DBND (B, t, heads, maxlen, -)  ... and its dbnd_slab
+ *   VPT_WS_FRAME_AFFINE_BACKWARD (frames, HW, per_element, pass, C)   vpt_frame_affine_backward's partials for that pass
+ *   VPT_WS_CONV_FIRST_BACKWARD   (frames, H, W, -, Cout)     vpt_conv_first_backward's partials (depends on the device's CU count)
  * Returns -1 for an unknown op. */
-enum { VPT_WS_CONV3X3_WGRAD = 1, VPT_WS_CONV_BACKWARD_PREPARE = 2, VPT_WS_LINEAR_SPLITK = 3 };
+enum { VPT_WS_CONV3X3_WGRAD = 1, VPT_WS_CONV_BACKWARD_PREPARE = 2, VPT_WS_LINEAR_SPLITK = 3, VPT_WS_LAYERNORM_BACKWARD = 4, VPT_WS_COLUMN_SUM = 5,
+       VPT_WS_ATTENTION_BACKWARD_DKV = 6, VPT_WS_ATTENTION_BACKWARD_DBND = 7, VPT_WS_FRAME_AFFINE_BACKWARD = 8, VPT_WS_CONV_FIRST_BACKWARD = 9 };
 int64_t vpt_workspace_bytes(int op, int frames, int H, int W, int Cin, int Cout);
 int vpt_pack_conv3x3(const float* weight, const float* gain, const float* bias, void* wpk, float* edge_sa, float* edge_sg,
                      int Cout, int Cin, void* stream);
@@ -327,22 +334,27 @@ int vpt_heads_logprob_backward(const float* lp_buttons, const float* lp_camera, 
                                int M, int nb, int nc, int ldz, float temperature, float grad_scale, void* stream);
 
 /* nn.LayerNorm backward (optionally through a ReLU on the LayerNorm's input): dx = dx_add + dLN(x, dy);
- * dgain / dbias are accumulated with atomics (caller zeroes). */
+ * dgain / dbias += the column sums (caller zeroes), reduced in a FIXED order through `partials` (fp32 workspace of
+ * vpt_workspace_bytes(VPT_WS_LAYERNORM_BACKWARD, M, D, ...) bytes): the same inputs give the same bits, as torch autograd on one device does for
+ * behavioural_cloning.py:117-119.  (ABI 5; ABI 4 accumulated with fp32 atomics in arrival order.) */
 int vpt_layernorm_backward(const float* x, const float* gain, const float* dy, const float* dx_add, float* dx,
-                           float* dgain, float* dbias, int M, int D, int relu_in, void* stream);
+                           float* dgain, float* dbias, float* partials, int M, int D, int relu_in, void* stream);
 
 /* out16[M][ldo] = (mask > 0 ? x : 0) with columns >= N zeroed: the ReLU backward gate (F.relu at lib/util.py:81,
  * lib/policy.py:211) fused with the cast / K-padding that turns an fp32 gradient into a GEMM A operand. */
 int vpt_gate_cast(const float* x, const void* mask, void* out, int M, int N, int ldx, int ldm, int ldo, void* stream);
 
-/* out[N] += column sums of a bf16 [M][ld] matrix (bias gradients). */
-int vpt_column_sum(const void* x_bf16, float* out, int M, int N, int ld, void* stream);
+/* out[N] += column sums of a 16-bit [M][ld] matrix (bias gradients), in a fixed order through `partials` (VPT_WS_COLUMN_SUM (M, N) bytes; may be
+ * NULL when that is 0). */
+int vpt_column_sum(const void* x_bf16, float* out, float* partials, int M, int N, int ld, void* stream);
 
-/* Backward of vpt_masked_attention_forward (causal = 1): dqkvr [B*t][ld] receives dQ and dR (written) and dK, dV
- * (accumulated: caller zeroes); db_nd [10][maxlen] accumulated.  The KV memory is detached state
- * (behavioural_cloning.py:111) and gets no gradient. */
+/* Backward of vpt_masked_attention_forward (causal = 1): dqkvr [B*t][ld] receives dQ, dK, dV and dR (every column written, nothing to zero);
+ * db_nd [10][maxlen] accumulated (caller zeroes).  The KV memory is detached state (behavioural_cloning.py:111) and gets no gradient.
+ * A key is reached by up to five 32-query tiles and b_nd by every workgroup: each contribution is written to its own slot of a workspace and the
+ * slots are added in a fixed order (bit-reproducible).  dkv_slab: VPT_WS_ATTENTION_BACKWARD_DKV (B, t, hid) bytes, dbnd_slab:
+ * VPT_WS_ATTENTION_BACKWARD_DBND (B, t, heads, maxlen) bytes.  ld must be a multiple of 4. */
 int vpt_masked_attention_backward(const float* qkvr, const float* kmem, const float* vmem, const uint8_t* memvalid,
-                                  const float* b_nd, const float* dout, float* dqkvr, float* db_nd,
+                                  const float* b_nd, const float* dout, float* dqkvr, float* db_nd, float* dkv_slab, float* dbnd_slab,
                                   int B, int t, int heads, int hid, int ld, int maxlen, void* stream);
 
 /* ---- backward of the IMPALA CNN (behavioural_cloning.py:117-119 obtains these from torch autograd) ---- */
@@ -352,8 +364,9 @@ int vpt_masked_attention_backward(const float* qkvr, const float* kmem, const fl
  * c1 = -rstd^2 T1 / n, c0 = -rstd T2 / n - c1 mu, the statistics terms vpt_conv3x3_dgrad adds as c0 + c1 x;
  * d_sa / d_sg [9][CoutPad] += sum dz / sum dz (-rstd mu) (accumulated: caller zeroes once per step).
  * stats_in are the statistics of the layer's INPUT (Cin*H*W elements).  With dy = NULL the layer is followed by the
- * max-pool and (dpooled, argmax) are given instead: the pool's backward is applied on the fly.  scratch: fp32
- * [frames][9*Cout + Cout/32] work buffer.  W must be 8, 16, 32 or 64. */
+ * max-pool and (dpooled, argmax) are given instead: the pool's backward is applied on the fly.  scratch: fp32 work buffer of
+ * vpt_workspace_bytes(VPT_WS_CONV_BACKWARD_PREPARE, frames, 0, 0, 0, Cout) bytes (per-frame sums, then per-32-frame partial sums of d_sa / d_sg that
+ * are added in a fixed order).  W must be 8, 16, 32 or 64. */
 int vpt_conv_backward_prepare(const void* dy, const void* dpooled, const uint8_t* argmax, const void* y, const void* res,
                               const double* stats_in, const float* edge_sa, const float* edge_sg, void* dacc, double* t12,
                               float* coef, float* d_sa, float* d_sg, float* scratch, int frames, int H, int W, int Cin, int Cout, void* stream);
@@ -391,8 +404,9 @@ int vpt_conv_backward_prepare_pooled(const void* dpooled, const void* pooled, co
 
 /* Backward of vpt_conv_first_forward w.r.t. its weight and bias (the input is the uint8 image): recomputes the pre-pool
  * tile, routes dpooled to the arg-max conv pixel of every pooling window and accumulates dw[Cout][27] (kh, kw, ch order)
- * and db[Cout] (fp32 atomics; caller zeroes). */
-int vpt_conv_first_backward(const uint8_t* img, const void* wfrag, const void* dpooled, float* dw, float* db,
+ * and db[Cout] (caller zeroes) -- per-workgroup partial sums in `partials` (VPT_WS_CONV_FIRST_BACKWARD (frames, H, W, -, Cout) bytes), added in
+ * a fixed order. */
+int vpt_conv_first_backward(const uint8_t* img, const void* wfrag, const void* dpooled, float* dw, float* db, float* partials,
                             int frames, int H, int W, int Cout, void* stream);
 
 /* Weight gradient of the folded convolution: dw[o][tap][c] += sum_{f,p} dacc[f][o][p] * x[f][c][p + tap] (fp32; caller
@@ -406,9 +420,11 @@ int vpt_maxpool_backward(const void* pre, const void* pooled, const void* dpoole
                          int frames, int C, int H, int W, void* stream);
 
 /* Backward of vpt_frame_affine_forward.  pass 1: ab[f] += (sum dy g, sum dy g xhat) and (per_element = 0) dgain/dbias;
- * pass 2: dx = rstd (dy g - ab0/n - xhat ab1/n) + dx_add; pass 3 (per_element = 1): dgain/dbias reduced over frames. */
+ * pass 2: dx = rstd (dy g - ab0/n - xhat ab1/n) + dx_add; pass 3 (per_element = 1): dgain/dbias reduced over frames.
+ * partials: fp32 workspace of VPT_WS_FRAME_AFFINE_BACKWARD (frames, HW, per_element, pass, C) bytes (0 for pass 2 and for pass 1 with
+ * per_element = 1: may be NULL there): dgain / dbias are summed through it in a fixed order. */
 int vpt_frame_affine_backward(const void* x, const void* dy, const void* dx_add, void* dx, const float* gain,
-                              const double* stats_in, double* ab, float* dgain, float* dbias,
+                              const double* stats_in, double* ab, float* dgain, float* dbias, float* partials,
                               int frames, int C, int HW, int per_element, int pass, void* stream);
 
 /* ---- action codec on the device: int64 / fp64 arrays, one row per action ---- */
@@ -437,6 +453,13 @@ int vpt_action_to_factored(const long* joint_buttons, const long* joint_camera, 
  * cursor_state may be null (no compositing); cursor_bgr [cursor_h][cursor_w][3], cursor_alpha fp64 [cursor_h][cursor_w] in 0..1. */
 int vpt_clip_frames(const uint8_t* src_bgr, int frames, int height, int width, const int32_t* cursor_state, const uint8_t* cursor_bgr,
                     const double* cursor_alpha, int cursor_h, int cursor_w, uint8_t* dst_rgb, int out_height, int out_width, void* stream);
+
+/* ---- diagnostics ---- */
+
+/* Fill the LDS of every compute unit with NaN bit patterns (0x7fc07fc0: a NaN as fp32 and as either 16-bit operand format), enqueued on
+ * `stream`.  A kernel that reads LDS before writing it then produces NaN instead of whatever the previous workgroup on that CU left behind
+ * (tools/diag_r06.py, VPT_POISON_LDS=1 in ops.py).  No reference counterpart; never on a product path. */
+int vpt_debug_poison_lds(void* stream);
 
 #ifdef __cplusplus
 }

@@ -680,7 +680,7 @@ def test_device_pack_first_convs_and_permutes_bit_exact(dtype):
     assert torch.equal(ops.chw_to_blocked(v, c, h, w), packing.chw_to_blocked_vector(v, c, h, w))
     lib = _native.load("bf16")
     assert lib.vpt_workspace_bytes(1, 8, 0, 0, 64, 128) == 4 * lib.vpt_conv3x3_wgrad_scratch_floats(8, 64, 128)
-    assert lib.vpt_workspace_bytes(2, 8, 0, 0, 0, 128) == 4 * 8 * (9 * 128 + 4)
+    assert lib.vpt_workspace_bytes(2, 8, 0, 0, 0, 128) == 4 * (8 * (9 * 128 + 4) + 1 * 2 * 9 * 128)      # per-frame sums + one 32-frame block of d_sa / d_sg partials
     assert lib.vpt_workspace_bytes(3, 16, 1024, 256, 0, 0) == 4 * 16 * 1024 * 256 and lib.vpt_workspace_bytes(99, 1, 1, 1, 1, 1) == -1
 
 

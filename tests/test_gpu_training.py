@@ -516,6 +516,78 @@ def test_conv_prepare_pooled_equals_prepare_with_argmax(f, cin, cout, h, w, fmt)
         assert _l2(o.double().cpu(), q.double().cpu()) < eps
 
 
+@pytest.mark.parametrize("fmt", ["bf16", "fp16"])
+@pytest.mark.parametrize("f,cin,cout,h,w", [(3, 32, 64, 8, 8), (2, 64, 32, 16, 16), (2, 32, 32, 32, 32)])
+def test_conv_prepare_kernels_bitwise_reproducible(f, cin, cout, h, w, fmt):
+    """Every output of the three `prepare` kernels is a function of the inputs alone: 12 launches, torch.equal.  8 x 8 / 16 x 16 images are the shapes
+    where TWO lanes of one wave share an edge-class entry of the ordered LDS reduction (add_edge_sums_ordered, J > 1 -- W = 8 in the per-pixel
+    kernels, pooled width 8 in the pooled one): a lost addend or an order that depends on wave arrival shows here."""
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[fmt]
+    g = torch.Generator().manual_seed(71)
+    W = torch.randn(cout, cin, 3, 3, generator=g) * (1.6 / (cin * 9) ** 0.5)
+    gain, bias = 1 + 0.2 * torch.randn(cin, generator=g), 0.1 * torch.randn(cin, generator=g)
+    x = torch.relu(torch.randn(f, cin, h, w, generator=g)).to(dt).float()
+    wpk, sa, sg = packing.pack_conv3x3(W.to(DEV), gain.to(DEV), bias.to(DEV), dtype=dt)
+    xb, st_in = packing.nchw_to_blocked(x, dtype=dt).to(DEV), _stats_of(x).to(DEV)
+    # (the layer output only gates and centres the sums here: any non-negative tensor serves, and the conv kernel needs multiples of 16 pixels)
+    y = packing.nchw_to_blocked(torch.relu(torch.randn(f, cout, h, w, generator=g)), dtype=dt).to(DEV)
+    sc = 1e-2 if fmt == "fp16" else 1.0
+    dy = packing.nchw_to_blocked(torch.randn(f, cout, h, w, generator=g) * sc, dtype=dt).to(DEV)
+    res = packing.nchw_to_blocked(torch.randn(f, cout, h, w, generator=g), dtype=dt).to(DEV)
+
+    def runs(fn):
+        outs = []
+        for _ in range(12):
+            d_sa, d_sg = torch.zeros_like(sa), torch.zeros_like(sg)
+            o = fn(d_sa, d_sg)
+            outs.append([t.clone() for t in o if t is not None] + [d_sa, d_sg])
+        torch.cuda.synchronize()
+        for o in outs[1:]:
+            for a, b in zip(o, outs[0]):
+                assert torch.equal(a.view(torch.int16) if a.dtype == dt else a, b.view(torch.int16) if b.dtype == dt else b)
+
+    runs(lambda d_sa, d_sg: ops.conv_backward_prepare(dy, y, None, st_in, sa, sg, cin, d_sa=d_sa, d_sg=d_sg, want_t12=True))
+    runs(lambda d_sa, d_sg: ops.conv_backward_prepare(dy, y, res, st_in, sa, sg, cin, d_sa=d_sa, d_sg=d_sg, want_t12=True))
+    if w >= 16:     # the pool-fused pair (pre-pool width >= 16): pooled width 8 at w = 16
+        pooled, mask = ops.conv3x3_pool_argmax(xb, wpk, sa, sg, st_in, cout)
+        dp = packing.nchw_to_blocked(torch.randn(f, cout, h // 2, w // 2, generator=g) * sc, dtype=dt).to(DEV)
+        runs(lambda d_sa, d_sg: ops.conv_backward_prepare_pooled(dp, pooled, mask, st_in, sa, sg, cin, d_sa=d_sa, d_sg=d_sg, want_t12=True))
+
+
+def test_bc_gradients_bitwise_reproducible(trainer_1x):
+    """behavioural_cloning.py:117-122: loss.backward() on one device returns the same bits for the same batch, and so does this backward --
+    every cross-workgroup sum goes through a partial slab added in a fixed order (vpt_reduce.hip), every in-workgroup sum through an ordered
+    LDS reduction, the frame scalars through fp64 sums of fp32 partials (exact).  The same batch 20 times in one process: torch.equal on every
+    gradient tensor and on the loss.  B = 2, T = 70: three 32-query tiles per head (the dK / dV slab slots and the db_nd rows are exercised);
+    140 frames in CNN chunks of 48 alternate over three streams with per-stream accumulators merged in stream order."""
+    pol, cfg, sd = trainer_1x
+    tr = BCTrainer(pol, train_cnn=True)
+    b, t = 2, 70
+    g = torch.Generator().manual_seed(77)
+    img = torch.randint(0, 256, (b, t, 128, 128, 3), generator=g, dtype=torch.uint8).to(DEV)
+    first = torch.zeros(b, t, dtype=torch.bool, device=DEV)
+    first[1, 0] = True
+    ab, ac = torch.randint(0, 8641, (b, t), generator=g).to(DEV), torch.randint(0, 121, (b, t), generator=g).to(DEV)
+    eng = pol._engine
+    saved = eng.cnn_chunk, tr.cnn_streams
+    try:
+        eng.cnn_chunk, tr.cnn_streams = 48, 3
+        runs = []
+        for _ in range(20):
+            loss, grads, _ = tr.loss_and_grads(img, first, pol.initial_state(b), ab, ac)
+            runs.append((loss.clone(), {k: v.clone() for k, v in grads.items()}))
+        torch.cuda.synchronize()
+    finally:
+        eng.cnn_chunk, tr.cnn_streams = saved
+    l0, g0 = runs[0]
+    assert len(g0) >= 120 and all(bool(torch.isfinite(v).all()) for v in g0.values())
+    differing = set()
+    for loss, grads in runs[1:]:
+        assert torch.equal(loss, l0)
+        differing |= {k for k in g0 if not torch.equal(grads[k], g0[k])}
+    assert not differing, sorted(differing)[:8]
+
+
 def test_trainer_checkpoint_resume(trainer_1x, tmp_path):
     """Policy weights (.weights format) + BCTrainer.state_dict() restore a run: the resumed step equals the uninterrupted
     one up to the order of the fp32 atomics inside the backward (same inputs, same Adam moments and step count)."""

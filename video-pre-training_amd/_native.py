@@ -11,7 +11,7 @@ _LIB_PATH = os.environ.get("VPT_HIP_LIB") or os.path.join(_HERE, "libvpt_hip.so"
 _LIB_PATHS = {"bf16": _LIB_PATH, "fp16": os.path.join(_HERE, "libvpt_hip_f16.so")}
 _libs = {}
 
-ABI_VERSION = 4      # VPT_HIP_ABI of the include/vpt_hip.h this signature table was written against
+ABI_VERSION = 5      # VPT_HIP_ABI of the include/vpt_hip.h this signature table was written against
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -53,7 +53,7 @@ SIGNATURES = {
     "vpt_conv_backward_prepare_pooled": [_P] * 15 + [_I, _I, _I, _I, _I, _P],
     "vpt_conv3x3_dgrad_gated": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_conv_backward_reduce": [_P] * 10 + [_I, _I, _I, _I, _I, _P],
-    "vpt_conv_first_backward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vpt_conv_first_backward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_conv3x3_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_conv3x3_wgrad_scratch_floats": [_I, _I, _I],
     "vpt_camera_discretize": [_P, _P, _L, _D, _D, _D, _I, _P],
@@ -61,13 +61,13 @@ SIGNATURES = {
     "vpt_action_from_factored": [_P, _P, _P, _P, _L, _I, _P],
     "vpt_action_to_factored": [_P, _P, _P, _P, _L, _I, _P],
     "vpt_maxpool_backward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "vpt_frame_affine_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vpt_frame_affine_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_bc_nll_backward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "vpt_heads_logprob_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P],
-    "vpt_layernorm_backward": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "vpt_layernorm_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "vpt_gate_cast": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "vpt_column_sum": [_P, _P, _I, _I, _I, _P],
-    "vpt_masked_attention_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vpt_column_sum": [_P, _P, _P, _I, _I, _I, _P],
+    "vpt_masked_attention_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vpt_adam_step": [_P, _P, _P, _P, ctypes.c_uint64, _I, _F, _F, _F, _F, _F, _F, _P],
     "vpt_adam_step_multi": [_P, _I, _L, _I, _F, _F, _F, _F, _F, _F, _P, _P],
     "vpt_grads_nonfinite_multi": [_P, _I, _L, _P, _P],
@@ -76,6 +76,7 @@ SIGNATURES = {
     "vpt_masked_attention_step_inplace": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_act_epilogue": [_P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P, _I, _P],
     "vpt_clip_frames": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _P],
+    "vpt_debug_poison_lds": [_P],
 }
 
 

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["vpt_conv3x3.hip", "vpt_conv_first.hip", "vpt_conv3d.hip", "vpt_elementwise.hip", "vpt_gemm.hip", "vpt_gemv.hip", "vpt_action_codec.hip", "vpt_clip.hip",
-           "vpt_transformer.hip", "vpt_optim.hip", "vpt_backward.hip", "vpt_cnn_backward.hip", "vpt_conv_wgrad.hip", "vpt_conv_first_bwd.hip", "vpt_pack.hip", "vpt_capi.hip"]
+           "vpt_transformer.hip", "vpt_optim.hip", "vpt_backward.hip", "vpt_cnn_backward.hip", "vpt_conv_wgrad.hip", "vpt_conv_first_bwd.hip", "vpt_pack.hip", "vpt_reduce.hip", "vpt_capi.hip"]
 LIB = os.path.join(HERE, "libvpt_hip.so")
 LIB_F16 = os.path.join(HERE, "libvpt_hip_f16.so")   # same sources, 16-bit operands = IEEE half (precision="fp16")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc"]

@@ -6,12 +6,14 @@
 //
 //  vpt_nll_bwd_kernel    : d/dz of -(log_softmax(z/T)[a]) summed over the two heads -> bf16 dz (GEMM operand).
 //  vpt_ln_bwd_kernel     : nn.LayerNorm backward (optionally through a ReLU on its input), dgain/dbias by
-//                          per-workgroup register partials + one fp32 atomic per column.
+//                          per-workgroup register partials -> the workgroup's row of a partial slab -> vpt_ln_bwd_finish_kernel
+//                          (fixed summation order: bit-reproducible).
 //  vpt_colsum_kernel     : bias gradients (column sums of a bf16 matrix).
 //  vpt_attn_bwd_kernel   : backward of vpt_attn_kernel (banded attention with KV memory + rel-pos bias): per
 //                          (sequence, head, 32-query tile) recompute P, then dV = P^T dO, dP = dO V^T,
 //                          dS = P (dP - rowsum(P dP)), dQ = dS K / d, dK = dS^T Q / d, dR = dS B, db_nd = R^T dS.
-//                          Keys are shared by up to five query tiles -> dK / dV / db_nd accumulate with fp32 atomics;
+//                          Keys are shared by up to five query tiles -> each tile's dK / dV piece goes to its own slab slot, db_nd to
+//                          the workgroup's slab row; vpt_attn_bwd_finish_kernel / vpt_slab_sum add them in a fixed order (bit-reproducible);
 //                          memory keys (detached state, behavioural_cloning.py:111) receive no gradient.
 #include "vpt_common.h"
 #include "vpt_kernels.h"
@@ -186,37 +188,67 @@ __global__ __launch_bounds__(256) void vpt_ln_bwd_kernel(VptLnBwdArgs a) {
       }
     }
   }
-  // column partials: the four waves combine in LDS, then ONE global atomic per column per workgroup
+  // column partials: the four waves add into the LDS table ONE AFTER THE OTHER (a fixed order; each lane owns its columns inside a wave), then the
+  // workgroup's sums go to its own row of the partial slab -- vpt_ln_bwd_finish_kernel adds the rows in row order.  (Until round 5: LDS float
+  // atomics + one global fp32 atomic per column per workgroup, i.e. sums in arrival order.)
+#pragma unroll 1
+  for (int ww = 0; ww < 4; ++ww) {
+    if (w == ww) {
 #pragma unroll
-  for (int q = 0; q < ND4; ++q) {
-    const int i = lane + 64 * q;
-    if (i < n4) {
+      for (int q = 0; q < ND4; ++q) {
+        const int i = lane + 64 * q;
+        if (i < n4) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        atomicAdd(&comb_[4 * i + k], pg[q][k]);
-        atomicAdd(&comb_[256 * ND4 + 4 * i + k], pb[q][k]);
+          for (int k = 0; k < 4; ++k) {
+            comb_[4 * i + k] += pg[q][k];
+            comb_[256 * ND4 + 4 * i + k] += pb[q][k];
+          }
+        }
       }
     }
+    __syncthreads();
   }
-  __syncthreads();
+  float* part = a.partials + (size_t)blockIdx.x * 2 * a.D;
   for (int c = threadIdx.x; c < a.D; c += 256) {
-    atomicAdd(a.dgain + c, comb_[c]);
-    atomicAdd(a.dbias + c, comb_[256 * ND4 + c]);
+    part[c] = comb_[c];
+    part[a.D + c] = comb_[256 * ND4 + c];
+  }
+}
+
+// dgain[c] += sum_b partials[b][0][c], dbias[c] += sum_b partials[b][1][c], b ascending inside each of four contiguous segments, the segments combined
+// as (s0 + s1) + (s2 + s3): one fixed summation tree per column, whatever the order the workgroups above ran in.
+__global__ __launch_bounds__(256) void vpt_ln_bwd_finish_kernel(const float* __restrict__ partials, int nblocks, int D, float* dgain, float* dbias) {
+  __shared__ float seg_[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6;     // col indexes the 2 D columns [dgain ; dbias]
+  const int per = (nblocks + 3) >> 2, b0 = sg * per, b1 = min(b0 + per, nblocks);
+  float s = 0.f;
+  if (col < 2 * D)
+    for (int b = b0; b < b1; ++b) s += partials[(size_t)b * 2 * D + col];
+  seg_[sg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sg == 0 && col < 2 * D) {
+    const int l = threadIdx.x;
+    const float tot = (seg_[0][l] + seg_[1][l]) + (seg_[2][l] + seg_[3][l]);
+    if (col < D) dgain[col] += tot;
+    else dbias[col - D] += tot;
   }
 }
 
 extern "C" int vpt_ln_bwd_launch(const VptLnBwdArgs* a, hipStream_t stream) {
-  if (a->M <= 0 || (a->D & 3) || a->D > 4 * 64 * LNB_MAXD4) return -1;
+  if (a->M <= 0 || (a->D & 3) || a->D > 4 * 64 * LNB_MAXD4 || !a->partials) return -1;
   const dim3 g((a->M + LNB_ROWS - 1) / LNB_ROWS), b(256);
   const int nd4 = ((a->D >> 2) + 63) >> 6;
   if (nd4 <= 4) hipLaunchKernelGGL(vpt_ln_bwd_kernel<4>, g, b, 0, stream, *a);
   else if (nd4 <= 8) hipLaunchKernelGGL(vpt_ln_bwd_kernel<8>, g, b, 0, stream, *a);
   else if (nd4 <= 12) hipLaunchKernelGGL(vpt_ln_bwd_kernel<12>, g, b, 0, stream, *a);
   else hipLaunchKernelGGL(vpt_ln_bwd_kernel<16>, g, b, 0, stream, *a);
+  hipLaunchKernelGGL(vpt_ln_bwd_finish_kernel, dim3((2 * a->D + 63) / 64), b, 0, stream, (const float*)a->partials, (int)g.x, a->D, a->dgain, a->dbias);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 // ------------------------------------------------------------------------------------------------
+// out[col] += sum_r x[r][col]: the rows are cut into gridDim.y slices, slice sums go to the slab partials[slice][col] and
+// vpt_colsum_finish_kernel adds them in slice order (bit-reproducible; until round 5 one fp32 atomic per slice).
 __global__ __launch_bounds__(256) void vpt_colsum_kernel(VptColsumArgs a) {
   const int col = blockIdx.x * 256 + threadIdx.x;
   const int rows_per = (a.M + gridDim.y - 1) / gridDim.y;
@@ -224,13 +256,27 @@ __global__ __launch_bounds__(256) void vpt_colsum_kernel(VptColsumArgs a) {
   if (col >= a.N) return;
   float s = 0.f;
   for (int r = r0; r < r1; ++r) s += (float)a.x[(size_t)r * a.ld + col];
-  atomicAdd(a.out + col, s);
+  if (gridDim.y == 1) a.out[col] += s;
+  else a.partials[(size_t)blockIdx.y * a.N + col] = s;
 }
+
+__global__ __launch_bounds__(256) void vpt_colsum_finish_kernel(VptColsumArgs a, int slices) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= a.N) return;
+  float s = 0.f;
+  for (int y = 0; y < slices; ++y) s += a.partials[(size_t)y * a.N + col];
+  a.out[col] += s;
+}
+
+static int colsum_slices(int M) { return M >= 4096 ? 64 : (M >= 256 ? 16 : 1); }
+extern "C" long vpt_colsum_partial_floats(int M, int N) { const int gy = colsum_slices(M); return gy > 1 ? (long)gy * N : 0; }
 
 extern "C" int vpt_colsum_launch(const VptColsumArgs* a, hipStream_t stream) {
   if (a->M <= 0 || a->N <= 0) return -1;
-  const int gy = a->M >= 4096 ? 64 : (a->M >= 256 ? 16 : 1);
+  const int gy = colsum_slices(a->M);
+  if (gy > 1 && !a->partials) return -1;
   hipLaunchKernelGGL(vpt_colsum_kernel, dim3((a->N + 255) / 256, gy), dim3(256), 0, stream, *a);
+  if (gy > 1) hipLaunchKernelGGL(vpt_colsum_finish_kernel, dim3((a->N + 255) / 256), dim3(256), 0, stream, *a, gy);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -273,6 +319,7 @@ __global__ __launch_bounds__(256, 2) void vpt_attn_bwd_kernel(VptAttnBwdArgs a) 
   const size_t tok0 = (size_t)b * t;
   const float inv_dh = 1.0f / ATT_DH;
   const int jbase = q0 + 1;             // key kk of the band = row jbase + kk of [memory ; chunk]
+  float* dbnd_row = a.dbnd_slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (10 * a.maxlen);
 
   for (int idx = tid; idx < ATT_QT * 10; idx += 256) {
     const int r = idx / 10, n = idx - r * 10;
@@ -413,17 +460,23 @@ __global__ __launch_bounds__(256, 2) void vpt_attn_bwd_kernel(VptAttnBwdArgs a) 
         acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(xc[3 * ATT_SS], y[3], acc[kt], 0, 0, 0);
       }
     }
+    // A key of the chunk is reached by up to five query tiles (its own and the four behind it).  Each writes its piece into a slab slot of its own --
+    // slot = (this query tile) - (the key's 32-row tile), 0..4 -- and vpt_attn_bwd_finish_kernel adds the slots in slot order: bit-reproducible
+    // (until round 5: fp32 atomics into dqkvr, i.e. sums in arrival order).  Rows beyond q0 + 31 lie outside the band (their pieces are exact
+    // zeros) and are not written; the finish kernel knows which (row, slot) pairs exist from the same arithmetic.
     // wave-uniform base + one 32-bit per-lane index per element (80 64-bit vector addresses would not fit the register file)
-    float* colbase = a.dqkvr + tok0 * a.ld + which * hid + h * ATT_DH;
+    float* colbase = a.dkv_slab + tok0 * (2 * hid) + (which - 1) * hid + h * ATT_DH;
+    const int slot_stride = a.B * t * 2 * hid;        // (the launcher checks 5 x this fits 31 bits)
     const int jr0 = jbase - maxlen + 4 * hi;          // chunk row of accumulator register 0 of key tile 0
 #pragma unroll
     for (int kt = 0; kt < 5; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int jr = jr0 + kt * 32 + (r & 3) + 8 * (r >> 2);
-        asm volatile("" : "+v"(jr));     // keep the validity test next to its atomic: hoisted and shared between the two calls, the 80 lane masks
+        asm volatile("" : "+v"(jr));     // keep the validity test next to its store: hoisted and shared between the two calls, the 80 lane masks
                                          // were 160 scalar registers, all spilled
-        if ((unsigned)jr < (unsigned)t) atomicAdd(colbase + (jr * a.ld + dcol), acc[kt][r] * scale);
+        if ((unsigned)jr < (unsigned)t && jr <= q0 + ATT_QT - 1)
+          colbase[((int)blockIdx.x - (jr >> 5)) * slot_stride + jr * (2 * hid) + dcol] = acc[kt][r] * scale;
       }
   };
   // ---- 4. dV += P^T dO ;  5. dK += dS^T Q / d_h ----
@@ -474,16 +527,51 @@ __global__ __launch_bounds__(256, 2) void vpt_attn_bwd_kernel(VptAttnBwdArgs a) 
       const int kk = maxlen - 1 + r - off;
       if (kk >= 0 && kk < ATT_NK) s = fmaf(Ds[r * ATT_SS + kk], Rs[r * 10 + n], s);
     }
-    if (s != 0.f) atomicAdd(a.db_nd + idx, s);
+    dbnd_row[idx] = s;      // this workgroup's row of the slab; vpt_slab_sum adds the rows in row order (until round 5: an fp32 atomic per entry)
   }
 }
 
+// dqkvr[token][K and V columns] = sum over the slots that exist for the token's row, in slot order (see dv_like above).  One thread per float4.
+__global__ __launch_bounds__(256) void vpt_attn_bwd_finish_kernel(VptAttnBwdArgs a) {
+  const int c4n = (2 * a.hid) >> 2;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)a.B * a.t * c4n) return;
+  const int tok = (int)(i / c4n), c4 = (int)(i - (long)tok * c4n);
+  const int jr = tok % a.t, kt = jr >> 5;
+  const size_t slot_stride = (size_t)a.B * a.t * 2 * a.hid;
+  const float* p = a.dkv_slab + (size_t)tok * (2 * a.hid) + 4 * c4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int sl = 0; sl < 5; ++sl) {
+    const int q0 = (kt + sl) * ATT_QT;              // the query tile of slot sl
+    if (q0 < a.t && jr >= q0 - a.maxlen + 1) {      // it exists and its band reaches back to this row
+      const f32x4 v = *(const f32x4*)(p + sl * slot_stride);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  *(f32x4*)(a.dqkvr + (size_t)tok * a.ld + a.hid + 4 * c4) = s;
+}
+
+extern "C" long vpt_attn_bwd_dkv_floats(int B, int t, int hid) { return 5L * B * t * 2 * hid; }
+// rows of the db_nd slab (one per workgroup) followed by vpt_slab_sum's scratch
+extern "C" long vpt_attn_bwd_dbnd_floats(int B, int t, int heads, int maxlen) {
+  const long rows = (long)((t + ATT_QT - 1) / ATT_QT) * B * heads;
+  return rows * 10 * maxlen + vpt_slab_sum_scratch_floats((int)rows, 10 * maxlen);
+}
+
 extern "C" int vpt_attn_bwd_launch(const VptAttnBwdArgs* a, hipStream_t stream) {
-  if (a->hid != a->heads * ATT_DH || a->maxlen < 1 || a->maxlen > 129) return -1;
+  if (a->hid != a->heads * ATT_DH || a->maxlen < 1 || a->maxlen > 129 || !a->dkv_slab || !a->dbnd_slab || (a->ld & 3)) return -1;
+  if (vpt_attn_bwd_dkv_floats(a->B, a->t, a->hid) > 0x7fffffffL) return -2;       // 32-bit slab indices in the kernel
   static unsigned long long optin_done = 0;
   const size_t lds = AB_FLOATS * sizeof(float);
   if (!vpt_lds_optin((const void*)vpt_attn_bwd_kernel, (int)lds, &optin_done)) return -4;
   dim3 grid((a->t + ATT_QT - 1) / ATT_QT, a->B * a->heads);
+  const long rows = (long)grid.x * grid.y;
+  if (rows > 65536) return -2;
   hipLaunchKernelGGL(vpt_attn_bwd_kernel, grid, dim3(256), lds, stream, *a);
-  return hipGetLastError() == hipSuccess ? 0 : -3;
+  const long n4 = (long)a->B * a->t * ((2 * a->hid) >> 2);
+  hipLaunchKernelGGL(vpt_attn_bwd_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, *a);
+  if (hipGetLastError() != hipSuccess) return -3;
+  return vpt_slab_sum_launch(a->dbnd_slab, (int)rows, 10 * a->maxlen, 10L * a->maxlen, a->db_nd, 10 * a->maxlen, nullptr, 1,
+                             a->dbnd_slab + rows * 10 * a->maxlen, stream);
 }

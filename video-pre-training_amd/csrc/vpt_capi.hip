@@ -13,9 +13,21 @@ static int fail(int code, const char* what) {
 }
 #define CHECK_LAUNCH(expr, name) do { int rc_ = (expr); if (rc_ != 0) return fail(rc_, name); return 0; } while (0)
 
+// ---- diagnostics: fill the LDS of every CU with NaN patterns (vpt_debug_poison_lds) ---------------------------------------------
+// A kernel that reads LDS it has not written sees whatever the previous workgroup on that CU left there: benign while one process
+// repeats one kernel sequence, different when another process's workgroups interleave.  Launched before a kernel under test, this
+// makes such a read show as NaN at once.  One workgroup takes a CU's whole 160 KB and lingers, so that a launch of many covers all CUs.
+__global__ __launch_bounds__(256) void vpt_poison_lds_kernel(int words, unsigned pattern) {
+  extern __shared__ unsigned poison_lds_[];
+  volatile unsigned* l = poison_lds_;
+  for (int i = threadIdx.x; i < words; i += 256) l[i] = pattern;
+  __syncthreads();
+  for (int k = 0; k < 16; ++k) __builtin_amdgcn_s_sleep(127);
+}
+
 extern "C" {
 
-const char* vpt_version(void) { return "vpt_hip 0.4 gfx950"; }
+const char* vpt_version(void) { return "vpt_hip 0.5 gfx950"; }
 int vpt_abi_version(void) { return VPT_HIP_ABI; }
 const char* vpt_operand_format(void) { return VPT_OPERAND_NAME; }
 const char* vpt_last_error(void) { return g_err; }
@@ -60,7 +72,13 @@ int vpt_chw_to_blocked(const float* src, float* dst, int64_t rows, int C, int H,
 int64_t vpt_workspace_bytes(int op, int frames, int H, int W, int Cin, int Cout) {
   switch (op) {
     case VPT_WS_CONV3X3_WGRAD: return 4 * (int64_t)vpt_conv3x3_wgrad_scratch_floats(frames, Cin, Cout);
-    case VPT_WS_CONV_BACKWARD_PREPARE: return 4 * (int64_t)frames * (9LL * Cout + Cout / 32);
+    case VPT_WS_CONV_BACKWARD_PREPARE: return 4 * (int64_t)vpt_conv_bwd_prep_scratch_floats(frames, Cout);
+    case VPT_WS_LAYERNORM_BACKWARD: return 4 * (int64_t)((frames + 31) / 32) * 2 * H;                       /* (M, D): one row per 32-row workgroup */
+    case VPT_WS_COLUMN_SUM: return 4 * (int64_t)vpt_colsum_partial_floats(frames, H);                       /* (M, N) */
+    case VPT_WS_ATTENTION_BACKWARD_DKV: return 4 * (int64_t)vpt_attn_bwd_dkv_floats(frames, H, W);          /* (B, t, hid) */
+    case VPT_WS_ATTENTION_BACKWARD_DBND: return 4 * (int64_t)vpt_attn_bwd_dbnd_floats(frames, H, W, Cin);   /* (B, t, heads, maxlen) */
+    case VPT_WS_FRAME_AFFINE_BACKWARD: return 4 * (int64_t)vpt_affine_bwd_partial_floats(frames, Cout / 32, H, W, Cin);   /* (frames, HW, per_element, pass, C) */
+    case VPT_WS_CONV_FIRST_BACKWARD: return 4 * (int64_t)vpt_conv_first_bwd_partial_floats(frames, H, W, Cout);
     case VPT_WS_LINEAR_SPLITK: return 4 * (int64_t)frames * H * (int64_t)W;   /* splitk (= frames) x M (= H) x N (= W) fp32 partial slices */
     default: return -1;
   }
@@ -260,10 +278,11 @@ int vpt_conv_backward_prepare(const void* dy, const void* dpooled, const uint8_t
   CHECK_LAUNCH(vpt_conv_bwd_prep_launch(&a, (hipStream_t)stream), "vpt_conv_backward_prepare");
 }
 
-int vpt_conv_first_backward(const uint8_t* img, const void* wfrag, const void* dpooled, float* dw, float* db,
+int vpt_conv_first_backward(const uint8_t* img, const void* wfrag, const void* dpooled, float* dw, float* db, float* partials,
                             int frames, int H, int W, int Cout, void* stream) {
+  if (!partials) return fail(-1, "vpt_conv_first_backward: partials workspace is required");
   VptConvFirstBwdArgs a = {};
-  a.img = img; a.wfrag = (const vpt_op16*)wfrag; a.dpooled = (const vpt_op16*)dpooled; a.dw = dw; a.db = db;
+  a.img = img; a.wfrag = (const vpt_op16*)wfrag; a.dpooled = (const vpt_op16*)dpooled; a.dw = dw; a.db = db; a.partials = partials;
   a.frames = frames; a.H = H; a.W = W; a.Cout = Cout;
   CHECK_LAUNCH(vpt_conv_first_bwd_launch(&a, (hipStream_t)stream), "vpt_conv_first_backward");
 }
@@ -288,9 +307,10 @@ int vpt_maxpool_backward(const void* pre, const void* pooled, const void* dpoole
 }
 
 int vpt_frame_affine_backward(const void* x, const void* dy, const void* dx_add, void* dx, const float* gain,
-                              const double* stats_in, double* ab, float* dgain, float* dbias,
+                              const double* stats_in, double* ab, float* dgain, float* dbias, float* partials,
                               int frames, int C, int HW, int per_element, int pass, void* stream) {
   VptAffineBwdArgs a = {};
+  a.partials = partials;
   a.x = (const vpt_op16*)x; a.dy = (const vpt_op16*)dy; a.dx_add = (const vpt_op16*)dx_add; a.dx = (vpt_op16*)dx;
   a.gain = gain; a.stats_in = stats_in; a.ab = ab; a.dgain = dgain; a.dbias = dbias;
   a.frames = frames; a.CB = C / 32; a.HW = HW; a.per_element = per_element; a.inv_count = 1.0 / ((double)C * HW);
@@ -493,8 +513,10 @@ int vpt_heads_logprob_backward(const float* lp_buttons, const float* lp_camera, 
 }
 
 int vpt_layernorm_backward(const float* x, const float* gain, const float* dy, const float* dx_add, float* dx,
-                           float* dgain, float* dbias, int M, int D, int relu_in, void* stream) {
+                           float* dgain, float* dbias, float* partials, int M, int D, int relu_in, void* stream) {
+  if (!partials) return fail(-1, "vpt_layernorm_backward: partials workspace is required");
   VptLnBwdArgs a = {};
+  a.partials = partials;
   a.x = x; a.gain = gain; a.dy = dy; a.dx_add = dx_add; a.dx = dx; a.dgain = dgain; a.dbias = dbias;
   a.M = M; a.D = D; a.relu_in = relu_in;
   CHECK_LAUNCH(vpt_ln_bwd_launch(&a, (hipStream_t)stream), "vpt_layernorm_backward");
@@ -506,16 +528,19 @@ int vpt_gate_cast(const float* x, const void* mask, void* out, int M, int N, int
   CHECK_LAUNCH(vpt_gate_cast_launch(&a, (hipStream_t)stream), "vpt_gate_cast");
 }
 
-int vpt_column_sum(const void* x_bf16, float* out, int M, int N, int ld, void* stream) {
+int vpt_column_sum(const void* x_bf16, float* out, float* partials, int M, int N, int ld, void* stream) {
   VptColsumArgs a = {};
+  a.partials = partials;
   a.x = (const vpt_op16*)x_bf16; a.out = out; a.M = M; a.N = N; a.ld = ld;
   CHECK_LAUNCH(vpt_colsum_launch(&a, (hipStream_t)stream), "vpt_column_sum");
 }
 
 int vpt_masked_attention_backward(const float* qkvr, const float* kmem, const float* vmem, const uint8_t* memvalid,
-                                  const float* b_nd, const float* dout, float* dqkvr, float* db_nd,
+                                  const float* b_nd, const float* dout, float* dqkvr, float* db_nd, float* dkv_slab, float* dbnd_slab,
                                   int B, int t, int heads, int hid, int ld, int maxlen, void* stream) {
+  if (!dkv_slab || !dbnd_slab) return fail(-1, "vpt_masked_attention_backward: the dkv_slab / dbnd_slab workspaces are required");
   VptAttnBwdArgs a = {};
+  a.dkv_slab = dkv_slab; a.dbnd_slab = dbnd_slab;
   a.qkvr = qkvr; a.kmem = kmem; a.vmem = vmem; a.memvalid = memvalid; a.b_nd = b_nd; a.dout = dout;
   a.dqkvr = dqkvr; a.db_nd = db_nd; a.B = B; a.t = t; a.heads = heads; a.hid = hid; a.ld = ld; a.maxlen = maxlen;
   CHECK_LAUNCH(vpt_attn_bwd_launch(&a, (hipStream_t)stream), "vpt_masked_attention_backward");
@@ -548,4 +573,13 @@ int vpt_clip_frames(const uint8_t* src_bgr, int frames, int height, int width, c
   a.src = src_bgr; a.cursor = cursor_state; a.cursor_img = cursor_bgr; a.cursor_alpha = cursor_alpha; a.dst = dst_rgb;
   a.frames = frames; a.H = height; a.W = width; a.OH = out_height; a.OW = out_width; a.CH = cursor_h; a.CW = cursor_w;
   CHECK_LAUNCH(vpt_clip_launch(&a, (hipStream_t)stream), "vpt_clip_frames");
+}
+
+int vpt_debug_poison_lds(void* stream) {
+  static unsigned long long optin_done = 0;
+  const int bytes = 160 * 1024;
+  if (!vpt_lds_optin((const void*)vpt_poison_lds_kernel, bytes, &optin_done)) return fail(-4, "vpt_debug_poison_lds: LDS opt-in");
+  hipLaunchKernelGGL(vpt_poison_lds_kernel, dim3(1024), dim3(256), bytes, (hipStream_t)stream, bytes / 4, 0x7fc07fc0u);
+  if (hipGetLastError() != hipSuccess) return fail(-3, "vpt_debug_poison_lds");
+  return 0;
 }

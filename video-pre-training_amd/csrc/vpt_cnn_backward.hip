@@ -1,6 +1,7 @@
 // Backward of the HBM-bound pieces of the IMPALA CNN (gfx950): frame-wide affine norms, max-pool, and the
 // per-element preparation of a normed conv layer's backward.  All tensors bf16 channel-blocked
-// [frame][C/32][H][W][32]; reductions in fp32 registers -> LDS -> one fp32/fp64 atomic per workgroup.
+// [frame][C/32][H][W][32]; reductions in fp32 registers -> LDS -> the workgroup's row of a partial slab, summed in a fixed order
+// (vpt_reduce.hip; the per-frame scalars: fp64 atomics of fp32 workgroup sums, exact and therefore order-free).
 //
 //  vpt_affine_bwd_reduce / _apply : backward of y = (x - mu_f) rstd_f g + b with whole-frame statistics
 //        (CnnDownStack.n = GroupNorm(1,C), lib/impala_cnn.py:99-100,118-119; ImpalaCNN.dense's LayerNorm,
@@ -66,11 +67,16 @@ __device__ __forceinline__ void add_edge_sums_ordered(float* tab_, float* stage_
       const float r = sum_oct16((ex == 1) ? src[k] : 0.f);     // interior columns: most lanes (edge-column lanes contribute zero)
       if (lane < 4) mine[(g * 3 + 1) * 32 + k] = r;
     }
+    // J > 1 (images narrower than 16 pixels): two lanes of one wave add into the SAME entry, one after the other.  The accesses are volatile and a wave
+    // barrier separates the rows, so the compiler can neither keep the entry in a register across the loop nor merge the iterations (either would
+    // lose one lane's addend; LDS operations of one wave execute in program order).
+    volatile float* vm = mine;
     for (int j = 0; j < J; ++j) {
       if (ex != 1 && jrow == j) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) mine[(g * 3 + ex) * 32 + k] += src[k];
+        for (int k = 0; k < 8; ++k) vm[(g * 3 + ex) * 32 + k] = vm[(g * 3 + ex) * 32 + k] + src[k];
       }
+      __builtin_amdgcn_wave_barrier();
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -150,10 +156,10 @@ __global__ __launch_bounds__(256) void vpt_affine_bwd_reduce_kernel(VptAffineBwd
       }
     }
     __syncthreads();
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < 64) {   // this workgroup's entries of slab row (frame, pixel chunk): [dgain C | dbias C]; the launcher's vpt_slab_sum adds the rows in order
       const float v = (part_[threadIdx.x] + part_[64 + threadIdx.x]) + (part_[128 + threadIdx.x] + part_[192 + threadIdx.x]);
-      float* dst = (threadIdx.x < 32) ? a.dgain : a.dbias;
-      atomicAdd(dst + cb * 32 + (threadIdx.x & 31), v);
+      const int C = a.CB * 32;
+      a.partials[((size_t)f * chunks + chunk) * (2 * C) + (threadIdx.x < 32 ? 0 : C) + cb * 32 + (threadIdx.x & 31)] = v;
     }
   }
 }
@@ -226,11 +232,25 @@ __global__ __launch_bounds__(256) void vpt_affine_bwd_elem_kernel(VptAffineBwdAr
       db[k] += dy[k];
     }
   }
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    atomicAdd(a.dgain + item * 8 + k, dg[k]);
-    atomicAdd(a.dbias + item * 8 + k, db[k]);
+  // slab row = this frame slice: [dgain K | dbias K], K = elements per frame; the launcher's vpt_slab_sum adds the slices in order
+  float* row = a.partials + (size_t)blockIdx.y * (2 * (size_t)per_frame * 8);
+  *(f32x4*)(row + (size_t)item * 8) = (f32x4){dg[0], dg[1], dg[2], dg[3]};
+  *(f32x4*)(row + (size_t)item * 8 + 4) = (f32x4){dg[4], dg[5], dg[6], dg[7]};
+  row += (size_t)per_frame * 8;
+  *(f32x4*)(row + (size_t)item * 8) = (f32x4){db[0], db[1], db[2], db[3]};
+  *(f32x4*)(row + (size_t)item * 8 + 4) = (f32x4){db[4], db[5], db[6], db[7]};
+}
+
+static int affine_elem_slices(int frames) { return frames >= 512 ? 32 : (frames >= 16 ? 8 : 1); }
+
+// floats of `partials` a pass needs (pass 2 none): the slab rows followed by vpt_slab_sum's scratch
+extern "C" long vpt_affine_bwd_partial_floats(int frames, int CB, int HW, int per_element, int pass) {
+  if (pass == 1 && !per_element) {
+    const long rows = (long)frames * ((HW + RED_PIX - 1) / RED_PIX);
+    return rows * 2 * CB * 32 + vpt_slab_sum_scratch_floats((int)rows, 2 * CB * 32);
   }
+  if (pass == 3) return (long)affine_elem_slices(frames) * 2 * CB * 32 * HW;
+  return 0;
 }
 
 extern "C" int vpt_affine_bwd_launch(const VptAffineBwdArgs* a, int pass, hipStream_t stream) {
@@ -239,10 +259,18 @@ extern "C" int vpt_affine_bwd_launch(const VptAffineBwdArgs* a, int pass, hipStr
   const long grid = (long)a->frames * ((per_frame + EW_PER_BLOCK - 1) / EW_PER_BLOCK);
   if (grid > 0x7fffffffL) return -2;
   if (pass == 1) {
-    const long g1 = (long)a->frames * a->CB * ((a->HW + RED_PIX - 1) / RED_PIX);
+    const int chunks = (a->HW + RED_PIX - 1) / RED_PIX;
+    const long g1 = (long)a->frames * a->CB * chunks;
     if (g1 > 0x7fffffffL) return -2;
     if (a->per_element) hipLaunchKernelGGL(vpt_affine_bwd_reduce_kernel<true>, dim3((unsigned)g1), dim3(256), 0, stream, *a);
-    else hipLaunchKernelGGL(vpt_affine_bwd_reduce_kernel<false>, dim3((unsigned)g1), dim3(256), 0, stream, *a);
+    else {
+      const long rows = (long)a->frames * chunks;
+      const int C2 = 2 * a->CB * 32;
+      if (!a->partials || !a->dgain || !a->dbias || rows > 65536) return -1;
+      hipLaunchKernelGGL(vpt_affine_bwd_reduce_kernel<false>, dim3((unsigned)g1), dim3(256), 0, stream, *a);
+      if (hipGetLastError() != hipSuccess) return -3;
+      return vpt_slab_sum_launch(a->partials, (int)rows, C2, C2, a->dgain, C2 / 2, a->dbias, 1, a->partials + rows * C2, stream);
+    }
   }
   else if (pass == 2) {
     const dim3 g((unsigned)grid), b(256);
@@ -255,8 +283,12 @@ extern "C" int vpt_affine_bwd_launch(const VptAffineBwdArgs* a, int pass, hipStr
     }
   }
   else {
-    const int gy = a->frames >= 512 ? 32 : (a->frames >= 16 ? 8 : 1);
+    const int gy = affine_elem_slices(a->frames);
+    const long K2 = 2L * per_frame * 8;
+    if (!a->partials || K2 > 0x7fffffffL) return -1;
     hipLaunchKernelGGL(vpt_affine_bwd_elem_kernel, dim3((per_frame + 255) / 256, gy), dim3(256), 0, stream, *a);
+    if (hipGetLastError() != hipSuccess) return -3;
+    return vpt_slab_sum_launch(a->partials, gy, (int)K2, K2, a->dgain, (int)(K2 / 2), a->dbias, 1, nullptr, stream);
   }
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
@@ -641,7 +673,8 @@ __global__ __launch_bounds__(256, 3) void vpt_conv_bwd_prep_pooled_kernel(VptCon
 #define FIN_FB 32  // frames per column-sum workgroup
 // finish, one launch with two kinds of workgroups (all independent, so the launch is one round of loads deep):
 //   blocks [0, ceil(F/4)):  one WAVE per frame: T1, T2 and the (c0, c1) coefficients from that frame's row of sbuf;
-//   the rest:               one thread per column (e, c) of the [9][Cout] table x 32 frames: dSA, dSG partial sums -> atomics.
+//   the rest:               one thread per column (e, c) of the [9][Cout] table x 32 frames: dSA, dSG partial sums -> the block's slab row
+//                           (vpt_conv_bwd_sum_kernel adds the rows in order).
 __global__ __launch_bounds__(256) void vpt_conv_bwd_finish_kernel(VptConvBwdPrepArgs a) {
   __shared__ float nrm_[FIN_FB];
   const int Cout = a.CB * 32, ncol = 9 * Cout, ld = ncol + a.CB;
@@ -693,9 +726,29 @@ __global__ __launch_bounds__(256) void vpt_conv_bwd_finish_kernel(VptConvBwdPrep
     asa += S;
     asg = fmaf(nrm_[k], S, asg);
   }
-  const int e = i / Cout, c = i - e * Cout;
-  atomicAdd(a.d_sa + e * a.CoutPad + c, asa);
-  atomicAdd(a.d_sg + e * a.CoutPad + c, asg);
+  // this 32-frame block's partial sums; vpt_conv_bwd_sum_kernel adds the blocks in block order (until round 5: one fp32 atomic per block)
+  float* dsum = a.sbuf + (size_t)a.frames * ld + (size_t)(b / ncb) * 2 * ncol;
+  dsum[i] = asa;
+  dsum[ncol + i] = asg;
+}
+
+// dSA[e][c] += sum over the 32-frame blocks of their partial sums, in block order; likewise dSG
+__global__ __launch_bounds__(256) void vpt_conv_bwd_sum_kernel(VptConvBwdPrepArgs a) {
+  const int Cout = a.CB * 32, ncol = 9 * Cout, ld = ncol + a.CB;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * ncol) return;
+  const int nfb = (a.frames + FIN_FB - 1) / FIN_FB;
+  const float* p = a.sbuf + (size_t)a.frames * ld + i;
+  float s = 0.f;
+  for (int fb = 0; fb < nfb; ++fb) s += p[(size_t)fb * 2 * ncol];
+  const int j = i < ncol ? i : i - ncol;
+  const int e = j / Cout, c = j - e * Cout;
+  float* dst = (i < ncol ? a.d_sa : a.d_sg) + e * a.CoutPad + c;
+  *dst += s;
+}
+
+extern "C" long vpt_conv_bwd_prep_scratch_floats(int frames, int Cout) {
+  return (long)frames * (9L * Cout + Cout / 32) + (long)((frames + FIN_FB - 1) / FIN_FB) * 2 * 9 * Cout;
 }
 
 extern "C" int vpt_conv_bwd_prep_launch(const VptConvBwdPrepArgs* a0, hipStream_t stream) {
@@ -715,6 +768,7 @@ extern "C" int vpt_conv_bwd_prep_launch(const VptConvBwdPrepArgs* a0, hipStream_
     } else hipLaunchKernelGGL(vpt_conv_bwd_prep_pooled_kernel<false>, dim3((unsigned)gridp), dim3(256), 0, stream, a);
     const int fin_blocks_p = (a.frames + 3) / 4 + ((9 * a.CB * 32 + 255) / 256) * ((a.frames + FIN_FB - 1) / FIN_FB);
     hipLaunchKernelGGL(vpt_conv_bwd_finish_kernel, dim3((unsigned)fin_blocks_p), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(vpt_conv_bwd_sum_kernel, dim3((2 * 9 * a.CB * 32 + 255) / 256), dim3(256), 0, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
   }
   if (a.W < 8 || a.W > 64 || (a.W & (a.W - 1))) return -1;  // column-per-thread mapping: W in {8,16,32,64}
@@ -732,5 +786,6 @@ extern "C" int vpt_conv_bwd_prep_launch(const VptConvBwdPrepArgs* a0, hipStream_
   }
   const int fin_blocks = (a.frames + 3) / 4 + ((9 * a.CB * 32 + 255) / 256) * ((a.frames + FIN_FB - 1) / FIN_FB);
   hipLaunchKernelGGL(vpt_conv_bwd_finish_kernel, dim3((unsigned)fin_blocks), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(vpt_conv_bwd_sum_kernel, dim3((2 * 9 * a.CB * 32 + 255) / 256), dim3(256), 0, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

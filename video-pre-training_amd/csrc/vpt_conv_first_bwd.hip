@@ -22,7 +22,8 @@
 //      row pair) is its OWN pixel's gradient placed at slot k*: a one-hot built in registers from the table word; k-steps 16, 17 = offset 8 of the
 //      pixels 8 s .. 8 s + 7 of each row pair.  Twice the MFMAs of the scatter form (the matrix pipe is idle anyway); every gradient enters the
 //      fp32 accumulation un-merged (the scatter form summed up to four bf16 values into one bf16 entry of G first).
-//      16 fp32 accumulators per lane persist over the workgroup's tiles; the two waves of a channel block are added and flushed with atomics at the end.
+//      16 fp32 accumulators per lane persist over the workgroup's tiles; the two waves of a channel block are added and written to the workgroup's row of a partial slab at the end
+//      (summed in row order by vpt_slab_sum: bit-reproducible).
 // History.  Round 2: step 4 on the vector ALU (27 byte reads, conversions and FMAs per pooled value): 3.5 ms per 1024 frames.  Round 3: G by
 // merge-and-scatter + one MFMA contraction over the 289 conv pixels, thread = (channel, 32 pooled pixels), four waves: 2.0 ms; its ablation table
 // charged 1.33 ms to the scatter -- but removing the scatter had let the compiler delete the search as dead code too.  Round 4 ablations on this
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(CFB_THREADS, 4) void vpt_conv_first_bwd_kernel(VptC
   }
   // ---- flush: the two waves of a channel block (pixel groups 0 / 1) are added through LDS, then one atomic per (channel, tap) and workgroup ----
   float* red = (float*)smem;                               // [4 channel blocks][16 values][64 lanes] fp32 = 16 KB
+  float* prow = a.partials + (size_t)blockIdx.x * a.Cout * 28;
   if (ph == 1) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(cbw * 16 + r) * 64 + lane] = gacc[r];
@@ -257,14 +259,15 @@ __global__ __launch_bounds__(CFB_THREADS, 4) void vpt_conv_first_bwd_kernel(VptC
       const int o = nt * 128 + cbw * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       if (o >= a.Cout) continue;
       const float v = gacc[r] + red[(cbw * 16 + r) * 64 + lane];
-      if (l31 < 27) atomicAdd(a.dw + (size_t)o * 27 + l31, v * (1.0f / 255.0f));   // d(conv)/dW = img / 255
-      else atomicAdd(a.db + o, v);
+      // this workgroup's row of the partial slab, [dW Cout x 27 | db Cout]; the launcher's vpt_slab_sum adds the rows in row order (the tile ranges
+      // are a static function of the grid, so a row's content does not depend on scheduling either).  Until round 5: one fp32 atomic per entry.
+      if (l31 < 27) prow[(size_t)o * 27 + l31] = v * (1.0f / 255.0f);   // d(conv)/dW = img / 255
+      else prow[(size_t)a.Cout * 27 + o] = v;
     }
   }
 }
 
-extern "C" int vpt_conv_first_bwd_launch(const VptConvFirstBwdArgs* a, hipStream_t stream) {
-  if ((a->H & 15) || (a->W & 15) || (a->Cout & 31) || a->frames <= 0) return -1;
+static long conv_first_bwd_grid_x(int frames, int H, int W) {
   static int num_cu = 0;
   if (num_cu == 0) {
     int dev = 0;
@@ -272,10 +275,22 @@ extern "C" int vpt_conv_first_bwd_launch(const VptConvFirstBwdArgs* a, hipStream
     num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                  ? prop.multiProcessorCount : 256;
   }
-  const long tiles = (long)a->frames * (a->H >> 4) * (a->W >> 4);
+  const long tiles = (long)frames * (H >> 4) * (W >> 4);
+  const long gx = (long)num_cu * 2;
+  return tiles < gx ? tiles : gx;
+}
+
+// floats of the `partials` workspace: one row [Cout x 27 | Cout] per workgroup column + vpt_slab_sum's scratch
+extern "C" long vpt_conv_first_bwd_partial_floats(int frames, int H, int W, int Cout) {
+  const long gx = conv_first_bwd_grid_x(frames, H, W);
+  return gx * Cout * 28 + vpt_slab_sum_scratch_floats((int)gx, Cout * 28);
+}
+
+extern "C" int vpt_conv_first_bwd_launch(const VptConvFirstBwdArgs* a, hipStream_t stream) {
+  if ((a->H & 15) || (a->W & 15) || (a->Cout & 31) || a->frames <= 0 || !a->partials) return -1;
   if ((long)a->frames * a->H * a->W * 3 > 0x7fffffffL) return -2;   // 32-bit pixel offsets inside a launch
-  long gx = (long)num_cu * 2;
-  if (tiles < gx) gx = tiles;
+  const long gx = conv_first_bwd_grid_x(a->frames, a->H, a->W);
   hipLaunchKernelGGL(vpt_conv_first_bwd_kernel, dim3((unsigned)gx, (a->Cout + 127) / 128), dim3(CFB_THREADS), 0, stream, *a);
-  return hipGetLastError() == hipSuccess ? 0 : -3;
+  if (hipGetLastError() != hipSuccess) return -3;
+  return vpt_slab_sum_launch(a->partials, (int)gx, a->Cout * 28, (long)a->Cout * 28, a->dw, a->Cout * 27, a->db, 1, a->partials + gx * a->Cout * 28, stream);
 }

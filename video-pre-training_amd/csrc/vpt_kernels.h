@@ -211,6 +211,7 @@ struct VptAffineBwdArgs {
   double* ab;              // [F][2] sum dy g, sum dy g xhat (pass 1 accumulates, pass 2 reads)
   float* dgain;            // accumulated
   float* dbias;
+  float* partials;         // workspace of passes 1 (per-channel gain) and 3: vpt_affine_bwd_partial_floats
   int frames, CB, HW, per_element;
   double inv_count;
 };
@@ -227,7 +228,8 @@ struct VptConvBwdPrepArgs {
   const vpt_op16* dy;      // gradient w.r.t. the layer output (after ReLU and residual add); null -> (dpooled, argmax)
   const vpt_op16* dpooled; // gradient w.r.t. max_pool(y) [F][CB][H/2][W/2][32]   (fused max-pool backward)
   const uint8_t* argmax;   // window position code kh*3+kw of the maximum, same shape (vpt_pool_kernel)
-  float* sbuf;             // scratch [F][9*Cout + Cout/32] fp32: per-frame edge-class sums of dz, then per-plane sum dz v
+  float* sbuf;             // scratch (vpt_conv_bwd_prep_scratch_floats): [F][9*Cout + Cout/32] fp32 per-frame edge-class sums of dz and per-plane sums dz v,
+                           // then [ceil(F/32)][2][9*Cout] partial sums of dSA / dSG per block of 32 frames
   int wshift;              // log2(W), filled by the launcher
   const vpt_op16* y;       // saved layer output
   const vpt_op16* res;     // saved residual input or null
@@ -263,6 +265,7 @@ struct VptConvFirstBwdArgs {
   const vpt_op16* dpooled; // gradient w.r.t. the pooled output [F][Cout/32][H/2][W/2][32]
   float* dw;               // [Cout][27] in (kh, kw, ch) order, accumulated
   float* db;               // [Cout] accumulated
+  float* partials;         // workspace: vpt_conv_first_bwd_partial_floats
   int frames, H, W, Cout;
 };
 
@@ -314,6 +317,7 @@ struct VptLnBwdArgs {
   float* dx;               // [M][D]
   float* dgain;            // [D] accumulated (caller zeroes)
   float* dbias;            // [D]
+  float* partials;         // [ceil(M / 32)][2][D] workspace: per-workgroup column sums, added in row order by the finish kernel
   int M, D, relu_in;
 };
 
@@ -331,6 +335,7 @@ struct VptClipArgs {
 struct VptColsumArgs {
   const vpt_op16* x;       // [M][ld]
   float* out;              // [N] accumulated (caller zeroes)
+  float* partials;         // [vpt_colsum_partial_floats(M, N)] workspace (row-slice sums, added in slice order)
   int M, N, ld;
 };
 
@@ -341,8 +346,10 @@ struct VptAttnBwdArgs {
   const uint8_t* memvalid; // [B][maxlen]
   const float* b_nd;       // [10][maxlen]
   const float* dout;       // [B*t][hid] gradient w.r.t. the merged attention output
-  float* dqkvr;            // [B*t][ld]: Q and R columns written, K and V columns accumulated (caller zeroes)
+  float* dqkvr;            // [B*t][ld]: every column written (Q, R by the main kernel, K, V by the finish kernel)
   float* db_nd;            // [10][maxlen] accumulated (caller zeroes)
+  float* dkv_slab;         // [5][B*t][2 hid] workspace: per query tile pieces of dK / dV (vpt_attn_bwd_dkv_floats)
+  float* dbnd_slab;        // workspace: one db_nd row per workgroup + the slab sum's scratch (vpt_attn_bwd_dbnd_floats)
   int B, t, heads, hid, ld, maxlen;
 };
 
@@ -376,9 +383,12 @@ int vpt_adam_launch(const VptAdamArgs* a, hipStream_t s);
 int vpt_adam_multi_launch(const VptAdamTensor* table_dev, int ntensors, long total_blocks, const VptAdamArgs* h, hipStream_t s);
 int vpt_grads_nonfinite_launch(const VptAdamTensor* table_dev, int ntensors, long total_blocks, int* flag, hipStream_t s);
 int vpt_affine_bwd_launch(const VptAffineBwdArgs* a, int pass, hipStream_t s);
+long vpt_affine_bwd_partial_floats(int frames, int CB, int HW, int per_element, int pass);
 int vpt_pool_bwd_launch(const VptPoolBwdArgs* a, hipStream_t s);
 int vpt_conv_bwd_prep_launch(const VptConvBwdPrepArgs* a, hipStream_t s);
 int vpt_conv_first_bwd_launch(const VptConvFirstBwdArgs* a, hipStream_t s);
+long vpt_conv_first_bwd_partial_floats(int frames, int H, int W, int Cout);
+long vpt_conv_bwd_prep_scratch_floats(int frames, int Cout);
 int vpt_gemm_tn_launch(const VptGemmTnArgs* a, hipStream_t s);
 int vpt_splitk_epilogue_launch(const float* part, int splitk, const VptGemmArgs* a, hipStream_t s);
 int vpt_dense_fold_epilogue_launch(const float* part, int splitk, const double* stats, double inv_count, const float* sg, const float* sb, float* out, int M, int N, hipStream_t s);
@@ -399,6 +409,11 @@ int vpt_act_epilogue_launch(const int64_t* act_b, const int64_t* act_c, const fl
                             float scale, float shift, int64_t* keep, uint8_t* nan_flag, uint64_t* rng_state, int B, hipStream_t s);
 int vpt_uniform_noise_launch(const uint64_t* rng_state, uint32_t rng_stream, float* out, int M, int n, hipStream_t s);
 int vpt_attn_bwd_launch(const VptAttnBwdArgs* a, hipStream_t s);
+long vpt_attn_bwd_dkv_floats(int B, int t, int hid);
+long vpt_attn_bwd_dbnd_floats(int B, int t, int heads, int maxlen);
+long vpt_colsum_partial_floats(int M, int N);
+long vpt_slab_sum_scratch_floats(int rows, int cols);
+int vpt_slab_sum_launch(const float* slab, int rows, int cols, long ld, float* out_a, int split, float* out_b, int accumulate, float* scratch, hipStream_t s);
 int vpt_conv3x3_launch(const VptConv3x3Args* a, hipStream_t s);
 int vpt_pool_seam_launch(const VptPoolSeamArgs* a, hipStream_t s);
 int vpt_channel_stats_launch(const VptChannelStatsArgs* a, hipStream_t s);

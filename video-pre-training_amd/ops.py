@@ -57,7 +57,12 @@ class KernelTimer:
 TIMER = KernelTimer()
 
 
+POISON_LDS = os.environ.get("VPT_POISON_LDS", "0") == "1"    # diagnostics: NaN-fill every CU's LDS before each launch (vpt_debug_poison_lds)
+
+
 def _call(name, meta, *args, fmt="bf16", label=None):
+    if POISON_LDS:
+        _native.call("vpt_debug_poison_lds", _stream(), fmt=fmt)
     if TIMER.enabled:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
@@ -66,6 +71,18 @@ def _call(name, meta, *args, fmt="bf16", label=None):
         TIMER.records.append((label or name, a, b, meta or {}))
     else:
         _native.call(name, *args, fmt=fmt)
+
+
+WS_CONV3X3_WGRAD, WS_CONV_BACKWARD_PREPARE, WS_LINEAR_SPLITK, WS_LAYERNORM_BACKWARD, WS_COLUMN_SUM = 1, 2, 3, 4, 5      # include/vpt_hip.h VPT_WS_*
+WS_ATTENTION_BACKWARD_DKV, WS_ATTENTION_BACKWARD_DBND, WS_FRAME_AFFINE_BACKWARD, WS_CONV_FIRST_BACKWARD = 6, 7, 8, 9
+
+
+def _workspace(op, a=0, b=0, c=0, d=0, e=0, device=None, fmt="bf16"):
+    """fp32 scratch of vpt_workspace_bytes(op, ...) bytes (caller-owned: the library never allocates); None when the entry point needs none."""
+    nbytes = int(_native.load(fmt).vpt_workspace_bytes(int(op), int(a), int(b), int(c), int(d), int(e)))
+    if nbytes < 0:
+        raise RuntimeError(f"vpt_workspace_bytes({op}, {a}, {b}, {c}, {d}, {e}) failed")
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=device) if nbytes else None
 
 
 # The 16-bit operand format of a call (bf16: libvpt_hip.so, fp16: libvpt_hip_f16.so, see include/vpt_hip.h
@@ -275,7 +292,7 @@ def conv_backward_prepare_pooled(dpooled, pooled, mask, stats_in, edge_sa, edge_
     t12 = torch.empty(f, 2, dtype=torch.float64, device=dev) if want_t12 else None
     if d_sa is None:
         d_sa, d_sg = torch.zeros_like(edge_sa), torch.zeros_like(edge_sg)
-    scratch = torch.empty(f, 9 * cb * 32 + cb, dtype=torch.float32, device=dev)
+    scratch = _workspace(WS_CONV_BACKWARD_PREPARE, f, 0, 0, 0, cb * 32, device=dev)
     _call("vpt_conv_backward_prepare_pooled", dict(bytes=2.0 * dacc.numel() + 6.0 * pooled.numel()), ptr(dpooled), ptr(pooled), ptr(mask), ptr(stats_in), ptr(edge_sa), ptr(edge_sg),
           ptr(dacc), ptr(t12), ptr(coef), ptr(d_sa), ptr(d_sg), ptr(scratch), ptr(ng), ptr(pst), ptr(pab), f, h, w, cin, cb * 32, _stream(), fmt=fmt, label="vpt_conv_backward_prepare")
     return (dacc, coef, d_sa, d_sg, t12) if want_t12 else (dacc, coef, d_sa, d_sg)
@@ -713,7 +730,8 @@ def layernorm_backward(x, gain, dy, dgain, dbias, relu_in=False, dx_add=None):
         _chk(t, torch.float32, nme)
     m, d = x.shape
     dx = torch.empty_like(x)
-    _call("vpt_layernorm_backward", dict(bytes=20.0 * m * d), ptr(x), ptr(gain), ptr(dy), ptr(dx_add), ptr(dx), ptr(dgain), ptr(dbias),
+    part = _workspace(WS_LAYERNORM_BACKWARD, m, d, device=x.device)
+    _call("vpt_layernorm_backward", dict(bytes=20.0 * m * d), ptr(x), ptr(gain), ptr(dy), ptr(dx_add), ptr(dx), ptr(dgain), ptr(dbias), ptr(part),
           m, d, 1 if relu_in else 0, _stream())
     return dx
 
@@ -730,16 +748,19 @@ def gate_cast(x, ldo, mask=None, dtype=torch.bfloat16):
 
 def column_sum_(out, x_bf16, n):
     _chk(x_bf16, OP16, "x"); _chk(out, torch.float32, "out")
-    _call("vpt_column_sum", dict(bytes=2.0 * x_bf16.numel()), ptr(x_bf16), ptr(out), x_bf16.shape[0], n, x_bf16.shape[1], _stream(), fmt=_fmt(x_bf16)[1])
+    part = _workspace(WS_COLUMN_SUM, x_bf16.shape[0], n, device=out.device)
+    _call("vpt_column_sum", dict(bytes=2.0 * x_bf16.numel()), ptr(x_bf16), ptr(out), ptr(part), x_bf16.shape[0], n, x_bf16.shape[1], _stream(), fmt=_fmt(x_bf16)[1])
 
 
 def masked_attention_backward(qkvr, kmem, vmem, memvalid, b_nd, dout, db_nd, batch, t, heads, hid):
     for tt, nme in ((qkvr, "qkvr"), (kmem, "kmem"), (vmem, "vmem"), (b_nd, "b_nd"), (dout, "dout"), (db_nd, "db_nd")):
         _chk(tt, torch.float32, nme)
     _chk(memvalid, torch.uint8, "memvalid")
-    dqkvr = torch.zeros_like(qkvr)
+    dqkvr = torch.empty_like(qkvr) if qkvr.shape[1] == 3 * hid + 10 * heads else torch.zeros_like(qkvr)     # (every projection column is written)
+    dkv = _workspace(WS_ATTENTION_BACKWARD_DKV, batch, t, hid, device=qkvr.device)
+    dbnd = _workspace(WS_ATTENTION_BACKWARD_DBND, batch, t, heads, kmem.shape[1], device=qkvr.device)
     _call("vpt_masked_attention_backward", dict(flops=10.0 * batch * t * (t + kmem.shape[1]) * hid), ptr(qkvr), ptr(kmem), ptr(vmem),
-          ptr(memvalid), ptr(b_nd), ptr(dout), ptr(dqkvr), ptr(db_nd), batch, t, heads, hid, qkvr.shape[1], kmem.shape[1], _stream())
+          ptr(memvalid), ptr(b_nd), ptr(dout), ptr(dqkvr), ptr(db_nd), ptr(dkv), ptr(dbnd), batch, t, heads, hid, qkvr.shape[1], kmem.shape[1], _stream())
     return dqkvr
 
 
@@ -761,7 +782,7 @@ def conv_backward_prepare(dy, y, res, stats_in, edge_sa, edge_sg, cin, dpooled=N
     t12 = torch.empty(f, 2, dtype=torch.float64, device=dev) if want_t12 else None
     if d_sa is None:
         d_sa, d_sg = torch.zeros_like(edge_sa), torch.zeros_like(edge_sg)
-    scratch = torch.empty(f, 9 * cb * 32 + cb, dtype=torch.float32, device=dev)
+    scratch = _workspace(WS_CONV_BACKWARD_PREPARE, f, 0, 0, 0, cb * 32, device=dev)
     _call("vpt_conv_backward_prepare", dict(bytes=(6.0 if dy is not None else 4.75) * y.numel() + (2.0 * y.numel() if res is not None else 0)),
           ptr(dy), ptr(dpooled), ptr(argmax), ptr(y), ptr(res), ptr(stats_in), ptr(edge_sa), ptr(edge_sg),
           ptr(dacc), ptr(t12), ptr(coef), ptr(d_sa), ptr(d_sg), ptr(scratch), f, h, w, cin, cb * 32, _stream(), fmt=_fmt(dy, y, res, dpooled)[1])
@@ -805,7 +826,7 @@ def conv_backward_reduce(dacc, gate_u, stats_in, edge_sa, edge_sg, cin, d_sa=Non
     t12 = torch.empty(f, 2, dtype=torch.float64, device=dev) if want_t12 else None
     if d_sa is None:
         d_sa, d_sg = torch.zeros_like(edge_sa), torch.zeros_like(edge_sg)
-    scratch = torch.empty(f, 9 * cb * 32 + cb, dtype=torch.float32, device=dev)
+    scratch = _workspace(WS_CONV_BACKWARD_PREPARE, f, 0, 0, 0, cb * 32, device=dev)
     _call("vpt_conv_backward_reduce", dict(bytes=2.0 * dacc.numel()), ptr(dacc), ptr(gate_u), ptr(stats_in), ptr(edge_sa), ptr(edge_sg),
           ptr(t12), ptr(coef), ptr(d_sa), ptr(d_sg), ptr(scratch), f, h, w, cin, cb * 32, _stream(), fmt=_fmt(dacc)[1], label="vpt_conv_backward_prepare")
     return (coef, d_sa, d_sg, t12) if want_t12 else (coef, d_sa, d_sg)
@@ -827,7 +848,8 @@ def frame_affine_backward_reduce(x, dy, gain, stats_in, dgain, dbias):
     _chk(dgain, torch.float32, "dgain"); _chk(dbias, torch.float32, "dbias")
     f, cb, h, w, _ = x.shape
     ab = torch.zeros(f, 2, dtype=torch.float64, device=x.device)
-    _call("vpt_frame_affine_backward", dict(bytes=4.0 * x.numel()), ptr(x), ptr(dy), None, None, ptr(gain), ptr(stats_in), ptr(ab), ptr(dgain), ptr(dbias),
+    part = _workspace(WS_FRAME_AFFINE_BACKWARD, f, h * w, 0, 1, cb * 32, device=x.device)
+    _call("vpt_frame_affine_backward", dict(bytes=4.0 * x.numel()), ptr(x), ptr(dy), None, None, ptr(gain), ptr(stats_in), ptr(ab), ptr(dgain), ptr(dbias), ptr(part),
           f, cb * 32, h * w, 0, 1, _stream(), fmt=_fmt(x, dy)[1])
     return ab
 
@@ -839,12 +861,16 @@ def frame_affine_backward(x, dy, gain, stats_in, dgain, dbias, per_element=False
     f, cb, h, w, _ = x.shape
     ab = torch.zeros(f, 2, dtype=torch.float64, device=x.device)
     dx = torch.empty_like(x)
-    args = (ptr(x), ptr(dy), ptr(dx_add), ptr(dx), ptr(gain), ptr(stats_in), ptr(ab), ptr(dgain), ptr(dbias), f, cb * 32, h * w, 1 if per_element else 0)
+    pe = 1 if per_element else 0
+    head = (ptr(x), ptr(dy), ptr(dx_add), ptr(dx), ptr(gain), ptr(stats_in), ptr(ab), ptr(dgain), ptr(dbias))
+    tail = (f, cb * 32, h * w, pe)
     fmt = _fmt(x, dy, dx_add)[1]
-    _call("vpt_frame_affine_backward", dict(bytes=4.0 * x.numel()), *args, 1, _stream(), fmt=fmt)
-    _call("vpt_frame_affine_backward", dict(bytes=6.0 * x.numel()), *args, 2, _stream(), fmt=fmt)
+    part1 = _workspace(WS_FRAME_AFFINE_BACKWARD, f, h * w, pe, 1, cb * 32, device=x.device)      # (None for the per-element variant: pass 3 reduces)
+    _call("vpt_frame_affine_backward", dict(bytes=4.0 * x.numel()), *head, ptr(part1), *tail, 1, _stream(), fmt=fmt)
+    _call("vpt_frame_affine_backward", dict(bytes=6.0 * x.numel()), *head, None, *tail, 2, _stream(), fmt=fmt)
     if per_element:
-        _call("vpt_frame_affine_backward", dict(bytes=4.0 * x.numel()), *args, 3, _stream(), fmt=fmt)
+        part3 = _workspace(WS_FRAME_AFFINE_BACKWARD, f, h * w, pe, 3, cb * 32, device=x.device)
+        _call("vpt_frame_affine_backward", dict(bytes=4.0 * x.numel()), *head, ptr(part3), *tail, 3, _stream(), fmt=fmt)
     return dx
 
 
@@ -869,7 +895,8 @@ def conv_first_backward(img_u8, wfrag, dpooled, cout, out=None):
         out = (torch.zeros(cout, 27, dtype=torch.float32, device=img_u8.device), torch.zeros(cout, dtype=torch.float32, device=img_u8.device))
     dw, db = out
     _chk(dw, torch.float32, "dw"); _chk(db, torch.float32, "db")
-    _call("vpt_conv_first_backward", dict(flops=2.0 * f * (h // 2) * (w // 2) * cout * 27), ptr(img_u8), ptr(wfrag), ptr(dpooled), ptr(dw), ptr(db),
+    part = _workspace(WS_CONV_FIRST_BACKWARD, f, h, w, 0, cout, device=img_u8.device)
+    _call("vpt_conv_first_backward", dict(flops=2.0 * f * (h // 2) * (w // 2) * cout * 27), ptr(img_u8), ptr(wfrag), ptr(dpooled), ptr(dw), ptr(db), ptr(part),
           f, h, w, cout, _stream(), fmt=_fmt(wfrag, dpooled)[1])
     return dw, db
 

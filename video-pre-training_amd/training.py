@@ -313,6 +313,8 @@ class BCTrainer:
             dhb, _, g[p + "mlp0.layer.weight"] = linear_backward(dh16, hid * ratio, s["hb"], P[p + "mlp0.layer.weight"])
             g[p + "mlp0.norm.weight"], g[p + "mlp0.norm.bias"] = zeros(hid), zeros(hid)
             dx2 = ops.layernorm_backward(s["x2"], P[p + "mlp0.norm.weight"], dhb, g[p + "mlp0.norm.weight"], g[p + "mlp0.norm.bias"], dx_add=dx)
+            if debug is not None:
+                debug[f'dout16_{l}'] = dout16.clone(); debug[f'dh16_{l}'] = dh16.clone(); debug[f'dhb_{l}'] = dhb.clone()
             del dh16, dhb, dout16
             # proj: x2 = x1 + att Wp^T + bp
             dx2_16 = ops.gate_cast(dx2, hid, dtype=self.dtype)
@@ -336,6 +338,7 @@ class BCTrainer:
             dx = ops.layernorm_backward(s["x"], P[p + "pre_r_ln.weight"], dx1, g[p + "pre_r_ln.weight"], g[p + "pre_r_ln.bias"])
             if debug is not None:
                 debug[f'dx_block{l}'] = dx.clone(); debug[f'dx2_block{l}'] = dx2.clone(); debug[f'datt{l}'] = datt.clone(); debug[f'dqkvr{l}'] = dqkvr.clone()
+                debug[f'dx1_block{l}'] = dx1.clone(); debug[f'dq16_{l}'] = dq16.clone(); debug[f'dx2_16_{l}'] = dx2_16.clone()
             del dx2, dx2_16, datt, dqkvr, dq16, dx1, dwq
         if cfg["use_pre_lstm_ln"]:
             g["net.pre_lstm_ln.weight"], g["net.pre_lstm_ln.bias"] = zeros(hid), zeros(hid)
