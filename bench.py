@@ -45,6 +45,58 @@ FLOP_PER_FRAME = {"1x": 3.8235e9, "2x": 15.1016e9, "3x": 33.8409e9}  # BASELINE.
 MFMA_BF16_PEAK = 2.5e15
 
 
+class BoxSampler:
+    """Clock and power of the box WHILE a timed region runs (a thread polling torch.cuda.clock_rate / power_draw = amdsmi every 100 ms), so that two
+    bench lines can be compared: the round-5 boxes differed by +-2.5 % and nothing on the line said which one ran at what clock.  Host-side
+    driver queries only: nothing is enqueued on the GPU."""
+
+    def __init__(self, dev_index, period=0.1):
+        import threading
+        self.dev, self.period, self.clk, self.pw, self.err = dev_index, period, [], [], None
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                self.clk.append(float(torch.cuda.clock_rate(self.dev)))
+                self.pw.append(float(torch.cuda.power_draw(self.dev)) / 1e3)
+            except Exception as e:       # no amdsmi on this box: say so once and stop polling
+                self.err = f"{type(e).__name__}: {e}"[:120]
+                return
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._th.join(timeout=2.0)
+        return False
+
+    def record(self):
+        if not self.clk:
+            return dict(error=self.err or "no samples")
+        c, w = sorted(self.clk), sorted(self.pw)
+        rec = dict(sclk_mhz_sustained=round(c[len(c) // 2]), sclk_mhz_min=round(c[0]), sclk_mhz_max=round(c[-1]), power_w_avg=round(sum(w) / len(w)),
+                   power_w_max=round(w[-1]), samples=len(c), source="torch.cuda.clock_rate / power_draw (amdsmi), polled every 100 ms during the timed steps")
+        rec["power_cap_w"] = _power_cap_w(self.dev)
+        return rec
+
+
+def _power_cap_w(dev_index):
+    try:
+        import amdsmi
+        amdsmi.amdsmi_init()
+        h = amdsmi.amdsmi_get_processor_handles()[dev_index]
+        info = amdsmi.amdsmi_get_power_cap_info(h)
+        cap = float(info.get("power_cap", 0))
+        return round(cap / 1e6) if cap > 1e5 else round(cap)        # (microwatts in amdsmi >= 6, watts before)
+    except Exception:
+        return None
+
+
 def _host_threads(limit):
     try:
         avail = len(os.sched_getaffinity(0))
@@ -291,7 +343,9 @@ def headline_batch_parity(pol, model, img, first, dev, modes, rows=(0, -1)):
                      "centred_logits_rel_l2": round(max(m["buttons.c_l2"], m["camera.c_l2"]), 5), "value_rel": round(m["v_rel"], 5),
                      "argmax_mismatch_outside_noise_band": m["buttons.argmax_safe_mismatch"] + m["camera.argmax_safe_mismatch"],
                      "within_bounds": all(m[f"{h}.{k}"] < P.BOUNDS[mode][k] for h in ("buttons", "camera") for k in ("lp_l2", "lp_max", "c_l2", "c_max")),
-                     "meets_1e-3_logprob_rel_l2": max(m["buttons.lp_l2"], m["camera.lp_l2"]) < 1e-3}
+                     "meets_1e-3_logprob_rel_l2": max(m["buttons.lp_l2"], m["camera.lp_l2"]) < 1e-3,
+                     "meets_1e-3_logprob_max_rel": max(m["buttons.lp_max"], m["camera.lp_max"]) < 1e-3}
+        out[mode]["meets_1e-3"] = out[mode]["meets_1e-3_logprob_rel_l2"] and out[mode]["meets_1e-3_logprob_max_rel"]      # relative L2 AND max-norm, both sequences
         del pd, vpred
     return out
 
@@ -498,12 +552,13 @@ def _bc_leg(pol, args, img, first, g, dev, world, distributed, barrier, dist, mo
         l, st_bc = tr.step(img, first, st_bc, ab, ac)
         losses.append(l)
     barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.bc_steps):
-        l, st_bc = tr.step(img, first, st_bc, ab, ac)
-        losses.append(l)
-    barrier()
-    bc_el = time.perf_counter() - t0
+    with BoxSampler(dev.index if dev.index is not None else 0) as box_bc:
+        t0 = time.perf_counter()
+        for _ in range(args.bc_steps):
+            l, st_bc = tr.step(img, first, st_bc, ab, ac)
+            losses.append(l)
+        barrier()
+        bc_el = time.perf_counter() - t0
     if distributed:
         tt = torch.tensor([bc_el], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -517,7 +572,8 @@ def _bc_leg(pol, args, img, first, g, dev, world, distributed, barrier, dist, mo
               loss_first=round(losses[0], 4), loss_last=round(losses[-1], 4),
               tflops=round(3 * fl * B * T / sec / 1e12, 1), frac_of_mfma_peak=round(3 * fl * B * T / sec / MFMA_BF16_PEAK, 4),
               flop_accounting="3 x forward FLOPs (SURVEY 8d) x frames / step time, per GPU",
-              peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1))
+              peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1), box=box_bc.record(),
+              gradients="bit-reproducible: every cross-workgroup sum through a partial slab added in a fixed order (vpt_reduce.hip)")
     if distributed and tr._arenas is not None:
         # the gradient exchange by itself (nothing to overlap with): what the step would pay if none of it were hidden
         from vpt_amd import distributed as D
@@ -541,7 +597,7 @@ def _bc_leg(pol, args, img, first, g, dev, world, distributed, barrier, dist, mo
         ops.TIMER.enabled = False
         tf = lambda k: round(summ[k]["flops"] / (summ[k]["ms"] * 1e-3) / 1e12, 1) if k in summ and summ[k]["ms"] > 0 else None
         bc["conv_passes_tflops"] = dict(forward=tf("vpt_conv3x3_forward"), dgrad=tf("vpt_conv3x3_dgrad"), wgrad=tf("vpt_conv3x3_wgrad"))
-        bc["kernels_ms"] = {k: round(v["ms"], 2) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:12]}
+        bc["kernels_ms"] = {k: float(f"{v['ms']:.3g}") for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:16]}
     del tr
     return bc
 
@@ -642,6 +698,31 @@ def configs_block(dev):
     return out
 
 
+def _trim_kernels(kernels):
+    """Per-kernel table with 3 significant figures (the line's bulk is these tables)."""
+    if not isinstance(kernels, dict):
+        return kernels
+    out = {}
+    for k, v in kernels.items():
+        out[k] = {q: (float(f"{x:.3g}") if isinstance(x, float) else x) for q, x in v.items()} if isinstance(v, dict) else v
+    return out
+
+
+def _parity_status(parity, head):
+    """One sentence a reader of the parsed line cannot miss: which operand format is inside the north star's 1e-3 and which is not."""
+    try:
+        tb = parity.get("timed_batch") or {}
+        h, f = tb.get(head, {}), tb.get("fp16", {})
+        hm = h.get("meets_1e-3")
+        if head == "fp16":
+            return (f"fp16 headline {'inside' if hm else 'OUTSIDE'} 1e-3 (timed batch: log-prob rel-L2 {h.get('logprob_rel_l2')}, max {h.get('logprob_max_rel')}, "
+                    f"centred logits {h.get('centred_logits_rel_l2')})"), None
+        return (f"{head} headline {'inside' if hm else 'OUTSIDE'} 1e-3 (rel-L2 {h.get('logprob_rel_l2')}, max {h.get('logprob_max_rel')}, centred "
+                f"{h.get('centred_logits_rel_l2')}); fp16 {'inside' if f.get('meets_1e-3') else 'outside'} ({f.get('logprob_rel_l2')} / {f.get('logprob_max_rel')}): parity_mode"), None
+    except Exception as e:
+        return f"parity status unavailable: {type(e).__name__}", None
+
+
 def launch_plan(gpus: int, env, n_dev: int, backend: str):
     """What `bench.py --gpus N` does, as a pure function of (N, launcher environment, visible devices, transport) -- no GPU needed to test it:
          ("refuse", message)  never an N-GPU line from fewer ranks or devices than N, never a silent 1-GPU line for N > 1;
@@ -678,6 +759,7 @@ def main():
     ap.add_argument("--no-ingest", action="store_true", help="skip the host -> device ingest leg")
     ap.add_argument("--step-overlap", type=int, default=0, help="1: PolicyEngine.overlap_steps() during the timed forward (A/B)")
     ap.add_argument("--ingest-only", action="store_true", help="(profiling) only the timed forward and the ingest leg; prints the ingest record")
+    ap.add_argument("--value-blocks", type=int, default=1, help="0: skip the repeated short forward blocks (`value_blocks` on the line)")
     args = ap.parse_args()
 
     backend = os.environ.get("VPT_DIST_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm; "gloo" lets the N > 1 branch run with every rank on one GPU (tests)
@@ -778,14 +860,29 @@ def main():
 
     if args.step_overlap:
         pol.overlap_steps(True)
-    elapsed, state = timed_forward(args.steps, args.warmup)
+    with BoxSampler(dev_index) as box_fwd:
+        elapsed, state = timed_forward(args.steps, args.warmup)
     pol.overlap_steps(False)
+    # the same measurement again in short blocks spread over the run (after the headline steps, after the instrumented step, after the BC leg): a
+    # box that throttles as it warms up, or a +-2.5 % box effect, shows as the spread of these blocks on the line itself
+    blocks = []
+
+    def value_block(tag):
+        if args.ingest_only or args.value_blocks <= 0:
+            return
+        pol.set_precision(head)
+        k = max(2, args.steps // 2)
+        el_b, _ = timed_forward(k, 1)
+        blocks.append(dict(after=tag, steps=k, ms_per_step=round(1e3 * el_b / k, 3)))
+
+    value_block("headline steps")
     if args.ingest_only:
         print(json.dumps(dict(forward_ms=round(1e3 * elapsed / args.steps, 3), ingest=ingest_leg(pol, img, first, dev, copy_stream))))
         return
     roof = kernels = None
     if rank == 0:
         roof, kernels = _roofline(ops, pol, step, state, args, B, T, head)
+    value_block("instrumented step")
 
     # ---- the same workload in the OTHER operand format, as a full record (timed steps, roofline of the same kernel, per-kernel
     # table): with --precision bf16 (default) this is the parity mode, the one that meets the north star's 1e-3 ----
@@ -828,6 +925,7 @@ def main():
             except Exception as e:
                 bc_other = dict(precision=other, error=f"{type(e).__name__}: {e}")
         pol.set_precision(head)
+    value_block("BC leg")
 
     frames_total = world * B * T * args.steps
     fps = frames_total / elapsed
@@ -836,6 +934,15 @@ def main():
         if distributed:
             par += f"; torch.distributed backend={dist.get_backend()} world_size={dist.get_world_size()}" + (" (RCCL)" if dist.get_backend() == "nccl" else "")
             par += f"; collective_ranks={collective_ranks} (sum of ones over an all-reduce of device tensors)"
+        bms = sorted(b["ms_per_step"] for b in blocks)
+        vblocks = None
+        if bms:
+            med = bms[len(bms) // 2]
+            vblocks = dict(blocks=blocks, median_ms_per_step=med, spread_pct=round(100.0 * (bms[-1] - bms[0]) / med, 2),
+                           headline_ms_per_step=round(1e3 * elapsed / args.steps, 3),
+                           note="short repeats of the timed forward spread over the run; `value` itself comes from the K contract steps only")
+        # ---- key order: the contract keys, then the bulky detail, then -- LAST, so that the tail of stdout holds them -- parity_status, parity_mode,
+        # bc_step, box, value_blocks, roofline, cpu_baseline (the driver keeps the last few KB of stdout; round 5's bf16 bc_step was cut off) ----
         line = {
             "metric": "frames/sec (fwd) [+ bc_step.ms_per_step], 2x policy, 128x128x3 seq=128",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -846,14 +953,13 @@ def main():
                        "global_batch": world * B, "seq_len": T, "parallelism": par},
             "e2e_tflops": round(fps * FLOP_PER_FRAME.get(args.model, 0) / 1e12, 1),
             "e2e_frac_of_mfma_peak": round(fps * FLOP_PER_FRAME.get(args.model, 0) / MFMA_BF16_PEAK, 4),
-            "roofline": roof,
-            "bc_step": bc,
-            "kernels": kernels,
+            "kernels": _trim_kernels(kernels),
         }
+        tail = {"bc_step": bc, "box": box_fwd.record(), "value_blocks": vblocks, "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
+            if isinstance(other_rec, dict) and "kernels" in other_rec:
+                other_rec["kernels"] = _trim_kernels(other_rec["kernels"])
             line[f"{other}_mode"] = other_rec
-            if bc_other is not None:
-                line["bc_step_" + other] = bc_other
             try:
                 line["parity"] = parity_block(args.model, dev)
             except Exception as e:
@@ -865,13 +971,15 @@ def main():
                 line["parity"]["competitive_heads"] = dict(error=f"{type(e).__name__}: {e}")
             # which throughput has EARNED the north star's 1e-3 gate (log-prob relative L2 on the timed batch): the fp16 record
             pm = other_rec if other == "fp16" else dict(frames_per_s=round(fps, 1), roofline=roof)
+            status, pmode = _parity_status(line["parity"], head)
             if isinstance(pm, dict) and "error" not in pm:
-                tb = line["parity"].get("timed_batch", {}).get("fp16", {})
-                line["parity_mode"] = {"dtype": "fp16", "value": pm.get("frames_per_s"), "unit": "frames/s",
-                                       "roofline_frac": (pm.get("roofline") or {}).get("frac"),
-                                       "logprob_rel_l2_on_timed_batch": tb.get("logprob_rel_l2"), "meets_1e-3": tb.get("meets_1e-3_logprob_rel_l2"),
-                                       "note": "precision='fp16' (the policy classes' default) is the format whose log-probs are within 1e-3 relative L2 of the fp32 reference; the headline "
-                                               "`value` is the north star's bf16-tile format, whose parity figures are in parity.* (1.5-4x the tolerance by construction: bf16 operands carry 8 mantissa bits)"}
+                tb = (line["parity"].get("timed_batch") or {}).get("fp16", {})
+                pmode = {"dtype": "fp16", "value": pm.get("frames_per_s"), "unit": "frames/s",
+                         "roofline_frac": (pm.get("roofline") or {}).get("frac"),
+                         "logprob_rel_l2_on_timed_batch": tb.get("logprob_rel_l2"), "logprob_max_rel_on_timed_batch": tb.get("logprob_max_rel"),
+                         "centred_logits_rel_l2_on_timed_batch": tb.get("centred_logits_rel_l2"), "meets_1e-3": tb.get("meets_1e-3"),
+                         "note": "precision='fp16' (the policy classes' default) is the format whose log-probs are within 1e-3 relative L2 of the fp32 reference; the headline "
+                                 "`value` is the north star's bf16-tile format, whose parity figures are in parity.* (1.5-4x the tolerance by construction: bf16 operands carry 8 mantissa bits)"}
             del pol, img
             torch.cuda.empty_cache()
             if not args.no_ingest:
@@ -894,7 +1002,23 @@ def main():
                 line["configs"] = configs_block(dev)
             except Exception as e:
                 line["configs"] = dict(error=f"{type(e).__name__}: {e}")
-            line["cpu_baseline"] = cpu_baseline(args.model)
+            if bc_other is not None:
+                line["bc_step_" + other] = bc_other
+            line["parity_status"] = status
+            line["parity_mode"] = pmode
+            tail["cpu_baseline"] = cpu_baseline(args.model)
+        # scalars of the BC half of the metric and of the box ON the roofline object as well: the driver's record keeps `roofline` / `cpu_baseline` whole
+        if isinstance(roof, dict):
+            if isinstance(bc, dict) and "ms_per_step" in bc:
+                roof.update(bc_step_ms_per_step=bc["ms_per_step"], bc_step_frac_of_mfma_peak=bc.get("frac_of_mfma_peak"), bc_step_dtype=bc.get("precision"))
+            bx = tail["box"]
+            if isinstance(bx, dict) and "sclk_mhz_sustained" in bx:
+                roof.update(sclk_mhz_sustained=bx["sclk_mhz_sustained"], power_w_avg=bx["power_w_avg"], power_cap_w=bx.get("power_cap_w"))
+            if vblocks:
+                roof.update(value_blocks_spread_pct=vblocks["spread_pct"])
+            if line.get("parity_status"):
+                roof.update(parity_status=line["parity_status"][:118])
+        line.update(tail)
         print(json.dumps(line))
     if distributed:
         dist.destroy_process_group()

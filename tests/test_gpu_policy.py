@@ -245,6 +245,20 @@ def test_overlapped_steps_equal_serial_steps(pol_1x):
                 assert torch.equal(x, y) and torch.equal(x, z)
         for (k1, v1), (k2, v2) in zip(st_s, st_p):
             assert torch.equal(k1, k2) and torch.equal(v1, v2)
+        # a resident but NON-contiguous img under overlap: forward() makes the contiguous copy on the calling stream, which the pipelined
+        # chunk streams do not wait for by themselves -- they are handed an event behind the copy
+        wide = [torch.cat([im, torch.flip(im, dims=[-1])], dim=-1) for im in imgs]       # [b, t, 128, 128, 6]: the frames are the slice [..., :3]
+        pol.overlap_steps(True)
+        st, rec = pol.initial_state(b), []
+        for i in range(n_calls):
+            view = wide[i][..., :3]
+            assert not view.is_contiguous()
+            (pd, v, _), st = pol({"img": view}, first, st)
+            rec.append((pd["buttons"].clone(), pd["camera"].clone(), v.clone()))
+        torch.cuda.synchronize()
+        for a, c in zip(serial, rec):
+            for x, y in zip(a, c):
+                assert torch.equal(x, y)
         # new weights between two overlapped calls: the re-pack runs on the calling stream and the next call must wait for it
         pol.overlap_steps(True)
         (pd0, _, _), _ = pol({"img": imgs[0]}, first, pol.initial_state(b))

@@ -117,9 +117,6 @@ __global__ __launch_bounds__(256) void vpt_ln_bwd_kernel(VptLnBwdArgs a) {
   for (int q = 0; q < ND4; ++q) { pg[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; pb[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   const float invD = 1.0f / (float)a.D;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  __shared__ float comb_[2 * 256 * ND4];
-  for (int c = threadIdx.x; c < 2 * 256 * ND4; c += 256) comb_[c] = 0.f;
-  __syncthreads();
   for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
     const int row = blockIdx.x * LNB_ROWS + w * (LNB_ROWS / 4) + rr;
     if (row >= a.M) break;
@@ -188,34 +185,24 @@ __global__ __launch_bounds__(256) void vpt_ln_bwd_kernel(VptLnBwdArgs a) {
       }
     }
   }
-  // column partials: the four waves add into the LDS table ONE AFTER THE OTHER (a fixed order; each lane owns its columns inside a wave), then the
-  // workgroup's sums go to its own row of the partial slab -- vpt_ln_bwd_finish_kernel adds the rows in row order.  (Until round 5: LDS float
-  // atomics + one global fp32 atomic per column per workgroup, i.e. sums in arrival order.)
-#pragma unroll 1
-  for (int ww = 0; ww < 4; ++ww) {
-    if (w == ww) {
+  // column partials: every WAVE writes its sums to its own row of the partial slab (row = 4 x workgroup + wave; float4 per lane, coalesced) and
+  // vpt_ln_bwd_finish_kernel adds the rows in row order -- no LDS table, no barrier, nothing that depends on the order in which waves or
+  // workgroups run.  (Until round 5: LDS float atomics across the waves + one global fp32 atomic per column per workgroup.)
+  float* part = a.partials + ((size_t)blockIdx.x * 4 + w) * 2 * a.D;
 #pragma unroll
-      for (int q = 0; q < ND4; ++q) {
-        const int i = lane + 64 * q;
-        if (i < n4) {
+  for (int q = 0; q < ND4; ++q) {
+    const int i = lane + 64 * q;
+    if (i < n4) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            comb_[4 * i + k] += pg[q][k];
-            comb_[256 * ND4 + 4 * i + k] += pb[q][k];
-          }
-        }
+      for (int k = 0; k < 4; ++k) {      // (element stores: as 16-byte stores the partials would have to sit in aligned register quadruples -- 600 spills at ND4 = 8)
+        part[4 * i + k] = pg[q][k];
+        part[a.D + 4 * i + k] = pb[q][k];
       }
     }
-    __syncthreads();
-  }
-  float* part = a.partials + (size_t)blockIdx.x * 2 * a.D;
-  for (int c = threadIdx.x; c < a.D; c += 256) {
-    part[c] = comb_[c];
-    part[a.D + c] = comb_[256 * ND4 + c];
   }
 }
 
-// dgain[c] += sum_b partials[b][0][c], dbias[c] += sum_b partials[b][1][c], b ascending inside each of four contiguous segments, the segments combined
+// dgain[c] += sum_b partials[b][0][c], dbias[c] += sum_b partials[b][1][c] over the nblocks = 4 x workgroups rows, b ascending inside each of four contiguous segments, the segments combined
 // as (s0 + s1) + (s2 + s3): one fixed summation tree per column, whatever the order the workgroups above ran in.
 __global__ __launch_bounds__(256) void vpt_ln_bwd_finish_kernel(const float* __restrict__ partials, int nblocks, int D, float* dgain, float* dbias) {
   __shared__ float seg_[4][64];
@@ -242,7 +229,7 @@ extern "C" int vpt_ln_bwd_launch(const VptLnBwdArgs* a, hipStream_t stream) {
   else if (nd4 <= 8) hipLaunchKernelGGL(vpt_ln_bwd_kernel<8>, g, b, 0, stream, *a);
   else if (nd4 <= 12) hipLaunchKernelGGL(vpt_ln_bwd_kernel<12>, g, b, 0, stream, *a);
   else hipLaunchKernelGGL(vpt_ln_bwd_kernel<16>, g, b, 0, stream, *a);
-  hipLaunchKernelGGL(vpt_ln_bwd_finish_kernel, dim3((2 * a->D + 63) / 64), b, 0, stream, (const float*)a->partials, (int)g.x, a->D, a->dgain, a->dbias);
+  hipLaunchKernelGGL(vpt_ln_bwd_finish_kernel, dim3((2 * a->D + 63) / 64), b, 0, stream, (const float*)a->partials, 4 * (int)g.x, a->D, a->dgain, a->dbias);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -73,7 +73,7 @@ int64_t vpt_workspace_bytes(int op, int frames, int H, int W, int Cin, int Cout)
   switch (op) {
     case VPT_WS_CONV3X3_WGRAD: return 4 * (int64_t)vpt_conv3x3_wgrad_scratch_floats(frames, Cin, Cout);
     case VPT_WS_CONV_BACKWARD_PREPARE: return 4 * (int64_t)vpt_conv_bwd_prep_scratch_floats(frames, Cout);
-    case VPT_WS_LAYERNORM_BACKWARD: return 4 * (int64_t)((frames + 31) / 32) * 2 * H;                       /* (M, D): one row per 32-row workgroup */
+    case VPT_WS_LAYERNORM_BACKWARD: return 4 * (int64_t)((frames + 31) / 32) * 4 * 2 * H;                   /* (M, D): one row per wave of a 32-row workgroup */
     case VPT_WS_COLUMN_SUM: return 4 * (int64_t)vpt_colsum_partial_floats(frames, H);                       /* (M, N) */
     case VPT_WS_ATTENTION_BACKWARD_DKV: return 4 * (int64_t)vpt_attn_bwd_dkv_floats(frames, H, W);          /* (B, t, hid) */
     case VPT_WS_ATTENTION_BACKWARD_DBND: return 4 * (int64_t)vpt_attn_bwd_dbnd_floats(frames, H, W, Cin);   /* (B, t, heads, maxlen) */

@@ -536,13 +536,16 @@ __global__ __launch_bounds__(256, 3) void vpt_conv_bwd_prep_pooled_kernel(VptCon
   float tv = 0.f;
   // NFOLD: the backward of GroupNorm `n` (x = (P - mu_P) r_P gain + bias) applied to the incoming gradient G, exactly vpt_affine_bwd_apply_kernel's
   // arithmetic and rounding point (one 16-bit rounding of d(pooled))
-  float ng[8], mp = 0.f, rpool = 1.f, nA = 0.f, nB = 0.f;
+  // (the eight gains of the thread's channel octet are read from LDS where they are used: held in registers across the pass loop they were the
+  // eight registers that pushed this variant one over the three-waves-per-SIMD budget -- one spilled register, 8 bytes of scratch)
+  __shared__ __attribute__((aligned(16))) float ng_[32];
+  float mp = 0.f, rpool = 1.f, nA = 0.f, nB = 0.f;
   if (NFOLD) {
     frame_mean_rstd(a.pool_stats, f, a.inv_count_pool, mp, rpool);
     nA = (float)(a.pool_ab[2 * f] * a.inv_count_pool);
     nB = (float)(a.pool_ab[2 * f + 1] * a.inv_count_pool);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) ng[k] = a.n_gain[cb * 32 + oct * 8 + k];
+    if (threadIdx.x < 32) ng_[threadIdx.x] = a.n_gain[cb * 32 + threadIdx.x];
+    __syncthreads();
   }
   u32x4 rd, rp, rm;                         // this thread's pooled pixel of the pass being loaded: gradient, pooled value, mask
   auto load_pass = [&](int p) {
@@ -557,6 +560,8 @@ __global__ __launch_bounds__(256, 3) void vpt_conv_bwd_prep_pooled_kernel(VptCon
     unpack8(rd, df);
     unpack8(rp, pf);
     if (NFOLD) {
+      const f32x4 g0 = *(const f32x4*)(ng_ + oct * 8), g1 = *(const f32x4*)(ng_ + oct * 8 + 4);
+      const float ng[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float xh = (pf[k] - mp) * rpool;

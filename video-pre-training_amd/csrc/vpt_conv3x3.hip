@@ -688,6 +688,15 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
     }
   };
   if constexpr (POOL) {
+    // The four pointers only this epilogue uses are read from the kernarg segment HERE, through a pointer the compiler cannot see behind: taken from
+    // `a` they are loaded with the rest of the arguments at kernel entry and sit in eight scalar registers through the whole main loop -- in the
+    // arg-max mode (7) that was the eight registers too many (8 SGPRs spilled to VGPR lanes around the loop).
+    const __attribute__((address_space(4))) VptConv3x3Args* late = (const __attribute__((address_space(4))) VptConv3x3Args*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(late));
+    vpt_op16* const seam_r_p = late->seam_r;
+    vpt_op16* const seam_c_p = late->seam_c;
+    vpt_op16* const pool_mask_p = late->pool_mask;
+    double* const chs_out_p = late->chs_out;
     // ---- phase 1: GroupNorm fold + ReLU, rounded to 16 bits, into the LDS tile [16 x 16 pixels][128 channels] (pixel pitch PT_RS: the
     // 16 extra bytes spread a column of pixels over the banks).  The tile reuses the halo / weight buffers: every wave must be past
     // its last fragment read first.  A lane holds 4 consecutive channels of one pixel per accumulator group: one ds_write_b64 each.
@@ -778,7 +787,7 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
         }
         if (cg < a.Cout) {
           const size_t moff = ((size_t)(f * CB_out + (cg >> 5)) * PH * PW + (size_t)(((ty0 >> 1) + pj) * PW + (tx0 >> 1) + pi)) * 32 + (cg & 31);
-          *(u32x4*)(a.pool_mask + moff) = mk;
+          *(u32x4*)(pool_mask_p + moff) = mk;
         }
       }
       if (cg < a.Cout) {
@@ -798,7 +807,7 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
             vals[0] *= g0.x; vals[1] *= g0.y; vals[2] *= g0.z; vals[3] *= g0.w; vals[4] *= g1.x; vals[5] *= g1.y; vals[6] *= g1.z; vals[7] *= g1.w;
             mv = pack8(vals);
           }
-          if (a.chs_out) {
+          if (chs_out_p) {
             float q[8];
             unpack8(mv, q);
 #pragma unroll
@@ -816,16 +825,16 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
       if (cg < a.Cout) {
         if (ty0 + 16 < a.H) {
           const u32x4 v = *(const u32x4*)(smem + (15 * 16 + q) * PT_RS + oct * 16);
-          *(u32x4*)(a.seam_r + ((size_t)((f * CB_out + (cg >> 5)) * tilesY + ty) * a.W + tx0 + q) * 32 + (cg & 31)) = v;
+          *(u32x4*)(seam_r_p + ((size_t)((f * CB_out + (cg >> 5)) * tilesY + ty) * a.W + tx0 + q) * 32 + (cg & 31)) = v;
         }
         if (tx0 + 16 < a.W) {
           const u32x4 v = *(const u32x4*)(smem + (q * 16 + 15) * PT_RS + oct * 16);
-          *(u32x4*)(a.seam_c + ((size_t)((f * CB_out + (cg >> 5)) * tilesX + tx) * a.H + ty0 + q) * 32 + (cg & 31)) = v;
+          *(u32x4*)(seam_c_p + ((size_t)((f * CB_out + (cg >> 5)) * tilesX + tx) * a.H + ty0 + q) * 32 + (cg & 31)) = v;
         }
       }
     }
     s_sum2.x = p_sum; s_sum2.y = 0.f; s_sq2.x = p_sq; s_sq2.y = 0.f;
-    if (a.chs_out) {
+    if (chs_out_p) {
       // threads tid = octet + 16 q share an octet: lanes octet + 16 {0..3} of each wave (two exchanges), then the four waves through the
       // epilogue-table area of the LDS (dead since phase 1), then one fp64 atomic per (channel, moment): 256 per tile
       float* scr = (float*)(smem + KK_O);          // [4 waves][16 octets][16]
@@ -843,7 +852,7 @@ __global__ __launch_bounds__(TR * 16, 2) void vpt_conv3x3_kernel(VptConv3x3Args 
         const int o = tid >> 4, k = tid & 15;
         const float t = (scr[(0 * 16 + o) * 16 + k] + scr[(1 * 16 + o) * 16 + k]) + (scr[(2 * 16 + o) * 16 + k] + scr[(3 * 16 + o) * 16 + k]);
         const int ch = nt * 128 + o * 8 + (k & 7);
-        if (ch < a.Cout) atomicAdd(a.chs_out + ((size_t)f * a.Cout + ch) * 2 + (k >> 3), (double)t);
+        if (ch < a.Cout) atomicAdd(chs_out_p + ((size_t)f * a.Cout + ch) * 2 + (k >> 3), (double)t);
       }
     }
   } else {

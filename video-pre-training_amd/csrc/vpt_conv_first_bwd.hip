@@ -51,6 +51,8 @@ __global__ __launch_bounds__(CFB_THREADS, 4) void vpt_conv_first_bwd_kernel(VptC
   const int tilesX = PW >> 3, tilesY = PH >> 3;
   const long T = (long)a.frames * tilesY * tilesX;
   const int nt = blockIdx.y;
+  __shared__ int nt_stash_, bx_stash_;         // (read back by the flush behind the tile loop; the first barrier of the loop -- or the flush's own -- publishes them)
+  if (tid == 0) { nt_stash_ = nt; bx_stash_ = blockIdx.x; }
   const int CB_out = a.Cout >> 5;
 
   const int cbw = w & 3, ph = w >> 2;          // wave = (32-channel block, pooled rows 0-3 / 4-7)
@@ -184,9 +186,11 @@ __global__ __launch_bounds__(CFB_THREADS, 4) void vpt_conv_first_bwd_kernel(VptC
     if (!(VPT_CFB_ABLATE & 8)) {
       unsigned inl_t = (unsigned)(size_t)(inl - smem);   // opaque per tile: left alone the compiler hoists ~50 per-element LDS addresses out of the tile loop (spills)
       asm volatile("" : "+v"(inl_t));
+      int w_t = w;                                       // ... and the wave's k-step constants (five sets of scalar offsets) are re-derived per tile too: hoisted
+      asm volatile("" : "+s"(w_t));                      // out of the tile loop they were the scalar registers that spilled (a dozen scalar instructions per tile)
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
-        const int ksg = w + 8 * i;                     // wave-uniform
+        const int ksg = w_t + 8 * i;                   // wave-uniform
         if (ksg < 36) {
           const int pg = ksg >= 18 ? 1 : 0, ks = ksg - 18 * pg;
           const unsigned char* pgb = smem + inl_t + pg * (8 * 19 * 8);                          // pixel group 1: pooled rows 4..7 = conv rows 8..
@@ -245,24 +249,35 @@ __global__ __launch_bounds__(CFB_THREADS, 4) void vpt_conv_first_bwd_kernel(VptC
     }
     __syncthreads();
   }
-  // ---- flush: the two waves of a channel block (pixel groups 0 / 1) are added through LDS, then one atomic per (channel, tap) and workgroup ----
+  // ---- flush: the two waves of a channel block (pixel groups 0 / 1) are added through LDS, then the sums go to the workgroup's slab row ----
+  // What the flush needs is derived HERE, behind the tile loop: the lane / wave roles from the thread index again (through a register the compiler
+  // cannot see behind), the slab pointer and Cout from the kernarg segment, the N tile from an LDS word written at entry.  Taken from the values
+  // of the kernel's first lines they had to stay live across the loop: 4 SGPRs + 1 VGPR spilled (8 bytes of scratch) until round 5.
   float* red = (float*)smem;                               // [4 channel blocks][16 values][64 lanes] fp32 = 16 KB
-  float* prow = a.partials + (size_t)blockIdx.x * a.Cout * 28;
-  if (ph == 1) {
+  int tid_f = threadIdx.x;
+  asm volatile("" : "+v"(tid_f));
+  const int lane_f = tid_f & 63, w_f = __builtin_amdgcn_readfirstlane(tid_f >> 6);
+  const int hi_f = lane_f >> 5, l31_f = lane_f & 31, cbw_f = w_f & 3, ph_f = w_f >> 2;
+  const __attribute__((address_space(4))) VptConvFirstBwdArgs* late = (const __attribute__((address_space(4))) VptConvFirstBwdArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(late));
+  const int cout_f = late->Cout;
+  if (ph_f == 1) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[(cbw * 16 + r) * 64 + lane] = gacc[r];
+    for (int r = 0; r < 16; ++r) red[(cbw_f * 16 + r) * 64 + lane_f] = gacc[r];
   }
   __syncthreads();
-  if (ph == 0 && l31 < 28) {
+  const int nt_f = __builtin_amdgcn_readfirstlane(nt_stash_);      // (behind a barrier in every path, also when the workgroup had no tile)
+  float* prow = late->partials + (size_t)__builtin_amdgcn_readfirstlane(bx_stash_) * cout_f * 28;
+  if (ph_f == 0 && l31_f < 28) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int o = nt * 128 + cbw * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (o >= a.Cout) continue;
-      const float v = gacc[r] + red[(cbw * 16 + r) * 64 + lane];
+      const int o = nt_f * 128 + cbw_f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi_f;
+      if (o >= cout_f) continue;
+      const float v = gacc[r] + red[(cbw_f * 16 + r) * 64 + lane_f];
       // this workgroup's row of the partial slab, [dW Cout x 27 | db Cout]; the launcher's vpt_slab_sum adds the rows in row order (the tile ranges
       // are a static function of the grid, so a row's content does not depend on scheduling either).  Until round 5: one fp32 atomic per entry.
-      if (l31 < 27) prow[(size_t)o * 27 + l31] = v * (1.0f / 255.0f);   // d(conv)/dW = img / 255
-      else prow[(size_t)a.Cout * 27 + o] = v;
+      if (l31_f < 27) prow[(size_t)o * 27 + l31_f] = v * (1.0f / 255.0f);   // d(conv)/dW = img / 255
+      else prow[(size_t)cout_f * 27 + o] = v;
     }
   }
 }

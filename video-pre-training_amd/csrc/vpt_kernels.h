@@ -317,7 +317,7 @@ struct VptLnBwdArgs {
   float* dx;               // [M][D]
   float* dgain;            // [D] accumulated (caller zeroes)
   float* dbias;            // [D]
-  float* partials;         // [ceil(M / 32)][2][D] workspace: per-workgroup column sums, added in row order by the finish kernel
+  float* partials;         // [4 * ceil(M / 32)][2][D] workspace: per-wave column sums, added in row order by the finish kernel
   int M, D, relu_in;
 };
 

@@ -175,8 +175,10 @@ class PolicyEngine:
         """The device-resident {seed, step} the stochastic heads draw from.  One per engine: a captured acting step holds its address.
         Seeding follows torch's generator the way the reference's th.rand_like does (lib/action_head.py:200): unless seed() was called, the
         sampler's seed is DERIVED from the device generator's (seed, offset), and the engine leaves a mark on that generator (its offset
-        advanced by _RNG_MARK).  A later torch.manual_seed() -- even with the same seed -- resets the offset, the mark is gone, and the next
-        stochastic call re-derives {seed, step = 0} in place: "seed, run an episode, re-seed, run again" reproduces the draws."""
+        advanced by _RNG_MARK).  A later torch.manual_seed() -- even with the same seed -- resets the offset below the mark, and the next
+        stochastic call re-derives {seed, step = 0} in place: "seed, run an episode, re-seed, run again" reproduces the draws.  Other consumers
+        of the generator only move the offset forward and do not disturb the sampler (a re-seed followed by more than _RNG_MARK foreign draws
+        BEFORE the engine's next stochastic call would go unnoticed: call seed() for that)."""
         cur = self._rng_state
         if cur is None or cur.device.type != device.type or (device.index is not None and cur.device.index != device.index):
             pending = getattr(self, "_pending_seed", None)
@@ -189,7 +191,11 @@ class PolicyEngine:
         if self._rng_src != "explicit" and not torch.cuda.is_current_stream_capturing():
             gen = torch.cuda.default_generators[self._rng_state.device.index]
             here = (int(gen.initial_seed()), int(gen.get_offset()))
-            if self._rng_src != here:
+            src = self._rng_src
+            # re-derive only when a manual_seed happened: the seed changed, or the offset fell back below the engine's mark.  An offset that merely
+            # ADVANCED belongs to another consumer of the generator (torch.rand, dropout, a second engine): the sampler keeps its stream and the
+            # generator is left alone (every such consumer used to re-seed the sampler with step = 0 and cost a blocking copy per step)
+            if not (isinstance(src, tuple) and src[0] == here[0] and here[1] >= src[1]):
                 # splitmix-style mix of (seed, offset), masked to 63 bits (the state is int64)
                 z = (here[0] * 0x9E3779B97F4A7C15 + here[1] * 0xBF58476D1CE4E5B9 + 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
                 z ^= z >> 31
@@ -282,7 +288,9 @@ class PolicyEngine:
         of the chip idle).  Results are unchanged -- the same kernels on the same data in the same per-stream order.
         CONTRACT: the frames passed to forward() must be complete on the device when forward() is called (resident, or uploaded on a copy
         stream whose event the HOST has waited for): work enqueued on the calling stream after the previous forward() returned is NOT waited for
-        by the convolutions.  Off by default: a caller that produces frames on the calling stream right before forward() keeps working."""
+        by the convolutions.  A resident but NON-CONTIGUOUS img (a slice, a permute) is fine: forward() makes the contiguous copy on the calling
+        stream and orders the chunk streams behind it.  Off by default: a caller that produces frames on the calling stream right before
+        forward() keeps working."""
         self.step_overlap = bool(enable)
         self._handoff = None
 
@@ -460,8 +468,10 @@ class PolicyEngine:
         o32, o16 = ops.linear(ln16, wpk, n, bias=bias, res=res, relu=relu, out_f32=out_f32, out_bf16=out_bf16, tiling=tiling)
         return ln32, o32, o16
 
-    def _img_process(self, frames: torch.Tensor, tiling: str = "throughput") -> torch.Tensor:
-        """uint8 [N,128,128,3] -> fp32 [N,hid]  (ImgObsProcess.forward, lib/policy.py:79-80).  tiling: see ops.conv3x3."""
+    def _img_process(self, frames: torch.Tensor, tiling: str = "throughput", frames_ready=None) -> torch.Tensor:
+        """uint8 [N,128,128,3] -> fp32 [N,hid]  (ImgObsProcess.forward, lib/policy.py:79-80).  tiling: see ops.conv3x3.
+        frames_ready: an event on the calling stream behind which `frames` is complete (forward() made a contiguous copy there); the pipelined
+        chunk streams wait for it -- they do not wait for the calling stream itself."""
         cfg, w = self.cfg, self.w
         n = frames.shape[0]
         outs = []
@@ -478,6 +488,8 @@ class PolicyEngine:
             for st in self._streams[:n_streams]:
                 if pipelined:
                     st.wait_event(self._handoff)       # overlap_steps(): behind the previous call's hand-off, beside its transformer
+                    if frames_ready is not None:
+                        st.wait_event(frames_ready)    # ... and behind the copy kernel that made `frames` on the calling stream
                 else:
                     st.wait_stream(main)
         for ci, i in enumerate(range(0, n, self.cnn_chunk)):
@@ -513,9 +525,15 @@ class PolicyEngine:
         bsz, t = img_u8.shape[:2]
         hid, heads, maxlen = cfg["hidsize"], cfg["heads"], cfg["maxlen"]
         frames = img_u8.reshape(bsz * t, *img_u8.shape[2:]).contiguous()
+        frames_ready = None
+        if self.step_overlap and frames.data_ptr() != img_u8.data_ptr() and not torch.cuda.is_current_stream_capturing():
+            # a non-contiguous (but resident) img: .contiguous() just enqueued a copy kernel on the calling stream, which pipelined chunk streams
+            # do not wait for -- hand them an event behind the copy (without it the convolutions could read `frames` before it is written)
+            frames_ready = torch.cuda.Event()
+            frames_ready.record(torch.cuda.current_stream())
         # the acting step (agent.py:190-206: T = 1, a handful of environments) runs the convolutions on the latency tiling
         tiling = "latency" if (t == 1 and bsz <= ops.LN_LINEAR_MAX_ROWS) else "throughput"     # one choice for every kernel of the step
-        x = self._img_process(frames, tiling=tiling)
+        x = self._img_process(frames, tiling=tiling, frames_ready=frames_ready)
         if cfg["use_pre_lstm_ln"]:
             x, _ = ops.layernorm(x, w["prelstm.g"], w["prelstm.b"], out_f32=True, out_bf16=False, dtype=self.dtype)
 
