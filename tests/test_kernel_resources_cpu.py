@@ -37,7 +37,9 @@ def test_no_kernel_spills_or_uses_scratch(tag):
     conv = {k: v for k, v in res.items() if "vpt_conv3x3_kernel" in k}
     assert len(conv) >= 15
     for k, v in conv.items():
-        assert v["occupancy"] >= 2 and v["agprs"] == 0 and v["lds"] <= 82 * 1024, (k, v)
+        assert v["occupancy"] >= 2 and v["agprs"] == 0, (k, v)
+        if "ELi16EE" in k:      # the shipped 16-row tiles: 80 KB, two workgroups per CU (the opt-in 32-row tiling holds 101 KB)
+            assert v["lds"] <= 82 * 1024, (k, v)
 
 
 def test_layernorm_backward_has_no_packed_fp32_arithmetic(tmp_path):
