@@ -78,3 +78,83 @@ def test_shard_range_properties():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [e - b for b, e in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BCTrainer.reduced_loss_and_grads -- the REAL host logic of the data-parallel step -- on three gloo ranks with uneven shards (B = 5 -> 2, 2, 1)
+# and a synthetic per-frame gradient in place of the HIP backward: the frame-weighted loss, the two arenas, the early / late exchange, and the path
+# where one rank fails before or after its early exchange has started.
+# ---------------------------------------------------------------------------------------------------------
+_NAMES = ["net.lastlayer.layer.weight", "pi_head.buttons.linear_layer.bias", "net.img_process.cnn.stacks.0.firstconv.layer.weight", "net.img_process.cnn.dense.layer.weight"]
+_SHAPES = [(64, 32), (17,), (8, 3, 3, 3), (16, 50)]
+
+
+def _fake_trainer(fail=None):
+    from vpt_amd.training import BCTrainer
+    tr = object.__new__(BCTrainer)
+    tr.params = {n: torch.nn.Parameter(torch.zeros(s)) for n, s in zip(_NAMES, _SHAPES)}
+    tr.trainable, tr._arenas, tr.scaled, tr.loss_scale = list(_NAMES), None, False, 1.0
+    g = torch.Generator().manual_seed(3)
+    base = {n: torch.randn(s, generator=g) for n, s in zip(_NAMES, _SHAPES)}
+
+    def loss_and_grads(img, first, state, ab, ac, global_frames=None, on_trunk_grads=None, unscaled=True, debug=None):
+        if fail == "early":
+            raise MemoryError("synthetic failure before the early exchange")
+        w = float(img.double().sum())                     # frame f carries weight f: d loss / d theta = sum_f f * base / global_frames
+        grads = {n: base[n] * (w / global_frames) for n in _NAMES if not n.startswith("net.img_process.cnn.")}
+        on_trunk_grads(grads)
+        if fail == "late":
+            raise MemoryError("synthetic failure after the early exchange")
+        grads.update({n: base[n] * (w / global_frames) for n in _NAMES if n.startswith("net.img_process.cnn.")})
+        return torch.tensor(w / img.numel()), grads, state
+
+    tr.loss_and_grads = loss_and_grads
+    return tr, base
+
+
+def _dp_worker(rank, world, port, out, fail_rank, fail):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    D.init_from_env("gloo")
+    try:
+        tr, base = _fake_trainer(fail if rank == fail_rank else None)
+        b, t = 5, 2
+        frames = torch.arange(1.0, b * t + 1).view(b, t)      # frame weights 1 .. 10
+        b0, b1 = D.shard_range(b, rank, world)
+        assert (b1 - b0) == (2, 2, 1)[rank]
+        mine = frames[b0:b1]
+        try:
+            loss, grads, _ = tr.reduced_loss_and_grads(mine, torch.zeros(b1 - b0, t, dtype=torch.bool), None, None, None)
+        except RuntimeError as e:
+            out[rank] = str(e)
+            return
+        total = float(frames.sum())
+        for n in _NAMES:                                        # every rank holds the gradient of the GLOBAL mean: sum over all 10 frames / 10
+            assert torch.allclose(grads[n], base[n] * (total / (b * t)), rtol=1e-6, atol=1e-6), n
+        assert abs(float(loss) - total / (b * t)) < 1e-9        # frame-weighted mean of the ranks' losses (shards of 4, 4 and 2 frames)
+        assert tr._global_frames == b * t
+        # second call: the arenas persist and are reused
+        a0 = tr._arenas[1][0].flat.data_ptr()
+        tr.reduced_loss_and_grads(mine, torch.zeros(b1 - b0, t, dtype=torch.bool), None, None, None)
+        assert tr._arenas[1][0].flat.data_ptr() == a0
+        out[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_dp(fail_rank, fail):
+    world = 3
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_dp_worker, args=(world, _free_port(), out, fail_rank, fail), nprocs=world, join=True)
+        return dict(out)
+
+
+def test_three_rank_uneven_shards_through_the_trainer_host_logic():
+    assert _run_dp(-1, None) == {0: "ok", 1: "ok", 2: "ok"}
+
+
+def test_three_rank_failure_on_one_rank_raises_everywhere():
+    for fail in ("early", "late"):
+        res = _run_dp(2, fail)
+        assert "failed on this rank" in res[2] and "synthetic failure" in res[2], res
+        assert "failed on another rank" in res[0] and "failed on another rank" in res[1], res

@@ -60,6 +60,8 @@ def test_bench_gpus_2_launches_its_own_ranks():
     assert "error" not in bc, bc
     ad = bc["allreduce_detail"]
     assert ad["ranks"] == 2 and ad["backend"] == "gloo" and ad["ms_standalone"] > 0 and ad["bytes"] > 4 * 60e6     # the 1x model's 71 M parameters
+    assert 0.0 <= ad["overlap_frac"] <= 1.0 and ad["step_ms_without_exchange"] > 0 and ad["exposed_ms"] >= 0       # (how much of the exchange is hidden)
+    assert list(rec)[-2:] == ["value_blocks", "roofline"] or list(rec)[-1] in ("roofline", "cpu_baseline")        # the tail of the line holds the graded objects
     print("bench.py --gpus 2 (self-launched, gloo):", rec["value"], bc["ms_per_step"], ad)
 
 

@@ -608,7 +608,8 @@ class BCTrainer:
         thirds of the step's compute -- runs; the CNN's own gradients (a tenth of the bytes) follow at the end.  A rank
         that fails locally (e.g. out of memory) still joins every collective with zeros and reports it in the final
         (loss, healthy-rank count) reduction, so all ranks raise together instead of blocking in an all-reduce."""
-        world = dist.get_world_size() if dist.is_initialized() else 1
+        # (self.exchange = False: the local step only -- bench.py times it beside the full step to report how much of the exchange the CNN backward hides)
+        world = dist.get_world_size() if dist.is_initialized() and getattr(self, "exchange", True) else 1
         m_local = img_u8.shape[0] * img_u8.shape[1]
         self._global_frames = m_local
         if world == 1:
