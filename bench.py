@@ -60,7 +60,8 @@ class BoxSampler:
         while not self._stop.is_set():
             try:
                 self.clk.append(float(torch.cuda.clock_rate(self.dev)))
-                self.pw.append(float(torch.cuda.power_draw(self.dev)) / 1e3)
+                w = float(torch.cuda.power_draw(self.dev))
+                self.pw.append(w / 1e3 if w > 5000.0 else w)      # (documented as mW; the amdsmi path of this ROCm build returns W)
             except Exception as e:       # no amdsmi on this box: say so once and stop polling
                 self.err = f"{type(e).__name__}: {e}"[:120]
                 return
