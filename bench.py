@@ -533,7 +533,7 @@ def ingest_leg(pol, img, first, dev, copy_s=None, steps=5):
     return out
 
 
-TRAFFIC_FILES = {"bf16": ("r05_bench_conv3x3_traffic.json", "r04_bench_conv3x3_traffic.json"), "fp16": ("r05_bench_conv3x3_traffic_fp16.json", "r04_bench_conv3x3_traffic_fp16.json")}
+TRAFFIC_FILES = {"bf16": ("r06_bench_conv3x3_traffic.json", "r05_bench_conv3x3_traffic.json"), "fp16": ("r06_bench_conv3x3_traffic_fp16.json", "r05_bench_conv3x3_traffic_fp16.json")}
 
 
 def _bc_leg(pol, args, img, first, g, dev, world, distributed, barrier, dist, mode):

@@ -58,3 +58,29 @@ def test_layernorm_backward_has_no_packed_fp32_arithmetic(tmp_path):
                 packed[cur] = packed.get(cur, 0) + 1
     assert len(seen) == 4, seen          # the four row-length instantiations
     assert not packed, packed
+
+
+def test_inline_assembly_clamp_fma_sits_far_behind_the_last_mfma(tmp_path):
+    """vpt_common.h:pk_fma_clamp01 is inline assembly: the compiler's hazard recogniser does not see that it reads MFMA results.  The longest wait an XDL
+    write needs before a VALU read on this architecture is 19 wait states; every clamp FMA of every instantiation must sit at least 32 INSTRUCTIONS
+    (>= 32 issue cycles) behind the last MFMA in program order -- today the closest is 55."""
+    mod = _build_module()
+    out = tmp_path / "vpt_conv3x3.s"
+    subprocess.check_call([HIPCC] + mod.FLAGS + ["-S", "--cuda-device-only", os.path.join(mod.CSRC, "vpt_conv3x3.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    cur, idx, last_mfma, closest = None, 0, None, {}
+    for line in open(out):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur, idx, last_mfma = m.group(1), 0, None
+            continue
+        s = line.strip()
+        if cur is None or not s or s[0] in ";." or s.endswith(":"):
+            continue
+        idx += 1
+        if s.startswith("v_mfma"):
+            last_mfma = idx
+        elif s.startswith("v_pk_fma_f32") and " clamp" in s:
+            assert last_mfma is not None, cur
+            closest[cur] = min(closest.get(cur, 1 << 30), idx - last_mfma)
+    assert len(closest) >= 5, closest          # modes 1 and 5 of every tiling
+    assert min(closest.values()) >= 32, closest

@@ -26,6 +26,9 @@ REMARKS = ["-Rpass-analysis=kernel-resource-usage"]
 # tools/kernel_stress.py reproduces it in seconds: ~85 wrong launches in 54 000 with the flag off, 0 with it on, 0 at -O1).
 EXTRA_FLAGS = {"vpt_backward.hip": ["-fno-slp-vectorize"]}
 VARIANTS = [(LIB, "bf16", []), (LIB_F16, "f16", ["-DVPT_OPERAND_F16"])]
+# Test-only A/B library (never loaded by the product: tests/test_gpu_conv_clamp.py names it through VPT_HIP_LIB): the bf16 library with vpt_conv3x3.hip's
+# residual epilogues built WITHOUT the inline-assembly clamp FMA (the fp32 v_max ReLU of rounds 1-4) -- the two must agree bit for bit.
+LIB_NOCLAMP = os.path.join(HERE, "build", "libvpt_noclamp.so")
 
 
 def resource_log(tag: str, src: str) -> str:
@@ -71,7 +74,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     """Build both libraries (bf16 default + fp16 parity mode); returns the path of the default one."""
     stamp = LIB + ".stamp"
     fp = _fingerprint()
-    have = all(os.path.exists(lib) for lib, _, _ in VARIANTS)
+    have = all(os.path.exists(lib) for lib, _, _ in VARIANTS) and (os.path.exists(LIB_NOCLAMP) or not os.path.exists(shutil.which("hipcc") or "/opt/rocm/bin/hipcc"))
     have_logs = all(os.path.exists(resource_log(tag, src)) for _, tag, _ in VARIANTS for src in SOURCES)
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not force and have and os.path.exists(stamp) and open(stamp).read().strip() == fp and (have_logs or not os.path.exists(hipcc)):
@@ -102,6 +105,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
         if verbose:
             print(f"built {lib} ({os.path.getsize(lib) // 1024} KiB)")
+    objdir = os.path.join(HERE, "build", "var_noclamp")
+    os.makedirs(objdir, exist_ok=True)
+    obj = os.path.join(objdir, "vpt_conv3x3.o")
+    subprocess.check_call([hipcc] + FLAGS + ["-DVPT_EPI_NO_CLAMP_RELU=1", "-c", os.path.join(CSRC, "vpt_conv3x3.hip"), "-o", obj], stderr=subprocess.DEVNULL)
+    others = [o for o in link[0][1] if not o.endswith("vpt_conv3x3.o")]
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_NOCLAMP] + others + [obj])
     with open(stamp, "w") as f:
         f.write(fp)
     return LIB
