@@ -408,6 +408,13 @@ int vpt_conv_backward_prepare_pooled(const void* dpooled, const void* pooled, co
  * a fixed order. */
 int vpt_conv_first_backward(const uint8_t* img, const void* wfrag, const void* dpooled, float* dw, float* db, float* partials,
                             int frames, int H, int W, int Cout, void* stream);
+/* ... with the stack's GroupNorm `n` backward (lib/impala_cnn.py:118-119) applied on the fly, as vpt_conv_backward_prepare_pooled does for stacks 1..:
+ * `g` is d loss / d n(pooled), n_gain [Cout] the norm's gain, pool_stats [F][2] the frame statistics of the pooled tensor and pool_ab [F][2] the sums of
+ * vpt_frame_affine_backward's pass 1.  d(pooled) = r (g gain - ab0 / n - xhat ab1 / n) is formed per element with the separate pass's arithmetic and 16-bit
+ * rounding point; the pooled VALUE it needs is the window maximum the kernel's arg-max search finds anyway.  vpt_frame_affine_backward's pass 2 is not run
+ * for stack 0. */
+int vpt_conv_first_backward_nfold(const uint8_t* img, const void* wfrag, const void* g, const float* n_gain, const double* pool_stats, const double* pool_ab,
+                                  float* dw, float* db, float* partials, int frames, int H, int W, int Cout, void* stream);
 
 /* Weight gradient of the folded convolution: dw[o][tap][c] += sum_{f,p} dacc[f][o][p] * x[f][c][p + tap] (fp32; caller
  * zeroes or accumulates).  W in {16, 32, 64}.  scratch: fp32 work buffer of vpt_conv3x3_wgrad_scratch_floats() elements

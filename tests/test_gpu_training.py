@@ -434,6 +434,39 @@ def test_conv_first_backward(frames, cout, h, w, fmt):
     assert eW < 5e-3 and eb < 5e-3      # measured 4e-7 ... 4e-4 (every gradient enters the fp32 accumulation un-merged; round 3: 2e-3 through a bf16 scatter)
 
 
+@pytest.mark.parametrize("fmt", ["bf16", "fp16"])
+@pytest.mark.parametrize("frames,cout", [(3, 128), (2, 64), (9, 128)])
+def test_conv_first_backward_with_the_n_backward_folded_in(frames, cout, fmt):
+    """Round 6: stack 0's GroupNorm `n` backward inside the first conv's backward kernel (vpt_conv_first_backward_nfold) against the two-pass chain it
+    replaces -- vpt_frame_affine_backward (reduce + apply: d(pooled) written in 16 bits) -> vpt_conv_first_backward -- on the SAME pooled tensor, statistics
+    and incoming gradient.  Same arithmetic, same rounding point; the pooled value comes from the kernel's own arg-max search instead of a load.  A fused
+    multiply-add contracted differently may move a d(pooled) value by one 16-bit ulp, hence a bound instead of torch.equal."""
+    dt = torch.bfloat16 if fmt == "bf16" else torch.float16
+    g = torch.Generator().manual_seed(61)
+    h = w = 128
+    W = torch.randn(cout, 3, 3, 3, generator=g) * 0.3
+    b = 0.1 * torch.randn(cout, generator=g)
+    img = torch.randint(0, 256, (frames, h, w, 3), generator=g, dtype=torch.uint8).to(DEV)
+    wfrag = packing.pack_conv_first(W.to(DEV), b.to(DEV), dtype=dt)
+    s_pool = torch.zeros(frames, 2, dtype=torch.float64, device=DEV)
+    pooled = ops.conv_first(img, wfrag, cout, stats_out=s_pool)
+    ng = (1 + 0.3 * torch.randn(cout, generator=g)).to(DEV)
+    G = packing.nchw_to_blocked(torch.randn(frames, cout, h // 2, w // 2, generator=g) * (1e-2 if fmt == "fp16" else 1.0), dtype=dt).to(DEV)
+    dg1, db1, dg2, db2 = (torch.zeros(cout, device=DEV) for _ in range(4))
+    dp_ref = ops.frame_affine_backward(pooled, G, ng, s_pool, dg1, db1)
+    dW1, dB1 = ops.conv_first_backward(img, wfrag, dp_ref, cout)
+    ab = ops.frame_affine_backward_reduce(pooled, G, ng, s_pool, dg2, db2)
+    dW2, dB2 = ops.conv_first_backward(img, wfrag, G, cout, nfold=(ng, s_pool, ab))
+    torch.cuda.synchronize()
+    assert torch.equal(dg1, dg2) and torch.equal(db1, db2)            # the same pass 1, fixed summation order
+    eW, eb = _l2(dW2.cpu(), dW1.cpu()), _l2(dB2.cpu(), dB1.cpu())
+    print(f"PARITY[{fmt}] first-conv backward with the n backward folded in, {frames}x{cout}: dW {eW:.2e} db {eb:.2e} vs the two-pass chain")
+    assert eW < 2e-3 and eb < 2e-3
+    # run-to-run: the folded kernel is as reproducible as the plain one
+    dW3, dB3 = ops.conv_first_backward(img, wfrag, G, cout, nfold=(ng, s_pool, ab))
+    assert torch.equal(dW2, dW3) and torch.equal(dB2, dB3)
+
+
 def test_conv_prepare_fused_pool_backward():
     """prepare(dy=None, dpooled, argmax) vs prepare(dy = maxpool_backward(...)): same routing (all-zero windows differ only
     where the ReLU gate is closed); the fused route skips one bf16 rounding where a pixel wins several windows."""

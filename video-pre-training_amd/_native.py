@@ -54,6 +54,7 @@ SIGNATURES = {
     "vpt_conv3x3_dgrad_gated": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_conv_backward_reduce": [_P] * 10 + [_I, _I, _I, _I, _I, _P],
     "vpt_conv_first_backward": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vpt_conv_first_backward_nfold": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vpt_conv3x3_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vpt_conv3x3_wgrad_scratch_floats": [_I, _I, _I],
     "vpt_camera_discretize": [_P, _P, _L, _D, _D, _D, _I, _P],

@@ -287,6 +287,16 @@ int vpt_conv_first_backward(const uint8_t* img, const void* wfrag, const void* d
   CHECK_LAUNCH(vpt_conv_first_bwd_launch(&a, (hipStream_t)stream), "vpt_conv_first_backward");
 }
 
+int vpt_conv_first_backward_nfold(const uint8_t* img, const void* wfrag, const void* g, const float* n_gain, const double* pool_stats, const double* pool_ab,
+                                  float* dw, float* db, float* partials, int frames, int H, int W, int Cout, void* stream) {
+  if (!partials || !n_gain || !pool_stats || !pool_ab) return fail(-1, "vpt_conv_first_backward_nfold: partials, n_gain, pool_stats and pool_ab are required");
+  VptConvFirstBwdArgs a = {};
+  a.img = img; a.wfrag = (const vpt_op16*)wfrag; a.dpooled = (const vpt_op16*)g; a.dw = dw; a.db = db; a.partials = partials;
+  a.n_gain = n_gain; a.pool_stats = pool_stats; a.pool_ab = pool_ab; a.inv_count_pool = 1.0 / ((double)Cout * (H / 2) * (W / 2));
+  a.frames = frames; a.H = H; a.W = W; a.Cout = Cout;
+  CHECK_LAUNCH(vpt_conv_first_bwd_launch(&a, (hipStream_t)stream), "vpt_conv_first_backward_nfold");
+}
+
 long vpt_conv3x3_wgrad_scratch_floats(int frames, int Cin, int Cout) {
   return (long)vpt_conv_wgrad_groups(frames, Cin, Cout) * Cout * 9 * Cin;
 }

@@ -43,6 +43,11 @@
 // two waves per SIMD left the LDS latency exposed -- the same finding as for the forward kernel in round 3.  Needs <= 128 registers: 16 pooled pixels
 // per thread instead of 32.
 #define CFB_THREADS 512
+// NFOLD (round 6): `dpooled` holds G = d loss / d n(P), the gradient BEHIND the stack's GroupNorm `n` (lib/impala_cnn.py:118-119), and the `n` backward is
+// applied per element here -- d(P) = r (G gain - A - xhat B), xhat = (P - mu_P) r, (A, B) = pool_ab[f] / count from vpt_affine_bwd_reduce_kernel, exactly
+// vpt_affine_bwd_apply_kernel's arithmetic and 16-bit rounding point.  P needs no load: the window maximum the arg-max search finds IS the pooled value
+// (the recompute reproduces the forward bit for bit).  The separate apply pass over stack 0 (read P, read G, write dP: 3 MB per frame) disappears.
+template <bool NFOLD>
 __global__ __launch_bounds__(CFB_THREADS, 4) void vpt_conv_first_bwd_kernel(VptConvFirstBwdArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[CF_SMEM_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index: scalar (slice / pixel arithmetic of step 4 stays off the vector ALU)
@@ -71,7 +76,9 @@ __global__ __launch_bounds__(CFB_THREADS, 4) void vpt_conv_first_bwd_kernel(VptC
   // next tile's input bytes are fetched into registers while the current tile computes (as in the forward kernel)
   u32x2 nxt[CF_FETCH(CFB_THREADS)];
   auto fetch = [&](int f, int ty, int tx) {
-    cf_fetch_input<CFB_THREADS>(a.img + (size_t)f * a.H * a.W * 3, a.H, a.W, 2 * (ty * 8) - 2, 2 * (tx * 8) - 2, tid, nxt);
+    int tid_o = tid;                           // opaque per call: the record coordinates (tid / 19, tid % 19) are five instructions to recompute and two
+    asm volatile("" : "+v"(tid_o));            // registers to keep across the tile loop -- the two that spilled in the NFOLD instantiation
+    cf_fetch_input<CFB_THREADS>(a.img + (size_t)f * a.H * a.W * 3, a.H, a.W, 2 * (ty * 8) - 2, 2 * (tx * 8) - 2, tid_o, nxt);
   };
   const long per = (T + gridDim.x - 1) / gridDim.x;
   const long t_begin = blockIdx.x * per, t_end = min(t_begin + per, T);
@@ -124,6 +131,17 @@ __global__ __launch_bounds__(CFB_THREADS, 4) void vpt_conv_first_bwd_kernel(VptC
     // without compare / select chains: a signed 32-bit key = (16-bit pattern << 16) | (15 - scan index) per channel, one v_lshl_or / v_and_or and
     // one v_max_i32 per value: larger pattern wins, equal patterns keep the EARLIER position; a key below 0x10000 is a maximum <= 0. ----
     uint32_t kcode[2][2];    // [item][dword]: eight 4-bit codes (channel c of the octet at bits 4 c)
+    float mp = 0.f, rpool = 1.f, nA = 0.f, nB = 0.f;
+    if constexpr (NFOLD) {   // the frame's scalars of the `n` backward (broadcast loads; first used behind the first item's nine LDS reads)
+      frame_mean_rstd(a.pool_stats, f, a.inv_count_pool, mp, rpool);
+      nA = (float)(a.pool_ab[2 * f] * a.inv_count_pool);
+      nB = (float)(a.pool_ab[2 * f + 1] * a.inv_count_pool);
+      // wave-uniform: held in scalar registers across the two items (four vector registers were two too many for four waves per SIMD)
+      mp = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, mp)));
+      rpool = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rpool)));
+      nA = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, nA)));
+      nB = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, nB)));
+    }
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int item = tid + CFB_THREADS * it;
@@ -134,6 +152,11 @@ __global__ __launch_bounds__(CFB_THREADS, 4) void vpt_conv_first_bwd_kernel(VptC
       asm volatile("" : "+v"(src_o));             // (opaque per tile, as for the B build below)
       const unsigned char* src = smem + src_o;
       int klo[4] = {0, 0, 0, 0}, khi[4] = {0, 0, 0, 0};
+      f32x4 gl0 = {1.f, 1.f, 1.f, 1.f}, gl1 = gl0;
+      if constexpr (NFOLD) {   // the octet's eight gains: requested before the LDS reads of the search, used after them (128 floats: L1 / L2 hits)
+        const int og0 = nt * 128 + cbl * 32 + oct4 * 8;
+        if (og0 < a.Cout) { gl0 = *(const f32x4*)(a.n_gain + og0); gl1 = *(const f32x4*)(a.n_gain + og0 + 4); }
+      }
       if (!(VPT_CFB_ABLATE & 1)) {
 #pragma unroll
         for (int dy = 0; dy < ((VPT_CFB_ABLATE & 64) ? 1 : 3); ++dy)
@@ -156,6 +179,22 @@ __global__ __launch_bounds__(CFB_THREADS, 4) void vpt_conv_first_bwd_kernel(VptC
         codes |= (c0 | (c1 << 4)) << (8 * j);
       }
       kcode[it][0] = codes; kcode[it][1] = 0u;
+      if constexpr (NFOLD) {
+        // G -> d(P) in place.  The pooled value of (pooled pixel, channel) is the maximum the keys carry (pattern = key >> 16; 0 where no
+        // position is positive: the forward's pool starts from 0), so P is never loaded.
+        float df[8];
+        unpack8(dv[it], df);
+        const float ng[8] = {gl0.x, gl0.y, gl0.z, gl0.w, gl1.x, gl1.y, gl1.z, gl1.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t pw = ((uint32_t)klo[j] >> 16) | ((uint32_t)khi[j] & 0xffff0000u);
+          const float p0 = op16_lo_to_f32(pw), p1 = op16_hi_to_f32(pw);
+          const float xh0 = (p0 - mp) * rpool, xh1 = (p1 - mp) * rpool;
+          df[2 * j] = rpool * (df[2 * j] * ng[2 * j] - nA - xh0 * nB);
+          df[2 * j + 1] = rpool * (df[2 * j + 1] * ng[2 * j + 1] - nA - xh1 * nB);
+        }
+        dv[it] = pack8(df);          // (rounded to 16 bits where the separate pass stored it)
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();         // every search read of the conv tile is done: its LDS becomes the B operand and the code table
@@ -303,9 +342,12 @@ extern "C" long vpt_conv_first_bwd_partial_floats(int frames, int H, int W, int 
 
 extern "C" int vpt_conv_first_bwd_launch(const VptConvFirstBwdArgs* a, hipStream_t stream) {
   if ((a->H & 15) || (a->W & 15) || (a->Cout & 31) || a->frames <= 0 || !a->partials) return -1;
+  if (a->n_gain && (!a->pool_stats || !a->pool_ab)) return -1;
   if ((long)a->frames * a->H * a->W * 3 > 0x7fffffffL) return -2;   // 32-bit pixel offsets inside a launch
   const long gx = conv_first_bwd_grid_x(a->frames, a->H, a->W);
-  hipLaunchKernelGGL(vpt_conv_first_bwd_kernel, dim3((unsigned)gx, (a->Cout + 127) / 128), dim3(CFB_THREADS), 0, stream, *a);
+  const dim3 grid((unsigned)gx, (a->Cout + 127) / 128);
+  if (a->n_gain) hipLaunchKernelGGL(vpt_conv_first_bwd_kernel<true>, grid, dim3(CFB_THREADS), 0, stream, *a);
+  else hipLaunchKernelGGL(vpt_conv_first_bwd_kernel<false>, grid, dim3(CFB_THREADS), 0, stream, *a);
   if (hipGetLastError() != hipSuccess) return -3;
   return vpt_slab_sum_launch(a->partials, (int)gx, a->Cout * 28, (long)a->Cout * 28, a->dw, a->Cout * 27, a->db, 1, a->partials + gx * a->Cout * 28, stream);
 }

@@ -267,6 +267,11 @@ struct VptConvFirstBwdArgs {
   float* db;               // [Cout] accumulated
   float* partials;         // workspace: vpt_conv_first_bwd_partial_floats
   int frames, H, W, Cout;
+  // optional (n_gain != null): `dpooled` is the gradient BEHIND the stack's GroupNorm `n`, whose backward is applied per element on the fly
+  const float* n_gain;     // [Cout]
+  const double* pool_stats; // [F][2] sum / sum of squares of the pooled tensor P
+  const double* pool_ab;   // [F][2] (sum G gain, sum G gain xhat) from vpt_frame_affine_backward's pass 1
+  double inv_count_pool;   // 1 / (Cout * H/2 * W/2)
 };
 
 struct VptConvWgradArgs {

@@ -886,9 +886,11 @@ def conv3x3_wgrad(dacc, x, out=None):
     return dw
 
 
-def conv_first_backward(img_u8, wfrag, dpooled, cout, out=None):
+def conv_first_backward(img_u8, wfrag, dpooled, cout, out=None, nfold=None):
     """-> (dW fp32 [cout, 27] in (kh, kw, ch) tap order, db fp32 [cout]); accumulated into out=(dW, db) when given.
-    conv_first_grad_to_reference() maps dW to the reference's [cout, 3, 3, 3] (o, ch, kh, kw)."""
+    conv_first_grad_to_reference() maps dW to the reference's [cout, 3, 3, 3] (o, ch, kh, kw).
+    nfold = (n_gain fp32 [cout], pool_stats fp64 [F,2], ab fp64 [F,2] from frame_affine_backward_reduce): `dpooled` is the gradient w.r.t. n(pooled) and the
+    GroupNorm `n` backward is applied on the fly (vpt_conv_first_backward_nfold: no second affine-backward pass over stack 0)."""
     _chk(img_u8, torch.uint8, "img"); _chk(wfrag, OP16, "wfrag"); _chk(dpooled, OP16, "dpooled")
     f, h, w, _ = img_u8.shape
     if out is None:
@@ -896,6 +898,12 @@ def conv_first_backward(img_u8, wfrag, dpooled, cout, out=None):
     dw, db = out
     _chk(dw, torch.float32, "dw"); _chk(db, torch.float32, "db")
     part = _workspace(WS_CONV_FIRST_BACKWARD, f, h, w, 0, cout, device=img_u8.device)
+    if nfold is not None:
+        ng, pst, pab = nfold
+        _chk(ng, torch.float32, "n_gain"); _chk(pst, torch.float64, "pool_stats"); _chk(pab, torch.float64, "pool_ab")
+        _call("vpt_conv_first_backward_nfold", dict(flops=2.0 * f * (h // 2) * (w // 2) * cout * 27), ptr(img_u8), ptr(wfrag), ptr(dpooled), ptr(ng), ptr(pst), ptr(pab),
+              ptr(dw), ptr(db), ptr(part), f, h, w, cout, _stream(), fmt=_fmt(wfrag, dpooled)[1], label="vpt_conv_first_backward")
+        return dw, db
     _call("vpt_conv_first_backward", dict(flops=2.0 * f * (h // 2) * (w // 2) * cout * 27), ptr(img_u8), ptr(wfrag), ptr(dpooled), ptr(dw), ptr(db), ptr(part),
           f, h, w, cout, _stream(), fmt=_fmt(wfrag, dpooled)[1])
     return dw, db

@@ -105,6 +105,8 @@ class BCTrainer:
         self.fused_pool = os.environ.get("VPT_BC_FUSED_POOL", "1") != "0"
         # ... and with it the second pass of the GroupNorm-`n` backward of stacks 1.. folded into that consumer (needs fused_pool); 0: two passes (A/B)
         self.fold_n_backward = os.environ.get("VPT_BC_FOLD_N_BWD", "1") != "0"
+        # ... and stack 0's inside the first conv's backward kernel (ops.conv_first_backward(nfold=...), round 6); 0: two passes + the plain kernel (A/B)
+        self.fold_n_backward0 = os.environ.get("VPT_BC_FOLD_N_BWD0", "1") != "0"
         self._arenas = None      # (key, (GradArena trunk + heads, GradArena CNN)) of the data-parallel step, built on first use
         self._streams: List[torch.cuda.Stream] = []
         self.params: Dict[str, torch.nn.Parameter] = dict(policy.named_parameters())
@@ -556,6 +558,13 @@ class BCTrainer:
                 dx = self._block_backward(p, b, rec["blocks"][b], acc, dx)
             dgn, dbn = acc["n"][s]
             nfold = None
+            if s == 0 and self.fold_n_backward0:
+                # stack 0 (round 6): the reduction pass only; vpt_conv_first_bwd_kernel forms d(pooled) per element itself -- the pooled value it needs is the
+                # window maximum its arg-max search finds anyway
+                ab = ops.frame_affine_backward_reduce(rec["pooled"], dx, w[p + "n.g"], rec["s_pool"], dgn, dbn)
+                c = cfg["chans"][0]
+                acc["first"] = ops.conv_first_backward(sv["img"], w[p + "firstconv"], dx, c, out=acc.get("first"), nfold=(w[p + "n.g"], rec["s_pool"], ab))
+                continue
             if "mask" in rec and self.fold_n_backward:
                 # GroupNorm `n` backward: the reduction pass only; the consumer below forms d(pooled) from (G, pooled) per element itself
                 nfold = (w[p + "n.g"], rec["s_pool"], ops.frame_affine_backward_reduce(rec["pooled"], dx, w[p + "n.g"], rec["s_pool"], dgn, dbn))
