@@ -109,7 +109,7 @@ def worker(rank, world, d, iters):
 
         def idm_fwd():
             with torch.no_grad():
-                (pd, _, _), _ = idm.net_forward_for_test(vid) if hasattr(idm, "net_forward_for_test") else idm({"img": vid}, torch.zeros(1, 16, dtype=torch.bool, device=dev), idm.initial_state(1))
+                (pd, _, _), _ = idm({"img": vid}, torch.zeros(1, 16, dtype=torch.bool, device=dev), idm.initial_state(1))
             return pd["buttons"], pd["camera"]
         heavy["IDM tiny T=16"] = idm_fwd
         tr = BCTrainer(pol, train_cnn=True, weight_decay=0.0)
