@@ -1,0 +1,83 @@
+"""Stress the variants built by make_variants.py: every process loads each .hsaco with the HIP module API, launches vpt_ln_bwd_kernel<4> (M = 10 rows,
+D = 1024: the 2-rank test's shape) `iters` times on fixed inputs and counts the launches whose dx differs from the first one in any bit.
+    python tools/ubench/pk_hazard/run.py [procs=3] [iters=4000]"""
+import ctypes
+import os
+import sys
+import tempfile
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(HERE)))
+OUT = os.path.join(ROOT, "video-pre-training_amd", "build", "pk_hazard")
+KERNEL = b"_Z17vpt_ln_bwd_kernelILi4EEv12VptLnBwdArgs"
+
+
+class Args(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("x", "gain", "dy", "dx_add", "dx", "dgain", "dbias", "partials")] + [(n, ctypes.c_int) for n in ("M", "D", "relu_in")]
+
+
+def _barrier(d, tag, rank, world):
+    open(os.path.join(d, f"bar_{tag}_{rank}"), "w").close()
+    while not all(os.path.exists(os.path.join(d, f"bar_{tag}_{r}")) for r in range(world)):
+        pass
+
+
+def worker(rank, world, d, iters, variants):
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(5)
+    m, dd = 10, 1024
+    x = torch.randn(m, dd, generator=g).to(dev)
+    dy = torch.randn(m, dd, generator=g).to(dev)
+    gain = (1 + 0.1 * torch.randn(dd, generator=g)).to(dev)
+    dx = torch.empty_like(x)
+    dg, db = torch.zeros(dd, device=dev), torch.zeros(dd, device=dev)
+    part = torch.empty(4 * ((m + 31) // 32) * 2 * dd, device=dev)
+    a = Args(x.data_ptr(), gain.data_ptr(), dy.data_ptr(), None, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), part.data_ptr(), m, dd, 0)
+    size = ctypes.c_size_t(ctypes.sizeof(a))
+    extra = (ctypes.c_void_p * 5)(1, ctypes.cast(ctypes.pointer(a), ctypes.c_void_p), 2, ctypes.cast(ctypes.pointer(size), ctypes.c_void_p), 3)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    lines = []
+    for vi, name in enumerate(variants):
+        mod, fn = ctypes.c_void_p(), ctypes.c_void_p()
+        rc = hip.hipModuleLoad(ctypes.byref(mod), os.path.join(OUT, name + ".hsaco").encode())
+        rc = rc or hip.hipModuleGetFunction(ctypes.byref(fn), mod, KERNEL)
+        if rc:
+            lines.append(f"  rank {rank} {name}: module load failed ({rc})")
+            continue
+
+        def launch():
+            r = hip.hipModuleLaunchKernel(fn, (m + 31) // 32, 1, 1, 256, 1, 1, 0, stream, None, extra)
+            assert r == 0, r
+        launch()
+        torch.cuda.synchronize()
+        ref = dx.clone()
+        _barrier(d, f"{vi}_{name}", rank, world)
+        bad = torch.zeros(1, dtype=torch.int64, device=dev)
+        for _ in range(iters):
+            launch()
+            bad += (dx != ref).any().to(torch.int64)
+        torch.cuda.synchronize()
+        lines.append(f"  rank {rank} {name}: {int(bad.item())} wrong launches of {iters}")
+        hip.hipModuleUnload(mod)
+    with open(os.path.join(d, f"out{rank}.txt"), "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+
+
+def main():
+    import torch.multiprocessing as mp
+    procs = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
+    variants = sorted(f[:-6] for f in os.listdir(OUT) if f.endswith(".hsaco"))
+    variants = ["base"] + [v for v in variants if v != "base"] + ["base"]          # the failing build first AND last: the box must still show the fault at the end
+    print(f"=== pk_hazard: {procs} processes, {iters} launches per variant: {variants}", flush=True)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(worker, args=(procs, d, iters, variants), nprocs=procs, join=True)
+        for r in range(procs):
+            print(open(os.path.join(d, f"out{r}.txt")).read().rstrip(), flush=True)
+
+
+if __name__ == "__main__":
+    main()
