@@ -202,22 +202,31 @@ __global__ __launch_bounds__(256) void vpt_ln_bwd_kernel(VptLnBwdArgs a) {
   }
 }
 
-// dgain[c] += sum_b partials[b][0][c], dbias[c] += sum_b partials[b][1][c] over the nblocks = 4 x workgroups rows, b ascending inside each of four contiguous segments, the segments combined
-// as (s0 + s1) + (s2 + s3): one fixed summation tree per column, whatever the order the workgroups above ran in.
+// dgain[c] += sum_b partials[b][0][c], dbias[c] += sum_b partials[b][1][c] over the nblocks = 4 x workgroups rows: a workgroup takes 16 columns x 16 contiguous
+// row segments (b ascending inside a segment), the segments are combined by a fixed binary tree -- one summation order per column, a function of
+// (nblocks, D) alone, whatever the order the workgroups above ran in.  (16 segments: 64 dependent-free loads per thread at M = 8192 instead of 256.)
 __global__ __launch_bounds__(256) void vpt_ln_bwd_finish_kernel(const float* __restrict__ partials, int nblocks, int D, float* dgain, float* dbias) {
-  __shared__ float seg_[4][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6;     // col indexes the 2 D columns [dgain ; dbias]
-  const int per = (nblocks + 3) >> 2, b0 = sg * per, b1 = min(b0 + per, nblocks);
+  __shared__ float seg_[16][16];
+  const int lc = threadIdx.x & 15, sg = threadIdx.x >> 4;
+  const int col = blockIdx.x * 16 + lc;                                   // col indexes the 2 D columns [dgain ; dbias]
+  const int per = (nblocks + 15) >> 4, b0 = sg * per, b1 = min(b0 + per, nblocks);
   float s = 0.f;
-  if (col < 2 * D)
+  if (col < 2 * D) {
+#pragma unroll 8
     for (int b = b0; b < b1; ++b) s += partials[(size_t)b * 2 * D + col];
-  seg_[sg][threadIdx.x & 63] = s;
+  }
+  seg_[sg][lc] = s;
   __syncthreads();
   if (sg == 0 && col < 2 * D) {
-    const int l = threadIdx.x;
-    const float tot = (seg_[0][l] + seg_[1][l]) + (seg_[2][l] + seg_[3][l]);
-    if (col < D) dgain[col] += tot;
-    else dbias[col - D] += tot;
+    float t[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = seg_[i][lc];
+#pragma unroll
+    for (int w = 1; w < 16; w <<= 1)
+#pragma unroll
+      for (int i = 0; i < 16; i += 2 * w) t[i] += t[i + w];
+    if (col < D) dgain[col] += t[0];
+    else dbias[col - D] += t[0];
   }
 }
 
@@ -229,7 +238,7 @@ extern "C" int vpt_ln_bwd_launch(const VptLnBwdArgs* a, hipStream_t stream) {
   else if (nd4 <= 8) hipLaunchKernelGGL(vpt_ln_bwd_kernel<8>, g, b, 0, stream, *a);
   else if (nd4 <= 12) hipLaunchKernelGGL(vpt_ln_bwd_kernel<12>, g, b, 0, stream, *a);
   else hipLaunchKernelGGL(vpt_ln_bwd_kernel<16>, g, b, 0, stream, *a);
-  hipLaunchKernelGGL(vpt_ln_bwd_finish_kernel, dim3((2 * a->D + 63) / 64), b, 0, stream, (const float*)a->partials, 4 * (int)g.x, a->D, a->dgain, a->dbias);
+  hipLaunchKernelGGL(vpt_ln_bwd_finish_kernel, dim3((2 * a->D + 15) / 16), b, 0, stream, (const float*)a->partials, 4 * (int)g.x, a->D, a->dgain, a->dbias);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
