@@ -40,8 +40,127 @@ def describe(name, ref, got):
     return "\n".join(out)
 
 
+def patch_layernorm_backward(ops, hsaco):
+    """STRESS_LN_HSACO=<code object>: ops.layernorm_backward launches vpt_ln_bwd_kernel / vpt_ln_bwd_finish_kernel from THAT code object (hipModuleLaunchKernel)
+    instead of the library's -- everything else of the stress unchanged.  tools/ubench/pk_hazard/make_variants.py builds the SLP-packed kernel and variants of
+    its assembly with s_nop inserted: which of them still fail here bisects the fault at the ISA level."""
+    import ctypes
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    mod = ctypes.c_void_p()
+    assert hip.hipModuleLoad(ctypes.byref(mod), hsaco.encode()) == 0, hsaco
+    fns = {}
+    for nd4 in (4, 8, 12, 16):
+        f = ctypes.c_void_p()
+        assert hip.hipModuleGetFunction(ctypes.byref(f), mod, f"_Z17vpt_ln_bwd_kernelILi{nd4}EEv12VptLnBwdArgs".encode()) == 0
+        fns[nd4] = f
+    fin = ctypes.c_void_p()
+    assert hip.hipModuleGetFunction(ctypes.byref(fin), mod, b"_Z24vpt_ln_bwd_finish_kernelPKfiiPfS1_") == 0
+
+    debug = os.environ.get("STRESS_LN_DEBUG") == "1"      # debug.hsaco: the kernel also writes every lane's partial (s1, s2) and the reduced (s1, s2) of every row
+
+    class A(ctypes.Structure):
+        _fields_ = [(n, ctypes.c_void_p) for n in ("x", "gain", "dy", "dx_add", "dx", "dgain", "dbias", "partials")] + [(n, ctypes.c_int) for n in ("M", "D", "relu_in")] + \
+                   ([("pad", ctypes.c_int), ("debug", ctypes.c_void_p)] if debug else [])
+
+    class F(ctypes.Structure):
+        _fields_ = [("partials", ctypes.c_void_p), ("nblocks", ctypes.c_int), ("D", ctypes.c_int), ("dgain", ctypes.c_void_p), ("dbias", ctypes.c_void_p)]
+
+    def launch(fn, grid, st):
+        size = ctypes.c_size_t(ctypes.sizeof(st))
+        extra = (ctypes.c_void_p * 5)(1, ctypes.cast(ctypes.pointer(st), ctypes.c_void_p), 2, ctypes.cast(ctypes.pointer(size), ctypes.c_void_p), 3)
+        assert hip.hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), None, extra) == 0
+
+    def layernorm_backward(x, gain, dy, dgain, dbias, relu_in=False, dx_add=None):
+        m, d = x.shape
+        dx = torch.empty_like(x)
+        g = (m + 31) // 32
+        part = torch.empty(4 * g * 2 * d, dtype=torch.float32, device=x.device)
+        nd4 = ((d >> 2) + 63) >> 6
+        key = 4 if nd4 <= 4 else (8 if nd4 <= 8 else (12 if nd4 <= 12 else 16))
+        st = A(x.data_ptr(), gain.data_ptr(), dy.data_ptr(), dx_add.data_ptr() if dx_add is not None else None, dx.data_ptr(), dgain.data_ptr(),
+               dbias.data_ptr(), part.data_ptr(), m, d, 1 if relu_in else 0)
+        if debug:
+            ops._ln_debug_last = torch.zeros(m, 64, 4, dtype=torch.float32, device=x.device)
+            st.debug = ops._ln_debug_last.data_ptr()
+        launch(fns[key], g, st)
+        launch(fin, (2 * d + 15) // 16, F(part.data_ptr(), 4 * g, d, dgain.data_ptr(), dbias.data_ptr()))
+        return dx
+
+    ops.layernorm_backward = layernorm_backward
+    ops._pk_hazard_keep = (hip, mod)
+
+
+def forensic(inputs, ref, got):
+    """A wrong row of dx is right + beta.  dx = rstd (dy g - s1 - xhat s2): beta = rstd (s1_right - s1_wrong).  Which part of s1 = (1/D) sum_i dy_i g_i is missing?
+    Candidates: the contribution of ONE vector instruction (element slot (q, k) of every lane: i = 4 (lane + 64 q) + k), of a whole float4 slot q, or of one side of a
+    butterfly step of the wave reduction (the lanes with bit b set / clear).  Reports the best match."""
+    x, dy, gain, relu_in = (t.double().cpu() if torch.is_tensor(t) else t for t in inputs)
+    r, g = ref.double(), got.double()
+    rows = ((r != g).sum(1) > 0).nonzero().flatten().tolist()
+    out = []
+    d_ = x.shape[1]
+    nd4 = ((d_ >> 2) + 63) >> 6
+    for row in rows[:3]:
+        xr = x[row].clamp_min(0) if relu_in else x[row]
+        mean = xr.mean()
+        rstd = 1.0 / torch.sqrt(((xr - mean) ** 2).mean() + 1e-5)
+        dg = dy[row] * gain
+        beta = float((g[row] - r[row]).mean())
+        want = beta / float(rstd) * d_                    # the missing part of sum_i dy_i g_i  (s1_right - s1_wrong) * D
+        idx = torch.arange(d_)
+        lane, q, k = (idx // 4) % 64, (idx // 4) // 64, idx % 4
+        cands = {}
+        for qq in range(nd4):
+            cands[f"float4 slot q={qq} (all lanes)"] = float(dg[q == qq].sum())
+            for kk in range(4):
+                cands[f"element slot (q={qq}, k={kk}) of every lane"] = float(dg[(q == qq) & (k == kk)].sum())
+            for kk in (0, 2):
+                cands[f"element pair (q={qq}, k={kk},{kk + 1}) of every lane"] = float(dg[(q == qq) & ((k == kk) | (k == kk + 1))].sum())
+        for b in range(6):
+            cands[f"lanes with bit {b} set"] = float(dg[((lane >> b) & 1) == 1].sum())
+            cands[f"lanes with bit {b} clear"] = float(dg[((lane >> b) & 1) == 0].sum())
+        cands["everything (s1 = 0)"] = float(dg.sum())
+        best = sorted([(abs(v - want), n, v) for n, v in cands.items()] + [(abs(-v - want), "MINUS " + n, -v) for n, v in cands.items()])[:3]
+        out.append(f"    forensic row {row}: shift {beta:.6e}, i.e. sum dy g is off by {want:.6e}; closest candidates: " +
+                   " | ".join(f"{n}: {v:.6e} (|diff| {e:.1e})" for e, n, v in best))
+    return "\n".join(out)
+
+
+def debug_report(inputs, r_, g_):
+    """The instrumented kernel's buffer [M][64 lanes][partial s1, partial s2, reduced s1, reduced s2]: which lanes' PARTIAL sums are wrong, and is the error of
+    each such lane one term dy_i g_i of that lane (missing: right - term, or added twice: right + term) -- the same element slot (q, k) for all of them?"""
+    out = []
+    for row in ((r_ != g_).flatten(1).sum(1) > 0).nonzero().flatten().tolist()[:3]:
+        parts = []
+        for c, nm in enumerate(("partial s1", "partial s2", "reduced s1", "reduced s2")):
+            bad_l = (r_[row, :, c] != g_[row, :, c]).nonzero().flatten().tolist()
+            if bad_l:
+                parts.append(f"{nm}: {len(bad_l)} lanes differ {bad_l[0]}..{bad_l[-1]} (lane {bad_l[0]}: right {r_[row, bad_l[0], c]:.9e} wrong {g_[row, bad_l[0], c]:.9e})")
+        out.append(f"    debug row {row}: " + (" | ".join(parts) if parts else "equal"))
+        bad_l = (r_[row, :, 0] != g_[row, :, 0]).nonzero().flatten()
+        if inputs is not None and len(bad_l):
+            x, dy, gain, relu_in = (t.double().cpu() if torch.is_tensor(t) else t for t in inputs)
+            d_ = x.shape[1]
+            nd4 = ((d_ >> 2) + 63) >> 6
+            dg = (dy[row] * gain).view(-1, 4)                      # [float4 index i = lane + 64 q][k]
+            diff = g_[row, bad_l, 0] - r_[row, bad_l, 0]
+            best = []
+            for q in range(nd4):
+                for k in range(4):
+                    term = dg[bad_l + 64 * q, k]
+                    for sign, what in ((-1.0, "missing"), (1.0, "added twice")):
+                        best.append((float((diff - sign * term).abs().max() / diff.abs().max().clamp_min(1e-300)), f"term (q={q}, k={k}) {what}"))
+                for sign, what in ((-1.0, "missing"), (1.0, "added twice")):
+                    best.append((float((diff - sign * dg[bad_l + 64 * q].sum(1)).abs().max() / diff.abs().max().clamp_min(1e-300)), f"whole float4 q={q} {what}"))
+            best.sort()
+            out.append(f"      partial-s1 error of those lanes vs one term of the lane: best {best[0][1]} (relative misfit {best[0][0]:.2e}), then {best[1][1]} ({best[1][0]:.2e}), {best[2][1]} ({best[2][0]:.2e})")
+    return "\n".join(out)
+
+
 def worker(rank, world, d, iters):
     from vpt_amd import ops, packing
+    if os.environ.get("STRESS_LN_HSACO"):
+        patch_layernorm_backward(ops, os.environ["STRESS_LN_HSACO"])
     dev = torch.device("cuda")
     g = torch.Generator().manual_seed(5)
     cases = {}
@@ -55,7 +174,10 @@ def worker(rank, world, d, iters):
         def run():
             dg, db = torch.zeros(dd, device=dev), torch.zeros(dd, device=dev)
             dx = ops.layernorm_backward(x, gain, dy, dg, db, relu_in=relu_in, dx_add=dxa)
+            if getattr(ops, "_ln_debug_last", None) is not None:
+                return dx, dg, db, ops._ln_debug_last
             return dx, dg, db
+        run.inputs = (x, dy, gain, relu_in)
         return run
 
     for m, dd in ((10, 1024), (70, 1024), (10, 2048)):
@@ -148,8 +270,12 @@ def worker(rank, world, d, iters):
         torch.cuda.synchronize()
         lines.append(f"  rank {rank} {name}: {int(bad.item())} mismatching outputs in {n_it} launches")
         for j, o in enumerate(last_bad):
-            if not torch.equal(o, refs[name][j]) and o.dim() >= 2:
+            if not torch.equal(o, refs[name][j]) and o.dim() == 3 and tuple(o.shape[1:]) == (64, 4):
+                lines.append(debug_report(getattr(f, "inputs", None), refs[name][j].double().cpu(), o.double().cpu()))
+            elif not torch.equal(o, refs[name][j]) and o.dim() >= 2:
                 lines.append("  " + describe(f"output {j}", refs[name][j].float().cpu(), o.float().cpu()))
+                if j == 0 and hasattr(f, "inputs"):
+                    lines.append(forensic(f.inputs, refs[name][j].float().cpu(), o.float().cpu()))
             elif not torch.equal(o, refs[name][j]):
                 lines.append(f"    output {j} (shape {tuple(o.shape)}) differs")
     lines.append(f"  rank {rank}: {time.time() - t0:.1f} s")

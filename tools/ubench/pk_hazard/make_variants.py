@@ -55,6 +55,20 @@ def main():
         hsaco = os.path.join(OUT, f"{name}.hsaco")
         subprocess.check_call([CLANG, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", src, "-o", hsaco])
         print(f"  {name}: {n} s_nop inserted -> {hsaco} ({os.path.getsize(hsaco)} B)")
+    # the SLP build with the diagnostics stores (per-lane partial sums and reduced sums of every row): debug.hsaco
+    dbg = os.path.join(OUT, "debug.s")
+    subprocess.check_call(["hipcc"] + FLAGS + ["-DVPT_LN_DEBUG", "-S", "--cuda-device-only", os.path.join(CSRC, "vpt_backward.hip"), "-o", dbg], stderr=subprocess.DEVNULL)
+    subprocess.check_call([CLANG, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", dbg, "-o", os.path.join(OUT, "debug.hsaco")])
+    n_pk = 0
+    inside = False
+    for ln in open(dbg):
+        if ln.startswith(KERNEL + ":"):
+            inside = True
+        if inside and re.search(r"v_pk_(fma|add|mul)_f32", ln):
+            n_pk += 1
+        if inside and ln.strip() == "s_endpgm":
+            break
+    print(f"  debug: {n_pk} packed fp32 instructions in the instrumented kernel -> {os.path.join(OUT, 'debug.hsaco')}")
 
 
 if __name__ == "__main__":

@@ -18,13 +18,17 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
 # every compile also reports each kernel's registers / spills / scratch / LDS (stderr remarks, saved next to the object as <source>.resources.txt):
 # tests/test_kernel_resources_cpu.py holds the convolution kernels to zero spills and zero scratch
 REMARKS = ["-Rpass-analysis=kernel-resource-usage"]
-# Per-source flags.  vpt_backward.hip: NO SLP vectorisation.  Left on, the compiler (ROCm 7.2) packs vpt_ln_bwd_kernel's two running row sums (s1, s2)
-# into one VGPR pair that is updated alternately by packed fp32 instructions with lane swizzles (v_pk_fma_f32 / v_pk_add_f32 op_sel:[0,1]
-# op_sel_hi:[1,0]) and by scalar v_fmac_f32 on the pair's high register.  On gfx950 that sequence occasionally loses an addend of the LOW half when
-# another wave's instructions are interleaved on the SIMD -- in practice: a second process on the same GPU.  One row of dx then comes out shifted by a
-# constant (rstd x the missing part of s1, 1e-3 .. 1e-2 of the row); this was the "2-rank deviation" of round 5 (DESIGN.md section 8b;
-# tools/kernel_stress.py reproduces it in seconds: ~85 wrong launches in 54 000 with the flag off, 0 with it on, 0 at -O1).
-EXTRA_FLAGS = {"vpt_backward.hip": ["-fno-slp-vectorize"]}
+# Per-source flags: NO SLP vectorisation where the compiler (ROCm 7.2) would otherwise emit a packed fp32 add whose LOW lane reads the HIGH register of a
+# source pair (`v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]`, its way of adding two neighbouring scalars).  In vpt_ln_bwd_kernel that instruction -- inside the
+# packed update of the two running row sums (s1, s2) -- occasionally returns, in lanes 48..63 only (the wave's last 16-lane pass), the sum WITHOUT that
+# operand when another process's waves share the SIMD: one term dy_i g_i of 16 lanes is missing from s1, one row of dx comes out shifted by a constant.
+# This was the "2-rank deviation" of round 5.  Found with an instrumented build of the kernel (per-lane partial sums of every row:
+# tools/kernel_stress.py STRESS_LN_HSACO / STRESS_LN_DEBUG, tools/ubench/pk_hazard/): 11 of 11 captured events are lanes 48..63, term k = 1 or 3 of a float4
+# (the two terms added by that instruction), misfit 1e-7.  `s_nop 7` behind every packed instruction does not remove it (not a missing wait state);
+# -fno-slp-vectorize and -O1 do (0 wrong launches in 54 000 against ~85).  vpt_conv3d.hip and vpt_conv_first.hip carry the same instruction in their
+# frame-statistics sums (8 each, compiler-generated); they never failed in the stress, and are built without it as a precaution (+0.006 ms per 1024 frames on the
+# first conv).
+EXTRA_FLAGS = {"vpt_backward.hip": ["-fno-slp-vectorize"], "vpt_conv3d.hip": ["-fno-slp-vectorize"], "vpt_conv_first.hip": ["-fno-slp-vectorize"]}
 VARIANTS = [(LIB, "bf16", []), (LIB_F16, "f16", ["-DVPT_OPERAND_F16"])]
 # Test-only A/B library (never loaded by the product: tests/test_gpu_conv_clamp.py names it through VPT_HIP_LIB): the bf16 library with vpt_conv3x3.hip's
 # residual epilogues built WITHOUT the inline-assembly clamp FMA (the fp32 v_max ReLU of rounds 1-4) -- the two must agree bit for bit.

@@ -160,8 +160,14 @@ __global__ __launch_bounds__(256) void vpt_ln_bwd_kernel(VptLnBwdArgs a) {
         }
       }
     }
+#ifdef VPT_LN_DEBUG   // diagnostics build (tools/ubench/pk_hazard): every lane's partial sums and the reduced values of every row, [M][64][4]
+    if (a.debug) { a.debug[((size_t)row * 64 + lane) * 4 + 0] = s1; a.debug[((size_t)row * 64 + lane) * 4 + 1] = s2; }
+#endif
     s1 = wave_sum(s1) * invD;
     s2 = wave_sum(s2) * invD;
+#ifdef VPT_LN_DEBUG
+    if (a.debug) { a.debug[((size_t)row * 64 + lane) * 4 + 2] = s1; a.debug[((size_t)row * 64 + lane) * 4 + 3] = s2; }
+#endif
 #pragma unroll
     for (int q = 0; q < ND4; ++q) {
       const int i = lane + 64 * q;

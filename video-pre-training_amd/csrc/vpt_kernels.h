@@ -324,6 +324,9 @@ struct VptLnBwdArgs {
   float* dbias;            // [D]
   float* partials;         // [4 * ceil(M / 32)][2][D] workspace: per-wave column sums, added in row order by the finish kernel
   int M, D, relu_in;
+#ifdef VPT_LN_DEBUG
+  float* debug;            // diagnostics build only (tools/ubench/pk_hazard)
+#endif
 };
 
 struct VptClipArgs {
