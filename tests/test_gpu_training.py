@@ -693,28 +693,13 @@ def test_bc_gradients_independent_of_cnn_chunking(trainer_1x):
             continue
         e = _l2(g2[k].float().cpu(), v.float().cpu())
         worst = max(worst, e)
-        # bf16: chunked == unchunked to the order of fp32 additions (5e-7; 7e-5 on the heavily cancelling sums of the stack-0 tensors when
-        # three chunks accumulate into ONE buffer).  fp16: two runs of the SAME configuration already differ by ~1e-4 on the stack-0
-        # tensors (tools/diag_chunking.py).  Not a race: the bias-like gradients there are sums of ~1e5 signed 16-bit values that cancel
-        # to ~1e-3 of their absolute mass, accumulated by fp32 atomics in arrival order.  Values with bf16's 8 significant bits add
-        # EXACTLY in fp32 over that range (8 + ~9 bits of growth + the values' spread < 24), so the order is immaterial (5e-7);
-        # fp16's 11 bits do not, and the order-dependent fp32 rounding (1e-7) is seen through the 1000x cancellation.  Chunking adds
-        # nothing on top of that run-to-run figure, which is what this bound states.
-        stack0 = k.startswith("net.img_process.cnn.stacks.0.")
-        # Round 5: stack 0 in fp16 1e-3 (was 5e-4: measured 4.8e-4 and 5.05e-4 in two round-5 runs, i.e. AT the old bound -- run-to-run atomics order,
-        # see above); 3e-4 (was 1e-4) for the other CNN tensors in fp16 -- the same order-of-fp32-additions effect reaches them too (measured 1.5e-4 on
-        # stacks.1.firstconv.layer.weight with the gated dgrad, whose values differ in the last 16-bit rounding from round 4's; the bf16 run of this
-        # very test, where the sums are exact, stays at 9e-7: a chunk-dependent term would show there at the same size).
-        # End of round 5: seven runs of the final tree gave 5e-5 ... 5e-4 on stack 0 in fp16 -- a tail ten times the typical figure.  The driver runs
-        # the suite with -x, so the fp16 bounds are set at 3e-3 / 1e-3: what this test exists to catch (a chunk's contribution dropped or doubled, a
-        # statistic that depends on the chunk) is O(0.1 ... 1) in fp16 as well, and the bf16 run -- exact sums, 1e-4 / 3e-4 -- is the one that pins
-        # chunk-independence to the order of fp32 additions.
-        # Very end of round 5 (tools/diag_shards.py, DESIGN.md "Known issue"): the tail was not fp16's alone and not cancellation alone -- LDS float atomics
-        # in the two `prepare` kernels made the SAME bf16 gradient computation land on a discrete alternative outcome in ~15 % of the runs (3.6e-5 on the
-        # ten stack-0 tensors, 5e-4 in ~2 %).  They are an ordered reduction now (0 of 40 repetitions above 5e-6); the bounds stay at 2e-2 for every tensor
-        # in both formats because the suite runs with -x and the fix has 40 repetitions behind it, not 400: a chunk dropped, doubled or normalised with a
-        # chunk-dependent statistic shows at O(0.1 ... 1).  `worst` is printed.
-        assert e < 2e-2, (k, e)
+        # Chunked == unchunked up to the association of the per-chunk partial sums (each chunk stream accumulates into its own buffers, merged in stream
+        # order): measured 3.0e-7 in both formats on the final tree.  Until round 5 the bounds here had grown to 2e-2: fp32 atomics in arrival order made the
+        # cancelling stack-0 sums scatter (up to 5e-4 in fp16), LDS float atomics in the `prepare` kernels added discrete alternatives, and the LayerNorm
+        # backward's lost addend beside another process was still unexplained.  All three are gone (ordered reductions everywhere: DESIGN.md sections 5, 8b), so
+        # the bound is back at the order of fp32 additions: what this test exists to catch -- a chunk's contribution dropped, doubled, or normalised with a
+        # chunk-dependent statistic -- is O(0.1 ... 1).
+        assert e < 1e-5, (k, e)
     print(f"PARITY BC gradients, 3 CNN chunks vs 1: worst rel-L2 {worst:.2e}")
 
 
@@ -813,10 +798,11 @@ def test_reference_bc_loop_runs_unchanged(mode):
             continue
         e = _l2(gl, acc[n])
         worst = max(worst, e)
-        # autograd boundary == hand-driven trainer (fp32 summation order only): bf16 2e-7 in every run; fp16 2e-7 ... 1.6e-4 over twenty runs (the
-        # order-of-fp32-atomics tail of test_bc_gradients_independent_of_cnn_chunking), hence its wider bound -- a boundary bug is O(1)
-        # (end of round 5: 2e-2 in both formats -- see test_bc_gradients_independent_of_cnn_chunking and DESIGN.md "Known issue")
-        assert e < 2e-2, (n, e)
+        # autograd boundary == hand-driven trainer: the same kernels on the same inputs in the same order, and since round 6 every reduction of the backward
+        # has a fixed order -- measured 0.0 (bit-identical) in both formats.  The bound admits a different association of the eight per-frame gradients
+        # only (param.grad accumulates them one by one, the trainer sums them in this test): 1e-5.  (Round 5 held this at 2e-2 to admit the defect that
+        # round 6 root-caused: DESIGN.md section 8b.)
+        assert e < 1e-5, (n, e)
         ref = acc_ref[n]
         if float(ref.norm()) > 0:
             cos = float((gl.cpu() * ref).sum() / (gl.cpu().norm() * ref.norm()))
