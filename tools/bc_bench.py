@@ -20,6 +20,12 @@ dev = "cuda"
 pk = configs.policy_kwargs_for(a.model)
 pol = MinecraftAgentPolicy(minecraft_action_space(), pk, dict(temperature=2.0), precision=__import__("os").environ.get("VPT_PRECISION", "bf16")); configs.randomize_(pol, 0); pol = pol.to(dev)
 tr = BCTrainer(pol, train_cnn=not a.no_cnn)
+if os.environ.get("VPT_DP_FORCE_EXCHANGE") == "1":      # the data-parallel step over RCCL in a ONE-rank group (what the exchange plumbing costs on the real transport)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29571"), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    print("data-parallel path forced over", dist.get_backend(), "with", dist.get_world_size(), "rank")
 g = torch.Generator().manual_seed(1)
 B, T = a.batch, a.seq
 img = torch.randint(0, 256, (B, T, 128, 128, 3), generator=g, dtype=torch.uint8).to(dev)

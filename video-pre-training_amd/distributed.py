@@ -109,9 +109,10 @@ class GradArena:
         if dst:
             torch._foreach_copy_(dst, src)
 
-    def all_reduce_start(self):
-        """Asynchronous in-place sum of every bucket; returns the work handles (wait() on each, or all_reduce_finish)."""
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+    def all_reduce_start(self, force: bool = False):
+        """Asynchronous in-place sum of every bucket; returns the work handles (wait() on each, or all_reduce_finish).
+        force: issue the collectives in a one-rank group too (a test that the transport -- RCCL on a 1-GPU box -- takes the arena's slices)."""
+        if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
             return []
         return [(dist.all_reduce(self.flat[b:e], op=dist.ReduceOp.SUM, async_op=True), None, None) for b, e in self.buckets]
 

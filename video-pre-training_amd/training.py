@@ -107,6 +107,7 @@ class BCTrainer:
         self.fold_n_backward = os.environ.get("VPT_BC_FOLD_N_BWD", "1") != "0"
         # ... and stack 0's inside the first conv's backward kernel (ops.conv_first_backward(nfold=...), round 6); 0: two passes + the plain kernel (A/B)
         self.fold_n_backward0 = os.environ.get("VPT_BC_FOLD_N_BWD0", "1") != "0"
+        self.force_exchange = os.environ.get("VPT_DP_FORCE_EXCHANGE", "0") == "1"      # see reduced_loss_and_grads
         self._arenas = None      # (key, (GradArena trunk + heads, GradArena CNN)) of the data-parallel step, built on first use
         self._streams: List[torch.cuda.Stream] = []
         self.params: Dict[str, torch.nn.Parameter] = dict(policy.named_parameters())
@@ -621,7 +622,10 @@ class BCTrainer:
         world = dist.get_world_size() if dist.is_initialized() and getattr(self, "exchange", True) else 1
         m_local = img_u8.shape[0] * img_u8.shape[1]
         self._global_frames = m_local
-        if world == 1:
+        # force_exchange (VPT_DP_FORCE_EXCHANGE=1): take the data-parallel path in a ONE-rank group too -- the frame-count reduction, both arenas, the early exchange
+        # under the CNN backward, the late one, the health reduction -- so that the whole step can be run (and timed) over the real transport on a 1-GPU box
+        force = bool(getattr(self, "force_exchange", False)) and dist.is_initialized()
+        if world == 1 and not force:
             return self.loss_and_grads(img_u8, first, state_in, act_buttons, act_camera, global_frames=m_local, unscaled=False)
         dev = img_u8.device
         # Shards may differ by one sequence when B % world != 0 (distributed.shard_range): the mean runs over the TRUE global
@@ -641,7 +645,7 @@ class BCTrainer:
 
         def start_trunk_exchange(g):
             arena_early.adopt(g)
-            pending.extend(arena_early.all_reduce_start())
+            pending.extend(arena_early.all_reduce_start(force))
             state["early_sent"] = True
 
         err, loss, grads, state_out = None, None, None, None
@@ -649,14 +653,14 @@ class BCTrainer:
             loss, grads, state_out = self.loss_and_grads(img_u8, first, state_in, act_buttons, act_camera,
                                                          global_frames=m_global, on_trunk_grads=start_trunk_exchange, unscaled=False)
             arena_late.adopt(grads)
-            pending.extend(arena_late.all_reduce_start())
+            pending.extend(arena_late.all_reduce_start(force))
         except Exception as e:          # e.g. out of memory on this rank: still take part in every collective (with zeros of
             err = e                     # the same shapes) so that the other ranks are not left blocked, then fail everywhere
             if not state["early_sent"]:
                 arena_early.flat.zero_()
-                pending.extend(arena_early.all_reduce_start())
+                pending.extend(arena_early.all_reduce_start(force))
             arena_late.flat.zero_()
-            pending.extend(arena_late.all_reduce_start())
+            pending.extend(arena_late.all_reduce_start(force))
         D.bucketed_all_reduce_finish(pending)
         tail = torch.tensor([0.0 if err is not None else float(loss) * m_local, 0.0 if err is not None else 1.0], device=dev)
         dist.all_reduce(tail)           # (sum over ranks of loss x local frames, number of healthy ranks)
