@@ -604,6 +604,33 @@ def _bc_leg(pol, args, img, first, g, dev, world, distributed, barrier, dist, mo
                                       collectives=len(arenas[0].buckets) + len(arenas[1].buckets), backend=dist.get_backend(), ranks=dist.get_world_size(),
                                       early_wave_bytes=int(4 * arenas[0].flat.numel()), note="early wave (trunk + heads) is launched before the CNN backward and overlaps it; "
                                       "the late wave (CNN) is exposed; ms_standalone = both waves back to back with nothing to hide behind")
+    if not distributed and not getattr(args, "no_dp_probe", False):
+        # The data-parallel path of the SAME step over RCCL in a one-rank group (BCTrainer.force_exchange): frame-count reduction, arenas, early exchange under
+        # the CNN backward, late exchange, health reduction.  One rank measures what the plumbing costs on the real transport, not link bandwidth.
+        try:
+            import socket
+            import torch.distributed as dist1
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            dist1.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            try:
+                tr.force_exchange = True
+                tr.step(img, first, st_bc, ab, ac)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    _, st_bc = tr.step(img, first, st_bc, ab, ac)
+                torch.cuda.synchronize()
+                dp_ms = (time.perf_counter() - t0) / 3 * 1e3
+                bc["dp_path_one_rank"] = dict(ms_per_step=round(dp_ms, 2), extra_ms=round(dp_ms - 1e3 * sec, 2), backend=dist1.get_backend(), ranks=1,
+                                              note="the data-parallel BC step (all collectives issued on RCCL, arenas reduced in place) in a one-rank group on this GPU")
+            finally:
+                tr.force_exchange = False
+                dist1.destroy_process_group()
+        except Exception as e:
+            bc["dp_path_one_rank"] = dict(error=f"{type(e).__name__}: {e}"[:200])
     if int(os.environ.get("RANK", "0")) == 0 and not distributed:
         tr.cnn_streams = 1          # per-kernel durations are only meaningful without cross-stream overlap
         ops.TIMER.enabled = True
@@ -776,6 +803,7 @@ def main():
     ap.add_argument("--step-overlap", type=int, default=0, help="1: PolicyEngine.overlap_steps() during the timed forward (A/B)")
     ap.add_argument("--ingest-only", action="store_true", help="(profiling) only the timed forward and the ingest leg; prints the ingest record")
     ap.add_argument("--value-blocks", type=int, default=1, help="0: skip the repeated short forward blocks (`value_blocks` on the line)")
+    ap.add_argument("--no-dp-probe", action="store_true", help="skip bc_step.dp_path_one_rank (the data-parallel step over RCCL in a one-rank group)")
     args = ap.parse_args()
 
     backend = os.environ.get("VPT_DIST_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm; "gloo" lets the N > 1 branch run with every rank on one GPU (tests)
@@ -937,6 +965,7 @@ def main():
                 import copy
                 a2 = copy.copy(args)
                 a2.bc_steps = max(2, args.bc_steps // 2)
+                a2.no_dp_probe = True          # (the one-rank RCCL probe once, in the headline format)
                 bc_other = _bc_leg(pol, a2, img, first, g, dev, world, distributed, barrier, dist, other)
             except Exception as e:
                 bc_other = dict(precision=other, error=f"{type(e).__name__}: {e}")
