@@ -391,6 +391,13 @@ def nk_splitk(n: int, k: int) -> int:
     return max(1, min(16, k // 512, 256 // tiles))
 
 
+def _every_split_has_k_steps(k: int, sk: int) -> bool:
+    """vpt_gemm_kernel cuts the K / 64 steps into `sk` runs of ceil(steps / sk): when the last run is not empty every [M, N] slice of the partial buffer
+    is written in full and needs no zero-fill (the dense layer: 1024 steps in 32 runs)."""
+    steps = k // 64
+    return sk >= 1 and (sk - 1) * ((steps + sk - 1) // sk) < steps
+
+
 def linear(a_bf16, wpk, n, bias=None, res=None, relu=False, out_f32=True, out_bf16=False, splitk=1, mask=None,
            out_bf16_ld=None, splitk_raw=False, tiling="auto"):
     """a [M,K] bf16 (row stride = K) x packed weight -> ([M,n] fp32 or None, [M,ld] bf16 or None).
@@ -422,7 +429,7 @@ def linear(a_bf16, wpk, n, bias=None, res=None, relu=False, out_f32=True, out_bf
         if tiles < 128:
             auto_sk = max(1, min(16, k // 512, 256 // tiles))
     if auto_sk > 1:
-        part = torch.zeros(auto_sk, m, n, dtype=torch.float32, device=dev)
+        part = (torch.empty if _every_split_has_k_steps(k, auto_sk) else torch.zeros)(auto_sk, m, n, dtype=torch.float32, device=dev)      # (this branch is always the MFMA GEMM)
         _call("vpt_linear_forward_tiled", dict(flops=2.0 * m * n * k, bytes=2.0 * (m * k + n * k) + 4.0 * m * n), ptr(a_bf16), ptr(wpk), None, None, ptr(part), None,
               m, n, k, k, n, n, n, 0, auto_sk, None, 0, tl, _stream(), fmt=fmt, label="vpt_linear_forward")
         o32 = torch.empty(m, n, dtype=torch.float32, device=dev) if out_f32 else None
@@ -434,7 +441,11 @@ def linear(a_bf16, wpk, n, bias=None, res=None, relu=False, out_f32=True, out_bf
         return o32, o16
     o32 = None
     if out_f32:   # split-K: one [m, n] slice per split (zeroed: a split without k-steps writes nothing), summed below
-        o32 = torch.zeros(splitk, m, n, dtype=torch.float32, device=dev) if splitk > 1 else torch.empty(m, n, dtype=torch.float32, device=dev)
+        if splitk > 1:
+            gemm = tl in (1, 4) or (tl == 0 and m > 8)          # the MFMA GEMM's K partition (the weight-streaming kernel cuts K its own way: keep its zero-fill)
+            o32 = (torch.empty if gemm and _every_split_has_k_steps(k, splitk) else torch.zeros)(splitk, m, n, dtype=torch.float32, device=dev)
+        else:
+            o32 = torch.empty(m, n, dtype=torch.float32, device=dev)
     o16 = None
     if out_bf16:
         o16 = torch.zeros(m, ld16, dtype=dt, device=dev) if ld16 > n else torch.empty(m, n, dtype=dt, device=dev)
