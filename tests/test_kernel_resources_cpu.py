@@ -86,16 +86,18 @@ def test_inline_assembly_clamp_fma_sits_far_behind_the_last_mfma(tmp_path):
     assert min(closest.values()) >= 32, closest
 
 
-def test_no_kernel_contains_the_cross_half_packed_add(tmp_path):
+@pytest.mark.parametrize("variant", ["bf16", "f16"])
+def test_no_kernel_contains_the_cross_half_packed_add(tmp_path, variant):
     """`v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` (low lane = src0.lo + src1.HI) is the instruction that lost its swizzled operand in lanes 48..63 beside
     another process (build.py EXTRA_FLAGS).  The compiler's SLP vectoriser emits it for sums of neighbouring scalars; no source of the
     library may contain it, in either src position, with whatever flags build.py gives the file."""
     mod = _build_module()
+    extra = {tag: flags for _, tag, flags in mod.VARIANTS}[variant]
     bad = {}
     procs = []
     for src in mod.SOURCES:
         out = tmp_path / (src + ".s")
-        cmd = [HIPCC] + mod.FLAGS + mod.EXTRA_FLAGS.get(src, []) + ["-S", "--cuda-device-only", os.path.join(mod.CSRC, src), "-o", str(out)]
+        cmd = [HIPCC] + mod.FLAGS + mod.EXTRA_FLAGS.get(src, []) + extra + ["-S", "--cuda-device-only", os.path.join(mod.CSRC, src), "-o", str(out)]
         procs.append((src, out, subprocess.Popen(cmd, stderr=subprocess.DEVNULL)))
     for src, out, p in procs:
         assert p.wait() == 0, src

@@ -207,7 +207,8 @@ def worker(rank, world, d, iters):
         from vpt_amd.lib.policy import MinecraftAgentPolicy, InverseActionPolicy
         from vpt_amd.lib.types import minecraft_action_space, idm_action_space
         from vpt_amd.training import BCTrainer
-        pol = MinecraftAgentPolicy(minecraft_action_space(), configs.policy_kwargs_for("1x"), dict(temperature=2.0), precision="bf16")
+        prec, width = os.environ.get("STRESS_PRECISION", "bf16"), os.environ.get("STRESS_WIDTH", "1x")     # the fp16 library is a separate binary
+        pol = MinecraftAgentPolicy(minecraft_action_space(), configs.policy_kwargs_for(width), dict(temperature=2.0), precision=prec)
         configs.randomize_(pol, 0)
         pol = pol.to(dev)
         img = torch.randint(0, 256, (2, 8, 128, 128, 3), generator=g, dtype=torch.uint8).to(dev)
@@ -222,9 +223,9 @@ def worker(rank, world, d, iters):
             with torch.no_grad():
                 (pd, v, _), st = pol({"img": img[:1, :1]}, first[:1, :1], pol.initial_state(1))
             return pd["buttons"], v, st[0][1][1]
-        heavy["policy forward 1x B=2 T=8"] = fwd
-        heavy["acting step 1x B=1 T=1"] = act
-        idm = InverseActionPolicy(idm_action_space(), pi_head_kwargs=dict(temperature=2.0), idm_net_kwargs=configs.idm_kwargs_for("tiny"), precision="bf16")
+        heavy[f"policy forward {width} {prec} B=2 T=8"] = fwd
+        heavy[f"acting step {width} {prec} B=1 T=1"] = act
+        idm = InverseActionPolicy(idm_action_space(), pi_head_kwargs=dict(temperature=2.0), idm_net_kwargs=configs.idm_kwargs_for("tiny"), precision=prec)
         configs.randomize_(idm, 1)
         idm = idm.to(dev)
         vid = torch.randint(0, 256, (1, 16, 128, 128, 3), generator=g, dtype=torch.uint8).to(dev)
@@ -233,14 +234,14 @@ def worker(rank, world, d, iters):
             with torch.no_grad():
                 (pd, _, _), _ = idm({"img": vid}, torch.zeros(1, 16, dtype=torch.bool, device=dev), idm.initial_state(1))
             return pd["buttons"], pd["camera"]
-        heavy["IDM tiny T=16"] = idm_fwd
+        heavy[f"IDM tiny {prec} T=16"] = idm_fwd
         tr = BCTrainer(pol, train_cnn=True, weight_decay=0.0)
         ab, ac = torch.randint(0, 8641, (2, 8), generator=g).to(dev), torch.randint(0, 121, (2, 8), generator=g).to(dev)
 
         def bc():
             loss, grads, _ = tr.loss_and_grads(img, first, pol.initial_state(2), ab, ac)
             return [loss] + [grads[k] for k in sorted(grads)]
-        heavy["BC gradients 1x B=2 T=8 (all tensors)"] = bc
+        heavy[f"BC gradients {width} {prec} B=2 T=8 (all tensors)"] = bc
     for k, f in heavy.items():
         try:
             f()
