@@ -96,7 +96,11 @@ __global__ __launch_bounds__(CFB_THREADS, 4) void vpt_conv_first_bwd_kernel(VptC
   for (long tile = t_begin; tile < t_end; ++tile, tx = ntx, ty = nty, f = nf) {
     const int py0 = ty * 8, px0 = tx * 8;
     if (++ntx == tilesX) { ntx = 0; if (++nty == tilesY) { nty = 0; ++nf; } }
-    cf_stage_input<CFB_THREADS>(smem, nxt, tid);
+    {
+      int tid_s = tid;                         // opaque per tile, as in fetch(): the record coordinates are recomputed, not kept (they spilled)
+      asm volatile("" : "+v"(tid_s));
+      cf_stage_input<CFB_THREADS>(smem + IN_OFF, nxt, tid_s, a.H, a.W, 2 * (ty * 8) - 2, 2 * (tx * 8) - 2);
+    }
     if (tid == 0) *(int*)(smem + CTR_OFF) = 0;
     __syncthreads();
     if (tile + 1 < t_end) fetch(nf, nty, ntx);

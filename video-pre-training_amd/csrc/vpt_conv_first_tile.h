@@ -43,39 +43,57 @@ __device__ __forceinline__ u32x4 cf_bytes8(u32x2 rec) {
 }
 
 // Fetch (one tile ahead, into registers) and staging of the input records.  Thread t < 361 owns record (t / 19, t % 19) of the
-// tile whose input window starts at image pixel (iy0, ix0) = (2 py0 - 2, 2 px0 - 2): one unaligned 8-byte global load when
-// pixels x .. x + 2 of the row are inside the image, byte loads with zero fill on the image border (the conv's zero padding).
+// tile whose input window starts at image pixel (iy0, ix0) = (2 py0 - 2, 2 px0 - 2).  The fetch is ONE unaligned 8-byte global load per
+// record, unconditional and branch-free: a record that hangs over the left / right image border (pixels x .. x + 2 not all inside the row: two records per row
+// in a quarter of the tiles) is loaded from its own address all the same -- the bytes beside the row belong to the neighbouring row -- with the
+// address clamped into the frame (only the first row's left and the last row's right records move), and the staging shifts the bytes back and
+// zeroes those outside the row (the conv's zero padding).  Until round 6 those records were assembled from up to six byte loads, each in its own
+// divergent branch with its own s_waitcnt: six dependent global round trips in front of a border tile's compute.
 #define CF_FETCH(THREADS) ((IN_RECS + (THREADS) - 1) / (THREADS))   // 2 per thread at 256 threads, 1 at 512
+struct CfRecFix { int lo, hi, d; bool live; };     // valid bytes [lo, hi) of the record; d = wanted offset - loaded offset; live: any byte inside the image
+__device__ __forceinline__ CfRecFix cf_rec_fix(int H, int W, int gy, int gx, int t, int& oc) {
+  CfRecFix r;
+  r.live = t < IN_RECS && gy >= 0 && gy < H && gx > -3 && gx < W;
+  const int o = (gy * W + gx) * 3;
+  oc = min(max(o, 0), H * W * 3 - 8);
+  r.d = o - oc;
+  r.lo = max(0, -3 * gx);
+  r.hi = min(8, 3 * (W - gx));
+  return r;
+}
 template <int THREADS>
 __device__ __forceinline__ void cf_fetch_input(const uint8_t* img, int H, int W, int iy0, int ix0, int tid, u32x2 (&nxt)[CF_FETCH(THREADS)]) {
 #pragma unroll
   for (int m = 0; m < CF_FETCH(THREADS); ++m) {
     const int t = tid + THREADS * m;
     const int y = t / 19, x = t - y * 19;
-    const int gy = iy0 + y, gx = ix0 + x;
-    u32x2 v = {0u, 0u};
-    if (t < IN_RECS && gy >= 0 && gy < H) {
-      const uint8_t* src = img + (gy * W + gx) * 3;
-      if (gx >= 0 && gx + 2 < W) {
-        __builtin_memcpy(&v, src, 8);
-      } else {
-        uint64_t acc = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int q = gx + j / 3;
-          if (q >= 0 && q < W) acc |= (uint64_t)src[j] << (8 * j);
-        }
-        v.x = (uint32_t)acc; v.y = (uint32_t)(acc >> 32);
-      }
-    }
-    nxt[m] = v;
+    int oc;
+    const CfRecFix fx = cf_rec_fix(H, W, iy0 + y, ix0 + x, t, oc);
+    (void)fx;
+    __builtin_memcpy(&nxt[m], img + oc, 8);      // unconditional (the clamped address is inside the frame for every thread): records outside the image are zeroed by the staging
   }
 }
 template <int THREADS>
-__device__ __forceinline__ void cf_stage_input(unsigned char* smem, const u32x2 (&nxt)[CF_FETCH(THREADS)], int tid) {
+__device__ __forceinline__ void cf_stage_input(unsigned char* raw, const u32x2 (&nxt)[CF_FETCH(THREADS)], int tid, int H, int W, int iy0, int ix0) {
 #pragma unroll
-  for (int m = 0; m < CF_FETCH(THREADS); ++m)
-    if (tid + THREADS * m < IN_RECS) *(u32x2*)(smem + IN_OFF + (tid + THREADS * m) * 8) = nxt[m];
+  for (int m = 0; m < CF_FETCH(THREADS); ++m) {
+    const int t = tid + THREADS * m;
+    if (t < IN_RECS) {
+      const int y = t / 19, x = t - y * 19;
+      int oc;
+      const CfRecFix fx = cf_rec_fix(H, W, iy0 + y, ix0 + x, t, oc);
+      u32x2 v = nxt[m];
+      if (!fx.live) v = (u32x2){0u, 0u};
+      else if (fx.lo | (8 - fx.hi) | fx.d) {               // border records only
+        uint64_t r = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        r = fx.d < 0 ? r << (8 * -fx.d) : r >> (8 * fx.d);  // loaded from a clamped address: move the bytes to where they belong
+        const uint64_t below_hi = fx.hi >= 8 ? ~0ull : ((1ull << (8 * fx.hi)) - 1ull);
+        r &= below_hi & ~((1ull << (8 * fx.lo)) - 1ull);
+        v.x = (uint32_t)r; v.y = (uint32_t)(r >> 32);
+      }
+      *(u32x2*)(raw + t * 8) = v;
+    }
+  }
 }
 
 // One 32-pixel slice `sub` of the tile: conv + bias (1/255 is folded into the weights), rounded to 16 bits and stored RAW into
