@@ -787,6 +787,24 @@ def launch_plan(gpus: int, env, n_dev: int, backend: str):
     return "run", world
 
 
+_LINE_OUT = None
+
+
+def _claim_stdout():
+    """stdout carries the JSON line and NOTHING else.  Libraries that write to descriptor 1 themselves -- RCCL prints a five-line version banner through C stdio, which a
+    pipe delivers at process exit, i.e. BEHIND the line -- are pointed at stderr for the life of the process; the line goes to the saved descriptor."""
+    global _LINE_OUT
+    sys.stdout.flush()
+    _LINE_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+
+def _emit(obj):
+    out = _LINE_OUT or sys.stdout
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -825,6 +843,7 @@ def main():
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd, env=env))
 
+    _claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = arg
@@ -921,7 +940,7 @@ def main():
 
     value_block("headline steps")
     if args.ingest_only:
-        print(json.dumps(dict(forward_ms=round(1e3 * elapsed / args.steps, 3), ingest=ingest_leg(pol, img, first, dev, copy_stream))))
+        _emit(dict(forward_ms=round(1e3 * elapsed / args.steps, 3), ingest=ingest_leg(pol, img, first, dev, copy_stream)))
         return
     roof = kernels = None
     if rank == 0:
@@ -1064,7 +1083,7 @@ def main():
             if line.get("parity_status"):
                 roof.update(parity_status=line["parity_status"][:118])
         line.update(tail)
-        print(json.dumps(line))
+        _emit(line)
     if distributed:
         dist.destroy_process_group()
 

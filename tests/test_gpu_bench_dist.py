@@ -25,6 +25,7 @@ def test_bench_two_ranks_through_torchrun():
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]          # rank 0 prints ONE line
+    assert p.stdout.strip() == lines[0], p.stdout[-600:]          # ... and stdout holds nothing else (RCCL's version banner, written through C stdio, used to follow it)
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak" and rec["dtype"] == "bf16"
     assert rec["config"]["global_batch"] == 4 and "world_size=2" in rec["config"]["parallelism"] and "backend=gloo" in rec["config"]["parallelism"]
@@ -40,6 +41,7 @@ def test_bench_two_ranks_through_torchrun():
 def _check_two_rank_line(stdout):
     lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, stdout[-2000:]
+    assert stdout.strip() == lines[0], stdout[-600:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4
     assert "world_size=2" in rec["config"]["parallelism"] and "collective_ranks=2" in rec["config"]["parallelism"]
@@ -80,3 +82,19 @@ def test_bench_refuses_more_ranks_than_gpus_and_a_mismatched_launcher():
     p = subprocess.run(cmd, cwd=ROOT, env=env2, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")], p.stdout[-2000:]
     assert "WORLD_SIZE" in p.stderr
+
+
+def test_bench_stdout_is_exactly_one_json_line_with_the_rccl_probe():
+    """The driver's single-GPU command runs the one-rank RCCL probe (bc_step.dp_path_one_rank); RCCL writes a version banner to descriptor 1 through C stdio, which
+    a pipe delivers at exit -- behind the line.  bench.py points descriptor 1 at stderr and writes the line to the saved descriptor."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--bc-steps", "1", "--bc-warmup", "1", "--batch", "2", "--seq", "16",
+           "--model", "1x", "--no-cpu-baseline", "--no-ingest", "--value-blocks", "0"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    out = p.stdout.strip()
+    assert out.startswith("{") and "\n" not in out, p.stdout[-800:]
+    rec = json.loads(out)
+    probe = rec["bc_step"].get("dp_path_one_rank")
+    assert probe and "error" not in probe and probe["ranks"] == 1, probe          # the probe ran (so RCCL was initialised in this process)

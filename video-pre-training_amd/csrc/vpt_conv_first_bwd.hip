@@ -78,7 +78,7 @@ __global__ __launch_bounds__(CFB_THREADS, 4) void vpt_conv_first_bwd_kernel(VptC
   auto fetch = [&](int f, int ty, int tx) {
     int tid_o = tid;                           // opaque per call: the record coordinates (tid / 19, tid % 19) are five instructions to recompute and two
     asm volatile("" : "+v"(tid_o));            // registers to keep across the tile loop -- the two that spilled in the NFOLD instantiation
-    cf_fetch_input<CFB_THREADS>(a.img + (size_t)f * a.H * a.W * 3, a.H, a.W, 2 * (ty * 8) - 2, 2 * (tx * 8) - 2, tid_o, nxt);
+    cf_fetch_input_assembled<CFB_THREADS>(a.img + (size_t)f * a.H * a.W * 3, a.H, a.W, 2 * (ty * 8) - 2, 2 * (tx * 8) - 2, tid_o, nxt);
   };
   const long per = (T + gridDim.x - 1) / gridDim.x;
   const long t_begin = blockIdx.x * per, t_end = min(t_begin + per, T);
@@ -96,11 +96,7 @@ __global__ __launch_bounds__(CFB_THREADS, 4) void vpt_conv_first_bwd_kernel(VptC
   for (long tile = t_begin; tile < t_end; ++tile, tx = ntx, ty = nty, f = nf) {
     const int py0 = ty * 8, px0 = tx * 8;
     if (++ntx == tilesX) { ntx = 0; if (++nty == tilesY) { nty = 0; ++nf; } }
-    {
-      int tid_s = tid;                         // opaque per tile, as in fetch(): the record coordinates are recomputed, not kept (they spilled)
-      asm volatile("" : "+v"(tid_s));
-      cf_stage_input<CFB_THREADS>(smem + IN_OFF, nxt, tid_s, a.H, a.W, 2 * (ty * 8) - 2, 2 * (tx * 8) - 2);
-    }
+    cf_stage_input_plain<CFB_THREADS>(smem + IN_OFF, nxt, tid);
     if (tid == 0) *(int*)(smem + CTR_OFF) = 0;
     __syncthreads();
     if (tile + 1 < t_end) fetch(nf, nty, ntx);

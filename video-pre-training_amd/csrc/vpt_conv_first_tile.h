@@ -96,6 +96,42 @@ __device__ __forceinline__ void cf_stage_input(unsigned char* raw, const u32x2 (
   }
 }
 
+// The backward kernel's fetch / staging (the form both kernels had until round 6): border records are assembled in the FETCH from byte loads under
+// divergent branches and staged with a plain store.  In that kernel the fetch is issued behind the tile's first barrier, where the other waves' recompute
+// covers its waits, while the staging sits in front of that barrier: the branch-free pair above (fix-up in the staging) measured 2.5 % slower there
+// (1.20 -> 1.23 ms per 1024 frames), the opposite of the forward kernel, whose staging is off the critical path.
+template <int THREADS>
+__device__ __forceinline__ void cf_fetch_input_assembled(const uint8_t* img, int H, int W, int iy0, int ix0, int tid, u32x2 (&nxt)[CF_FETCH(THREADS)]) {
+#pragma unroll
+  for (int m = 0; m < CF_FETCH(THREADS); ++m) {
+    const int t = tid + THREADS * m;
+    const int y = t / 19, x = t - y * 19;
+    const int gy = iy0 + y, gx = ix0 + x;
+    u32x2 v = {0u, 0u};
+    if (t < IN_RECS && gy >= 0 && gy < H) {
+      const uint8_t* src = img + (gy * W + gx) * 3;
+      if (gx >= 0 && gx + 2 < W) {
+        __builtin_memcpy(&v, src, 8);
+      } else {
+        uint64_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int q = gx + j / 3;
+          if (q >= 0 && q < W) acc |= (uint64_t)src[j] << (8 * j);
+        }
+        v.x = (uint32_t)acc; v.y = (uint32_t)(acc >> 32);
+      }
+    }
+    nxt[m] = v;
+  }
+}
+template <int THREADS>
+__device__ __forceinline__ void cf_stage_input_plain(unsigned char* raw, const u32x2 (&nxt)[CF_FETCH(THREADS)], int tid) {
+#pragma unroll
+  for (int m = 0; m < CF_FETCH(THREADS); ++m)
+    if (tid + THREADS * m < IN_RECS) *(u32x2*)(raw + (tid + THREADS * m) * 8) = nxt[m];
+}
+
 // One 32-pixel slice `sub` of the tile: conv + bias (1/255 is folded into the weights), rounded to 16 bits and stored RAW into
 // the conv tile -- the ReLU commutes with the max-pool and is applied once per pooled value.  Pixels outside the image
 // (the pool's padding row / column of the tiles on the top / left border: `edge`) are stored as 0.
