@@ -105,3 +105,22 @@ def test_no_kernel_contains_the_cross_half_packed_add(tmp_path, variant):
         if n:
             bad[src] = n
     assert not bad, bad
+
+
+def test_no_bit_cast_of_a_vector_element():
+    """ROCm 7.2 clang: `__builtin_bit_cast(T, v[i])` with `v` an ext_vector_type value reads element 0 whatever `i` is -- `v.y`, `v.w` likewise (a four-line kernel stores the same dword
+    four times; found while rewriting vpt_conv_first_kernel, profiles/r06_experiments.md section 4).  Elements of plain C arrays are fine.  Every indexed operand of
+    a bit cast in the sources must be a known C array (or an array OF vectors, whose element is a whole vector); cast the whole vector otherwise."""
+    mod = _build_module()
+    c_arrays = {"mi", "vv", "wq", "m", "pk", "q", "vals"}
+    bad = []
+    for src in sorted(os.listdir(mod.CSRC)):
+        if not src.endswith((".hip", ".h")):
+            continue
+        for n, ln in enumerate(open(os.path.join(mod.CSRC, src)), 1):
+            for mt in re.finditer(r"__builtin_bit_cast\(\s*[\w:]+\s*,\s*(\w+)\s*\[", ln):
+                if mt.group(1) not in c_arrays:
+                    bad.append(f"{src}:{n}: {ln.strip()[:120]}")
+            if re.search(r"__builtin_bit_cast\(\s*[\w:]+\s*,\s*[\w\[\]\. ]+\.(x|y|z|w|s[0-9a-f]|lo|hi|even|odd)\s*\)", ln):      # v.y, v.w ...: the same defect
+                bad.append(f"{src}:{n}: {ln.strip()[:120]}")
+    assert not bad, "\n".join(bad)
