@@ -207,6 +207,35 @@ def test_conv_first_pool(frames, cout, h, w):
         assert torch.allclose(chs, ops.channel_stats(y3), rtol=1e-6, atol=1e-4), (chs - ops.channel_stats(y3)).abs().max()
 
 
+def test_conv_first_does_not_depend_on_how_the_batch_is_cut():
+    """The persistent workgroups of vpt_conv_first_kernel take contiguous tile ranges that depend on the number of frames in the launch; a frame's pooled tensor,
+    its statistics and its per-channel sums must not (fp32 sums only inside a tile / a 16-tile group, fp64 across).  600 frames = three groups per
+    workgroup, ranges that cross frame boundaries; against the same frames in six launches of 100 and in single-frame launches: every bit equal."""
+    g = torch.Generator().manual_seed(11)
+    cout, frames = 128, 600
+    W = torch.randn(cout, 3, 3, 3, generator=g) * 0.3
+    b = 0.1 * torch.randn(cout, generator=g)
+    wf = packing.pack_conv_first(W.to(DEV), b.to(DEV))
+    gain = (1 + 0.3 * torch.randn(cout, generator=g)).to(DEV)
+    img = torch.randint(0, 256, (frames, 128, 128, 3), generator=g, dtype=torch.uint8).to(DEV)
+
+    def run(lo, hi, with_chs):
+        st = torch.zeros(hi - lo, 2, dtype=torch.float64, device=DEV)
+        chs = torch.zeros(hi - lo, cout, 2, dtype=torch.float64, device=DEV) if with_chs else None
+        y = ops.conv_first(img[lo:hi], wf, cout, stats_out=st, out_gain=gain if with_chs else None, chs_out=chs)
+        return y, st, chs
+    for with_chs in (True, False):
+        y, st, chs = run(0, frames, with_chs)
+        for lo in range(0, frames, 100):
+            y2, st2, chs2 = run(lo, lo + 100, with_chs)
+            assert torch.equal(y2.view(torch.int16), y[lo:lo + 100].view(torch.int16)) and torch.equal(st2, st[lo:lo + 100])
+            assert not with_chs or torch.equal(chs2, chs[lo:lo + 100])
+        for f in (0, 257, frames - 1):
+            y1, st1, chs1 = run(f, f + 1, with_chs)
+            assert torch.equal(y1.view(torch.int16), y[f:f + 1].view(torch.int16)) and torch.equal(st1, st[f:f + 1])
+            assert not with_chs or torch.equal(chs1, chs[f:f + 1])
+
+
 def test_maxpool_and_affine():
     g = torch.Generator().manual_seed(3)
     x = torch.relu(torch.randn(2, 64, 32, 32, generator=g)).to(torch.bfloat16)
