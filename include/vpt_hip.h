@@ -92,7 +92,7 @@ int vpt_pack_linear(const float* weight, void* wpk, int N, int K, int transposed
  * Replaces ImgPreprocessing.forward (lib/policy.py:39-45), the permute at lib/impala_cnn.py:190,
  * CnnDownStack.firstconv of stack 0 (lib/impala_cnn.py:86-97,115) and F.max_pool2d (lib/impala_cnn.py:117).
  * img: uint8 [frames][H][W][3]; wfrag: bf16 [NT][4][2][64][8]; y: blocked [frames][Cout/32][H/2][W/2][32].
- * out_gain (optional, [Cout]): y is stored multiplied by it per channel -- the gain of the stack's GroupNorm `n` when that norm is
+ * out_gain (optional, [Cout], Cout <= 256): y is stored multiplied by it per channel -- the gain of the stack's GroupNorm `n` when that norm is
  * folded into the first block (vpt_nfold_coef); stats_out always holds the statistics of the UNscaled pooled tensor.
  * chs_out (optional, [frames][Cout][2] fp64, ACCUMULATED, Cout <= 128): per-channel (sum, sum of squares) of y as stored -- what
  * vpt_channel_stats would compute in a pass of its own; here the sums run in registers across the tiles of a frame. */

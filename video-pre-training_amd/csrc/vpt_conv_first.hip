@@ -322,6 +322,7 @@ extern "C" int vpt_conv_first_launch(const VptConvFirstArgs* a, hipStream_t stre
   }
   long grid = (long)a->frames * (a->H >> 4) * (a->W >> 4) * a->NT;
   if ((long)a->frames * a->H * a->W * 3 > 0x7fffffffL) return -2;   // 32-bit pixel offsets inside a launch
+  if (a->out_gain && a->Cout > 256) return -1;                      // the kernel keeps the launch's gains in 1 KB of LDS (the model's widest stack 0 is 192 channels)
   if (a->chs_out && a->NT != 1) return -1;                          // running per-channel sums: one channel tile (Cout <= 128); else vpt_channel_stats
   const long per_cu = 16 / CF2_WAVES;
   if (grid > per_cu * num_cu) grid = per_cu * num_cu;
